@@ -1,0 +1,201 @@
+/*
+ * enigma_hip.h -- C ABI of the MI355X (gfx950) PathIntegrator back end.
+ *
+ * The reference renderer ("Enigma", namespace RayTrace) has no FFI: its hot path
+ * sits behind the C++ virtual `Integrator::Render(const Scene&)`
+ * (Enigma/Integrator.h:35-41, Enigma/Integrator.cpp:225-322) and is reached from
+ * `renderOptions->m_integrator->Render(*renderOptions->m_scene)`
+ * (Enigma/Main.h:245).  This header is the boundary a `GpuPathIntegrator :
+ * SamplerIntegrator` binds instead: plain pointers and sizes, POD structs,
+ * caller-owned host memory, device memory behind an opaque handle.
+ *
+ * Conventions
+ *  - every call returns 0 on success and a negative ENIGMA_E_* code on failure;
+ *    enigma_last_error(h) returns a human readable reason (never NULL).
+ *    (The reference only prints and continues, Enigma/Error.h:5-10.)
+ *  - one host thread per handle; calls on one handle are serialised by the caller.
+ *  - all matrices are 16 floats, row-major in the sense of the reference's
+ *    `m_mat[r][c]` as used by Transform::transformPoint (Enigma/Transform.h:36-45).
+ *  - geometry is world space (TriangleMesh stores world-space m_p,
+ *    Enigma/TriangleMesh.cpp:35-37); no transform composition happens here.
+ */
+#ifndef ENIGMA_HIP_H
+#define ENIGMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENIGMA_OK 0
+#define ENIGMA_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define ENIGMA_E_STATE (-2)       /* call order violated (e.g. render before upload) */
+#define ENIGMA_E_DEVICE (-3)      /* HIP runtime error */
+#define ENIGMA_E_UNSUPPORTED (-4) /* feature of the reference that is out of scope */
+
+/* Material kinds: Enigma/Material.cpp:76-93 (matte), :115-136 (metal),
+ * :176-220 (glass), :232-255 (plastic).  Parameters are the values the
+ * reference's ConstantTexture::Evaluate would return (Enigma/Texture.h:119-131). */
+enum { ENIGMA_MAT_MATTE = 0, ENIGMA_MAT_METAL = 1, ENIGMA_MAT_GLASS = 2, ENIGMA_MAT_PLASTIC = 3 };
+
+typedef struct EnigmaMaterial {
+    uint32_t type;            /* ENIGMA_MAT_* */
+    uint32_t remap_roughness; /* remaproughness flag (metal / glass / plastic) */
+    float kd[3];              /* matte, plastic: Kd */
+    float ks[3];              /* plastic: Ks */
+    float kr[3];              /* glass: Kr */
+    float kt[3];              /* glass: Kt */
+    float eta[3];             /* metal: eta (RGB) */
+    float k[3];               /* metal: k (RGB) */
+    float sigma;              /* matte: Oren-Nayar sigma, must be 0 (Lambertian) */
+    float uroughness;         /* metal / glass: u roughness; plastic: roughness */
+    float vroughness;         /* metal / glass: v roughness; plastic: roughness */
+    float index;              /* glass: index of refraction */
+} EnigmaMaterial;
+
+/* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651).
+ * One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
+enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1 };
+
+typedef struct EnigmaLight {
+    uint32_t type;      /* ENIGMA_LIGHT_* */
+    uint32_t triangle;  /* area light: index of its triangle */
+    uint32_t two_sided; /* area light: twosided flag */
+    uint32_t pad;
+    float L[3];         /* area: emitted radiance Lemission; point: intensity I */
+    float pos[3];       /* point light: world position */
+} EnigmaLight;
+
+#define ENIGMA_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness */
+
+typedef struct EnigmaSceneDesc {
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    const float* vertices;        /* [n_vertices*3] world space */
+    const uint32_t* indices;      /* [n_triangles*3] */
+    const uint32_t* tri_material; /* [n_triangles] index into materials */
+    const int32_t* tri_light;     /* [n_triangles] index into lights or -1 */
+    const uint32_t* tri_flags;    /* [n_triangles] ENIGMA_TRI_* (NULL = all 0) */
+    const uint32_t* tri_prim_id;  /* [n_triangles] reference m_primitiveId
+                                     (Enigma/Primitive.cpp:19-26); NULL = i+1 */
+    const float* normals;         /* optional per-vertex normals; must be NULL */
+    const float* uvs;             /* optional per-vertex uvs; must be NULL */
+    uint32_t n_materials;
+    uint32_t n_lights;
+    const EnigmaMaterial* materials;
+    const EnigmaLight* lights;    /* in the order of Scene::m_lights */
+} EnigmaSceneDesc;
+
+/* PerspectiveCamera state read by GenerateRayDifferential (Enigma/Camera.cpp:144-192):
+ * ProjectiveCamera::m_rasterToCamera, Camera::m_cameraToWorld (start transform),
+ * m_lensRadius, m_focalDistance (Enigma/Camera.h:40-56). */
+typedef struct EnigmaCameraDesc {
+    float raster_to_camera[16];
+    float camera_to_world[16];
+    float lens_radius;
+    float focal_distance;
+} EnigmaCameraDesc;
+
+/* Film state read by GetSampleBounds/GetFilmTile/AddSample (Enigma/Film.cpp:73-99,
+ * 263-300): cropped pixel bounds, filter radius and the 16x16 filter table the
+ * Film constructor tabulates (Enigma/Film.cpp:61-70). */
+typedef struct EnigmaFilmDesc {
+    int32_t full_resolution[2];
+    int32_t cropped_pixel_bounds[4]; /* x0, y0, x1, y1 (max exclusive) */
+    float filter_radius[2];
+    float filter_table[256];
+    float max_sample_luminance;      /* +inf by default */
+} EnigmaFilmDesc;
+
+enum { ENIGMA_LIGHTS_UNIFORM = 0, ENIGMA_LIGHTS_POWER = 1 };
+
+/* PathIntegrator + SobolSampler parameters (Enigma/PathIntegrator.cpp:30-44,
+ * 182-201; Enigma/Sampler.cpp:211-222). */
+typedef struct EnigmaIntegratorDesc {
+    int32_t max_depth;
+    float rr_threshold;
+    int32_t light_strategy;     /* ENIGMA_LIGHTS_*; one light always means uniform
+                                   (Enigma/LightDist.cpp:22) */
+    int32_t pixel_bounds[4];    /* SamplerIntegrator::m_pixelBounds, x0,y0,x1,y1 */
+    int64_t samples_per_pixel;  /* rounded up to a power of two like SobolSampler */
+    int32_t sample_bounds[4];   /* SobolSampler::m_sampleBounds = Film::GetSampleBounds() */
+} EnigmaIntegratorDesc;
+
+typedef struct EnigmaStats {
+    uint64_t camera_samples;  /* camera samples started */
+    uint64_t rays_closest;    /* Scene::intersect equivalents: path rays */
+    uint64_t rays_shadow;     /* Scene::intersectP equivalents: shadow rays */
+    uint64_t rays_mis;        /* Scene::intersect equivalents: BSDF-sampled MIS rays */
+    double ms_render;         /* wall time inside enigma_render, last call */
+    double ms_intersect;      /* device time of the closest-hit kernel launches, last call */
+    uint64_t intersect_launches;
+    uint64_t bvh_nodes;       /* device BVH size */
+    uint64_t bvh_depth;
+    double ms_bvh_build;
+} EnigmaStats;
+
+typedef struct EnigmaCtx EnigmaCtx;
+
+/* Replaces construction of the integrator object graph (Enigma/Api.cpp:1170-1254). */
+int enigma_ctx_create(int device_id, EnigmaCtx** out);
+void enigma_ctx_destroy(EnigmaCtx* h);
+const char* enigma_last_error(const EnigmaCtx* h);
+
+/* Replaces RenderOptions::MakeScene + BVHAccel construction (Enigma/BVH.cpp:148-189,
+ * Enigma/Scene.cpp:19-30): flattens the scene, builds the device BVH, uploads. */
+int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* scene);
+/* Replaces RenderOptions::MakeCamera (Enigma/Camera.cpp:80-118). */
+int enigma_camera_set(EnigmaCtx* h, const EnigmaCameraDesc* cam);
+/* Replaces Film construction (Enigma/Film.cpp:39-71); clears the device film. */
+int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* film);
+/* Replaces CreatePathIntegrator + SobolSampler construction + PathIntegrator::Preprocess
+ * (Enigma/PathIntegrator.cpp:41-44,182-201; Enigma/Sampler.cpp:211-222). */
+int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* integ);
+
+/* Replaces the tile loop of SamplerIntegrator::Render (Enigma/Integrator.cpp:239-320)
+ * for sample numbers [sample_begin, sample_end) of every pixel; accumulates into the
+ * device film (FilmTile::AddSample, Enigma/Film.cpp:263-300).  Blocking. */
+int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end);
+
+/* Device film as one FilmTile covering the cropped pixel bounds: per pixel
+ * {contribSum.r, contribSum.g, contribSum.b, filterWeightSum} (Enigma/Film.h:24-27),
+ * row-major.  What Film::MergeFilmTile consumes (Enigma/Film.cpp:101-125). */
+int enigma_film_read(EnigmaCtx* h, float* rgbw, uint64_t n_floats);
+int enigma_film_clear(EnigmaCtx* h);
+/* Device pointer of the film accumulators (float4 per pixel) and their float count,
+ * for in-place reductions across ranks (e.g. an RCCL reduce by the caller). */
+int enigma_film_device_ptr(EnigmaCtx* h, void** dev_ptr, uint64_t* n_floats);
+/* Film::WriteImage normalisation (Enigma/Film.cpp:157-209) on a host rgbw buffer:
+ * rgb = max(0, XYZToRGB(RGBToXYZ(sum)) / weight) * scale.  Host code, no device work. */
+int enigma_film_resolve(const float* rgbw, uint64_t n_pixels, float scale, float* rgb_out);
+
+int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out);
+
+/* ---- debug taps for bit-exact parity checks (run the device code paths) ---- */
+
+/* SobolSampler::GetIndexForSample + SampleDimension (Enigma/Sampler.cpp:224-240):
+ * for n (pixel, sampleNum) pairs return the 64-bit Sobol index and dimensions
+ * [0, n_dims) as floats (dims 0,1 are the pixel-relative offsets). */
+int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums,
+                       uint32_t n_dims, uint64_t* index_out, float* dims_out);
+/* GetCameraSample + PerspectiveCamera::GenerateRayDifferential main ray
+ * (Enigma/Sampler.cpp:30-37, Enigma/Camera.cpp:144-192): out_ray = o.xyz,d.xyz;
+ * out_pfilm = CameraSample::m_image. */
+int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums,
+                             float* out_ray, float* out_pfilm);
+/* Scene::intersect / intersectP (Enigma/Scene.cpp:33-44) for n rays given as
+ * o.xyz, d.xyz, tMax: closest-hit returns the triangle index (or -1), its
+ * reference primitive id (0 on miss), t and barycentrics; any-hit returns 0/1. */
+int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
+                           uint32_t* prim_id_out, float* t_out, float* bary_out);
+int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out);
+/* FilmTile::AddSample footprint (Enigma/Film.cpp:269-292) for n film positions:
+ * up to max_per (pixel x, pixel y) pairs and filter weights each, count in counts. */
+int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per,
+                                int32_t* pixels_xy_out, float* weights_out, uint32_t* counts_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENIGMA_HIP_H */

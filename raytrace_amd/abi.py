@@ -1,0 +1,151 @@
+"""ctypes mirror of include/enigma_hip.h (POD structs shared by the product library and,
+in tests only, by the CPU oracle)."""
+import ctypes as C
+import numpy as np
+
+MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
+LIGHT_POINT, LIGHT_DIFFUSE_AREA = 0, 1
+LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
+TRI_FLIP_NORMAL = 1
+
+
+class EnigmaMaterial(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("remap_roughness", C.c_uint32),
+                ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
+                ("eta", C.c_float * 3), ("k", C.c_float * 3),
+                ("sigma", C.c_float), ("uroughness", C.c_float), ("vroughness", C.c_float), ("index", C.c_float)]
+
+
+class EnigmaLight(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("triangle", C.c_uint32), ("two_sided", C.c_uint32), ("pad", C.c_uint32),
+                ("L", C.c_float * 3), ("pos", C.c_float * 3)]
+
+
+class EnigmaSceneDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("vertices", C.c_void_p), ("indices", C.c_void_p), ("tri_material", C.c_void_p),
+                ("tri_light", C.c_void_p), ("tri_flags", C.c_void_p), ("tri_prim_id", C.c_void_p),
+                ("normals", C.c_void_p), ("uvs", C.c_void_p),
+                ("n_materials", C.c_uint32), ("n_lights", C.c_uint32),
+                ("materials", C.c_void_p), ("lights", C.c_void_p)]
+
+
+class EnigmaCameraDesc(C.Structure):
+    _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+
+
+class EnigmaFilmDesc(C.Structure):
+    _fields_ = [("full_resolution", C.c_int32 * 2), ("cropped_pixel_bounds", C.c_int32 * 4),
+                ("filter_radius", C.c_float * 2), ("filter_table", C.c_float * 256),
+                ("max_sample_luminance", C.c_float)]
+
+
+class EnigmaIntegratorDesc(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
+                ("pixel_bounds", C.c_int32 * 4), ("samples_per_pixel", C.c_int64), ("sample_bounds", C.c_int32 * 4)]
+
+
+class EnigmaStats(C.Structure):
+    _fields_ = [("camera_samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("rays_mis", C.c_uint64), ("ms_render", C.c_double), ("ms_intersect", C.c_double),
+                ("intersect_launches", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
+                ("ms_bvh_build", C.c_double)]
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class SceneArrays:
+    """Owns the numpy arrays an EnigmaSceneDesc points into."""
+
+    def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None):
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        nt = self.indices.shape[0]
+        self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32).reshape(nt)
+        self.tri_light = np.ascontiguousarray(tri_light, dtype=np.int32).reshape(nt)
+        self.tri_flags = None if tri_flags is None else np.ascontiguousarray(tri_flags, dtype=np.uint32).reshape(nt)
+        self.tri_prim_id = None if tri_prim_id is None else np.ascontiguousarray(tri_prim_id, dtype=np.uint32).reshape(nt)
+        self.materials = (EnigmaMaterial * len(materials))(*materials)
+        self.lights = (EnigmaLight * max(1, len(lights)))(*lights)
+        self.n_lights = len(lights)
+        self.n_materials = len(materials)
+
+    def desc(self):
+        d = EnigmaSceneDesc()
+        d.n_vertices = self.vertices.shape[0]
+        d.n_triangles = self.indices.shape[0]
+        d.vertices = ptr(self.vertices)
+        d.indices = ptr(self.indices)
+        d.tri_material = ptr(self.tri_material)
+        d.tri_light = ptr(self.tri_light)
+        d.tri_flags = ptr(self.tri_flags)
+        d.tri_prim_id = ptr(self.tri_prim_id)
+        d.normals = None
+        d.uvs = None
+        d.n_materials = self.n_materials
+        d.n_lights = self.n_lights
+        d.materials = C.cast(self.materials, C.c_void_p)
+        d.lights = C.cast(self.lights, C.c_void_p)
+        return d
+
+
+def matte(kd, sigma=0.0):
+    m = EnigmaMaterial()
+    m.type = MAT_MATTE
+    m.kd[:] = kd
+    m.sigma = sigma
+    return m
+
+
+def metal(eta, k, roughness=0.01, remap=True, uroughness=None, vroughness=None):
+    m = EnigmaMaterial()
+    m.type = MAT_METAL
+    m.eta[:] = eta
+    m.k[:] = k
+    m.uroughness = roughness if uroughness is None else uroughness
+    m.vroughness = roughness if vroughness is None else vroughness
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def glass(index=1.5, uroughness=0.0, vroughness=0.0, kr=(1, 1, 1), kt=(1, 1, 1), remap=True):
+    m = EnigmaMaterial()
+    m.type = MAT_GLASS
+    m.kr[:] = kr
+    m.kt[:] = kt
+    m.index = index
+    m.uroughness = uroughness
+    m.vroughness = vroughness
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def plastic(kd, ks, roughness=0.1, remap=True):
+    m = EnigmaMaterial()
+    m.type = MAT_PLASTIC
+    m.kd[:] = kd
+    m.ks[:] = ks
+    m.uroughness = roughness
+    m.vroughness = roughness
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def area_light(triangle, L, two_sided=False):
+    l = EnigmaLight()
+    l.type = LIGHT_DIFFUSE_AREA
+    l.triangle = triangle
+    l.two_sided = 1 if two_sided else 0
+    l.L[:] = L
+    return l
+
+
+def point_light(pos, I):
+    l = EnigmaLight()
+    l.type = LIGHT_POINT
+    l.pos[:] = pos
+    l.L[:] = I
+    return l

@@ -1,0 +1,382 @@
+"""Deterministic synthetic inputs for the PathIntegrator path.
+
+The reference ships no scene the ray tracer can load (its only call site asks for
+scenes/cornell-box/scene.pbrt, Enigma/Main.h:240-246, which is absent), so the fixtures are
+authored here: the classic Cornell-box data as triangle meshes, a procedural >= 1 M triangle
+scene and a many-light variant.  Everything is world space with final numeric matrices, which
+is what the C ABI takes (transform composition of the reference is not reproduced).
+"""
+import math
+import numpy as np
+
+from . import abi
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- camera / film
+def look_at(pos, look, up):
+    """camera-to-world, left-handed, +z forward (the numeric result of Inverse(LookAt))."""
+    pos, look, up = (np.asarray(v, dtype=np.float64) for v in (pos, look, up))
+    d = look - pos
+    d /= np.linalg.norm(d)
+    right = np.cross(up / np.linalg.norm(up), d)
+    right /= np.linalg.norm(right)
+    new_up = np.cross(d, right)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, new_up, d, pos
+    return m
+
+
+def perspective_raster_to_camera(fov_deg, xres, yres, n=1e-2, f=1000.0):
+    """rasterToCamera = Inverse(cameraToScreen) * Inverse(screenToRaster)
+    (Enigma/Camera.cpp:90-97,421-430) evaluated in float64."""
+    frame = xres / yres
+    if frame > 1.0:
+        screen = (-frame, frame, -1.0, 1.0)
+    else:
+        screen = (-1.0, 1.0, -1.0 / frame, 1.0 / frame)
+    persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], dtype=np.float64)
+    inv_tan = 1.0 / math.tan(math.radians(fov_deg) / 2)
+    cam_to_screen = np.diag([inv_tan, inv_tan, 1, 1]) @ persp
+    tr = np.eye(4)
+    tr[0, 3], tr[1, 3] = -screen[0], -screen[3]
+    screen_to_raster = np.diag([xres, yres, 1, 1]) @ np.diag([1 / (screen[1] - screen[0]), 1 / (screen[2] - screen[3]), 1, 1]) @ tr
+    return np.linalg.inv(cam_to_screen) @ np.linalg.inv(screen_to_raster)
+
+
+def camera_desc(pos, look, up, fov_deg, xres, yres, lens_radius=0.0, focal_distance=1e30):
+    c = abi.EnigmaCameraDesc()
+    r2c = perspective_raster_to_camera(fov_deg, xres, yres).astype(F32)
+    c2w = look_at(pos, look, up).astype(F32)
+    c.raster_to_camera[:] = r2c.reshape(-1).tolist()
+    c.camera_to_world[:] = c2w.reshape(-1).tolist()
+    c.lens_radius = lens_radius
+    c.focal_distance = focal_distance
+    return c
+
+
+def _filter_eval(kind, x, y, rx, ry, params):
+    """Filter::Evaluate (Enigma/Filter.cpp:8-32, Enigma/Filter.h:50-103) in binary32."""
+    x, y, rx, ry = F32(x), F32(y), F32(rx), F32(ry)
+    if kind == "box":
+        return F32(1.0)
+    if kind == "triangle":
+        return F32(max(F32(0), rx - abs(x)) * max(F32(0), ry - abs(y)))
+    if kind == "gaussian":
+        alpha = F32(params.get("alpha", 2.0))
+        ex, ey = F32(np.exp(-alpha * rx * rx)), F32(np.exp(-alpha * ry * ry))
+        g = lambda d, e: max(F32(0), F32(F32(np.exp(-alpha * d * d)) - e))
+        return F32(g(x, ex) * g(y, ey))
+    if kind == "mitchell":
+        b, c = F32(params.get("B", 1.0 / 3.0)), F32(params.get("C", 1.0 / 3.0))
+
+        def m1(v):
+            v = F32(abs(F32(2) * v))
+            if v > 1:
+                return F32(((-b - 6 * c) * v * v * v + (6 * b + 30 * c) * v * v + (-12 * b - 48 * c) * v + (8 * b + 24 * c)) * F32(1.0 / 6.0))
+            return F32(((12 - 9 * b - 6 * c) * v * v * v + (-18 + 12 * b + 6 * c) * v * v + (6 - 2 * b)) * F32(1.0 / 6.0))
+        return F32(m1(x * (F32(1) / rx)) * m1(y * (F32(1) / ry)))
+    raise ValueError(kind)
+
+
+def film_desc(xres, yres, filter_kind="box", radius=None, crop=(0.0, 1.0, 0.0, 1.0), max_sample_luminance=float("inf"), **params):
+    """Film constructor state (Enigma/Film.cpp:39-71): cropped pixel bounds + 16x16 filter table."""
+    default_r = {"box": 0.5, "triangle": 2.0, "gaussian": 2.0, "mitchell": 2.0}[filter_kind]
+    rx, ry = (default_r, default_r) if radius is None else radius
+    f = abi.EnigmaFilmDesc()
+    f.full_resolution[:] = [xres, yres]
+    f.cropped_pixel_bounds[:] = [int(math.ceil(xres * crop[0])), int(math.ceil(yres * crop[2])),
+                                 int(math.ceil(xres * crop[1])), int(math.ceil(yres * crop[3]))]
+    f.filter_radius[:] = [rx, ry]
+    tab = []
+    for y in range(16):
+        for x in range(16):
+            px = F32(F32(x + 0.5) * F32(rx) / F32(16))
+            py = F32(F32(y + 0.5) * F32(ry) / F32(16))
+            tab.append(float(_filter_eval(filter_kind, px, py, rx, ry, params)))
+    f.filter_table[:] = tab
+    f.max_sample_luminance = max_sample_luminance
+    return f
+
+
+def sample_bounds(film):
+    """Film::GetSampleBounds (Enigma/Film.cpp:73-81)."""
+    b = film.cropped_pixel_bounds
+    rx, ry = F32(film.filter_radius[0]), F32(film.filter_radius[1])
+    return [int(math.floor(F32(F32(b[0]) + F32(0.5) - rx))), int(math.floor(F32(F32(b[1]) + F32(0.5) - ry))),
+            int(math.ceil(F32(F32(b[2]) - F32(0.5) + rx))), int(math.ceil(F32(F32(b[3]) - F32(0.5) + ry)))]
+
+
+def integrator_desc(film, spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER, pixel_bounds=None):
+    d = abi.EnigmaIntegratorDesc()
+    sb = sample_bounds(film)
+    d.max_depth = max_depth
+    d.rr_threshold = rr_threshold
+    d.light_strategy = light_strategy
+    d.pixel_bounds[:] = sb if pixel_bounds is None else pixel_bounds
+    d.samples_per_pixel = spp
+    d.sample_bounds[:] = sb
+    return d
+
+
+# ----------------------------------------------------------------------------- mesh helpers
+class MeshBuilder:
+    def __init__(self):
+        self.v, self.t, self.mat, self.light, self.flags = [], [], [], [], []
+        self.materials, self.lights = [], []
+
+    def add_material(self, m):
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    @staticmethod
+    def _ref_normal(p0, p1, p2):
+        # Normalize(Cross(p0 - p2, p1 - p2)): the geometric normal Triangle::intersect assigns
+        # (Enigma/TriangleMesh.cpp:287)
+        return np.cross(np.asarray(p0, float) - p2, np.asarray(p1, float) - p2)
+
+    def add_tri(self, p0, p1, p2, mat, toward=None, emit=None, two_sided=False):
+        """toward: a point the reference geometric normal must face (winding is swapped if not)."""
+        p0, p1, p2 = (np.asarray(p, dtype=np.float64) for p in (p0, p1, p2))
+        if toward is not None:
+            n = self._ref_normal(p0, p1, p2)
+            if np.dot(n, np.asarray(toward, float) - p0) < 0:
+                p1, p2 = p2, p1
+        base = len(self.v)
+        self.v += [p0, p1, p2]
+        self.t.append((base, base + 1, base + 2))
+        self.mat.append(mat)
+        self.flags.append(0)
+        if emit is not None:
+            self.lights.append(abi.area_light(len(self.t) - 1, emit, two_sided))
+            self.light.append(len(self.lights) - 1)
+        else:
+            self.light.append(-1)
+
+    def add_quad(self, q, mat, toward=None, emit=None, two_sided=False):
+        self.add_tri(q[0], q[1], q[2], mat, toward, emit, two_sided)
+        self.add_tri(q[0], q[2], q[3], mat, toward, emit, two_sided)
+
+    def add_point_light(self, pos, I):
+        self.lights.append(abi.point_light(pos, I))
+
+    def weld(self):
+        """Share identical vertices (keeps triangle order and winding)."""
+        v = np.asarray(self.v, dtype=np.float32)
+        uniq, inv = np.unique(v, axis=0, return_inverse=True)
+        t = inv.reshape(-1)[np.asarray(self.t, dtype=np.int64)]
+        return uniq, t.astype(np.uint32)
+
+    def arrays(self, weld=True):
+        if weld:
+            v, t = self.weld()
+        else:
+            v, t = np.asarray(self.v, dtype=np.float32), np.asarray(self.t, dtype=np.uint32)
+        return abi.SceneArrays(v, t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags)
+
+
+# ----------------------------------------------------------------------------- S1: Cornell box
+_CORNELL = {
+    "floor": [(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)],
+    "ceiling": [(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)],
+    "back": [(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)],
+    "right": [(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)],
+    "left": [(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)],
+    # the classic data puts the light in the ceiling plane (y = 548.8); it is lowered slightly
+    # so no two surfaces are coplanar (closest-hit ties would depend on BVH traversal order).
+    "light": [(343, 548.0, 227), (343, 548.0, 332), (213, 548.0, 332), (213, 548.0, 227)],
+    "short": [
+        [(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)],
+        [(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)],
+        [(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)],
+        [(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)],
+        [(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)],
+    ],
+    "tall": [
+        [(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)],
+        [(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)],
+        [(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)],
+        [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)],
+        [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)],
+    ],
+}
+CORNELL_CENTER = (278.0, 274.4, 279.6)
+COPPER_ETA = (0.200, 0.924, 1.102)
+COPPER_K = (3.912, 2.452, 2.142)
+
+
+def cornell_box(variant="diffuse"):
+    """S1 (all matte) or S1m (short block metal, tall block rough glass).  32 triangles, 2 lights."""
+    b = MeshBuilder()
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    if variant == "diffuse":
+        short_m = tall_m = white
+    elif variant == "microfacet":
+        short_m = b.add_material(abi.metal(COPPER_ETA, COPPER_K, roughness=0.1, remap=True))
+        tall_m = b.add_material(abi.glass(1.5, 0.05, 0.05))
+    elif variant == "specular":
+        short_m = b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05))
+        tall_m = b.add_material(abi.glass(1.5, 0.0, 0.0))
+    else:
+        raise ValueError(variant)
+    c = CORNELL_CENTER
+    for name, m in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        b.add_quad(_CORNELL[name], m, toward=c)
+    for name, m in (("short", short_m), ("tall", tall_m)):
+        faces = _CORNELL[name]
+        centre = np.mean([p for f in faces for p in f], axis=0)
+        centre[1] = centre[1] * 0.5
+        for f in faces:
+            outward = np.mean(f, axis=0) * 2 - centre  # a point on the outer side of the face
+            b.add_quad(f, m, toward=outward)
+    b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
+    return b.arrays()
+
+
+def cornell_camera(xres, yres, lens_radius=0.0, focal_distance=1e30):
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))  # 39.3 degrees: the narrower image side
+    return camera_desc((278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, lens_radius, focal_distance)
+
+
+# ----------------------------------------------------------------------------- S3: many lights
+def many_lights(n_quads=256, n_points=64, seed=0x11647):
+    """Cornell geometry + n_quads small emissive quads on the ceiling/walls + point lights."""
+    rng = np.random.RandomState(seed)
+    b = MeshBuilder()
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    plast = b.add_material(abi.plastic((0.3, 0.3, 0.3), (0.5, 0.5, 0.5), roughness=0.08))
+    c = CORNELL_CENTER
+    for name, m in (("floor", plast), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        b.add_quad(_CORNELL[name], m, toward=c)
+    for name in ("short", "tall"):
+        faces = _CORNELL[name]
+        centre = np.mean([p for f in faces for p in f], axis=0)
+        centre[1] *= 0.5
+        for f in faces:
+            b.add_quad(f, white, toward=np.mean(f, axis=0) * 2 - centre)
+    for _ in range(n_quads):
+        x, z = rng.uniform(30, 520), rng.uniform(30, 520)
+        y = rng.uniform(440, 540)
+        s = rng.uniform(3, 9)
+        rad = float(np.exp(rng.uniform(math.log(1.0), math.log(100.0))))
+        col = rng.uniform(0.3, 1.0, size=3) * rad
+        q = [(x - s, y, z - s), (x - s, y, z + s), (x + s, y, z + s), (x + s, y, z - s)]
+        b.add_quad(q, white, toward=(x, 0, z), emit=tuple(float(v) for v in col))
+    for _ in range(n_points):
+        p = (rng.uniform(40, 510), rng.uniform(200, 430), rng.uniform(40, 510))
+        inten = rng.uniform(2000, 20000) * rng.uniform(0.3, 1.0, size=3)
+        b.add_point_light(p, tuple(float(v) for v in inten))
+    return b.arrays()
+
+
+# ----------------------------------------------------------------------------- S2: big mesh
+def _icosphere(level):
+    t = (1.0 + 5 ** 0.5) / 2
+    v = np.array([(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+                  (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+                  (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+                  (8, 6, 7), (9, 8, 1)], dtype=np.int64)
+    for _ in range(level):
+        edges = {}
+        verts = list(v)
+        nf = []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in edges:
+                m = (verts[a] + verts[b]) * 0.5
+                verts.append(m / np.linalg.norm(m))
+                edges[key] = len(verts) - 1
+            return edges[key]
+        for a, b_, c in f:
+            ab, bc, ca = mid(a, b_), mid(b_, c), mid(c, a)
+            nf += [(a, ab, ca), (b_, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        v, f = np.array(verts), np.array(nf, dtype=np.int64)
+    return v, f
+
+
+def big_mesh(grid=512, sphere_level=6, n_spheres=8, seed=0xE16A):
+    """S2: grid x grid displaced terrain (2*grid^2 triangles) + n_spheres icospheres
+    (20*4^level triangles each) inside a closed box with one overhead quad light.
+    Defaults: 524,288 + 8*81,920 + 12 + 2 = 1,179,662 triangles."""
+    rng = np.random.RandomState(seed)
+    mats = [abi.matte((0.55, 0.5, 0.45))]
+    mats += [abi.metal(COPPER_ETA, COPPER_K, roughness=float(r), remap=True) for r in (0.05, 0.15, 0.3)]
+    mats += [abi.glass(1.5, float(r), float(r)) for r in (0.0, 0.1, 0.2)]
+    mats += [abi.matte((0.7, 0.7, 0.75))]
+    size = 1000.0
+    # terrain
+    xs = np.linspace(0, size, grid + 1)
+    X, Z = np.meshgrid(xs, xs, indexing="xy")
+    H = np.zeros_like(X)
+    for _ in range(24):
+        kx, kz = rng.uniform(0.5, 9, size=2) * 2 * math.pi / size
+        H += rng.uniform(2, 14) * np.sin(kx * X + rng.uniform(0, 6.28)) * np.cos(kz * Z + rng.uniform(0, 6.28)) / 4
+    H += rng.uniform(-0.3, 0.3, size=H.shape)
+    tv = np.stack([X, H + 40.0, Z], axis=-1).reshape(-1, 3)
+    i0 = (np.arange(grid)[:, None] * (grid + 1) + np.arange(grid)[None, :]).reshape(-1)
+    # winding chosen so the reference normal cross(p0-p2, p1-p2) faces +y
+    ta = np.stack([i0, i0 + 1, i0 + grid + 2], axis=1)
+    tb = np.stack([i0, i0 + grid + 2, i0 + grid + 1], axis=1)
+    tris = [np.stack([ta, tb], axis=1).reshape(-1, 3)]
+    verts = [tv]
+    tmat = [np.zeros(2 * grid * grid, dtype=np.uint32)]
+    nv = tv.shape[0]
+    sv, sf = _icosphere(sphere_level)
+    for s in range(n_spheres):
+        r = rng.uniform(60, 110)
+        c = np.array([rng.uniform(150, 850), rng.uniform(170, 300), rng.uniform(150, 850)])
+        verts.append(sv * r + c)
+        # outward normal for cross(p0-p2, p1-p2): keep (a,b,c) if it faces out else swap
+        tris.append(sf + nv)
+        tmat.append(np.full(sf.shape[0], 1 + (s % 6), dtype=np.uint32))
+        nv += sv.shape[0]
+    V = np.concatenate(verts).astype(np.float32)
+    T = np.concatenate(tris).astype(np.int64)
+    M = np.concatenate(tmat)
+    # fix winding of every non-terrain triangle to face away from its sphere centre / terrain up
+    p0, p1, p2 = V[T[:, 0]].astype(np.float64), V[T[:, 1]].astype(np.float64), V[T[:, 2]].astype(np.float64)
+    n = np.cross(p0 - p2, p1 - p2)
+    want = np.zeros_like(n)
+    want[: 2 * grid * grid] = (0, 1, 0)
+    off = 2 * grid * grid
+    k = 0
+    for s in range(n_spheres):
+        cnt = sf.shape[0]
+        cen = verts[1 + s].mean(axis=0)
+        want[off:off + cnt] = (p0[off:off + cnt] + p1[off:off + cnt] + p2[off:off + cnt]) / 3 - cen
+        off += cnt
+    swap = np.einsum("ij,ij->i", n, want) < 0
+    T[swap, 1], T[swap, 2] = T[swap, 2].copy(), T[swap, 1].copy()
+    b = MeshBuilder()
+    b.materials = mats
+    # enclosing box (inward facing) + light, appended after the bulk mesh
+    box = [(-1, 0, -1), (size + 1, 0, -1), (size + 1, 0, size + 1), (-1, 0, size + 1)]
+    top = [(x, 620.0, z) for x, _, z in box]
+    quads = [box, top, [box[0], box[1], top[1], top[0]], [box[1], box[2], top[2], top[1]], [box[2], box[3], top[3], top[2]],
+             [box[3], box[0], top[0], top[3]]]
+    centre = (size / 2, 300.0, size / 2)
+    for q in quads:
+        b.add_quad(q, 7, toward=centre)
+    b.add_quad([(350, 600, 350), (350, 600, 650), (650, 600, 650), (650, 600, 350)], 7, toward=centre, emit=(40.0, 38.0, 34.0))
+    ev = np.asarray(b.v, dtype=np.float32)
+    et = np.asarray(b.t, dtype=np.int64) + V.shape[0]
+    V = np.concatenate([V, ev])
+    T = np.concatenate([T, et]).astype(np.uint32)
+    M = np.concatenate([M, np.asarray(b.mat, dtype=np.uint32)])
+    Lt = np.concatenate([np.full(T.shape[0] - len(b.t), -1, dtype=np.int32), np.asarray(b.light, dtype=np.int32)])
+    lights = b.lights
+    for l in lights:
+        l.triangle += T.shape[0] - len(b.t)
+    return abi.SceneArrays(V, T, M, Lt, mats, lights)
+
+
+def big_mesh_camera(xres, yres):
+    return camera_desc((500, 330, 20), (500, 140, 560), (0, 1, 0), 50.0, xres, yres)
