@@ -1,0 +1,190 @@
+"""raytrace_amd -- MI355X-native PathIntegrator back end for the Enigma renderer.
+
+Python here is harness only: it loads the C-ABI shared library (raytrace_amd/libenigma_hip.so,
+built from raytrace_amd/csrc by `make -C raytrace_amd/csrc` or __graft_entry__.build()) through
+ctypes and wraps the handle.  There is no Python or CPU rendering path: if the library is missing
+or no GPU is present, the calls fail.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libenigma_hip.so")
+
+# every symbol include/enigma_hip.h declares
+SYMBOLS = [
+    "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
+    "enigma_film_config", "enigma_integrator_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
+    "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
+    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C raytrace_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.enigma_last_error.restype = C.c_char_p
+        L.enigma_last_error.argtypes = [C.c_void_p]
+        L.enigma_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.enigma_ctx_destroy.argtypes = [C.c_void_p]
+        L.enigma_ctx_destroy.restype = None
+        L.enigma_render.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.enigma_film_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.enigma_film_resolve.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
+        L.enigma_film_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        for name in ("enigma_scene_upload", "enigma_camera_set", "enigma_film_config", "enigma_integrator_config", "enigma_get_stats"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.enigma_film_clear.argtypes = [C.c_void_p]
+        L.enigma_debug_sobol.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.enigma_debug_camera_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.enigma_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.enigma_debug_intersect_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.enigma_debug_film_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class EnigmaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("enigma error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Renderer:
+    """Thin handle wrapper: scene/camera/film/integrator descs in, film out."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.enigma_ctx_create(device, C.byref(self.h))
+        if rc != 0:
+            raise EnigmaError(rc, "enigma_ctx_create failed (no HIP device %d?)" % device)
+        self._keep = []
+        self.w = self.hgt = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EnigmaError(rc, self.L.enigma_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.enigma_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, scene, camera, film, integ):
+        self.upload_scene(scene)
+        self.set_camera(camera)
+        self.set_film(film)
+        self.set_integrator(integ)
+        return self
+
+    def upload_scene(self, scene):
+        d = scene.desc()
+        self._keep.append(scene)
+        self._chk(self.L.enigma_scene_upload(self.h, C.byref(d)))
+
+    def set_camera(self, camera):
+        self._chk(self.L.enigma_camera_set(self.h, C.byref(camera)))
+
+    def set_film(self, film):
+        self._chk(self.L.enigma_film_config(self.h, C.byref(film)))
+        b = film.cropped_pixel_bounds
+        self.w, self.hgt = b[2] - b[0], b[3] - b[1]
+
+    def set_integrator(self, integ):
+        self._chk(self.L.enigma_integrator_config(self.h, C.byref(integ)))
+
+    def render(self, s0, s1):
+        self._chk(self.L.enigma_render(self.h, s0, s1))
+
+    def clear(self):
+        self._chk(self.L.enigma_film_clear(self.h))
+
+    def film(self):
+        out = np.zeros((self.hgt, self.w, 4), dtype=np.float32)
+        self._chk(self.L.enigma_film_read(self.h, abi.ptr(out), out.size))
+        return out
+
+    def film_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.enigma_film_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def image(self, scale=1.0, film=None):
+        return resolve(self.film() if film is None else film, scale)
+
+    def stats(self):
+        s = abi.EnigmaStats()
+        self._chk(self.L.enigma_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in abi.EnigmaStats._fields_}
+
+    # ---- debug taps ----
+    def sobol(self, pixels, sample_nums, n_dims):
+        pixels = np.ascontiguousarray(pixels, dtype=np.int32).reshape(-1, 2)
+        sn = np.ascontiguousarray(sample_nums, dtype=np.int64)
+        n = pixels.shape[0]
+        idx = np.zeros(n, dtype=np.uint64)
+        dims = np.zeros((n, n_dims), dtype=np.float32)
+        self._chk(self.L.enigma_debug_sobol(self.h, n, abi.ptr(pixels), abi.ptr(sn), n_dims, abi.ptr(idx), abi.ptr(dims)))
+        return idx, dims
+
+    def camera_rays(self, pixels, sample_nums):
+        pixels = np.ascontiguousarray(pixels, dtype=np.int32).reshape(-1, 2)
+        sn = np.ascontiguousarray(sample_nums, dtype=np.int64)
+        n = pixels.shape[0]
+        rays = np.zeros((n, 6), dtype=np.float32)
+        pf = np.zeros((n, 2), dtype=np.float32)
+        self._chk(self.L.enigma_debug_camera_rays(self.h, n, abi.ptr(pixels), abi.ptr(sn), abi.ptr(rays), abi.ptr(pf)))
+        return rays, pf
+
+    def intersect(self, rays7):
+        rays7 = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)
+        n = rays7.shape[0]
+        tri = np.zeros(n, dtype=np.int32)
+        pid = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+        bary = np.zeros((n, 3), dtype=np.float32)
+        self._chk(self.L.enigma_debug_intersect(self.h, n, abi.ptr(rays7), abi.ptr(tri), abi.ptr(pid), abi.ptr(t), abi.ptr(bary)))
+        return dict(tri=tri, prim_id=pid, t=t, bary=bary)
+
+    def intersect_any(self, rays7):
+        rays7 = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)
+        out = np.zeros(rays7.shape[0], dtype=np.int32)
+        self._chk(self.L.enigma_debug_intersect_any(self.h, rays7.shape[0], abi.ptr(rays7), abi.ptr(out)))
+        return out
+
+    def film_footprint(self, pfilm, max_per=64):
+        pfilm = np.ascontiguousarray(pfilm, dtype=np.float32).reshape(-1, 2)
+        n = pfilm.shape[0]
+        pix = np.zeros((n, max_per, 2), dtype=np.int32)
+        w = np.zeros((n, max_per), dtype=np.float32)
+        cnt = np.zeros(n, dtype=np.uint32)
+        self._chk(self.L.enigma_debug_film_footprint(self.h, n, abi.ptr(pfilm), max_per, abi.ptr(pix), abi.ptr(w), abi.ptr(cnt)))
+        return pix, w, cnt
+
+
+def resolve(film_rgbw, scale=1.0):
+    """Film::WriteImage normalisation of an rgbw film (host code inside the library)."""
+    L = load_library()
+    f = np.ascontiguousarray(film_rgbw, dtype=np.float32)
+    out = np.zeros(f.shape[:-1] + (3,), dtype=np.float32)
+    rc = L.enigma_film_resolve(abi.ptr(f), f.size // 4, scale, abi.ptr(out))
+    if rc != 0:
+        raise EnigmaError(rc, "enigma_film_resolve")
+    return out

@@ -1,0 +1,377 @@
+// BSDF evaluation / sampling on the device.
+//
+// Replaces the arena-allocated BxDF object graph (Enigma/BxDF.cpp:843-985 BSDF;
+// :729-732 Lambertian; :1075-1121 MicrofacetReflection; :1007-1073 MicrofacetTransmission;
+// :1124-1158 FresnelSpecular; :453-503 Fresnel terms; Enigma/MicrofacetDist.cpp:165-328
+// Trowbridge-Reitz) with a POD of at most two lobes held in registers.  Formulas keep the
+// reference's operation order and its deviations from pbrt:
+//  * the local frame's z axis is the GEOMETRIC normal (BxDF.cpp:872-882);
+//  * FresnelSpecular scales its reflection by T, not R (BxDF.cpp:1135);
+//  * MicrofacetTransmission::pdf uses etaA/etaB where f uses etaB/etaA (BxDF.cpp:1027,1063).
+#pragma once
+#include "dev_types.h"
+
+namespace edev {
+
+enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
+enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR };
+
+DEV int lobeType(int k) {
+    switch (k) {
+    case LOBE_LAMBERT: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case LOBE_MICRO_REFL_CONDUCTOR:
+    case LOBE_MICRO_REFL_DIELECTRIC: return BSDF_REFLECTION | BSDF_GLOSSY;
+    case LOBE_MICRO_TRANS: return BSDF_TRANSMISSION | BSDF_GLOSSY;
+    default: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+    }
+}
+
+// ---- BxDF.h:28-106 helpers ----
+DEV float cosTheta(F3 w) { return w.z; }
+DEV float absCosTheta(F3 w) { return fabsf(w.z); }
+DEV float cos2Theta(F3 w) { return w.z * w.z; }
+DEV float sin2Theta(F3 w) { return smax(0.f, 1.f - cos2Theta(w)); }
+DEV float sinTheta(F3 w) { return sqrtf(sin2Theta(w)); }
+DEV float tanTheta(F3 w) { return sinTheta(w) / cosTheta(w); }
+DEV float tan2Theta(F3 w) { return sin2Theta(w) / cos2Theta(w); }
+DEV float cosPhi(F3 w) { float s = sinTheta(w); return (s == 0.f) ? 1.f : clampf(w.x / s, -1.f, 1.f); }
+DEV float sinPhi(F3 w) { float s = sinTheta(w); return (s == 0.f) ? 0.f : clampf(w.y / s, -1.f, 1.f); }
+DEV float cos2Phi(F3 w) { float c = cosPhi(w); return c * c; }
+DEV float sin2Phi(F3 w) { float s = sinPhi(w); return s * s; }
+DEV bool sameHemisphere(F3 w, F3 wp) { return w.z * wp.z > 0.f; }
+DEV F3 reflect(F3 wo, F3 n) { return -wo + 2 * dot(wo, n) * n; }
+DEV bool refract(F3 wi, F3 n, float eta, F3* wt) {
+    float cosThetaI = dot(n, wi);
+    float sin2ThetaI = smax(0.f, 1 - cosThetaI * cosThetaI);
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = sqrtf(1 - sin2ThetaT);
+    *wt = eta * -wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+
+// BxDF.cpp:453-475
+DEV float frDielectric(float cosThetaI, float etaI, float etaT) {
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    bool entering = cosThetaI > 0.f;
+    if (!entering) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
+    float sinThetaI = sqrtf(smax(0.f, 1 - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1) return 1.0f;
+    float cosThetaT = sqrtf(smax(0.f, 1 - sinThetaT * sinThetaT));
+    float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+// BxDF.cpp:478-503 with etai = 1 (Material.cpp:131)
+DEV F3 frConductor(float cosThetaI, F3 etat, F3 k) {
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    F3 eta = etat / F3(1.f), etak = k / F3(1.f);
+    float cosThetaI2 = cosThetaI * cosThetaI;
+    float sinThetaI2 = 1.f - cosThetaI2; // 1. - x in double then float == the float difference (exact in double)
+    F3 eta2 = eta * eta, etak2 = etak * etak;
+    F3 t0 = eta2 - etak2 - F3(sinThetaI2);
+    F3 a2plusb2 = sqrt3(t0 * t0 + (eta2 * 4.f) * etak2);
+    F3 t1 = a2plusb2 + F3(cosThetaI2);
+    F3 a = sqrt3((a2plusb2 + t0) * 0.5f);
+    F3 t2 = a * (2.f * cosThetaI);
+    F3 Rs = (t1 - t2) / (t1 + t2);
+    F3 t3 = a2plusb2 * cosThetaI2 + F3(sinThetaI2 * sinThetaI2);
+    F3 t4 = t2 * sinThetaI2;
+    F3 Rp = Rs * (t3 - t4) / (t3 + t4);
+    return (Rp + Rs) * 0.5f;
+}
+
+// ---- Trowbridge-Reitz, MicrofacetDist.cpp:165-328 (sample visible area) ----
+DEV float trD(float ax, float ay, F3 wh) {
+    float t2 = tan2Theta(wh);
+    if (isinf(t2)) return 0.f;
+    float cos4Theta = cos2Theta(wh) * cos2Theta(wh);
+    float e = (cos2Phi(wh) / (ax * ax) + sin2Phi(wh) / (ay * ay)) * t2;
+    return 1 / (kPi * ax * ay * cos4Theta * (1 + e) * (1 + e));
+}
+DEV float trLambda(float ax, float ay, F3 w) {
+    float absTanTheta = fabsf(tanTheta(w));
+    if (isinf(absTanTheta)) return 0.f;
+    float alpha = sqrtf(cos2Phi(w) * ax * ax + sin2Phi(w) * ay * ay);
+    float a2t2 = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1.f + a2t2)) / 2;
+}
+DEV float trG1(float ax, float ay, F3 w) { return 1 / (1 + trLambda(ax, ay, w)); }
+DEV float trG(float ax, float ay, F3 wo, F3 wi) { return 1 / (1 + trLambda(ax, ay, wo) + trLambda(ax, ay, wi)); }
+DEV float trPdf(float ax, float ay, F3 wo, F3 wh) { return trD(ax, ay, wh) * trG1(ax, ay, wo) * absdot(wo, wh) / absCosTheta(wo); }
+DEV void trSample11(float cosT, float U1, float U2, float* slope_x, float* slope_y) {
+    if (cosT > .9999f) { // the reference compares in double against .9999; same decision for every float
+        float r = sqrtf(U1 / (1 - U1));
+        float phi = (float)(6.28318530718 * (double)U2);
+        *slope_x = r * cosf(phi);
+        *slope_y = r * sinf(phi);
+        return;
+    }
+    float sinT = sqrtf(smax(0.f, 1.f - cosT * cosT));
+    float tanT = sinT / cosT;
+    float a = 1 / tanT;
+    float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if (tmp > 1e10f) tmp = 1e10f;
+    float B = tanT;
+    float D = sqrtf(smax(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    *slope_x = (A < 0 || slope_x_2 > 1.f / tanT) ? slope_x_1 : slope_x_2;
+    float S;
+    if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+    else { S = -1.f; U2 = 2.f * (.5f - U2); }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    *slope_y = S * z * sqrtf(1.f + *slope_x * *slope_x);
+}
+DEV F3 trSampleWh(float ax, float ay, F3 wo, float u0, float u1) {
+    bool flip = wo.z < 0;
+    F3 wi = flip ? -wo : wo;
+    F3 wiS = normalize(F3(ax * wi.x, ay * wi.y, wi.z));
+    float sx, sy;
+    trSample11(cosTheta(wiS), u0, u1, &sx, &sy);
+    float tmp = cosPhi(wiS) * sx - sinPhi(wiS) * sy;
+    sy = sinPhi(wiS) * sx + cosPhi(wiS) * sy;
+    sx = tmp;
+    sx = ax * sx;
+    sy = ay * sy;
+    F3 wh = normalize(F3(-sx, -sy, 1.f));
+    return flip ? -wh : wh;
+}
+
+// ---- MonteCarlo.cpp:50-68,156-161 ----
+DEV void concentricSampleDisk(float ux, float uy, float* dx, float* dy) {
+    float ox = 2.f * ux - 1, oy = 2.f * uy - 1;
+    if (ox == 0 && oy == 0) { *dx = 0; *dy = 0; return; }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
+    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
+    *dx = r * cosf(theta); *dy = r * sinf(theta);
+}
+DEV F3 cosineSampleHemisphere(float ux, float uy) {
+    float dx, dy;
+    concentricSampleDisk(ux, uy, &dx, &dy);
+    float z = sqrtf(smax(0.f, 1 - dx * dx - dy * dy));
+    return F3(dx, dy, z);
+}
+
+// ---- the per-hit BSDF ----
+struct Bsdf {
+    int n;                 // number of lobes (0..2)
+    int kind[2];
+    F3 col[2];             // R / T / Kd / Ks (glass smooth: col[0] = R, col[1] = T)
+    F3 cEta, cK;           // conductor eta, k
+    float ax, ay;          // shared microfacet distribution of the material
+    float eta;             // BSDF::m_eta (glass index, else 1)
+    float dEtaI, dEtaT;    // dielectric Fresnel / transmission interface
+    F3 ng, ss, ts;         // frame: ss, ts, geometric normal (ns == ng without shading normals)
+};
+
+DEV F3 toLocal(const Bsdf& b, F3 v) { return F3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ng)); }
+DEV F3 toWorld(const Bsdf& b, F3 v) {
+    return F3(b.ss.x * v.x + b.ts.x * v.y + b.ng.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ng.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ng.z * v.z);
+}
+
+// Material::computeScatteringFunctions for the four materials (Enigma/Material.cpp:76-93,115-136,176-220,232-255).
+template <int MK>
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 dpdu, Bsdf* b) {
+    b->ng = ng;
+    b->ss = normalize(dpdu);
+    b->ts = cross(ng, b->ss);
+    b->n = 0;
+    b->eta = 1.f;
+    b->ax = m.alphax; b->ay = m.alphay;
+    F3 c0(m.c0[0], m.c0[1], m.c0[2]), c1(m.c1[0], m.c1[1], m.c1[2]);
+    bool has0 = m.flags & 1u, has1 = m.flags & 2u;
+    if (MK == MK_MATTE) {
+        if (has0) { b->kind[0] = LOBE_LAMBERT; b->col[0] = c0; b->n = 1; }
+    } else if (MK == MK_METAL) {
+        b->kind[0] = LOBE_MICRO_REFL_CONDUCTOR; b->col[0] = F3(1.f); b->cEta = c0; b->cK = c1; b->n = 1;
+    } else if (MK == MK_GLASS_SMOOTH) {
+        b->eta = m.eta;
+        if (has0 || has1) { b->kind[0] = LOBE_FRESNEL_SPECULAR; b->col[0] = c0; b->col[1] = c1; b->dEtaI = 1.f; b->dEtaT = m.eta; b->n = 1; }
+    } else if (MK == MK_GLASS_ROUGH) {
+        b->eta = m.eta;
+        b->dEtaI = 1.f; b->dEtaT = m.eta;
+        if (has0) { b->kind[b->n] = LOBE_MICRO_REFL_DIELECTRIC; b->col[b->n] = c0; b->n++; }
+        if (has1) { b->kind[b->n] = LOBE_MICRO_TRANS; b->col[b->n] = c1; b->n++; }
+    } else { // plastic: FresnelDielectric(1.5f, 1.f), Material.cpp:244
+        b->dEtaI = 1.5f; b->dEtaT = 1.f;
+        if (has0) { b->kind[b->n] = LOBE_LAMBERT; b->col[b->n] = c0; b->n++; }
+        if (has1) { b->kind[b->n] = LOBE_MICRO_REFL_DIELECTRIC; b->col[b->n] = c1; b->n++; }
+    }
+}
+
+DEV bool lobeMatches(int kind, int flags) { int t = lobeType(kind); return (t & flags) == t; }
+DEV int numComponents(const Bsdf& b, int flags) {
+    int c = 0;
+    for (int i = 0; i < 2; ++i) if (i < b.n && lobeMatches(b.kind[i], flags)) ++c;
+    return c;
+}
+
+DEV F3 microReflF(const Bsdf& b, int i, F3 wo, F3 wi) { // BxDF.cpp:1084-1100
+    float cosThetaO = absCosTheta(wo), cosThetaI = absCosTheta(wi);
+    F3 wh = wi + wo;
+    if (cosThetaI == 0 || cosThetaO == 0) return F3(0.f);
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3(0.f);
+    wh = normalize(wh);
+    float c = dot(wi, faceForward(wh, F3(0, 0, 1)));
+    F3 F = (b.kind[i] == LOBE_MICRO_REFL_CONDUCTOR) ? frConductor(fabsf(c), b.cEta, b.cK) : F3(frDielectric(c, b.dEtaI, b.dEtaT));
+    return b.col[i] * trD(b.ax, b.ay, wh) * trG(b.ax, b.ay, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+}
+DEV float microReflPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1116-1121
+    if (!sameHemisphere(wo, wi)) return 0;
+    F3 wh = normalize(wo + wi);
+    return trPdf(b.ax, b.ay, wo, wh) / (4 * dot(wo, wh));
+}
+DEV F3 microTransF(const Bsdf& b, int i, F3 wo, F3 wi) { // BxDF.cpp:1018-1043 (radiance transport)
+    if (sameHemisphere(wo, wi)) return F3(0.f);
+    float cosThetaO = cosTheta(wo), cosThetaI = cosTheta(wi);
+    if (cosThetaI == 0 || cosThetaO == 0) return F3(0.f);
+    float eta = cosTheta(wo) > 0 ? (b.dEtaT / b.dEtaI) : (b.dEtaI / b.dEtaT);
+    F3 wh = normalize(wo + wi * eta);
+    if (wh.z < 0) wh = -wh;
+    if (dot(wo, wh) * dot(wi, wh) > 0) return F3(0.f);
+    float F = frDielectric(dot(wo, wh), b.dEtaI, b.dEtaT);
+    float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    float factor = 1 / eta;
+    float s = fabsf(trD(b.ax, b.ay, wh) * trG(b.ax, b.ay, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                    (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    return (F3(1.f) - F3(F)) * b.col[i] * s;
+}
+DEV float microTransPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1059-1073
+    if (sameHemisphere(wo, wi)) return 0;
+    float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
+    F3 wh = normalize(wo + wi * eta);
+    if (dot(wo, wh) * dot(wi, wh) > 0) return 0;
+    float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+    float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+    return trPdf(b.ax, b.ay, wo, wh) * dwh_dwi;
+}
+
+DEV F3 lobeF(const Bsdf& b, int i, F3 wo, F3 wi) {
+    switch (b.kind[i]) {
+    case LOBE_LAMBERT: return b.col[i] * kInvPi;
+    case LOBE_MICRO_REFL_CONDUCTOR:
+    case LOBE_MICRO_REFL_DIELECTRIC: return microReflF(b, i, wo, wi);
+    case LOBE_MICRO_TRANS: return microTransF(b, i, wo, wi);
+    default: return F3(0.f);
+    }
+}
+DEV float lobePdf(const Bsdf& b, int i, F3 wo, F3 wi) {
+    switch (b.kind[i]) {
+    case LOBE_LAMBERT: return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF.cpp:568-571
+    case LOBE_MICRO_REFL_CONDUCTOR:
+    case LOBE_MICRO_REFL_DIELECTRIC: return microReflPdf(b, wo, wi);
+    case LOBE_MICRO_TRANS: return microTransPdf(b, wo, wi);
+    default: return 0.f;
+    }
+}
+// BxDF::sample_f of one lobe.  Returns f; *pdf stays 0 when the lobe fails to sample.
+DEV F3 lobeSample(const Bsdf& b, int i, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
+    switch (b.kind[i]) {
+    case LOBE_LAMBERT: { // BxDF.cpp:529-536
+        *wi = cosineSampleHemisphere(u0, u1);
+        if (wo.z < 0.f) wi->z *= -1.f;
+        *pdf = lobePdf(b, i, wo, *wi);
+        return lobeF(b, i, wo, *wi);
+    }
+    case LOBE_MICRO_REFL_CONDUCTOR:
+    case LOBE_MICRO_REFL_DIELECTRIC: { // BxDF.cpp:1102-1114
+        if (wo.z == 0) return F3(0.f);
+        F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
+        if (dot(wo, wh) < 0) return F3(0.f);
+        *wi = reflect(wo, wh);
+        if (!sameHemisphere(wo, *wi)) return F3(0.f);
+        *pdf = trPdf(b.ax, b.ay, wo, wh) / (4 * dot(wo, wh));
+        return microReflF(b, i, wo, *wi);
+    }
+    case LOBE_MICRO_TRANS: { // BxDF.cpp:1045-1056
+        if (wo.z == 0) return F3(0.f);
+        F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
+        if (dot(wo, wh) < 0) return F3(0.f);
+        float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
+        if (!refract(wo, wh, eta, wi)) return F3(0.f);
+        *pdf = microTransPdf(b, wo, *wi);
+        return microTransF(b, i, wo, *wi);
+    }
+    default: { // FresnelSpecular, BxDF.cpp:1124-1158; col[0] = R (unused by the reference), col[1] = T
+        float F = frDielectric(cosTheta(wo), b.dEtaI, b.dEtaT);
+        if (u0 < F) {
+            *wi = F3(-wo.x, -wo.y, wo.z);
+            *sampledType = BSDF_SPECULAR | BSDF_REFLECTION;
+            *pdf = F;
+            return (b.col[1] * F) / absCosTheta(*wi);
+        } else {
+            bool entering = cosTheta(wo) > 0;
+            float etaI = entering ? b.dEtaI : b.dEtaT;
+            float etaT = entering ? b.dEtaT : b.dEtaI;
+            if (!refract(wo, faceForward(F3(0, 0, 1), wo), etaI / etaT, wi)) return F3(0.f);
+            F3 ft = b.col[1] * (1 - F);
+            ft *= (etaI * etaI) / (etaT * etaT);
+            *sampledType = BSDF_SPECULAR | BSDF_TRANSMISSION;
+            *pdf = 1 - F;
+            return ft / absCosTheta(*wi);
+        }
+    }
+    }
+}
+
+// BSDF::f, BxDF.cpp:972-985
+DEV F3 bsdfF(const Bsdf& b, F3 woW, F3 wiW, int flags) {
+    F3 wi = toLocal(b, wiW), wo = toLocal(b, woW);
+    if (wo.z == 0) return F3(0.f);
+    bool refl = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    F3 f(0.f);
+    for (int i = 0; i < 2; ++i)
+        if (i < b.n && lobeMatches(b.kind[i], flags)) {
+            int t = lobeType(b.kind[i]);
+            if ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION))) f += lobeF(b, i, wo, wi);
+        }
+    return f;
+}
+// BSDF::Pdf, BxDF.cpp:954-970
+DEV float bsdfPdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {
+    if (b.n == 0) return 0.f;
+    F3 wo = toLocal(b, woW), wi = toLocal(b, wiW);
+    float pdf = 0.f; int matching = 0;
+    for (int i = 0; i < 2; ++i)
+        if (i < b.n && lobeMatches(b.kind[i], flags)) { ++matching; pdf += lobePdf(b, i, wo, wi); }
+    return matching > 0 ? pdf / matching : 0.f;
+}
+// BSDF::sample_f, BxDF.cpp:885-952.  *pdf == 0 or a black return mean "no sample".
+DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf, int flags, int* sampledType) {
+    *pdf = 0; *sampledType = 0;
+    int matching = numComponents(b, flags);
+    if (matching == 0) return F3(0.f);
+    int comp = min((int)floorf(u0 * matching), matching - 1);
+    int sel = -1, count = comp;
+    for (int i = 0; i < 2; ++i)
+        if (sel < 0 && i < b.n && lobeMatches(b.kind[i], flags) && count-- == 0) sel = i;
+    float ur0 = smin(u0 * matching - comp, kOneMinusEpsilon);
+    F3 wo = toLocal(b, woW), wi(0.f);
+    if (wo.z == 0) return F3(0.f);
+    *sampledType = lobeType(b.kind[sel]);
+    F3 f = lobeSample(b, sel, wo, ur0, u1, &wi, pdf, sampledType);
+    if (*pdf == 0) { *sampledType = 0; return F3(0.f); }
+    *wiW = toWorld(b, wi);
+    bool specular = (lobeType(b.kind[sel]) & BSDF_SPECULAR) != 0;
+    if (!specular && matching > 1)
+        for (int i = 0; i < 2; ++i)
+            if (i != sel && i < b.n && lobeMatches(b.kind[i], flags)) *pdf += lobePdf(b, i, wo, wi);
+    if (matching > 1) *pdf /= matching;
+    if (!specular) {
+        bool refl = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+        f = F3(0.f);
+        for (int i = 0; i < 2; ++i)
+            if (i < b.n && lobeMatches(b.kind[i], flags)) {
+                int t = lobeType(b.kind[i]);
+                if ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION))) f += lobeF(b, i, wo, wi);
+            }
+    }
+    return f;
+}
+
+} // namespace edev

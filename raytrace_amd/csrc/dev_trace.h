@@ -1,0 +1,193 @@
+// Ray / box / triangle tests and per-lane stack traversal of the device BVH.
+//
+// Replaces BVHAccel::intersect / intersectP (Enigma/BVH.cpp:639-722), the slab test
+// BBox3::intersectP (Enigma/BBox.h:267-295) and the watertight Triangle::intersects
+// (Enigma/TriangleMesh.cpp:491-602).  The arithmetic of the two tests is the reference's,
+// operation for operation, so hit/miss decisions, t and barycentrics are bit-identical;
+// only the tree being walked differs.
+#pragma once
+#include "dev_types.h"
+
+namespace edev {
+
+struct RaySetup {
+    F3 o, d, invDir;
+    bool negX, negY, negZ;   // dirIsNeg
+    bool kz0, kz1;           // largest |d| component is x (kz0) / y (kz1) / z (neither)
+    float Sx, Sy, Sz;        // shear constants (depend on the ray only)
+};
+
+DEV F3 permuteK(F3 v, bool kz0, bool kz1) {
+    // (kx,ky,kz) = (1,2,0) | (2,0,1) | (0,1,2)
+    return F3(kz0 ? v.y : (kz1 ? v.z : v.x), kz0 ? v.z : (kz1 ? v.x : v.y), kz0 ? v.x : (kz1 ? v.y : v.z));
+}
+
+DEV RaySetup setupRay(F3 o, F3 d) {
+    RaySetup r;
+    r.o = o; r.d = d;
+    r.invDir = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);      // Inverted(), MathCommon.h:225-230
+    r.negX = r.invDir.x < 0; r.negY = r.invDir.y < 0; r.negZ = r.invDir.z < 0;
+    // MaxDimension(Abs(d)), MathCommon.h:342-353
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int kz;
+    if (ax > ay) kz = (ax > az) ? 0 : 2;
+    else kz = (ay > az) ? 1 : 2;
+    r.kz0 = kz == 0; r.kz1 = kz == 1;
+    F3 dp = permuteK(d, r.kz0, r.kz1);
+    r.Sx = -dp.x / dp.z; r.Sy = -dp.y / dp.z; r.Sz = 1.f / dp.z;
+    return r;
+}
+
+// BBox3::intersectP(ray, invDir, dirIsNeg), Enigma/BBox.h:267-295.  tEntry = the final tMin.
+DEV bool slabTest(const RaySetup& r, float tMaxRay, F3 lo, F3 hi, float* tEntry) {
+    constexpr float kRobust = 1 + 2 * gammaf(3);
+    float tMin = ((r.negX ? hi.x : lo.x) - r.o.x) * r.invDir.x;
+    float tMax = ((r.negX ? lo.x : hi.x) - r.o.x) * r.invDir.x;
+    float tyMin = ((r.negY ? hi.y : lo.y) - r.o.y) * r.invDir.y;
+    float tyMax = ((r.negY ? lo.y : hi.y) - r.o.y) * r.invDir.y;
+    tMax *= kRobust;
+    tyMax *= kRobust;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((r.negZ ? hi.z : lo.z) - r.o.z) * r.invDir.z;
+    float tzMax = ((r.negZ ? lo.z : hi.z) - r.o.z) * r.invDir.z;
+    tzMax *= kRobust;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    *tEntry = tMin;
+    return (tMin < tMaxRay) && (tMax > 0);
+}
+
+// Triangle::intersects, Enigma/TriangleMesh.cpp:491-602.
+DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o) {
+    F3 p0t = permuteK(p0 - r.o, r.kz0, r.kz1);
+    F3 p1t = permuteK(p1 - r.o, r.kz0, r.kz1);
+    F3 p2t = permuteK(p2 - r.o, r.kz0, r.kz1);
+    p0t.x += r.Sx * p0t.z; p0t.y += r.Sy * p0t.z;
+    p1t.x += r.Sx * p1t.z; p1t.y += r.Sy * p1t.z;
+    p2t.x += r.Sx * p2t.z; p2t.y += r.Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= r.Sz; p1t.z *= r.Sz; p2t.z *= r.Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMaxRay * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMaxRay * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = maxComponent(fabs3(F3(p0t.z, p1t.z, p2t.z)));
+    float deltaZ = gammaf(3) * maxZt;
+    float maxXt = maxComponent(fabs3(F3(p0t.x, p1t.x, p2t.x)));
+    float maxYt = maxComponent(fabs3(F3(p0t.y, p1t.y, p2t.y)));
+    float deltaX = gammaf(5) * (maxXt + maxZt);
+    float deltaY = gammaf(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gammaf(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = maxComponent(fabs3(F3(e0, e1, e2)));
+    float deltaT = 3 * (gammaf(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+    if (t <= deltaT) return false;
+    *tOut = t; *b0o = b0; *b1o = b1; *b2o = b2;
+    return true;
+}
+
+struct Hit { int tri; float t, b0, b1, b2; };
+
+DEV void nodeBoxes(const float4* n, F3* lo0, F3* hi0, F3* lo1, F3* hi1, int* c0, int* c1) {
+    float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+    *lo0 = F3(q0.x, q0.y, q0.z); *hi0 = F3(q0.w, q1.x, q1.y);
+    *lo1 = F3(q1.z, q1.w, q2.x); *hi1 = F3(q2.y, q2.z, q2.w);
+    *c0 = __float_as_int(q3.x); *c1 = __float_as_int(q3.y);
+}
+
+// Per-lane traversal stack in LDS: entry (level, lane) lives at stack[level * STRIDE + lane], so a
+// lane always uses LDS bank (lane % 32) whatever its depth -- conflict free for the two 32-lane
+// groups of ds_read_b32 / ds_write_b32.
+template <int STACK, int STRIDE>
+DEV Hit traceClosest(const DevScene& sc, F3 o, F3 d, float tMax, uint32_t* stack) {
+    RaySetup r = setupRay(o, d);
+    Hit h; h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
+    int cur = 0, sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
+            nodeBoxes(sc.nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
+            bool h0 = slabTest(r, h.t, lo0, hi0, &t0);
+            bool h1 = slabTest(r, h.t, lo1, hi1, &t1);
+            if (h0 && h1) {
+                bool swp = t1 < t0;
+                int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
+                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)farC; ++sp; }
+                cur = nearC;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; --sp; cur = (int)stack[sp * STRIDE]; }
+        } else {
+            uint32_t leaf = ~(uint32_t)cur;
+            uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4* tp = sc.tris + (size_t)(first + i) * 3;
+                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                float t, b0, b1, b2;
+                if (triangleTest(r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) {
+                    // degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
+                    F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
+                    F3 dpdu = (p1 - p2) - (p0 - p2);           // see shading: -dp02 + dp12
+                    F3 dpdv = -(p1 - p2);
+                    bool ok = true;
+                    if (lengthSqr(cross(dpdu, dpdv)) == 0) ok = lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
+                    if (ok) { h.t = t; h.tri = (int)(first + i); h.b0 = b0; h.b1 = b1; h.b2 = b2; }
+                }
+            }
+            if (sp == 0) break;
+            --sp; cur = (int)stack[sp * STRIDE];
+        }
+    }
+    return h;
+}
+
+template <int STACK, int STRIDE>
+DEV bool traceAny(const DevScene& sc, F3 o, F3 d, float tMax, uint32_t* stack) {
+    RaySetup r = setupRay(o, d);
+    int cur = 0, sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
+            nodeBoxes(sc.nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
+            bool h0 = slabTest(r, tMax, lo0, hi0, &t0);
+            bool h1 = slabTest(r, tMax, lo1, hi1, &t1);
+            if (h0 && h1) {
+                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)c1; ++sp; }
+                cur = c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { if (sp == 0) break; --sp; cur = (int)stack[sp * STRIDE]; }
+        } else {
+            uint32_t leaf = ~(uint32_t)cur;
+            uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4* tp = sc.tris + (size_t)(first + i) * 3;
+                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                float t, b0, b1, b2;
+                if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) return true; // Triangle::intersectP
+            }
+            if (sp == 0) break;
+            --sp; cur = (int)stack[sp * STRIDE];
+        }
+    }
+    return false;
+}
+
+} // namespace edev

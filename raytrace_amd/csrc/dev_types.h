@@ -1,0 +1,111 @@
+// Device data layout of the wavefront path tracer (all arrays live in HBM for a whole render).
+#pragma once
+#include "dev_common.h"
+
+namespace edev {
+
+// Material kinds the shade kernels are sorted by.  ENIGMA_MAT_GLASS splits by roughness at
+// upload: a smooth glass is one FresnelSpecular lobe (allowMultipleLobes is always true on the
+// PathIntegrator path, Enigma/PathIntegrator.cpp:89, Enigma/Material.cpp:190-194).
+enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4, MK_COUNT = 5 };
+
+struct DevMaterial {        // 64 bytes
+    uint32_t kind;          // MatKind
+    uint32_t flags;         // bit0: first colour non-black, bit1: second colour non-black
+    float alphax, alphay;   // TrowbridgeReitz alphas after remap + clamp (Enigma/MicrofacetDist.cpp:256-263,323-328)
+    float c0[3]; float eta; // matte/plastic: Kd.  metal: eta rgb.  glass: Kr; eta = index
+    float c1[3]; float pad; // plastic: Ks.  metal: k rgb.  glass: Kt
+    float pad2[4];
+};
+
+struct DevLight {           // 48 bytes
+    uint32_t type;          // 0 point, 1 diffuse area
+    uint32_t tri;           // area: triangle position in the device (BVH) order
+    uint32_t twoSided;
+    float area;             // Triangle::area() (Enigma/TriangleMesh.cpp:438-446)
+    float L[3]; float pad0;
+    float pos[3]; float pad1;
+};
+
+// One triangle, 48 bytes, three float4 loads:
+//   v0 = {p0.xyz, bits(original triangle index)}
+//   v1 = {p1.xyz, bits(material index | flip << 31)}
+//   v2 = {p2.xyz, bits(light index or -1)}
+struct DevScene {
+    const float4* nodes;        // BVH nodes, 4 float4 each
+    const float4* tris;         // triangles in BVH order, 3 float4 each
+    const DevMaterial* materials;
+    const DevLight* lights;
+    const float* lightCdf;      // Distribution1D::cdf, nLights + 1
+    const float* lightFunc;     // Distribution1D::func, nLights
+    const uint32_t* primId;     // reference m_primitiveId by original triangle index
+    float lightFuncInt;
+    int nLights;
+    uint32_t nTris;
+};
+
+struct DevCamera {
+    float r2c[16];
+    float c2w[16];
+    float lensRadius, focalDistance;
+};
+
+struct DevFilm {
+    int x0, y0, x1, y1;         // cropped pixel bounds
+    float radiusX, radiusY, invRadiusX, invRadiusY;
+    float maxSampleLuminance;
+    float4* pixels;             // {sum r, g, b, filter weight sum} per pixel
+    const float* filterTable;   // 16 x 16
+};
+
+struct DevSampler {
+    const uint32_t* tx;         // [nDims][res] pixel-x XOR table
+    const uint32_t* ty;         // [nDims][res]
+    const uint32_t* sampleConst;// [samples in flight][nDims]
+    uint32_t res, nDims;
+    int sbx0, sby0;             // sample bounds origin
+    float resolutionF;          // (float)m_resolution
+};
+
+struct DevIntegrator {
+    int maxDepth;
+    float rrThreshold;
+    int rx0, ry0, rw, rh;       // render region = sample bounds clipped to pixel bounds
+};
+
+// Per-path state, structure of arrays (float4 where the fields travel together).
+struct DevPaths {
+    float4* rayO;     // o.xyz, unused
+    float4* rayD;     // d.xyz, unused
+    float4* L;        // radiance accumulated so far, unused
+    float4* beta;     // throughput rgb, etaScale
+    float4* hit;      // t, b0, b1, b2
+    int32_t* hitTri;  // triangle (device order) or -1
+    uint32_t* pixel;  // x | y << 16 (absolute raster pixel)
+    uint32_t* state;  // sampleSlot[0:12) | dim[12:22) | bounces[22:30) | specularBounce[30]
+    float2* pfilm;    // CameraSample::m_image
+};
+
+struct DevRayQueue {  // shadow rays and BSDF-sampled MIS rays
+    float4* o;        // o.xyz, bits(path index)
+    float4* d;        // d.xyz, bits(light index) (MIS) / tMax (shadow)
+    float4* w;        // contribution to add to the path's L (shadow) or weight of Le (MIS)
+};
+
+struct DevCounters {
+    uint32_t extCount[2];       // extension-ray queue sizes (current, next)
+    uint32_t matCount[MK_COUNT];
+    uint32_t shadowCount, misCount;
+    uint32_t workNext[4];       // dynamic work-fetch cursors of the traversal kernels
+    unsigned long long raysClosest, raysShadow, raysMis, samples;
+};
+
+DEV uint32_t packState(uint32_t slot, uint32_t dim, uint32_t bounces, uint32_t spec) {
+    return slot | (dim << 12) | (bounces << 22) | (spec << 30);
+}
+DEV uint32_t stSlot(uint32_t s) { return s & 0xfffu; }
+DEV uint32_t stDim(uint32_t s) { return (s >> 12) & 0x3ffu; }
+DEV uint32_t stBounces(uint32_t s) { return (s >> 22) & 0xffu; }
+DEV uint32_t stSpec(uint32_t s) { return (s >> 30) & 1u; }
+
+} // namespace edev

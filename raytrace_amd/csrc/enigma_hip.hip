@@ -1,0 +1,690 @@
+// C ABI of the MI355X PathIntegrator back end (see include/enigma_hip.h).
+// Host orchestration of the wavefront kernels in kernels.h; no CPU rendering path exists here:
+// every entry point that computes runs on the GPU or fails.
+#include "../../include/enigma_hip.h"
+
+#include "bvh_build.h"
+#include "kernels.h"
+#include "sobol_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace edev;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+uint32_t roundUpPow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; } // MathCommon.h:92-98
+int log2Int(float v) { static const float invLog2 = 1.f / logf(2.f); return (int)floorf(logf(v) * invLog2); }               // MathCommon.h:117-124
+
+} // namespace
+
+struct EnigmaCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error = "";
+
+    // scene
+    bool haveScene = false;
+    DevBuf<float4> nodes, tris;
+    DevBuf<DevMaterial> materials;
+    DevBuf<DevLight> lights;
+    DevBuf<float> lightCdf, lightFunc;
+    DevBuf<uint32_t> primId;
+    std::vector<DevLight> hostLights;
+    std::vector<float> lightPower; // Light::Power().y() per light
+    bool kindPresent[MK_COUNT] = {false, false, false, false, false};
+    DevScene scene{};
+    uint32_t bvhDepth = 0, bvhNodes = 0;
+    double msBvhBuild = 0;
+
+    // camera / film / integrator
+    bool haveCamera = false, haveFilm = false, haveInteg = false;
+    DevCamera camera{};
+    EnigmaFilmDesc filmDesc{};
+    DevBuf<float4> filmPixels;
+    DevBuf<float> filterTable;
+    DevFilm film{};
+    EnigmaIntegratorDesc integDesc{};
+    DevIntegrator integ{};
+    int64_t spp = 0;
+    uint32_t log2Res = 0, resolution = 0, nDims = 0;
+    DevBuf<uint32_t> tx, ty, sampleConst;
+    DevSampler sampler{};
+    bool lightDistDirty = true;
+
+    // wavefront state
+    size_t capacity = 0;
+    DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, shW, miO, miD, miW;
+    DevBuf<int32_t> hitTri;
+    DevBuf<uint32_t> pixel, state, extQ[2], matQ[MK_COUNT];
+    DevBuf<float2> pfilm;
+    DevBuf<DevCounters> counters;
+
+    // stats
+    EnigmaStats stats{};
+    std::vector<hipEvent_t> evPool;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return (h)->fail(ENIGMA_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" int enigma_ctx_create(int device_id, EnigmaCtx** out) {
+    if (!out) return ENIGMA_E_INVALID;
+    *out = nullptr;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0 || device_id < 0 || device_id >= nDev) return ENIGMA_E_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return ENIGMA_E_DEVICE;
+    EnigmaCtx* h = new EnigmaCtx();
+    h->device = device_id;
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
+    if (h->counters.alloc(1) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
+    (void)hipMemset(h->counters.p, 0, sizeof(DevCounters));
+    *out = h;
+    return ENIGMA_OK;
+}
+
+extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
+    DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->rayO, &h->rayD, &h->L, &h->beta, &h->hit,
+                            &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+    for (auto* b : f4) b->release();
+    h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
+    h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release(); h->hitTri.release();
+    h->pixel.release(); h->state.release(); h->extQ[0].release(); h->extQ[1].release();
+    for (auto& q : h->matQ) q.release();
+    h->pfilm.release(); h->counters.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char* enigma_last_error(const EnigmaCtx* h) { return h ? h->error.c_str() : "null context"; }
+
+extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
+    if (!h || !s) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (s->normals || s->uvs) return h->fail(ENIGMA_E_UNSUPPORTED, "per-vertex normals / uvs are not supported");
+    if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
+    if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
+    if (s->n_materials == 0 && s->n_triangles) return h->fail(ENIGMA_E_INVALID, "no materials");
+    for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
+        if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
+    for (uint32_t t = 0; t < s->n_triangles; ++t) {
+        if (s->tri_material[t] >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "material index out of range at triangle %u", t);
+        if (s->tri_light[t] >= (int32_t)s->n_lights) return h->fail(ENIGMA_E_INVALID, "light index out of range at triangle %u", t);
+    }
+    // materials (Enigma/Material.cpp:76-255 parameter evaluation with constant textures)
+    std::vector<DevMaterial> mats(s->n_materials);
+    for (int k = 0; k < MK_COUNT; ++k) h->kindPresent[k] = false;
+    auto clamp01inf = [](float v) { return v < 0.f ? 0.f : v; }; // Spectrum::Clamp(0, inf)
+    auto remap = [](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
+        r = std::max(r, (float)1e-3);
+        float x = std::log(r);
+        return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+    };
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const EnigmaMaterial& m = s->materials[i];
+        DevMaterial d;
+        memset(&d, 0, sizeof(d));
+        float ur = m.uroughness, vr = m.vroughness;
+        bool specularGlass = false;
+        switch (m.type) {
+        case ENIGMA_MAT_MATTE:
+            if (m.sigma != 0.f) return h->fail(ENIGMA_E_UNSUPPORTED, "matte sigma != 0 (Oren-Nayar) is not supported");
+            d.kind = MK_MATTE;
+            for (int c = 0; c < 3; ++c) d.c0[c] = clamp01inf(m.kd[c]);
+            break;
+        case ENIGMA_MAT_METAL:
+            d.kind = MK_METAL;
+            for (int c = 0; c < 3; ++c) { d.c0[c] = m.eta[c]; d.c1[c] = m.k[c]; }
+            if (m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
+            break;
+        case ENIGMA_MAT_GLASS:
+            specularGlass = (ur == 0.f && vr == 0.f);
+            d.kind = specularGlass ? MK_GLASS_SMOOTH : MK_GLASS_ROUGH;
+            for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kr[c]); d.c1[c] = clamp01inf(m.kt[c]); }
+            d.eta = m.index;
+            if (!specularGlass && m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
+            break;
+        case ENIGMA_MAT_PLASTIC:
+            d.kind = MK_PLASTIC;
+            for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kd[c]); d.c1[c] = clamp01inf(m.ks[c]); }
+            if (m.remap_roughness) ur = remap(ur);
+            vr = ur;
+            break;
+        default:
+            return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
+        }
+        d.alphax = std::max(float(0.001), ur); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
+        d.alphay = std::max(float(0.001), vr);
+        bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f;
+        bool nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
+        d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
+        h->kindPresent[d.kind] = true;
+        mats[i] = d;
+    }
+    // BVH + triangle reorder
+    auto t0 = std::chrono::steady_clock::now();
+    enigma::BvhResult bvh;
+    enigma::build_bvh(s->vertices, s->indices, s->n_triangles, 4, &bvh);
+    h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bvh.maxDepth > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (64)", bvh.maxDepth);
+    h->bvhDepth = bvh.maxDepth;
+    h->bvhNodes = (uint32_t)bvh.nodes.size();
+    std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> newPos(s->n_triangles);
+    for (uint32_t k = 0; k < s->n_triangles; ++k) {
+        uint32_t t = bvh.triOrder[k];
+        newPos[t] = k;
+        uint32_t flip = (s->tri_flags && (s->tri_flags[t] & ENIGMA_TRI_FLIP_NORMAL)) ? 1u : 0u;
+        uint32_t w[3] = {t, s->tri_material[t] | (flip << 31), (uint32_t)s->tri_light[t]};
+        for (int v = 0; v < 3; ++v) {
+            const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
+            float wf;
+            memcpy(&wf, &w[v], 4);
+            triData[(size_t)k * 3 + v] = make_float4(p[0], p[1], p[2], wf);
+        }
+    }
+    std::vector<float4> nodeData(bvh.nodes.size() * 4);
+    memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::BvhNode));
+    std::vector<uint32_t> prim(std::max(1u, s->n_triangles));
+    for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
+    // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
+    h->hostLights.assign(s->n_lights, DevLight());
+    h->lightPower.assign(s->n_lights, 0.f);
+    const float PI = 3.1415926535897932384f;
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const EnigmaLight& l = s->lights[i];
+        DevLight d;
+        memset(&d, 0, sizeof(d));
+        for (int c = 0; c < 3; ++c) { d.L[c] = l.L[c]; d.pos[c] = l.pos[c]; }
+        const float YW[3] = {0.212671f, 0.715160f, 0.072169f};
+        if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
+            if (l.triangle >= s->n_triangles) return h->fail(ENIGMA_E_INVALID, "light %u: triangle out of range", i);
+            if (s->tri_light[l.triangle] != (int32_t)i) return h->fail(ENIGMA_E_INVALID, "light %u: triangle %u does not point back at it", i, l.triangle);
+            d.type = 1; d.tri = newPos[l.triangle]; d.twoSided = l.two_sided ? 1u : 0u;
+            const float* a = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle]];
+            const float* b = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle + 1]];
+            const float* c = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle + 2]];
+            // Triangle::area: Length(Cross(v1 - v0, v2 - v0)) * 0.5f (Enigma/TriangleMesh.cpp:438-446)
+            float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            float cx = e1[1] * e2[2] - e2[1] * e1[2], cy = e1[2] * e2[0] - e2[2] * e1[0], cz = e1[0] * e2[1] - e2[0] * e1[1];
+            d.area = std::sqrt(cx * cx + cy * cy + cz * cz) * 0.5f;
+            float scale = d.twoSided ? 2.0f : 1.0f;
+            float k = d.area * PI * scale; // DiffuseAreaLight::Power, Enigma/Lights.cpp:647-651
+            h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
+        } else if (l.type == ENIGMA_LIGHT_POINT) {
+            d.type = 0;
+            float k = 4.0f * PI; // PointLight::Power, Enigma/Lights.cpp:126-129
+            h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
+        } else return h->fail(ENIGMA_E_UNSUPPORTED, "light type %u is not supported", l.type);
+        h->hostLights[i] = d;
+    }
+    HIPCHK(h, h->nodes.upload(nodeData));
+    HIPCHK(h, h->tris.upload(triData));
+    HIPCHK(h, h->materials.upload(mats));
+    HIPCHK(h, h->lights.upload(h->hostLights));
+    HIPCHK(h, h->primId.upload(prim));
+    h->scene.nodes = h->nodes.p;
+    h->scene.tris = h->tris.p;
+    h->scene.materials = h->materials.p;
+    h->scene.lights = h->lights.p;
+    h->scene.primId = h->primId.p;
+    h->scene.nLights = (int)s->n_lights;
+    h->scene.nTris = s->n_triangles;
+    h->lightDistDirty = true;
+    h->haveScene = true;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_camera_set(EnigmaCtx* h, const EnigmaCameraDesc* c) {
+    if (!h || !c) return ENIGMA_E_INVALID;
+    memcpy(h->camera.r2c, c->raster_to_camera, 64);
+    memcpy(h->camera.c2w, c->camera_to_world, 64);
+    h->camera.lensRadius = c->lens_radius;
+    h->camera.focalDistance = c->focal_distance;
+    h->haveCamera = true;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_clear(EnigmaCtx* h) {
+    if (!h || !h->haveFilm) return h ? h->fail(ENIGMA_E_STATE, "film not configured") : ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->filmPixels.p, 0, h->filmPixels.n * sizeof(float4), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* f) {
+    if (!h || !f) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int32_t* b = f->cropped_pixel_bounds;
+    if (b[2] < b[0] || b[3] < b[1]) return h->fail(ENIGMA_E_INVALID, "inverted cropped pixel bounds");
+    if (b[0] < 0 || b[1] < 0 || b[2] > 65535 || b[3] > 65535) return h->fail(ENIGMA_E_INVALID, "pixel bounds must lie in [0, 65535]");
+    if (!(f->filter_radius[0] > 0.f) || !(f->filter_radius[1] > 0.f)) return h->fail(ENIGMA_E_INVALID, "filter radius must be positive");
+    h->filmDesc = *f;
+    size_t nPix = (size_t)(b[2] - b[0]) * (size_t)(b[3] - b[1]);
+    HIPCHK(h, h->filmPixels.alloc(nPix));
+    h->filmPixels.n = nPix;
+    std::vector<float> tab(f->filter_table, f->filter_table + 256);
+    HIPCHK(h, h->filterTable.upload(tab));
+    h->film.x0 = b[0]; h->film.y0 = b[1]; h->film.x1 = b[2]; h->film.y1 = b[3];
+    h->film.radiusX = f->filter_radius[0]; h->film.radiusY = f->filter_radius[1];
+    h->film.invRadiusX = 1.0f / f->filter_radius[0]; h->film.invRadiusY = 1.0f / f->filter_radius[1]; // Inverted(), Enigma/Film.cpp:255
+    h->film.maxSampleLuminance = f->max_sample_luminance;
+    h->film.pixels = h->filmPixels.p;
+    h->film.filterTable = h->filterTable.p;
+    h->haveFilm = true;
+    return enigma_film_clear(h);
+}
+
+extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
+    if (d->samples_per_pixel <= 0 || d->samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
+    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
+    const int32_t* sb = d->sample_bounds;
+    int dx = sb[2] - sb[0], dy = sb[3] - sb[1];
+    if (dx <= 0 || dy <= 0) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
+    if (sb[0] < 0 || sb[1] < 0) return h->fail(ENIGMA_E_UNSUPPORTED, "negative sample bounds (filter wider than 0.5 at the image border) are not supported");
+    h->integDesc = *d;
+    // SobolSampler ctor, Enigma/Sampler.cpp:211-222
+    h->spp = (int64_t)roundUpPow2((uint32_t)d->samples_per_pixel);
+    h->resolution = roundUpPow2((uint32_t)std::max(dx, dy));
+    h->log2Res = (uint32_t)log2Int((float)h->resolution);
+    if ((1u << h->log2Res) != h->resolution) return h->fail(ENIGMA_E_INVALID, "Log2Int(resolution) is inexact for %u", h->resolution);
+    // dimensions a path can consume: 5 (camera) + per bounce 1+2+2 (light) + 2 (BSDF) + 1 (roulette)
+    uint32_t nDims = 5u + 8u * (uint32_t)d->max_depth;
+    if (nDims > (uint32_t)enigma::kNumSobolDimensions) return h->fail(ENIGMA_E_INVALID, "max_depth needs %u Sobol dimensions (> 1024)", nDims);
+    if (nDims > 1023u) return h->fail(ENIGMA_E_INVALID, "dimension cursor overflow");
+    h->nDims = nDims;
+    enigma::SobolPixelTables T;
+    enigma::build_pixel_tables(h->log2Res, nDims, &T);
+    HIPCHK(h, h->tx.upload(T.tx));
+    HIPCHK(h, h->ty.upload(T.ty));
+    h->sampler.tx = h->tx.p; h->sampler.ty = h->ty.p;
+    h->sampler.res = h->resolution; h->sampler.nDims = nDims;
+    h->sampler.sbx0 = sb[0]; h->sampler.sby0 = sb[1];
+    h->sampler.resolutionF = (float)(int)h->resolution;
+    // render region: pixels of the sample bounds that pass m_pixelBounds.insideExclusive (Enigma/Integrator.cpp:264)
+    int rx0 = std::max(sb[0], d->pixel_bounds[0]), ry0 = std::max(sb[1], d->pixel_bounds[1]);
+    int rx1 = std::min(sb[2], d->pixel_bounds[2]), ry1 = std::min(sb[3], d->pixel_bounds[3]);
+    h->integ.maxDepth = d->max_depth;
+    h->integ.rrThreshold = d->rr_threshold;
+    h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
+    if (rx1 > 65535 || ry1 > 65535) return h->fail(ENIGMA_E_INVALID, "render region exceeds 65535");
+    h->lightDistDirty = true;
+    h->haveInteg = true;
+    return ENIGMA_OK;
+}
+
+// CreateLightSampleDistribution + Distribution1D ctor (Enigma/LightDist.cpp:20-71, Enigma/MonteCarlo.h:17-38)
+static int buildLightDistribution(EnigmaCtx* h) {
+    int n = h->scene.nLights;
+    std::vector<float> func(std::max(1, n), 1.0f), cdf((size_t)n + 1, 0.f);
+    if (n > 0) {
+        bool uniform = h->integDesc.light_strategy == ENIGMA_LIGHTS_UNIFORM || n == 1;
+        for (int i = 0; i < n; ++i) func[i] = uniform ? 1.0f : h->lightPower[i];
+        cdf[0] = 0.;
+        for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+        float funcInt = cdf[n];
+        if (funcInt == 0.f) for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+        else for (int i = 1; i < n + 1; ++i) cdf[i] /= funcInt;
+        h->scene.lightFuncInt = funcInt;
+    }
+    HIPCHK(h, h->lightCdf.upload(cdf));
+    HIPCHK(h, h->lightFunc.upload(func));
+    h->scene.lightCdf = h->lightCdf.p;
+    h->scene.lightFunc = h->lightFunc.p;
+    h->lightDistDirty = false;
+    return ENIGMA_OK;
+}
+
+static int ensureCapacity(EnigmaCtx* h, size_t n) {
+    if (n <= h->capacity) return ENIGMA_OK;
+    DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit, &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+    for (auto* b : f4) HIPCHK(h, b->alloc(n));
+    HIPCHK(h, h->hitTri.alloc(n));
+    HIPCHK(h, h->pixel.alloc(n));
+    HIPCHK(h, h->state.alloc(n));
+    HIPCHK(h, h->pfilm.alloc(n));
+    HIPCHK(h, h->extQ[0].alloc(n));
+    HIPCHK(h, h->extQ[1].alloc(n));
+    for (auto& q : h->matQ) HIPCHK(h, q.alloc(n));
+    h->capacity = n;
+    return ENIGMA_OK;
+}
+
+template <int STACK>
+static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
+                         int gridShade, hipEvent_t e0, hipEvent_t e1) {
+    DevCounters* ctr = h->counters.p;
+    uint32_t cur = (uint32_t)bounce & 1u;
+    hipStream_t s = h->stream;
+    k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, bounce == 0 ? 1 : 0);
+    MatQueues mq;
+    for (int k = 0; k < MK_COUNT; ++k) mq.q[k] = h->matQ[k].p;
+    const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
+    const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur];
+    (void)hipEventRecord(e0, s);
+    k_intersect_closest<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
+    (void)hipEventRecord(e1, s);
+    if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
+    uint32_t* nextQ = h->extQ[cur ^ 1u].p;
+    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
+    if (h->scene.nLights > 0) {
+        k_shadow<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, shq, ctr);
+        k_mis<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, misq, ctr);
+    }
+}
+
+static int stackFor(uint32_t depth) { return depth <= 16 ? 16 : depth <= 24 ? 24 : depth <= 32 ? 32 : depth <= 48 ? 48 : 64; }
+
+extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
+    if (!h) return ENIGMA_E_INVALID;
+    if (!h->haveScene || !h->haveCamera || !h->haveFilm || !h->haveInteg) return h->fail(ENIGMA_E_STATE, "scene, camera, film and integrator must be configured before render");
+    if (sample_begin < 0 || sample_end < sample_begin || sample_end > h->spp) return h->fail(ENIGMA_E_INVALID, "sample range [%lld, %lld) outside [0, %lld)", (long long)sample_begin, (long long)sample_end, (long long)h->spp);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->lightDistDirty) { int rc = buildLightDistribution(h); if (rc) return rc; }
+    auto wall0 = std::chrono::steady_clock::now();
+    const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
+    h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
+    if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
+    // passes of k sample numbers over all pixels, ~8M paths in flight (capped by the 12-bit sample slot)
+    const size_t targetPaths = (size_t)8 << 20;
+    uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
+    int64_t nSamples = sample_end - sample_begin;
+    const int64_t chunkMax = 4096; // sample slots addressable per constant table
+    const int stack = stackFor(h->bvhDepth);
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
+    for (int64_t c0 = 0; c0 < nSamples; c0 += chunkMax) {
+        int64_t cn = std::min(chunkMax, nSamples - c0);
+        std::vector<uint32_t> consts((size_t)cn * h->nDims);
+        for (int64_t s = 0; s < cn; ++s) enigma::sample_constants(h->log2Res, (uint64_t)(sample_begin + c0 + s), h->nDims, &consts[(size_t)s * h->nDims]);
+        HIPCHK(h, h->sampleConst.upload(consts));
+        h->sampler.sampleConst = h->sampleConst.p;
+        size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
+        { int rc = ensureCapacity(h, passPathsMax); if (rc) return rc; }
+        DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->hitTri.p, h->pixel.p, h->state.p, h->pfilm.p};
+        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p}, misq{h->miO.p, h->miD.p, h->miW.p};
+        for (int64_t s0 = 0; s0 < cn; s0 += k) {
+            uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
+            uint32_t nPaths = nPixels * ks;
+            int gridAll = (int)((nPaths + kBlock - 1) / kBlock);
+            int ldsBlocks = std::max(1, (160 * 1024) / (stack * kBlock * 4));
+            int gridTrace = std::min(gridAll, cus * std::min(ldsBlocks, 8));
+            int gridShade = std::min(gridAll, cus * 8);
+            k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p);
+            for (int b = 0; b <= h->integ.maxDepth; ++b) {
+                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
+                while (h->evPool.size() < need) {
+                    hipEvent_t e;
+                    HIPCHK(h, hipEventCreate(&e));
+                    h->evPool.push_back(e);
+                }
+                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
+                switch (stack) {
+                case 16: launchBounce<16>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 24: launchBounce<24>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 32: launchBounce<32>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 48: launchBounce<48>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                default: launchBounce<64>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                }
+                h->stats.intersect_launches++;
+            }
+            k_film_splat<<<gridAll, kBlock, 0, h->stream>>>(P, h->film, nPaths);
+            HIPCHK(h, hipGetLastError());
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // the constant table is re-uploaded per chunk
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (uint64_t i = 0; i < h->stats.intersect_launches; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->evPool[i * 2], h->evPool[i * 2 + 1]) == hipSuccess) h->stats.ms_intersect += ms;
+    }
+    h->stats.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_read(EnigmaCtx* h, float* rgbw, uint64_t n_floats) {
+    if (!h || !rgbw) return ENIGMA_E_INVALID;
+    if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
+    if (n_floats != h->filmPixels.n * 4) return h->fail(ENIGMA_E_INVALID, "film has %zu floats, caller asked for %llu", h->filmPixels.n * 4, (unsigned long long)n_floats);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(rgbw, h->filmPixels.p, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_device_ptr(EnigmaCtx* h, void** dev_ptr, uint64_t* n_floats) {
+    if (!h || !dev_ptr || !n_floats) return ENIGMA_E_INVALID;
+    if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
+    *dev_ptr = h->filmPixels.p;
+    *n_floats = h->filmPixels.n * 4;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_resolve(const float* rgbw, uint64_t n_pixels, float scale, float* rgb_out) {
+    if (!rgbw || !rgb_out) return ENIGMA_E_INVALID;
+    for (uint64_t i = 0; i < n_pixels; ++i) {
+        const float* c = &rgbw[4 * i];
+        float xyz[3], rgb[3];
+        // FilmTile RGB -> Film XYZ on merge (Enigma/Film.cpp:115-118, Enigma/Spectrum.h:28-32)
+        xyz[0] = 0.412453f * c[0] + 0.357580f * c[1] + 0.180423f * c[2];
+        xyz[1] = 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2];
+        xyz[2] = 0.019334f * c[0] + 0.119193f * c[1] + 0.950227f * c[2];
+        // Film::WriteImage (Enigma/Film.cpp:174-196, Enigma/Spectrum.h:22-26)
+        rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+        rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+        rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+        float w = c[3];
+        if (w != 0) {
+            float invWt = (float)1 / w;
+            rgb[0] = std::max((float)0, rgb[0] * invWt);
+            rgb[1] = std::max((float)0, rgb[1] * invWt);
+            rgb[2] = std::max((float)0, rgb[2] * invWt);
+        }
+        rgb_out[3 * i] = rgb[0] * scale; rgb_out[3 * i + 1] = rgb[1] * scale; rgb_out[3 * i + 2] = rgb[2] * scale;
+    }
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
+    if (!h || !out) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    DevCounters c;
+    HIPCHK(h, hipMemcpy(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    h->stats.camera_samples = c.samples;
+    h->stats.rays_closest = c.raysClosest;
+    h->stats.rays_shadow = c.raysShadow;
+    h->stats.rays_mis = c.raysMis;
+    h->stats.bvh_nodes = h->bvhNodes;
+    h->stats.bvh_depth = h->bvhDepth;
+    h->stats.ms_bvh_build = h->msBvhBuild;
+    *out = h->stats;
+    return ENIGMA_OK;
+}
+
+// ---------------------------------------------------------------- debug taps
+static int debugSlots(EnigmaCtx* h, uint32_t n, const int32_t* pixels, const int64_t* sampleNums, DevBuf<int32_t>& dPix, DevBuf<uint32_t>& dSlots) {
+    if (!h->haveInteg) return h->fail(ENIGMA_E_STATE, "integrator not configured");
+    const int32_t* sb = h->integDesc.sample_bounds;
+    std::vector<uint32_t> consts((size_t)n * h->nDims), slots(n);
+    std::vector<int32_t> pix(pixels, pixels + 2 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pixels[2 * i] < sb[0] || pixels[2 * i] >= sb[2] || pixels[2 * i + 1] < sb[1] || pixels[2 * i + 1] >= sb[3])
+            return h->fail(ENIGMA_E_INVALID, "pixel %u outside the sample bounds", i);
+        if (sampleNums[i] < 0) return h->fail(ENIGMA_E_INVALID, "negative sample number");
+        enigma::sample_constants(h->log2Res, (uint64_t)sampleNums[i], h->nDims, &consts[(size_t)i * h->nDims]);
+        slots[i] = i;
+    }
+    HIPCHK(h, h->sampleConst.upload(consts));
+    h->sampler.sampleConst = h->sampleConst.p;
+    HIPCHK(h, dPix.upload(pix));
+    HIPCHK(h, dSlots.upload(slots));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums, uint32_t n_dims, uint64_t* index_out, float* dims_out) {
+    if (!h || !pixels_xy || !sample_nums || !dims_out) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n == 0) return ENIGMA_OK;
+    if (n_dims > h->nDims) return h->fail(ENIGMA_E_INVALID, "n_dims %u exceeds the %u dimensions tabulated for this max_depth", n_dims, h->nDims);
+    DevBuf<int32_t> dPix; DevBuf<uint32_t> dSlots; DevBuf<float> dOut;
+    int rc = debugSlots(h, n, pixels_xy, sample_nums, dPix, dSlots);
+    if (rc == ENIGMA_OK) {
+        hipError_t e = dOut.alloc((size_t)n * n_dims);
+        if (e == hipSuccess) {
+            k_debug_sobol<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, n, dPix.p, dSlots.p, n_dims, dOut.p);
+            e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = hipMemcpy(dims_out, dOut.p, (size_t)n * n_dims * sizeof(float), hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) rc = h->fail(ENIGMA_E_DEVICE, "debug_sobol: %s", hipGetErrorString(e));
+    }
+    if (rc == ENIGMA_OK && index_out) {
+        const int32_t* sb = h->integDesc.sample_bounds;
+        for (uint32_t i = 0; i < n; ++i)
+            index_out[i] = enigma::sobol_interval_to_index(h->log2Res, (uint64_t)sample_nums[i], (uint32_t)(pixels_xy[2 * i] - sb[0]), (uint32_t)(pixels_xy[2 * i + 1] - sb[1]));
+    }
+    dPix.release(); dSlots.release(); dOut.release();
+    return rc;
+}
+
+extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums, float* out_ray, float* out_pfilm) {
+    if (!h || !pixels_xy || !sample_nums || !out_ray || !out_pfilm) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->haveCamera) return h->fail(ENIGMA_E_STATE, "camera not configured");
+    if (n == 0) return ENIGMA_OK;
+    DevBuf<int32_t> dPix; DevBuf<uint32_t> dSlots; DevBuf<float> dRay, dPf;
+    int rc = debugSlots(h, n, pixels_xy, sample_nums, dPix, dSlots);
+    if (rc == ENIGMA_OK) {
+        hipError_t e = dRay.alloc((size_t)n * 6);
+        if (e == hipSuccess) e = dPf.alloc((size_t)n * 2);
+        if (e == hipSuccess) {
+            k_debug_camera<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, h->camera, n, dPix.p, dSlots.p, dRay.p, dPf.p);
+            e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = hipMemcpy(out_ray, dRay.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(out_pfilm, dPf.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) rc = h->fail(ENIGMA_E_DEVICE, "debug_camera_rays: %s", hipGetErrorString(e));
+    }
+    dPix.release(); dSlots.release(); dRay.release(); dPf.release();
+    return rc;
+}
+
+static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyHit, int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
+    if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
+    if (n == 0) return ENIGMA_OK;
+    DevBuf<float> dRays, dT, dB; DevBuf<int32_t> dTri; DevBuf<uint32_t> dPrim;
+    std::vector<float> r(rays7, rays7 + 7 * (size_t)n);
+    hipError_t e = dRays.upload(r);
+    if (e == hipSuccess) e = dT.alloc(n);
+    if (e == hipSuccess) e = dB.alloc((size_t)n * 3);
+    if (e == hipSuccess) e = dTri.alloc(n);
+    if (e == hipSuccess) e = dPrim.alloc(n);
+    if (e == hipSuccess) {
+        int grid = (int)((n + kBlock - 1) / kBlock);
+        switch (stackFor(h->bvhDepth)) {
+        case 16: k_debug_intersect<16><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        case 24: k_debug_intersect<24><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        case 32: k_debug_intersect<32><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        case 48: k_debug_intersect<48><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        default: k_debug_intersect<64><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        }
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && !anyHit) {
+            e = hipMemcpy(primOut, dPrim.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(tOut, dT.p, n * sizeof(float), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(baryOut, dB.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+        }
+    }
+    dRays.release(); dT.release(); dB.release(); dTri.release(); dPrim.release();
+    if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_intersect: %s", hipGetErrorString(e));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
+    if (!h || !rays7 || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return debugIntersect(h, n, rays7, 0, tri_out, prim_id_out, t_out, bary_out);
+}
+
+extern "C" int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out) {
+    if (!h || !rays7 || !hit_out) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    return debugIntersect(h, n, rays7, 1, hit_out, nullptr, nullptr, nullptr);
+}
+
+extern "C" int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per, int32_t* pixels_xy_out, float* weights_out, uint32_t* counts_out) {
+    if (!h || !pfilm_xy || !pixels_xy_out || !weights_out || !counts_out) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
+    if (n == 0) return ENIGMA_OK;
+    DevBuf<float> dPf, dW; DevBuf<int32_t> dPix; DevBuf<uint32_t> dCnt;
+    std::vector<float> pf(pfilm_xy, pfilm_xy + 2 * (size_t)n);
+    hipError_t e = dPf.upload(pf);
+    if (e == hipSuccess) e = dW.alloc((size_t)n * max_per);
+    if (e == hipSuccess) e = dPix.alloc((size_t)n * max_per * 2);
+    if (e == hipSuccess) e = dCnt.alloc(n);
+    if (e == hipSuccess) {
+        k_debug_footprint<<<(n + 255) / 256, 256, 0, h->stream>>>(h->film, n, dPf.p, max_per, dPix.p, dW.p, dCnt.p);
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(pixels_xy_out, dPix.p, (size_t)n * max_per * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(weights_out, dW.p, (size_t)n * max_per * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(counts_out, dCnt.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    }
+    dPf.release(); dW.release(); dPix.release(); dCnt.release();
+    if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_film_footprint: %s", hipGetErrorString(e));
+    return ENIGMA_OK;
+}
+

@@ -1,0 +1,575 @@
+// The wavefront PathIntegrator kernels (gfx950, wave64).
+//
+// One render pass = N camera samples in flight (every pixel of the render region times a
+// few sample numbers).  Stages per pass:
+//   k_generate              SobolSampler::GetCameraSample + PerspectiveCamera ray
+//                           (Enigma/Sampler.cpp:30-37,224-240; Enigma/Camera.cpp:144-192)
+//   per bounce:
+//     k_intersect_closest   Scene::intersect for the path rays + the head of the
+//                           PathIntegrator::Li loop body (emission, termination,
+//                           Enigma/PathIntegrator.cpp:67-86); bins survivors by material kind
+//     k_shade<kind>         BSDF construction, UniformSampleOneLight/EstimateDirect set-up,
+//                           BSDF sampling, Russian roulette
+//                           (Enigma/PathIntegrator.cpp:88-175, Enigma/Integrator.cpp:71-204)
+//     k_shadow              VisibilityTester::Unoccluded (Enigma/Lights.cpp:713-716)
+//     k_mis                 the BSDF-sampled MIS ray of EstimateDirect (Enigma/Integrator.cpp:180-197)
+//   k_film_splat            radiance scrub + FilmTile::AddSample
+//                           (Enigma/Integrator.cpp:284-295, Enigma/Film.cpp:263-300)
+// Queues hold path indices; they are compacted with 64-lane ballots + prefix popcounts, the
+// per-wave totals scanned through LDS so a block issues one atomic per queue.
+#pragma once
+#include "dev_bsdf.h"
+#include "dev_trace.h"
+
+namespace edev {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// ---------------------------------------------------------------- sampler
+DEV uint32_t sobolBits(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t slot, uint32_t dim) {
+    return S.tx[(size_t)dim * S.res + relx] ^ S.ty[(size_t)dim * S.res + rely] ^ S.sampleConst[(size_t)slot * S.nDims + dim];
+}
+// SobolSampleFloat + SobolSampler::SampleDimension (Enigma/SamplerInclude.h:2627-2637, Enigma/Sampler.cpp:229-240)
+DEV float sampleDimension(const DevSampler& S, int px, int py, uint32_t slot, uint32_t dim) {
+    uint32_t v = sobolBits(S, (uint32_t)(px - S.sbx0), (uint32_t)(py - S.sby0), slot, dim);
+    float s = smin((float)v * 0x1p-32f, kOneMinusEpsilon);
+    if (dim == 0 || dim == 1) {
+        s = s * S.resolutionF + (float)(dim == 0 ? S.sbx0 : S.sby0);
+        s = clampf(s - (float)(dim == 0 ? px : py), 0.f, kOneMinusEpsilon);
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------- camera
+DEV F3 xfPoint(const float* m, F3 p) { // Transform::transformPoint, Enigma/Transform.h:36-45
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1.f) return F3(xp, yp, zp);
+    return F3(xp, yp, zp) / wp;
+}
+DEV F3 xfVector(const float* m, F3 v) { // Transform::transformVector, Enigma/Transform.h:47-52
+    return F3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+DEV void cameraRay(const DevCamera& C, float fx, float fy, float lu, float lv, F3* o, F3* d) {
+    F3 Pcamera = xfPoint(C.r2c, F3(fx, fy, 0.f));
+    F3 ro(0.f, 0.f, 0.f), rd = normalize(Pcamera);
+    if (C.lensRadius > 0.f) {
+        float lx, ly;
+        concentricSampleDisk(lu, lv, &lx, &ly);
+        lx *= C.lensRadius; ly *= C.lensRadius;
+        float ft = C.focalDistance / rd.z;
+        F3 Pfocus = ro + rd * ft;
+        ro = F3(lx, ly, 0.f);
+        rd = normalize(Pfocus - ro);
+    }
+    *d = xfVector(C.c2w, rd);
+    *o = xfPoint(C.c2w, ro);
+}
+
+// ---------------------------------------------------------------- queue compaction
+// Block-wide append: every thread of the block must call this (uniform control flow).
+// Returns the queue slot for lanes with pred (undefined otherwise).
+DEV uint32_t blockReserve(bool pred, uint32_t* counter, uint32_t* lds /* kWavesPerBlock + 1 words */) {
+    unsigned long long mask = __ballot(pred);
+    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wid] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) { uint32_t c = lds[w]; lds[w] = total; total += c; }
+        lds[kWavesPerBlock] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t slot = lds[kWavesPerBlock] + lds[wid] + prefix;
+    __syncthreads(); // lds is reused by the next reservation
+    return slot;
+}
+// Wave-wide append for kernels whose waves run independent work loops.
+DEV uint32_t waveReserve(bool pred, uint32_t* counter) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+// Next 64 work items for this wave (dynamic fetch keeps the CUs busy while rays of very
+// different cost share a launch).  Every wave leaves its loop when the cursor passes count.
+DEV uint32_t waveFetch(uint32_t* cursor) {
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, 64u);
+    return __shfl(base, 0);
+}
+
+// ---------------------------------------------------------------- geometry at a hit
+struct HitGeom { F3 p, pError, n, dpdu; int matIdx, lightIdx; };
+
+DEV F3 triNormal(F3 p0, F3 p1, F3 p2, bool flip) { // Enigma/TriangleMesh.cpp:287-289
+    F3 n = normalize(cross(p0 - p2, p1 - p2));
+    return flip ? -n : n;
+}
+// Triangle::intersect after the hit test, Enigma/TriangleMesh.cpp:226-289 (default uvs, no normals)
+DEV HitGeom hitGeometry(const DevScene& sc, int tri, float b0, float b1, float b2) {
+    const float4* tp = sc.tris + (size_t)tri * 3;
+    float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+    F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
+    uint32_t mw = __float_as_uint(v1.w);
+    HitGeom g;
+    g.matIdx = (int)(mw & 0x7fffffffu);
+    g.lightIdx = __float_as_int(v2.w);
+    F3 dp02 = p0 - p2, dp12 = p1 - p2;
+    F3 dpdu = dp12 - dp02;
+    F3 dpdv = -dp12;
+    if (lengthSqr(cross(dpdu, dpdv)) == 0) {
+        F3 ng = cross(p2 - p0, p1 - p0);
+        coordinateSystem(normalize(ng), &dpdu, &dpdv);
+    }
+    g.dpdu = dpdu;
+    float xAbsSum = (fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x));
+    float yAbsSum = (fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y));
+    float zAbsSum = (fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z));
+    g.pError = gammaf(7) * F3(xAbsSum, yAbsSum, zAbsSum);
+    g.p = b0 * p0 + b1 * p1 + b2 * p2;
+    g.n = triNormal(p0, p1, p2, (mw >> 31) != 0);
+    return g;
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, DevCamera C, DevIntegrator I, uint32_t nPaths, uint32_t nPixels,
+                                                     uint32_t slotBase, DevCounters* ctr) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nPaths) return;
+    uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
+    int px = I.rx0 + (int)(pix % (uint32_t)I.rw), py = I.ry0 + (int)(pix / (uint32_t)I.rw);
+    // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
+    float fx = (float)px + sampleDimension(S, px, py, slot, 0);
+    float fy = (float)py + sampleDimension(S, px, py, slot, 1);
+    float lu = 0.f, lv = 0.f;
+    if (C.lensRadius > 0.f) { lu = sampleDimension(S, px, py, slot, 3); lv = sampleDimension(S, px, py, slot, 4); }
+    F3 o, d;
+    cameraRay(C, fx, fy, lu, lv, &o, &d);
+    P.rayO[i] = mk4(o, 0.f);
+    P.rayD[i] = mk4(d, 0.f);
+    P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.beta[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    P.pixel[i] = (uint32_t)px | ((uint32_t)py << 16);
+    P.state[i] = packState(slot, 5u, 0u, 0u);
+    P.pfilm[i] = make_float2(fx, fy);
+    if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
+}
+
+// Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
+struct MatQueues { uint32_t* q[MK_COUNT]; };
+
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
+                                                              const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr) {
+    __shared__ uint32_t stack[STACK * kBlock];
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    uint32_t* myStack = stack + threadIdx.x;
+    for (;;) {
+        uint32_t base = waveFetch(&ctr->workNext[0]);
+        if (base >= count) break;
+        uint32_t i = base + (threadIdx.x & 63u);
+        bool active = i < count;
+        int kind = -1;
+        uint32_t p = 0;
+        if (active) {
+            p = queue ? queue[i] : i;
+            F3 o = xyz(P.rayO[p]), d = xyz(P.rayD[p]);
+            Hit h = traceClosest<STACK, kBlock>(sc, o, d, EDEV_INF, myStack);
+            uint32_t st = P.state[p];
+            uint32_t bounces = stBounces(st);
+            if (h.tri >= 0) {
+                const float4* tp = sc.tris + (size_t)h.tri * 3;
+                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                int lightIdx = __float_as_int(v2.w);
+                uint32_t mw = __float_as_uint(v1.w);
+                if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
+                    const DevLight& lt = sc.lights[lightIdx];
+                    F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
+                    if (lt.twoSided || dot(n, -d) > 0) {
+                        float4 L = P.L[p], be = P.beta[p];
+                        F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+                    }
+                }
+                if ((int)bounces < I.maxDepth) {
+                    kind = (int)sc.materials[mw & 0x7fffffffu].kind;
+                    P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
+                    P.hitTri[p] = h.tri;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MK_COUNT; ++k) {
+            bool mine = kind == k;
+            uint32_t slot = waveReserve(mine, &ctr->matCount[k]);
+            if (mine) mq.q[k][slot] = p;
+        }
+    }
+}
+
+// Distribution1D::SampleDiscrete, Enigma/MonteCarlo.h:61-69 (std::upper_bound on the cdf)
+DEV int sampleDiscrete(const DevScene& sc, float u, float* pdf) {
+    int n = sc.nLights;
+    int lo = 0, len = n + 1; // first element > u in cdf[0..n]
+    while (len > 0) {
+        int half = len >> 1;
+        if (!(u < sc.lightCdf[lo + half])) { lo += half + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = max(0, lo - 1);
+    offset = min(offset, n - 1); // unreachable for u < 1 (cdf[n] == 1); keeps the read in bounds
+    *pdf = sc.lightFunc[offset] / (sc.lightFuncInt * n);
+    return offset;
+}
+
+DEV float powerHeuristic(float fPdf, float gPdf) { float f = 1 * fPdf, g = 1 * gPdf; return (f * f) / (f * f + g * g); }
+
+template <int MK>
+__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
+                                                  const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    const uint32_t count = ctr->matCount[MK];
+    const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        bool pushShadow = false, pushMis = false, pushNext = false;
+        uint32_t p = 0;
+        F3 shO(0.f), shD(0.f), shW(0.f), miO(0.f), miD(0.f), miW(0.f);
+        int miLight = 0;
+        if (active) {
+            p = matQueue[i];
+            F3 d = xyz(P.rayD[p]);
+            float4 hv = P.hit[p];
+            int tri = P.hitTri[p];
+            uint32_t st = P.state[p];
+            uint32_t slot = stSlot(st), dim = stDim(st), bounces = stBounces(st);
+            uint32_t pix = P.pixel[p];
+            int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+            float4 bv = P.beta[p];
+            F3 beta = xyz(bv);
+            float etaScale = bv.w;
+            HitGeom g = hitGeometry(sc, tri, hv.y, hv.z, hv.w);
+            Bsdf bsdf;
+            makeBsdf<MK>(sc.materials[g.matIdx], g.n, g.dpdu, &bsdf);
+            F3 ns = g.n; // shading normal == geometric normal (no per-vertex normals)
+            F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
+
+            // ---- UniformSampleOneLight (Enigma/Integrator.cpp:71-92) ----
+            if (numComponents(bsdf, kNonSpecular) > 0 && sc.nLights > 0) {
+                float pick;
+                int lightNum = sampleDiscrete(sc, sampleDimension(S, px, py, slot, dim), &pick);
+                dim += 1;
+                if (pick != 0) {
+                    float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
+                    float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
+                    dim += 4;
+                    const DevLight& lt = sc.lights[lightNum];
+                    // ---- EstimateDirect: light sampling (Enigma/Integrator.cpp:104-148) ----
+                    F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
+                    float lightPdf = 0.f;
+                    F3 q0(0.f), q1(0.f), q2(0.f);
+                    bool lflip = false;
+                    if (lt.type == 1) {
+                        const float4* tp = sc.tris + (size_t)lt.tri * 3;
+                        float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                        q0 = xyz(a0); q1 = xyz(a1); q2 = xyz(a2);
+                        lflip = (__float_as_uint(a1.w) >> 31) != 0;
+                        // Triangle::sample (Enigma/TriangleMesh.cpp:604-632)
+                        float su1 = sqrtf(ulx);
+                        float tb0 = 1.f - su1, tb1 = uly * su1;
+                        lp = tb0 * q0 + tb1 * q1 + (1 - tb0 - tb1) * q2;
+                        ln = normalize(cross(q1 - q0, q2 - q0));
+                        if (lflip) ln = ln * -1.f;
+                        lpErr = gammaf(6) * (fabs3(tb0 * q0) + fabs3(tb1 * q1) + fabs3((1 - tb0 - tb1) * q2));
+                        lightPdf = 1 / lt.area;
+                        // Shape::sample(ref, u) (Enigma/Shape.cpp:54-69)
+                        F3 w = lp - g.p;
+                        if (lengthSqr(w) == 0) lightPdf = 0;
+                        else {
+                            w = normalize(w);
+                            lightPdf *= lengthSqr(g.p - lp) / absdot(ln, -w);
+                            if (isinf(lightPdf)) lightPdf = 0.f;
+                        }
+                        // DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
+                        if (lightPdf == 0 || lengthSqr(lp - g.p) == 0) lightPdf = 0;
+                        else {
+                            wi = normalize(lp - g.p);
+                            if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+                        }
+                    } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124)
+                        lp = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
+                        wi = normalize(lp - g.p);
+                        lightPdf = 1.f;
+                        Li = F3(lt.L[0], lt.L[1], lt.L[2]) / lengthSqr(lp - g.p);
+                    }
+                    if (lightPdf > 0 && !isBlack(Li)) {
+                        F3 f = bsdfF(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
+                        float scatteringPdf = bsdfPdf(bsdf, woN, wi, kNonSpecular);
+                        if (!isBlack(f)) {
+                            // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
+                            F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
+                            F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
+                            shO = origin; shD = target - origin;
+                            F3 Ld;
+                            if (lt.type == 0) Ld = f * Li / lightPdf;
+                            else Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
+                            shW = beta * (Ld / pick);
+                            pushShadow = true;
+                        }
+                    }
+                    // ---- EstimateDirect: BSDF sampling (Enigma/Integrator.cpp:150-199) ----
+                    if (lt.type == 1) {
+                        F3 wi2(0.f);
+                        float scatPdf2; int sampledType;
+                        F3 f2 = bsdfSample(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
+                        f2 = f2 * absdot(wi2, ns);
+                        if (!isBlack(f2) && scatPdf2 > 0) {
+                            // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
+                            F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
+                            RaySetup rs = setupRay(o2, wi2);
+                            float lt_t, lb0, lb1, lb2;
+                            float lightPdf2 = 0.f;
+                            if (triangleTest(rs, EDEV_INF, q0, q1, q2, &lt_t, &lb0, &lb1, &lb2)) {
+                                F3 pl = lb0 * q0 + lb1 * q1 + lb2 * q2;
+                                F3 nl = normalize(cross(q0 - q2, q1 - q2));
+                                lightPdf2 = lengthSqr(g.p - pl) / (absdot(nl, -wi2) * lt.area);
+                                if (isinf(lightPdf2)) lightPdf2 = 0.f;
+                            }
+                            if (lightPdf2 != 0) {
+                                float weight = powerHeuristic(scatPdf2, lightPdf2);
+                                miO = o2; miD = wi2;
+                                miW = beta * ((f2 * weight / scatPdf2) / pick);
+                                miLight = lightNum;
+                                pushMis = true;
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- BSDF sampling for the next path vertex (Enigma/PathIntegrator.cpp:114-175) ----
+            F3 wo = -d, wi(0.f);
+            float pdf; int flags;
+            float u0 = sampleDimension(S, px, py, slot, dim), u1 = sampleDimension(S, px, py, slot, dim + 1);
+            dim += 2;
+            F3 f = bsdfSample(bsdf, wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+            if (!(isBlack(f) || pdf == 0.f)) {
+                beta *= f * absdot(wi, ns) / pdf;
+                uint32_t spec = (flags & BSDF_SPECULAR) ? 1u : 0u;
+                if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                    float eta = bsdf.eta;
+                    etaScale *= (dot(wo, g.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                }
+                F3 no = offsetRayOrigin(g.p, g.pError, g.n, wi); // isect.SpawnRay(wi)
+                bool alive = true;
+                F3 rrBeta = beta * etaScale;
+                if (maxComponentValue(rrBeta) < I.rrThreshold && bounces > 3) {
+                    float q = smax(.05f, 1.0f - maxComponentValue(rrBeta));
+                    float ur = sampleDimension(S, px, py, slot, dim);
+                    dim += 1;
+                    if (ur < q) alive = false;
+                    else beta = beta / (1 - q);
+                }
+                if (alive) {
+                    P.rayO[p] = mk4(no, 0.f);
+                    P.rayD[p] = mk4(wi, 0.f);
+                    P.beta[p] = mk4(beta, etaScale);
+                    P.state[p] = packState(slot, dim, bounces + 1, spec);
+                    pushNext = true;
+                }
+            }
+        }
+        uint32_t s;
+        s = blockReserve(pushShadow, &ctr->shadowCount, lds);
+        if (pushShadow) {
+            shq.o[s] = mk4(shO, __uint_as_float(p));
+            shq.d[s] = mk4(shD, 1 - kShadowEpsilon);
+            shq.w[s] = mk4(shW, 0.f);
+        }
+        s = blockReserve(pushMis, &ctr->misCount, lds);
+        if (pushMis) {
+            misq.o[s] = mk4(miO, __uint_as_float(p));
+            misq.d[s] = mk4(miD, __int_as_float(miLight));
+            misq.w[s] = mk4(miW, 0.f);
+        }
+        s = blockReserve(pushNext, &ctr->extCount[nextIdx], lds);
+        if (pushNext) nextQueue[s] = p;
+    }
+}
+
+// VisibilityTester::Unoccluded for the shadow queue: unoccluded rays add their contribution.
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue q, DevCounters* ctr) {
+    __shared__ uint32_t stack[STACK * kBlock];
+    const uint32_t count = ctr->shadowCount;
+    uint32_t* myStack = stack + threadIdx.x;
+    for (;;) {
+        uint32_t base = waveFetch(&ctr->workNext[1]);
+        if (base >= count) break;
+        uint32_t i = base + (threadIdx.x & 63u);
+        if (i < count) {
+            float4 o = q.o[i], d = q.d[i];
+            if (!traceAny<STACK, kBlock>(sc, xyz(o), xyz(d), d.w, myStack)) {
+                uint32_t p = __float_as_uint(o.w);
+                float4 w = q.w[i], L = P.L[p];
+                P.L[p] = make_float4(L.x + w.x, L.y + w.y, L.z + w.z, 0.f);
+            }
+        }
+    }
+}
+
+// The BSDF-sampled ray of EstimateDirect: closest hit must be the sampled light's triangle.
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue q, DevCounters* ctr) {
+    __shared__ uint32_t stack[STACK * kBlock];
+    const uint32_t count = ctr->misCount;
+    uint32_t* myStack = stack + threadIdx.x;
+    for (;;) {
+        uint32_t base = waveFetch(&ctr->workNext[2]);
+        if (base >= count) break;
+        uint32_t i = base + (threadIdx.x & 63u);
+        if (i < count) {
+            float4 o = q.o[i], d = q.d[i];
+            Hit h = traceClosest<STACK, kBlock>(sc, xyz(o), xyz(d), EDEV_INF, myStack);
+            if (h.tri >= 0) {
+                const float4* tp = sc.tris + (size_t)h.tri * 3;
+                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                int lightIdx = __float_as_int(v2.w);
+                if (lightIdx == __float_as_int(d.w)) { // lightIsect.m_primitive->getAreaLight() == &light
+                    const DevLight& lt = sc.lights[lightIdx];
+                    F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
+                    if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
+                        uint32_t p = __float_as_uint(o.w);
+                        float4 w = q.w[i], L = P.L[p];
+                        F3 add = xyz(w) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// FilmTile::AddSample footprint (Enigma/Film.cpp:263-300).  SINK(x, y, weight) per covered pixel.
+template <class SINK>
+DEV void filmFootprint(const DevFilm& F, float fx, float fy, SINK sink) {
+    float pdx = fx - 0.5f, pdy = fy - 0.5f;
+    int p0x = (int)ceilf(pdx - F.radiusX), p0y = (int)ceilf(pdy - F.radiusY);
+    int p1x = (int)floorf(pdx + F.radiusX) + 1, p1y = (int)floorf(pdy + F.radiusY) + 1;
+    p0x = max(p0x, F.x0); p0y = max(p0y, F.y0);
+    p1x = min(p1x, F.x1); p1y = min(p1y, F.y1);
+    for (int y = p0y; y < p1y; ++y) {
+        float fyv = fabsf(((float)y - pdy) * F.invRadiusY * 16.f);
+        int iy = min((int)floorf(fyv), 15);
+        for (int x = p0x; x < p1x; ++x) {
+            float fxv = fabsf(((float)x - pdx) * F.invRadiusX * 16.f);
+            int ix = min((int)floorf(fxv), 15);
+            sink(x, y, F.filterTable[iy * 16 + ix]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, uint32_t nPaths) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nPaths) return;
+    F3 L = xyz(P.L[i]);
+    // Enigma/Integrator.cpp:284-292
+    float y = luminance(L);
+    if (isnan(L.x) || isnan(L.y) || isnan(L.z)) L = F3(0.f);
+    else if ((double)y < -1e-5) L = F3(0.f);
+    else if (isinf(y)) L = F3(0.f);
+    float2 pf = P.pfilm[i];
+    float ly = luminance(L);
+    if (ly > F.maxSampleLuminance) L = L * (F.maxSampleLuminance / ly);
+    const int width = F.x1 - F.x0;
+    filmFootprint(F, pf.x, pf.y, [&](int x, int yy, float w) {
+        float* px = reinterpret_cast<float*>(F.pixels + ((size_t)(yy - F.y0) * width + (x - F.x0)));
+        F3 c = L * 1.f * w; // L * sampleWeight * filterWeight
+        atomicAdd(px + 0, c.x); atomicAdd(px + 1, c.y); atomicAdd(px + 2, c.z); atomicAdd(px + 3, w);
+    });
+}
+
+// Between stages: account rays, reset the queues the next stage fills, rewind work cursors.
+// phase 0: before a bounce's k_intersect_closest.  phase 1: after the shade kernels.  phase 2: after shadow/mis.
+__global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t countImm, int useImm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (phase == 0) {
+        ctr->raysClosest += useImm ? countImm : ctr->extCount[curIdx];
+        for (int k = 0; k < MK_COUNT; ++k) ctr->matCount[k] = 0;
+        ctr->workNext[0] = 0;
+        ctr->extCount[curIdx ^ 1u] = 0;
+        ctr->shadowCount = 0; ctr->misCount = 0;
+    } else if (phase == 1) {
+        ctr->raysShadow += ctr->shadowCount;
+        ctr->raysMis += ctr->misCount;
+        ctr->workNext[1] = 0; ctr->workNext[2] = 0;
+    }
+}
+
+// ---------------------------------------------------------------- debug taps
+__global__ void k_debug_sobol(DevSampler S, uint32_t n, const int32_t* pixels, const uint32_t* slots, uint32_t nDims, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (uint32_t d = 0; d < nDims; ++d) out[(size_t)i * nDims + d] = sampleDimension(S, pixels[2 * i], pixels[2 * i + 1], slots[i], d);
+}
+__global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int32_t* pixels, const uint32_t* slots, float* outRay, float* outPfilm) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px = pixels[2 * i], py = pixels[2 * i + 1];
+    uint32_t slot = slots[i];
+    float fx = (float)px + sampleDimension(S, px, py, slot, 0);
+    float fy = (float)py + sampleDimension(S, px, py, slot, 1);
+    float lu = 0.f, lv = 0.f;
+    if (C.lensRadius > 0.f) { lu = sampleDimension(S, px, py, slot, 3); lv = sampleDimension(S, px, py, slot, 4); }
+    F3 o, d;
+    cameraRay(C, fx, fy, lu, lv, &o, &d);
+    float* r = outRay + 6 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+    outPfilm[2 * (size_t)i] = fx; outPfilm[2 * (size_t)i + 1] = fy;
+}
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
+                                                            uint32_t* primOut, float* tOut, float* baryOut) {
+    __shared__ uint32_t stack[STACK * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays7 + 7 * (size_t)i;
+    F3 o(r[0], r[1], r[2]), d(r[3], r[4], r[5]);
+    if (anyHit) {
+        triOut[i] = traceAny<STACK, kBlock>(sc, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
+        return;
+    }
+    Hit h = traceClosest<STACK, kBlock>(sc, o, d, r[6], stack + threadIdx.x);
+    int orig = -1;
+    if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
+    triOut[i] = orig;
+    primOut[i] = orig >= 0 ? sc.primId[orig] : 0u;
+    tOut[i] = h.tri >= 0 ? h.t : EDEV_INF;
+    baryOut[3 * (size_t)i] = h.b0; baryOut[3 * (size_t)i + 1] = h.b1; baryOut[3 * (size_t)i + 2] = h.b2;
+}
+__global__ void k_debug_footprint(DevFilm F, uint32_t n, const float* pfilm, uint32_t maxPer, int32_t* pixOut, float* wOut, uint32_t* countOut) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = 0;
+    filmFootprint(F, pfilm[2 * i], pfilm[2 * i + 1], [&](int x, int y, float w) {
+        if (c < maxPer) {
+            pixOut[((size_t)i * maxPer + c) * 2] = x; pixOut[((size_t)i * maxPer + c) * 2 + 1] = y;
+            wOut[(size_t)i * maxPer + c] = w;
+        }
+        ++c;
+    });
+    countOut[i] = c;
+}
+
+} // namespace edev
