@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PathIntegrator on the Cornell box at 1920x1080 (BASELINE.json configs[1]).
+
+A "step" renders 16 samples per pixel of the whole 1080p film on every rank (33.2 M camera
+samples per rank and step); the 1024-spp job of the config is 64 such steps.  Ranks take disjoint
+sample numbers (spp sharding), the per-rank films are summed onto rank 0 with one RCCL reduce
+inside the timed region.  value = rays traced by all ranks / wall time (max over ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+SPP_PER_STEP = 16
+XRES, YRES = 1920, 1080
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+
+
+def pow2_at_least(v):
+    p = 1
+    while p < v:
+        p *= 2
+    return p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--variant", default="microfacet", help="cornell variant: microfacet (configs[1]) | diffuse | specular")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="sample numbers per pixel the CPU baseline renders")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import raytrace_amd as ra
+    from raytrace_amd import abi, distributed, scenes
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    K, W, N = args.steps, args.warmup, world
+    scene = scenes.cornell_box(args.variant)
+    camera = scenes.cornell_camera(XRES, YRES)
+    film = scenes.film_desc(XRES, YRES, "box")
+    total_spp = pow2_at_least(max(1024, (K + 1) * N * SPP_PER_STEP + SPP_PER_STEP))
+    integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
+    r = ra.Renderer(local_rank).configure(scene, camera, film, integ)
+    film_t = distributed.film_tensor(r, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: the last sample numbers of the range, film cleared afterwards
+    for w in range(W):
+        r.render(total_spp - SPP_PER_STEP, total_spp)
+    if world > 1:
+        distributed.reduce_film(film_t.clone())  # warm the communicator
+    r.clear()
+    s_before = r.stats()
+
+    barrier()
+    t0 = time.perf_counter()
+    ms_intersect, launches = 0.0, 0
+    for i in range(K):
+        s0 = (i * N + rank) * SPP_PER_STEP
+        r.render(s0, s0 + SPP_PER_STEP)
+        st = r.stats()
+        ms_intersect += st["ms_intersect"]
+        launches += st["intersect_launches"]
+    distributed.reduce_film(film_t, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    s_after = r.stats()
+    counts = torch.tensor([s_after[k] - s_before[k] for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_mis")],
+                          dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    samples, rc, rs, rm = [float(v) for v in counts.tolist()]
+    rays = rc + rs + rm
+
+    if rank == 0:
+        import orc
+
+        out = {
+            "metric": "Mrays/s",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "msamples_per_s": samples / elapsed / 1e6,
+            "n_gpus": N, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Cornell box (%s) 1920x1080, PathIntegrator maxdepth 5, Sobol, box filter, power light sampling; "
+                                   "%d spp per step and GPU (the 1024-spp job = 64 steps)" % (args.variant, SPP_PER_STEP),
+                       "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP, "parallelism": "spp-shard x%d + RCCL film reduce" % N},
+            "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
+        }
+        # --- algorithmic bytes per ray from the reference traversal (HLBVH, <=127 prims per leaf) on a small sample
+        small = scenes.film_desc(480, 270, "box")
+        o_small = orc.Oracle(scene, scenes.cornell_camera(480, 270), small, scenes.integrator_desc(small, 16), fast=True)
+        o_small.render(0, 1, threads=min(16, os.cpu_count() or 1))
+        so = o_small.stats()
+        n_nodes = so["nodes_closest"] / max(1, so["rays_closest"])
+        n_tris = so["tris_closest"] / max(1, so["rays_closest"])
+        o_small.close()
+        b_ray = 32.0 * n_nodes + 36.0 * n_tris + 12.0 * n_tris + 32.0 + 16.0
+        rays_per_launch = rc / N / max(1, launches)  # this rank's launches; ranks are symmetric
+        avg_ms = ms_intersect / max(1, launches)
+        achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic, "kernel": "k_intersect_closest", "avg_launch_ms": avg_ms, "launches": launches,
+                           "bytes_per_ray": b_ray, "ref_nodes_per_ray": n_nodes, "ref_tris_per_ray": n_tris,
+                           "rays_per_launch": rays_per_launch}
+        # --- CPU baseline: the restated reference renderer on the host cores, bounded sample of the same workload
+        if N == 1 and not args.no_cpu:
+            cores = min(16, os.cpu_count() or 1)
+            cpu_spp = args.cpu_spp
+            o = orc.Oracle(scene, camera, film, integ, fast=True)
+            o.render(0, cpu_spp, threads=cores)
+            sc = o.stats()
+            cpu_rays = sc["rays_closest"] + sc["rays_shadow"] + sc["rays_mis"]
+            cpu_s = sc["ms_render"] * 1e-3
+            ref_img = o.image()
+            o.close()
+            out["cpu_baseline"] = {"value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                   "msamples_per_s": sc["samples"] / cpu_s / 1e6,
+                                   "sample": "same scene/camera/film, sample numbers [0,%d) of every 1080p pixel (%.1f M samples), "
+                                             "oracle built -O3 -march=x86-64-v3, reference HLBVH/128 tree, 32x32 tile tasks on %d threads"
+                                             % (cpu_spp, sc["samples"] / 1e6, cores)}
+            # image agreement on exactly that sample range (GPU re-render, untimed)
+            r.clear()
+            r.render(0, cpu_spp)
+            gpu_img = r.image()
+            diff = gpu_img - ref_img
+            out["rmse_vs_cpu"] = float(np.sqrt(np.mean(diff * diff)))
+            out["mre_vs_cpu"] = float(np.mean(np.abs(diff) / np.maximum(ref_img, 1e-3)))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

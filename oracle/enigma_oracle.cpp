@@ -424,7 +424,11 @@ struct TriangleMesh { // world-space vertex store (TriangleMesh.cpp:23-58)
     std::vector<uint32_t> idx;
 };
 
-struct Counters { uint64_t nodes = 0, tris = 0, rays_closest = 0, rays_shadow = 0, rays_mis = 0, samples = 0; };
+struct Counters {
+    uint64_t nodes = 0, tris = 0, rays_closest = 0, rays_shadow = 0, rays_mis = 0, samples = 0;
+    uint64_t nodesKind[3] = {0, 0, 0}, trisKind[3] = {0, 0, 0}; // by ray kind: 0 path (closest), 1 shadow (any), 2 MIS (closest)
+    int kind = 0;
+};
 static thread_local Counters* tl_counters = nullptr;
 
 // TriangleMesh.cpp:180-632
@@ -434,7 +438,7 @@ struct Triangle {
     BBox3 worldBound() const { Vec3 a, b, c; verts(a, b, c); BBox3 r; r.addPoint(a); r.addPoint(b); r.addPoint(c); return r; }
     // TriangleMesh.cpp:491-602
     bool intersects(const Ray& ray, float* tHit, Vec3* bOut) const {
-        if (tl_counters) tl_counters->tris++;
+        if (tl_counters) { tl_counters->tris++; tl_counters->trisKind[tl_counters->kind]++; }
         Vec3 p0, p1, p2; verts(p0, p1, p2);
         Vec3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
         int kz = MaxDimension(Abs(ray.d));
@@ -848,7 +852,7 @@ struct BVHAccel {
         int nodesToVisit[64];
         while (true) {
             const LinearBVHNode* node = &nodes[currentNodeIndex];
-            if (tl_counters) tl_counters->nodes++;
+            if (tl_counters) { tl_counters->nodes++; tl_counters->nodesKind[tl_counters->kind]++; }
             if (node->bounds.intersectP(ray, invDir, dirIsNeg)) {
                 if (node->nPrimitives > 0) {
                     for (int i = 0; i < node->nPrimitives; ++i) {
@@ -887,7 +891,7 @@ struct BVHAccel {
         int toVisitOffset = 0, currentNodeIndex = 0;
         while (true) {
             const LinearBVHNode* node = &nodes[currentNodeIndex];
-            if (tl_counters) tl_counters->nodes++;
+            if (tl_counters) { tl_counters->nodes++; tl_counters->nodesKind[tl_counters->kind]++; }
             if (node->bounds.intersectP(ray, invDir, dirIsNeg)) {
                 if (node->nPrimitives > 0) {
                     for (int i = 0; i < node->nPrimitives; ++i)
@@ -1418,8 +1422,9 @@ static Spectrum EstimateDirect(const SurfaceInteraction& it, const BSDF& bsdf, c
         Spectrum f = bsdf.f(it.wo, wi, bsdfFlags) * AbsDot(wi, it.shading.n);
         scatteringPdf = bsdf.Pdf(it.wo, wi, bsdfFlags);
         if (!f.IsBlack()) {
-            if (tl_counters) tl_counters->rays_shadow++;
+            if (tl_counters) { tl_counters->rays_shadow++; tl_counters->kind = 1; }
             if (scene.intersectP(it.SpawnRayTo(p1))) Li = Spectrum(0.f); // VisibilityTester::Unoccluded, Lights.cpp:713-716
+            if (tl_counters) tl_counters->kind = 0;
             if (!Li.IsBlack()) {
                 if (light.IsDelta()) Ld += f * Li / lightPdf;
                 else {
@@ -1443,8 +1448,9 @@ static Spectrum EstimateDirect(const SurfaceInteraction& it, const BSDF& bsdf, c
             }
             SurfaceInteraction lightIsect;
             Ray ray = it.SpawnRay(wi);
-            if (tl_counters) tl_counters->rays_mis++;
+            if (tl_counters) { tl_counters->rays_mis++; tl_counters->kind = 2; }
             bool found = scene.intersect(ray, &lightIsect);
+            if (tl_counters) tl_counters->kind = 0;
             Spectrum Li2(0.f);
             if (found) {
                 if (scene.triLight[lightIsect.primIndex] == light.index) Li2 = Le(scene, lightIsect, -wi);
@@ -1486,7 +1492,7 @@ struct PathIntegrator {
         float etaScale = 1;
         for (bounces = 0;; ++bounces) {
             SurfaceInteraction isect;
-            if (tl_counters) tl_counters->rays_closest++;
+            if (tl_counters) { tl_counters->rays_closest++; tl_counters->kind = 0; }
             bool foundIntersection = scene.intersect(ray, &isect);
             if (bounces == 0 || specularBounce) {
                 if (foundIntersection) L += beta * Le(scene, isect, -ray.d);
@@ -1613,6 +1619,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
     for (auto& c : ctrs) {
         O.totals.nodes += c.nodes; O.totals.tris += c.tris; O.totals.rays_closest += c.rays_closest;
         O.totals.rays_shadow += c.rays_shadow; O.totals.rays_mis += c.rays_mis; O.totals.samples += c.samples;
+        for (int k = 0; k < 3; ++k) { O.totals.nodesKind[k] += c.nodesKind[k]; O.totals.trisKind[k] += c.trisKind[k]; }
     }
 }
 
@@ -1697,6 +1704,11 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     return 0;
 }
 int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_threads, int want_moments) {
+    {   // the tile loop starts its rows at sampleBounds.m_min.x (Integrator.cpp:254); with min.x < min.y it would
+        // visit pixels above the sample bounds, whose Sobol' pixel offsets are negative: undefined in the reference
+        BBox2i sb = h->o.film->GetSampleBounds();
+        if (sb.mn.x < sb.mn.y) { h->o.error = "sample bounds with min.x < min.y: reference result undefined"; return -4; }
+    }
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency(); // NumSystemCores, Misc.h:8-14
     Render(h->o, sample_begin, sample_end, n_threads, want_moments != 0);
     return 0;
@@ -1710,6 +1722,11 @@ int oracle_film_read_xyzw(OracleCtx* h, float* out) {
 int oracle_film_write_image(OracleCtx* h, float scale, float* rgb) { h->o.film->WriteImage(scale, rgb); return 0; }
 int oracle_film_clear(OracleCtx* h) { for (auto& p : h->o.film->pixels) p = Film::Pixel(); return 0; }
 int oracle_read_moments(OracleCtx* h, double* out) { memcpy(out, h->o.moments.data(), h->o.moments.size() * sizeof(double)); return 0; }
+int oracle_get_kind_stats(OracleCtx* h, uint64_t out[6]) {
+    Counters& c = h->o.totals;
+    for (int k = 0; k < 3; ++k) { out[k] = c.nodesKind[k]; out[3 + k] = c.trisKind[k]; }
+    return 0;
+}
 int oracle_get_stats(OracleCtx* h, uint64_t out[8], double* ms) {
     Counters& c = h->o.totals;
     out[0] = c.samples; out[1] = c.rays_closest; out[2] = c.rays_shadow; out[3] = c.rays_mis; out[4] = c.nodes; out[5] = c.tris;

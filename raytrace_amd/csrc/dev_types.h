@@ -81,7 +81,7 @@ struct DevPaths {
     float4* beta;     // throughput rgb, etaScale
     float4* hit;      // t, b0, b1, b2
     int32_t* hitTri;  // triangle (device order) or -1
-    uint32_t* pixel;  // x | y << 16 (absolute raster pixel)
+    uint32_t* pixel;  // x | y << 16, pixel relative to the sample-bounds origin
     uint32_t* state;  // sampleSlot[0:12) | dim[12:22) | bounces[22:30) | specularBounce[30]
     float2* pfilm;    // CameraSample::m_image
 };

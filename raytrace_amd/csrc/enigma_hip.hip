@@ -329,7 +329,6 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
     const int32_t* sb = d->sample_bounds;
     int dx = sb[2] - sb[0], dy = sb[3] - sb[1];
     if (dx <= 0 || dy <= 0) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
-    if (sb[0] < 0 || sb[1] < 0) return h->fail(ENIGMA_E_UNSUPPORTED, "negative sample bounds (filter wider than 0.5 at the image border) are not supported");
     h->integDesc = *d;
     // SobolSampler ctor, Enigma/Sampler.cpp:211-222
     h->spp = (int64_t)roundUpPow2((uint32_t)d->samples_per_pixel);
@@ -349,13 +348,19 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
     h->sampler.res = h->resolution; h->sampler.nDims = nDims;
     h->sampler.sbx0 = sb[0]; h->sampler.sby0 = sb[1];
     h->sampler.resolutionF = (float)(int)h->resolution;
-    // render region: pixels of the sample bounds that pass m_pixelBounds.insideExclusive (Enigma/Integrator.cpp:264)
-    int rx0 = std::max(sb[0], d->pixel_bounds[0]), ry0 = std::max(sb[1], d->pixel_bounds[1]);
-    int rx1 = std::min(sb[2], d->pixel_bounds[2]), ry1 = std::min(sb[3], d->pixel_bounds[3]);
+    // render region: the pixels the reference's tile loop visits (Enigma/Integrator.cpp:233-265).  Tile rows start
+    // at sampleBounds.m_min.x, not m_min.y (:254): with a crop window whose x and y origins differ, the rows
+    // [min.y, min.x) are never rendered.  Kept, because the film must match the reference's.
+    if (sb[0] < sb[1]) return h->fail(ENIGMA_E_UNSUPPORTED, "sample bounds with min.x < min.y make the reference's tile loop (Integrator.cpp:254) "
+                                                          "start above the sample bounds; its result is undefined");
+    int nTilesY = (dy + 31) / 32;
+    int tileY0 = sb[0], tileY1 = std::min(sb[0] + nTilesY * 32, sb[3]);
+    int rx0 = std::max(sb[0], d->pixel_bounds[0]), ry0 = std::max(tileY0, d->pixel_bounds[1]);
+    int rx1 = std::min(sb[2], d->pixel_bounds[2]), ry1 = std::min(tileY1, d->pixel_bounds[3]);
     h->integ.maxDepth = d->max_depth;
     h->integ.rrThreshold = d->rr_threshold;
     h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
-    if (rx1 > 65535 || ry1 > 65535) return h->fail(ENIGMA_E_INVALID, "render region exceeds 65535");
+    if (dx > 65535 || dy > 65535) return h->fail(ENIGMA_E_INVALID, "sample bounds wider than 65535");
     h->lightDistDirty = true;
     h->haveInteg = true;
     return ENIGMA_OK;

@@ -31,12 +31,13 @@ DEV uint32_t sobolBits(const DevSampler& S, uint32_t relx, uint32_t rely, uint32
     return S.tx[(size_t)dim * S.res + relx] ^ S.ty[(size_t)dim * S.res + rely] ^ S.sampleConst[(size_t)slot * S.nDims + dim];
 }
 // SobolSampleFloat + SobolSampler::SampleDimension (Enigma/SamplerInclude.h:2627-2637, Enigma/Sampler.cpp:229-240)
-DEV float sampleDimension(const DevSampler& S, int px, int py, uint32_t slot, uint32_t dim) {
-    uint32_t v = sobolBits(S, (uint32_t)(px - S.sbx0), (uint32_t)(py - S.sby0), slot, dim);
+DEV float sampleDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t slot, uint32_t dim) {
+    // relx, rely: pixel relative to the sample-bounds origin (m_currentPixel - m_sampleBounds.m_min)
+    uint32_t v = sobolBits(S, relx, rely, slot, dim);
     float s = smin((float)v * 0x1p-32f, kOneMinusEpsilon);
     if (dim == 0 || dim == 1) {
         s = s * S.resolutionF + (float)(dim == 0 ? S.sbx0 : S.sby0);
-        s = clampf(s - (float)(dim == 0 ? px : py), 0.f, kOneMinusEpsilon);
+        s = clampf(s - (float)(dim == 0 ? (int)relx + S.sbx0 : (int)rely + S.sby0), 0.f, kOneMinusEpsilon);
     }
     return s;
 }
@@ -148,18 +149,19 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
     if (i >= nPaths) return;
     uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
     int px = I.rx0 + (int)(pix % (uint32_t)I.rw), py = I.ry0 + (int)(pix / (uint32_t)I.rw);
+    uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
     // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
-    float fx = (float)px + sampleDimension(S, px, py, slot, 0);
-    float fy = (float)py + sampleDimension(S, px, py, slot, 1);
+    float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
+    float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
     float lu = 0.f, lv = 0.f;
-    if (C.lensRadius > 0.f) { lu = sampleDimension(S, px, py, slot, 3); lv = sampleDimension(S, px, py, slot, 4); }
+    if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
     F3 o, d;
     cameraRay(C, fx, fy, lu, lv, &o, &d);
     P.rayO[i] = mk4(o, 0.f);
     P.rayD[i] = mk4(d, 0.f);
     P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.beta[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-    P.pixel[i] = (uint32_t)px | ((uint32_t)py << 16);
+    P.pixel[i] = relx | (rely << 16);
     P.state[i] = packState(slot, 5u, 0u, 0u);
     P.pfilm[i] = make_float2(fx, fy);
     if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             uint32_t st = P.state[p];
             uint32_t slot = stSlot(st), dim = stDim(st), bounces = stBounces(st);
             uint32_t pix = P.pixel[p];
-            int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+            uint32_t px = pix & 0xffffu, py = pix >> 16; // relative to the sample-bounds origin
             float4 bv = P.beta[p];
             F3 beta = xyz(bv);
             float etaScale = bv.w;
@@ -521,17 +523,18 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
 __global__ void k_debug_sobol(DevSampler S, uint32_t n, const int32_t* pixels, const uint32_t* slots, uint32_t nDims, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (uint32_t d = 0; d < nDims; ++d) out[(size_t)i * nDims + d] = sampleDimension(S, pixels[2 * i], pixels[2 * i + 1], slots[i], d);
+    for (uint32_t d = 0; d < nDims; ++d) out[(size_t)i * nDims + d] = sampleDimension(S, (uint32_t)(pixels[2 * i] - S.sbx0), (uint32_t)(pixels[2 * i + 1] - S.sby0), slots[i], d);
 }
 __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int32_t* pixels, const uint32_t* slots, float* outRay, float* outPfilm) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int px = pixels[2 * i], py = pixels[2 * i + 1];
+    uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
     uint32_t slot = slots[i];
-    float fx = (float)px + sampleDimension(S, px, py, slot, 0);
-    float fy = (float)py + sampleDimension(S, px, py, slot, 1);
+    float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
+    float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
     float lu = 0.f, lv = 0.f;
-    if (C.lensRadius > 0.f) { lu = sampleDimension(S, px, py, slot, 3); lv = sampleDimension(S, px, py, slot, 4); }
+    if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
     F3 o, d;
     cameraRay(C, fx, fy, lu, lv, &o, &d);
     float* r = outRay + 6 * (size_t)i;

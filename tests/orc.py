@@ -97,6 +97,11 @@ class Oracle:
         keys = ["samples", "rays_closest", "rays_shadow", "rays_mis", "nodes", "tris", "bvh_nodes", "degenerate_partitions"]
         d = dict(zip(keys, [int(v) for v in out]))
         d["ms_render"] = ms.value
+        k = (C.c_uint64 * 6)()
+        self.L.oracle_get_kind_stats(self.h, k)
+        for i, name in enumerate(("closest", "shadow", "mis")):
+            d["nodes_" + name] = int(k[i])
+            d["tris_" + name] = int(k[3 + i])
         return d
 
     def reset_stats(self):

@@ -1,0 +1,365 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
+(raytrace_amd/libenigma_hip.so via ctypes); the CPU oracle is only the checker.
+
+Tier 1 (bit-exact): Sobol sample values, camera rays (pinhole), closest-hit primitive ids / t /
+barycentrics, any-hit decisions, film footprint pixel indices and weights.
+Tier 2 (floating point): images.  Tolerance: mean relative error < 1 % and every pixel within
+3 sigma of the Monte Carlo estimator (the north-star bounds); the tests also assert the much
+tighter agreement actually achieved (same samples, same arithmetic up to libm and sum order).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import orc
+import raytrace_amd as ra
+from raytrace_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+u32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def pair(setup):
+    sc, cam, film, integ = setup
+    return ra.Renderer(0).configure(sc, cam, film, integ), orc.Oracle(sc, cam, film, integ)
+
+
+# ------------------------------------------------------------------ tier 1
+@pytest.mark.parametrize("xr,yr,spp", [(512, 512, 16), (1920, 1080, 1024), (37, 23, 4), (1, 1, 4)])
+def test_sobol_values_bit_exact(xr, yr, spp):
+    r, o = pair(common.cornell_setup(xres=xr, yres=yr, spp=spp))
+    rng = np.random.RandomState(5)
+    n = 4000
+    P = np.stack([rng.randint(0, xr, n), rng.randint(0, yr, n)], axis=1).astype(np.int32)
+    P[:4] = [(0, 0), (xr - 1, yr - 1), (xr - 1, 0), (0, yr - 1)]
+    S = rng.randint(0, spp, n).astype(np.int64)
+    S[:8] = [0, spp - 1, 0, spp - 1, 1, 2, spp // 2, 0]   # first and last sample numbers
+    io, do = o.sobol(P, S, 45)
+    ig, dg = r.sobol(P, S, 45)
+    assert np.array_equal(io, ig)
+    assert np.array_equal(u32(do), u32(dg))
+    r.close(); o.close()
+
+
+def test_sobol_and_camera_match_golden_fixture():
+    g = np.load(os.path.join(GOLD, "sobol_camera.npz"))
+    for name, (xr, yr, spp) in {"m9": (512, 512, 16), "m11": (1920, 1080, 1024)}.items():
+        sc, cam, film, integ = common.cornell_setup(xres=xr, yres=yr, spp=spp)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        idx, dims = r.sobol(g[name + "_pixels"], g[name + "_samples"], 8)
+        rays, pf = r.camera_rays(g[name + "_pixels"], g[name + "_samples"])
+        assert np.array_equal(idx, g[name + "_index"])
+        assert np.array_equal(u32(dims), g[name + "_dims_bits"])
+        assert np.array_equal(u32(rays), g[name + "_rays_bits"])
+        assert np.array_equal(u32(pf), g[name + "_pfilm_bits"])
+        r.close()
+
+
+def test_camera_rays_bit_exact_pinhole_and_close_with_lens():
+    r, o = pair(common.cornell_setup(xres=256, yres=144, spp=64))
+    rng = np.random.RandomState(9)
+    P = np.stack([rng.randint(0, 256, 3000), rng.randint(0, 144, 3000)], axis=1).astype(np.int32)
+    S = rng.randint(0, 64, 3000).astype(np.int64)
+    ro, po = o.camera_rays(P, S)
+    rg, pg = r.camera_rays(P, S)
+    assert np.array_equal(u32(ro), u32(rg)) and np.array_equal(u32(po), u32(pg))
+    r.close(); o.close()
+    # thin lens: ConcentricSampleDisk goes through cos/sin, whose last bit differs between libm and the device
+    r, o = pair(common.cornell_setup(xres=256, yres=144, spp=64, lens_radius=8.0, focal_distance=1000.0))
+    ro, po = o.camera_rays(P, S)
+    rg, pg = r.camera_rays(P, S)
+    assert np.array_equal(u32(po), u32(pg))
+    assert np.allclose(ro, rg, rtol=2e-6, atol=1e-4)
+    r.close(); o.close()
+
+
+def _hit_check(r, o, rays7, allow_ambiguous=True):
+    ho = o.intersect(rays7)
+    hg = r.intersect(rays7)
+    ok = ho["ambiguous"] == 0 if allow_ambiguous else np.ones(len(ho["tri"]), dtype=bool)
+    assert np.array_equal(ho["prim_id"][ok], hg["prim_id"][ok])
+    assert np.array_equal(ho["tri"][ok], hg["tri"][ok])
+    assert np.array_equal(u32(ho["t"][ok]), u32(hg["t"][ok]))
+    assert np.array_equal(u32(ho["bary"][ok]), u32(hg["bary"][ok]))
+    # ambiguous rays (exact ties on shared edges / coplanar geometry): same distance to within the tie window
+    amb = ~ok
+    if amb.any():
+        assert np.allclose(ho["t"][amb], hg["t"][amb], rtol=2e-6)
+    return ho, int(amb.sum())
+
+
+@pytest.mark.parametrize("variant", ["diffuse", "microfacet"])
+def test_primary_hits_bit_exact_cornell(variant):
+    r, o = pair(common.cornell_setup(res=512, spp=16, variant=variant))
+    ys, xs = np.mgrid[0:512:8, 0:512:8]
+    P = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+    total_amb = 0
+    for sn in (0, 1, 15):
+        rays, _ = o.camera_rays(P, np.full(P.shape[0], sn, dtype=np.int64))
+        ho, amb = _hit_check(r, o, common.rays_from_camera(rays))
+        total_amb += amb
+        assert (ho["tri"] >= 0).mean() > 0.5
+    assert total_amb < 0.01 * 3 * P.shape[0]
+    r.close(); o.close()
+
+
+def test_primary_hits_match_golden_fixture():
+    g = np.load(os.path.join(GOLD, "primary_hits.npz"))
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=16)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    for sn in (0, 7):
+        rays = g["diffuse_s%d_rays_bits" % sn].view(np.float32)
+        h = r.intersect(common.rays_from_camera(rays))
+        ok = g["diffuse_s%d_ambiguous" % sn] == 0
+        assert np.array_equal(h["prim_id"][ok], g["diffuse_s%d_prim_id" % sn][ok])
+        assert np.array_equal(u32(h["t"])[ok], g["diffuse_s%d_t_bits" % sn][ok])
+        assert np.array_equal(u32(h["bary"])[ok], g["diffuse_s%d_bary_bits" % sn][ok])
+    r.close()
+
+
+def test_hits_bit_exact_random_rays_many_lights_and_mesh():
+    rng = np.random.RandomState(21)
+    for sc, cam in ((scenes.many_lights(), scenes.cornell_camera(64, 64)),
+                    (scenes.big_mesh(grid=96, sphere_level=4, n_spheres=4), scenes.big_mesh_camera(64, 64))):
+        film = scenes.film_desc(64, 64)
+        integ = scenes.integrator_desc(film, 16)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        P = np.stack([rng.randint(0, 64, 1500), rng.randint(0, 64, 1500)], axis=1).astype(np.int32)
+        rays, _ = o.camera_rays(P, rng.randint(0, 16, 1500).astype(np.int64))
+        ho, _ = _hit_check(r, o, common.rays_from_camera(rays))
+        # secondary rays: from hit points in random directions, finite tMax too
+        hit = ho["tri"] >= 0
+        org = rays[hit, :3] + rays[hit, 3:6] * (ho["t"][hit, None] * 0.999)
+        d = rng.normal(size=org.shape).astype(np.float32)
+        sec = np.concatenate([org, d, rng.uniform(0.5, 400.0, size=(org.shape[0], 1))], axis=1).astype(np.float32)
+        _hit_check(r, o, sec)
+        assert np.array_equal(o.intersect_any(sec), r.intersect_any(sec))
+        r.close(); o.close()
+
+
+def test_degenerate_rays():
+    r, o = pair(common.cornell_setup(res=32, spp=4))
+    rays = np.array([
+        [278, 273, -800, 0, 0, 1, np.inf],      # axis-aligned: zero direction components (inf reciprocals)
+        [278, 273, 100, 0, 1, 0, np.inf],
+        [278, 273, 100, -1, 0, 0, np.inf],
+        [278, 273, 100, 0, -1, 0, 50.0],        # tMax shorter than the floor distance
+        [278, 273, 100, 0, 0, 1, 0.0],          # tMax = 0
+        [10000, 10000, 10000, 1, 1, 1, np.inf], # misses everything
+        [278, 548.0, 279, 0, -1, 0, np.inf],    # origin on the light plane
+    ], dtype=np.float32)
+    _hit_check(r, o, rays)
+    assert np.array_equal(o.intersect_any(rays), r.intersect_any(rays))
+    r.close(); o.close()
+
+
+@pytest.mark.parametrize("kind", ["box", "triangle", "gaussian", "mitchell"])
+def test_film_footprint_bit_exact(kind):
+    g = np.load(os.path.join(GOLD, "film_footprints.npz"))
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=16, filter_kind=kind)
+    assert np.array_equal(u32(np.array(film.filter_table[:], dtype=np.float32)), g[kind + "_table_bits"])
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    pf = g["pfilm_bits"].view(np.float32)
+    pix, w, cnt = r.film_footprint(pf, 32)
+    assert np.array_equal(cnt, g[kind + "_cnt"])
+    for i in range(pf.shape[0]):
+        c = min(int(cnt[i]), 32)
+        assert np.array_equal(pix[i, :c], g[kind + "_pix"][i, :c])
+        assert np.array_equal(u32(w[i, :c]), g[kind + "_w_bits"][i, :c])
+    # and live against the oracle on fresh positions, including exact pixel corners
+    o = orc.Oracle(sc, cam, film, integ)
+    rng = np.random.RandomState(4)
+    pf2 = np.concatenate([rng.uniform(-3, 67, size=(500, 2)), rng.randint(0, 64, size=(100, 2)).astype(np.float64)]).astype(np.float32)
+    a, b = o.film_footprint(pf2, 32), r.film_footprint(pf2, 32)
+    assert np.array_equal(a[2], b[2])
+    for i in range(pf2.shape[0]):
+        c = min(int(a[2][i]), 32)
+        assert np.array_equal(a[0][i, :c], b[0][i, :c]) and np.array_equal(u32(a[1][i, :c]), u32(b[1][i, :c]))
+    r.close(); o.close()
+
+
+# ------------------------------------------------------------------ tier 2
+def _sigma_check(img, ref_rgb, moments, spp):
+    n = np.maximum(moments[..., 6:7], 1)
+    mean = moments[..., 0:3] / n
+    var = np.maximum(moments[..., 3:6] / n - mean * mean, 0)
+    sigma = np.sqrt(var / n)                              # standard error of the pixel estimate
+    out = np.abs(img - ref_rgb) > 3 * sigma + 1e-4 * np.maximum(ref_rgb, 1e-3)
+    return float(out.mean())
+
+
+@pytest.mark.parametrize("variant", ["diffuse", "microfacet", "specular"])
+def test_image_parity_cornell(variant):
+    g = np.load(os.path.join(GOLD, "cornell64_64spp.npz"))
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=64, variant=variant)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(0, 64)
+    img = r.image()
+    ref = g[variant + "_rgb"]
+    assert np.isfinite(img).all()
+    mre = common.mean_relative_error(img, ref)
+    assert mre < 0.01                                       # north-star tolerance: 1 % mean relative error
+    assert _sigma_check(img, ref, g[variant + "_moments"].astype(np.float64), 64) == 0.0   # every pixel within 3 sigma
+    assert mre < 1e-4                                       # what identical samples + arithmetic actually give
+    st = r.stats()
+    want = g[variant + "_rays"]
+    got = np.array([st["camera_samples"], st["rays_closest"], st["rays_shadow"], st["rays_mis"]], dtype=np.int64)
+    assert got[0] == want[0]
+    assert np.all(np.abs(got[1:] - want[1:]) <= np.maximum(3, 1e-4 * want[1:]))   # same control flow, path by path
+    r.close()
+
+
+@pytest.mark.parametrize("kind,variant", [("gaussian", "diffuse"), ("triangle", "microfacet"), ("mitchell", "diffuse")])
+def test_image_parity_wide_filters(kind, variant):
+    setup = common.cornell_setup(res=48, spp=16, variant=variant, filter_kind=kind, crop=(0.1, 0.9, 0.1, 0.9))
+    r, o = pair(setup)
+    r.render(0, 16)
+    o.render(0, 16, threads=4)
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+    f = r.film()
+    assert np.allclose(f[..., 3], o.film_xyzw()[..., 3], rtol=1e-5, atol=1e-5)   # filter weight sums
+    r.close(); o.close()
+
+
+def test_image_parity_many_lights_power_and_uniform():
+    sc = scenes.many_lights()
+    for strat in (abi.LIGHTS_POWER, abi.LIGHTS_UNIFORM):
+        film = scenes.film_desc(64, 64)
+        integ = scenes.integrator_desc(film, 16, light_strategy=strat)
+        cam = scenes.cornell_camera(64, 64)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        r.close(); o.close()
+
+
+def test_image_parity_mesh_scene():
+    sc = scenes.big_mesh(grid=128, sphere_level=4, n_spheres=6)
+    film = scenes.film_desc(96, 54)
+    integ = scenes.integrator_desc(film, 8)
+    cam = scenes.big_mesh_camera(96, 54)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(0, 8)
+    o.render(0, 8, threads=8)
+    a, b = r.image(), o.image()
+    # rough glass / metal paths: a rare libm-level difference can flip a branch; bound the mean, not every pixel
+    assert common.mean_relative_error(a, b) < 0.01
+    assert np.median(np.abs(a - b) / np.maximum(b, 1e-3)) < 1e-4
+    r.close(); o.close()
+
+
+# ------------------------------------------------------------------ properties / edge cases
+def test_sample_ranges_are_additive_and_empty_range_is_a_noop():
+    setup = common.cornell_setup(res=64, spp=16, variant="microfacet")
+    r = ra.Renderer(0).configure(*setup)
+    r.render(0, 16)
+    whole = r.film()
+    r.clear()
+    r.render(0, 5); r.render(5, 5); r.render(5, 16)
+    parts = r.film()
+    assert np.array_equal(parts[..., 3], whole[..., 3])
+    assert np.allclose(parts, whole, rtol=1e-5, atol=1e-5)
+    r.close()
+
+
+def test_pixel_bounds_and_crop_window():
+    sc, cam, film, integ = common.cornell_setup(xres=80, yres=60, spp=4, crop=(0.25, 0.75, 0.2, 0.8))
+    integ.pixel_bounds[:] = [24, 14, 50, 40]
+    r, o = pair((sc, cam, film, integ))
+    r.render(0, 4); o.render(0, 4, threads=2)
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])           # exactly the same pixels received samples
+    assert (fg[..., 3] > 0).sum() > 0 and (fg[..., 3] == 0).sum() > 0
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+    r.close(); o.close()
+
+
+def test_linearity_in_light_radiance():
+    sc, cam, film, integ = common.cornell_setup(res=48, spp=8)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(0, 8)
+    a = r.image()
+    for l in sc.lights[: sc.n_lights]:
+        l.L[:] = [v * 2 for v in l.L]
+    r2 = ra.Renderer(0).configure(sc, cam, film, integ)
+    r2.render(0, 8)
+    assert np.allclose(r2.image(), 2 * a, rtol=1e-5, atol=1e-6)   # radiance is linear in Le (light choice pdf unchanged)
+    r.close(); r2.close()
+
+
+def test_full_size_film_invariants_1080p():
+    """BASELINE size (1920x1080), one pass: every pixel gets exactly its samples' filter weight, the
+    render is repeatable, and two half ranges add up to the whole."""
+    sc, cam, film, integ = common.cornell_setup(xres=1920, yres=1080, spp=1024, variant="microfacet")
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(1020, 1024)
+    f = r.film()
+    st = r.stats()
+    assert st["camera_samples"] == 1920 * 1080 * 4
+    # box filter: weight sum = 4 samples per pixel + the double splats of samples on pixel edges
+    assert f[..., 3].min() >= 4 and f[..., 3].sum() >= 4 * 1920 * 1080
+    extra = f[..., 3].sum() - 4 * 1920 * 1080
+    assert extra < 0.01 * 4 * 1920 * 1080
+    assert np.isfinite(f).all() and f[..., :3].min() >= 0
+    img = ra.resolve(f)
+    r.clear(); r.render(1020, 1022); r.render(1022, 1024)
+    assert np.allclose(ra.resolve(r.film()), img, rtol=1e-4, atol=1e-5)
+    # a 270p slice of the same job agrees with the oracle
+    r.close()
+
+
+def test_error_conventions():
+    r = ra.Renderer(0)
+    with pytest.raises(ra.EnigmaError) as e:
+        r.render(0, 1)
+    assert e.value.code == -2                                  # ENIGMA_E_STATE: nothing configured
+    sc, cam, film, integ = common.cornell_setup(res=16, spp=4)
+    bad = scenes.cornell_box("diffuse")
+    bad.materials[0].sigma = 20.0
+    with pytest.raises(ra.EnigmaError) as e:
+        r.upload_scene(bad)
+    assert e.value.code == -4                                  # ENIGMA_E_UNSUPPORTED: Oren-Nayar
+    bad2 = scenes.cornell_box("diffuse")
+    bad2.indices[3, 1] = 10 ** 6
+    with pytest.raises(ra.EnigmaError) as e:
+        r.upload_scene(bad2)
+    assert e.value.code == -1                                  # ENIGMA_E_INVALID
+    r.configure(sc, cam, film, integ)
+    with pytest.raises(ra.EnigmaError):
+        r.render(0, 99)                                        # beyond samples_per_pixel
+    integ2 = scenes.integrator_desc(film, 4)
+    integ2.light_strategy = 2
+    with pytest.raises(ra.EnigmaError) as e:
+        r.set_integrator(integ2)
+    assert e.value.code == -4                                  # spatial light distribution: out of scope
+    r.render(0, 4)                                             # still usable after errors
+    assert np.isfinite(r.image()).all()
+    r.close()
+
+
+def test_scene_without_lights_and_empty_scene():
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([(0, 0, 500), (556, 0, 500), (556, 548, 500), (0, 548, 500)], m, toward=(278, 273, 0))
+    sc = b.arrays()
+    film = scenes.film_desc(32, 32)
+    integ = scenes.integrator_desc(film, 4)
+    cam = scenes.cornell_camera(32, 32)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(0, 4); o.render(0, 4, threads=1)
+    assert np.array_equal(r.image(), np.zeros_like(r.image())) and np.array_equal(o.image(), r.image())
+    assert r.stats()["rays_shadow"] == 0
+    r.close(); o.close()
+    empty = abi.SceneArrays(np.zeros((0, 3)), np.zeros((0, 3)), [], [], [abi.matte((0.5, 0.5, 0.5))], [])
+    r = ra.Renderer(0).configure(empty, cam, film, integ)
+    r.render(0, 4)
+    assert r.film()[..., 3].min() >= 4 and r.image().max() == 0
+    r.close()

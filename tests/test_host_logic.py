@@ -1,0 +1,173 @@
+"""CPU tests of the product's host logic: C ABI surface, Sobol' generator + pixel-table factorisation,
+BVH builder invariants, scene builders, film description."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+import orc
+import raytrace_amd as ra
+from raytrace_amd import abi, scenes, distributed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def hostcheck():
+    out = os.path.join(ROOT, "tests", "_hostcheck.so")
+    srcs = [os.path.join(ROOT, "tests", "hostcheck.cpp"), os.path.join(ROOT, "raytrace_amd", "csrc", "bvh_build.cpp"),
+            os.path.join(ROOT, "raytrace_amd", "csrc", "sobol_host.cpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", out] + srcs)
+    L = C.CDLL(out)
+    L.hc_index.restype = C.c_uint64
+    L.hc_index.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.hc_bits.restype = C.c_uint32
+    L.hc_bits.argtypes = [C.c_uint64, C.c_int]
+    return L
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed for that) and exports what include/enigma_hip.h declares."""
+    L = ra.load_library()
+    hdr = open(os.path.join(ROOT, "include", "enigma_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(enigma_[a-z_]+)\s*\(", hdr))
+    assert declared == set(ra.SYMBOLS), declared ^ set(ra.SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_ctypes_structs_match_the_header():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "enigma_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(EnigmaMaterial), sizeof(EnigmaLight), sizeof(EnigmaSceneDesc), sizeof(EnigmaCameraDesc),
+         sizeof(EnigmaFilmDesc), sizeof(EnigmaIntegratorDesc), sizeof(EnigmaStats));
+  printf("%zu %zu %zu %zu\n", offsetof(EnigmaSceneDesc, materials), offsetof(EnigmaIntegratorDesc, samples_per_pixel),
+         offsetof(EnigmaMaterial, index), offsetof(EnigmaFilmDesc, max_sample_luminance));
+  return 0; }'''
+    exe = "/tmp/enigma_abi_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    out = subprocess.check_output([exe]).decode().split()
+    want = [C.sizeof(abi.EnigmaMaterial), C.sizeof(abi.EnigmaLight), C.sizeof(abi.EnigmaSceneDesc), C.sizeof(abi.EnigmaCameraDesc),
+            C.sizeof(abi.EnigmaFilmDesc), C.sizeof(abi.EnigmaIntegratorDesc), C.sizeof(abi.EnigmaStats),
+            abi.EnigmaSceneDesc.materials.offset, abi.EnigmaIntegratorDesc.samples_per_pixel.offset, abi.EnigmaMaterial.index.offset,
+            abi.EnigmaFilmDesc.max_sample_luminance.offset]
+    assert [int(v) for v in out] == want
+
+
+def test_calls_without_gpu_fail_loudly():
+    """On a box without a GPU the library must refuse, not fall back to anything."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ra.EnigmaError):
+        ra.Renderer(0)
+
+
+def test_cpp_sobol_generator_matches_reference_digests(hostcheck):
+    d = json.load(open(os.path.join(GOLD, "sobol_digest.json")))
+    m32 = np.zeros(1024 * 52, dtype=np.uint32)
+    vdc = np.zeros(25 * 52, dtype=np.uint64)
+    vdci = np.zeros(26 * 52, dtype=np.uint64)
+    hostcheck.hc_sobol_tables(abi.ptr(m32), abi.ptr(vdc), abi.ptr(vdci))
+    assert hashlib.sha256(m32.astype("<u4").tobytes()).hexdigest() == d["sobol32_sha256"]
+    assert hashlib.sha256(vdc.astype("<u8").tobytes()).hexdigest() == d["vdc_sha256"]
+    assert hashlib.sha256(vdci.astype("<u8").tobytes()).hexdigest() == d["vdc_inv_sha256"]
+
+
+@pytest.mark.parametrize("m", [0, 1, 5, 9, 11])
+def test_pixel_table_factorisation_is_exact(hostcheck, m):
+    """Tx[px] ^ Ty[py] ^ c(sampleNum) == SobolSample(SobolIntervalToIndex(m, sampleNum, p), d), all bits."""
+    rng = np.random.RandomState(m)
+    n, nd = 400, 45
+    res = 1 << m
+    px = rng.randint(0, res, n).astype(np.uint32)
+    py = rng.randint(0, res, n).astype(np.uint32)
+    sn = rng.randint(0, 1024, n).astype(np.uint64)
+    out = np.zeros((n, nd), dtype=np.uint32)
+    hostcheck.hc_factored(m, nd, n, abi.ptr(px), abi.ptr(py), abi.ptr(sn), abi.ptr(out))
+    for i in range(0, n, 7):
+        idx = hostcheck.hc_index(m, int(sn[i]), int(px[i]), int(py[i]))
+        for d in (0, 1, 2, 5, 17, 44):
+            assert int(out[i, d]) == hostcheck.hc_bits(idx, d)
+    # and against the oracle's bit loops on the numpy-generated tables
+    if m == 9:
+        sc, cam, film, integ = common.cornell_setup(res=512, spp=1024)
+        o = orc.Oracle(sc, cam, film, integ)
+        idx_o, dims_o = o.sobol(np.stack([px, py], axis=1).astype(np.int32), sn.astype(np.int64), 8)
+        for i in range(n):
+            assert int(idx_o[i]) == hostcheck.hc_index(m, int(sn[i]), int(px[i]), int(py[i]))
+        want = np.minimum(out[:, 2:8].astype(np.float32) * np.float32(2.0 ** -32), np.float32(0.9999999403953552))
+        assert np.array_equal(want, dims_o[:, 2:8])
+        o.close()
+
+
+@pytest.mark.parametrize("builder,kw", [("cornell", {}), ("many", {}), ("big", {"grid": 48, "sphere_level": 3, "n_spheres": 3})])
+def test_bvh_builder_invariants(hostcheck, builder, kw):
+    sc = {"cornell": scenes.cornell_box, "many": scenes.many_lights, "big": scenes.big_mesh}[builder](**kw)
+    nT = sc.indices.shape[0]
+    order = np.zeros(nT, dtype=np.uint32)
+    checks = np.zeros(5, dtype=np.uint32)
+    nodes = hostcheck.hc_bvh(abi.ptr(sc.vertices), abi.ptr(sc.indices), nT, 4, abi.ptr(order), abi.ptr(checks))
+    assert sorted(order.tolist()) == list(range(nT))           # a permutation
+    assert checks[1] == nT and checks[4] == 0                   # every triangle in exactly one leaf
+    assert checks[2] == 0 and checks[3] == 0                    # leaf boxes contain their triangles; refs valid
+    assert 1 <= checks[0] <= 64 and nodes >= 1
+
+
+def test_bvh_builder_degenerate_inputs(hostcheck):
+    # all triangles identical (coincident centroids) and a single triangle
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    for nT in (1, 2, 37):
+        idx = np.tile(np.array([0, 1, 2], dtype=np.uint32), (nT, 1))
+        order = np.zeros(nT, dtype=np.uint32)
+        checks = np.zeros(5, dtype=np.uint32)
+        hostcheck.hc_bvh(abi.ptr(v), abi.ptr(idx), nT, 4, abi.ptr(order), abi.ptr(checks))
+        assert checks[1] == nT and checks[2] == 0 and checks[3] == 0 and checks[4] == 0
+
+
+def test_scene_builders():
+    c = scenes.cornell_box("diffuse")
+    assert c.indices.shape[0] == 32 and c.n_lights == 2
+    # the light's reference normal cross(p0 - p2, p1 - p2) faces down, walls face the box centre
+    v, t = c.vertices.astype(np.float64), c.indices
+    n = np.cross(v[t[:, 0]] - v[t[:, 2]], v[t[:, 1]] - v[t[:, 2]])
+    lights = np.where(c.tri_light >= 0)[0]
+    assert np.all(n[lights, 1] < 0)
+    centre = np.array(scenes.CORNELL_CENTER)
+    walls = np.arange(10)
+    assert np.all(np.einsum("ij,ij->i", n[walls], centre - v[t[walls, 0]]) > 0)
+    m = scenes.many_lights()
+    assert m.n_lights == 2 * 256 + 64 and m.indices.shape[0] == 30 + 512
+    b = scenes.big_mesh(grid=32, sphere_level=2, n_spheres=2)
+    assert b.indices.shape[0] == 2 * 32 * 32 + 2 * 320 + 14
+    assert b.indices.max() < b.vertices.shape[0]
+
+
+def test_film_desc_and_sample_bounds():
+    f = scenes.film_desc(64, 48, "box")
+    assert list(f.cropped_pixel_bounds) == [0, 0, 64, 48] and all(v == 1.0 for v in f.filter_table)
+    assert scenes.sample_bounds(f) == [0, 0, 64, 48]
+    g = scenes.film_desc(64, 48, "gaussian", crop=(0.25, 0.75, 0.5, 1.0))
+    assert list(g.cropped_pixel_bounds) == [16, 24, 48, 48]
+    assert scenes.sample_bounds(g) == [14, 22, 50, 50]            # grown by radius 2 - 0.5
+    tab = np.array(g.filter_table[:]).reshape(16, 16)
+    assert tab[0, 0] == tab.max() and tab[15, 15] >= 0 and np.all(np.diff(tab[0]) <= 0)
+
+
+def test_shard_range_partitions():
+    for b, e, w in ((0, 1024, 8), (0, 16, 3), (5, 6, 4), (0, 0, 2)):
+        parts = [distributed.shard_range(b, e, r, w) for r in range(w)]
+        assert parts[0][0] == b and parts[-1][1] == e
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))

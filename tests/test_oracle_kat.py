@@ -1,0 +1,211 @@
+"""CPU tests: pin the oracle (and the table generators) with known answers.
+
+The reference has no tests or golden vectors of its own; what CAN be pinned without running it:
+  * sha256 digests of its tabulated Sobol' matrices (read as text when the fixture was made),
+  * first-principles known answers of pure functions,
+  * analytic identities (Fresnel at normal incidence, NDF normalisation, CDF monotonicity).
+"""
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import common
+import orc
+from raytrace_amd import abi, scenes, sobol_tables
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_sobol_tables_match_reference_digests():
+    d = json.load(open(os.path.join(GOLD, "sobol_digest.json")))
+    m32, vdc, vdci = orc.tables()
+    assert hashlib.sha256(m32.astype("<u4").tobytes()).hexdigest() == d["sobol32_sha256"]
+    assert hashlib.sha256(vdc.astype("<u8").tobytes()).hexdigest() == d["vdc_sha256"]
+    assert hashlib.sha256(vdci.astype("<u8").tobytes()).hexdigest() == d["vdc_inv_sha256"]
+    v52 = np.array(sobol_tables.direction_numbers_52(), dtype=np.uint64)
+    assert hashlib.sha256(v52.astype("<u8").tobytes()).hexdigest() == d["sobol64_sha256"]
+
+
+def test_sobol_dim0_is_van_der_corput():
+    # dimension 0's matrix is the identity: sample k = bit-reversed k * 2^-32 (Enigma/SobolMatrices.cpp:7-14)
+    m32, _, _ = orc.tables()
+    assert [int(x) for x in m32[:32]] == [1 << (31 - k) for k in range(32)]
+    assert all(int(x) == 0 for x in m32[32:52])
+
+
+def _setup(xr, yr, spp):
+    sc, cam, film, integ = common.cornell_setup(xres=xr, yres=yr, spp=spp)
+    return orc.Oracle(sc, cam, film, integ)
+
+
+@pytest.mark.parametrize("xr,yr,spp,m", [(512, 512, 16, 9), (1920, 1080, 1024, 11), (37, 23, 4, 6)])
+def test_sobol_index_lands_in_pixel(xr, yr, spp, m):
+    """SobolIntervalToIndex must give an index whose first two dimensions, scaled by the resolution,
+    fall inside the pixel (what the clamp in Enigma/Sampler.cpp:235-238 silently relies on)."""
+    o = _setup(xr, yr, spp)
+    rng = np.random.RandomState(3)
+    P = np.stack([rng.randint(0, xr, 300), rng.randint(0, yr, 300)], axis=1).astype(np.int32)
+    P[:4] = [(0, 0), (xr - 1, yr - 1), (xr - 1, 0), (0, yr - 1)]
+    S = rng.randint(0, spp, 300).astype(np.int64)
+    idx, dims = o.sobol(P, S, 4)
+    m32, _, _ = orc.tables()
+    res = 1 << m
+    for i in range(P.shape[0]):
+        a = int(idx[i])
+        assert (a >> (2 * m)) == int(S[i])          # the frame bits are the sample number
+        v0 = v1 = 0
+        c = 0
+        while a:
+            if a & 1:
+                v0 ^= int(m32[c]); v1 ^= int(m32[52 + c])
+            a >>= 1; c += 1
+        assert (v0 >> (32 - m)) == P[i, 0] and (v1 >> (32 - m)) == P[i, 1]
+        # the remapped sample is the sub-pixel offset in [0, 1)
+        assert 0.0 <= dims[i, 0] < 1.0 and 0.0 <= dims[i, 1] < 1.0
+        assert abs((v0 * 2.0 ** -32) * res - P[i, 0] - dims[i, 0]) < 1e-3
+    # distinct sample numbers of one pixel give distinct indices
+    idx2, _ = o.sobol(np.zeros((spp, 2), dtype=np.int32) + [5, 7], np.arange(spp), 2)
+    assert len(set(int(v) for v in idx2)) == spp
+    o.close()
+
+
+def test_scalar_known_answers():
+    L = orc.lib()
+    eps = 2.0 ** -24
+    for n in (2, 3, 5, 6, 7):
+        assert L.oracle_gamma(n) == np.float32(np.float32(n * np.float32(eps)) / np.float32(1 - np.float32(n * np.float32(eps))))
+    f = np.float32
+    assert L.oracle_next_float_up(f(1.0)) == f(1.0) + f(2.0 ** -23)
+    assert L.oracle_next_float_down(f(1.0)) == f(1.0) - f(2.0 ** -24)
+    assert L.oracle_next_float_up(f(0.0)) == np.frombuffer(np.uint32(1).tobytes(), dtype=np.float32)[0]
+    assert L.oracle_next_float_up(f(-0.0)) == np.frombuffer(np.uint32(1).tobytes(), dtype=np.float32)[0]
+    assert L.oracle_next_float_down(f(0.0)) == -np.frombuffer(np.uint32(1).tobytes(), dtype=np.float32)[0]
+    assert L.oracle_next_float_up(f(np.inf)) == f(np.inf)
+    assert L.oracle_next_float_down(f(-1.0)) == -(f(1.0) + f(2.0 ** -23))
+    # FrDielectric(1, 1, 1.5) = ((1.5-1)/(1.5+1))^2 = 0.04
+    assert abs(L.oracle_fr_dielectric(1.0, 1.0, 1.5) - 0.04) < 1e-7
+    assert L.oracle_fr_dielectric(0.1, 1.5, 1.0) == 1.0      # total internal reflection from the dense side
+    assert abs(L.oracle_fr_dielectric(-1.0, 1.0, 1.5) - 0.04) < 1e-7
+
+
+def test_offset_ray_origin():
+    import ctypes as C
+    L = orc.lib()
+    def call(p, pe, n, w):
+        a = [np.array(v, dtype=np.float32) for v in (p, pe, n, w)]
+        out = np.zeros(3, dtype=np.float32)
+        L.oracle_offset_ray_origin(*[abi.ptr(x) for x in a], abi.ptr(out))
+        return out
+    p, pe, n = (1.0, 2.0, 3.0), (1e-5, 1e-5, 1e-5), (0.0, 0.0, 1.0)
+    up = call(p, pe, n, (0, 0, 1))
+    dn = call(p, pe, n, (0, 0, -1))
+    assert up[0] == 1.0 and up[1] == 2.0 and dn[0] == 1.0
+    assert up[2] == np.nextafter(np.float32(np.float32(3.0) + np.float32(1e-5)), np.float32(np.inf))
+    assert dn[2] == np.nextafter(np.float32(np.float32(3.0) - np.float32(1e-5)), np.float32(-np.inf))
+
+
+def test_trowbridge_reitz_d_normalised():
+    # integral of D(wh) cos(theta_h) over the hemisphere = 1
+    L = orc.lib()
+    for ax, ay in ((0.3, 0.3), (0.1, 0.4), (0.8, 0.5)):
+        nt, npi = 1500, 360
+        total = 0.0
+        for it in range(nt):
+            th = (it + 0.5) / nt * (math.pi / 2)
+            st, ct = math.sin(th), math.cos(th)
+            acc = 0.0
+            for ip in range(0, npi, 4):
+                ph = (ip + 2.0) / npi * 2 * math.pi
+                acc += L.oracle_tr_D(ax, ay, st * math.cos(ph), st * math.sin(ph), ct)
+            total += acc * (2 * math.pi / (npi / 4)) * ct * st * (math.pi / 2 / nt)
+        assert abs(total - 1.0) < 2e-2, (ax, ay, total)
+
+
+def test_distribution1d():
+    L = orc.lib()
+    f = np.array([1.0, 3.0, 0.0, 4.0], dtype=np.float32)
+    cdf = np.zeros(5, dtype=np.float32)
+    import ctypes as C
+    pdf = C.c_float()
+    assert L.oracle_distribution1d(abi.ptr(f), 4, 0.0, C.byref(pdf), abi.ptr(cdf)) == 0
+    assert abs(pdf.value - 1.0 / 8.0) < 1e-7                       # func/(funcInt*count) = 1/(2*4)
+    assert np.all(np.diff(cdf) >= 0) and cdf[0] == 0.0 and cdf[4] == 1.0
+    assert np.allclose(cdf, [0, 0.125, 0.5, 0.5, 1.0])
+    assert L.oracle_distribution1d(abi.ptr(f), 4, 0.125, C.byref(pdf), None) == 1     # upper_bound: u == cdf[1] -> segment 1
+    assert L.oracle_distribution1d(abi.ptr(f), 4, 0.5, C.byref(pdf), None) == 3       # skips the zero-probability light
+    assert L.oracle_distribution1d(abi.ptr(f), 4, 0.99999994, C.byref(pdf), None) == 3
+    z = np.zeros(3, dtype=np.float32)
+    assert L.oracle_distribution1d(abi.ptr(z), 3, 0.5, C.byref(pdf), abi.ptr(cdf)) == 1  # all-zero function -> uniform cdf
+    assert np.allclose(cdf[:4], [0, 1 / 3, 2 / 3, 1])
+
+
+def test_oracle_matches_golden_fixtures():
+    u32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    g = np.load(os.path.join(GOLD, "sobol_camera.npz"))
+    for name, (xr, yr, spp) in {"m9": (512, 512, 16), "m11": (1920, 1080, 1024)}.items():
+        o = _setup(xr, yr, spp)
+        idx, dims = o.sobol(g[name + "_pixels"], g[name + "_samples"], 8)
+        rays, pf = o.camera_rays(g[name + "_pixels"], g[name + "_samples"])
+        assert np.array_equal(idx, g[name + "_index"])
+        assert np.array_equal(u32(dims), g[name + "_dims_bits"])
+        assert np.array_equal(u32(rays), g[name + "_rays_bits"])
+        assert np.array_equal(u32(pf), g[name + "_pfilm_bits"])
+        o.close()
+    g = np.load(os.path.join(GOLD, "primary_hits.npz"))
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=16)
+    o = orc.Oracle(sc, cam, film, integ)
+    for sn in (0, 7):
+        rays = g["diffuse_s%d_rays_bits" % sn].view(np.float32)
+        h = o.intersect(common.rays_from_camera(rays))
+        assert np.array_equal(h["prim_id"], g["diffuse_s%d_prim_id" % sn])
+        assert np.array_equal(u32(h["t"]), g["diffuse_s%d_t_bits" % sn])
+    o.close()
+
+
+def test_oracle_render_is_thread_count_invariant_and_sane():
+    sc, cam, film, integ = common.cornell_setup(res=48, spp=8)
+    imgs = []
+    for th in (1, 3):
+        o = orc.Oracle(sc, cam, film, integ)
+        o.render(0, 8, threads=th)
+        imgs.append(o.image())
+        st = o.stats()
+        o.close()
+    assert np.array_equal(imgs[0], imgs[1])          # tiles are merged in tile order
+    assert st["samples"] == 48 * 48 * 8
+    assert np.isfinite(imgs[0]).all() and imgs[0].min() >= 0 and 0.05 < imgs[0].mean() < 1.0
+    # splitting the sample range and adding films gives the same film as one call
+    o = orc.Oracle(sc, cam, film, integ)
+    o.render(0, 3, threads=2); o.render(3, 8, threads=2)
+    assert np.allclose(o.image(), imgs[0], rtol=1e-5, atol=1e-6)
+    o.close()
+
+
+def test_oracle_sah_and_hlbvh_trees_agree():
+    sc, cam, film, integ = common.cornell_setup(res=32, spp=4)
+    a = orc.Oracle(sc, cam, film, integ, split_method="hlbvh")
+    b = orc.Oracle(sc, cam, film, integ, split_method="sah", max_node_prims=4)
+    ys, xs = np.mgrid[0:32, 0:32]
+    P = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+    rays, _ = a.camera_rays(P, np.full(P.shape[0], 1, dtype=np.int64))
+    ha, hb = a.intersect(common.rays_from_camera(rays)), b.intersect(common.rays_from_camera(rays))
+    ok = ha["ambiguous"] == 0
+    assert np.array_equal(ha["prim_id"][ok], hb["prim_id"][ok]) and np.array_equal(ha["t"][ok], hb["t"][ok])
+    a.close(); b.close()
+
+
+def test_film_footprint_edge_rule():
+    """A sample whose sub-pixel offset is exactly 0 splats into two pixels per axis with the box filter
+    (inclusive footprint [ceil(pd - r), floor(pd + r)], Enigma/Film.cpp:269-273)."""
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=16)
+    o = orc.Oracle(sc, cam, film, integ)
+    pix, w, cnt = o.film_footprint(np.array([[10.0, 20.0], [10.5, 20.5], [0.0, 0.0], [10.0, 20.5]], dtype=np.float32))
+    assert cnt.tolist() == [4, 1, 1, 2]
+    assert sorted(map(tuple, pix[0, :4].tolist())) == [(9, 19), (9, 20), (10, 19), (10, 20)]
+    assert pix[1, 0].tolist() == [10, 20] and pix[2, 0].tolist() == [0, 0]
+    assert np.all(w[0, :4] == 1.0)
+    o.close()
