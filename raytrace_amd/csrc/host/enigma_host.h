@@ -1,0 +1,395 @@
+// Host-side mirror of the reference's interface for the PathIntegrator path (C++17, header only).
+//
+// Same class and method names, argument meaning and error behaviour as the reference's public
+// interface for this path, so host code written against Enigma reads the same:
+//   Integrator / SamplerIntegrator        Enigma/Integrator.h:35-70
+//   PathIntegrator ctor arguments         Enigma/PathIntegrator.cpp:30-39, CreatePathIntegrator :182-201
+//   Scene (m_lights, worldBound)          Enigma/Scene.h:20-33
+//   Camera / ProjectiveCamera / PerspectiveCamera public data   Enigma/Camera.h:40-76
+//   Film / FilmTile / FilmTilePixel       Enigma/Film.h:24-114, Enigma/Film.cpp:39-125,157-209
+//   Filter hierarchy                      Enigma/Filter.h:8-117
+//   Sampler / SobolSampler public data    Enigma/Sampler.h:13-50,143-158, Enigma/Sampler.cpp:211-222
+//   TriangleMesh public data              Enigma/TriangleMesh.h:28-37
+// What differs, on purpose:
+//  * Transform holds the FINAL numeric matrix (m_mat[r][c] as used by transformPoint,
+//    Enigma/Transform.h:36-45); the reference's transpose-on-construct composition is not rebuilt.
+//  * Scene carries a flat registry (meshes, materials, lights) filled at creation time: the
+//    reference's primitives/materials are private behind shared_ptr graphs (Enigma/BVH.h:52,
+//    Enigma/Primitive.h:59-62) and cannot be read back by an integrator.
+//  * GpuPathIntegrator::Render does the work on the MI355X through the C ABI (enigma_hip.h) and
+//    deposits the film through ONE FilmTile covering the cropped pixel bounds + MergeFilmTile +
+//    WriteImage, exactly like the reference's tile tasks do (Enigma/Integrator.cpp:295-321).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/enigma_hip.h"
+
+namespace RayTrace {
+
+struct Vector2i { int x = 0, y = 0; Vector2i() {} Vector2i(int a, int b) : x(a), y(b) {} };
+struct Vector2f { float x = 0, y = 0; Vector2f() {} Vector2f(float a, float b) : x(a), y(b) {} float operator[](int i) const { return i ? y : x; } };
+struct Vector3f { float x = 0, y = 0, z = 0; Vector3f() {} Vector3f(float a, float b, float c) : x(a), y(b), z(c) {} };
+struct BBox2i { Vector2i m_min, m_max; BBox2i() {} BBox2i(Vector2i a, Vector2i b) : m_min(a), m_max(b) {}
+    int area() const { return (m_max.x - m_min.x) * (m_max.y - m_min.y); } };
+struct BBox2f { Vector2f m_min{0, 0}, m_max{1, 1}; };
+static constexpr float InfinityF32 = std::numeric_limits<float>::infinity();
+
+// RGBSpectrum (Enigma/Spectrum.h:295-313): three floats
+class Spectrum {
+public:
+    Spectrum(float v = 0.f) { c[0] = c[1] = c[2] = v; }
+    Spectrum(float r, float g, float b) { c[0] = r; c[1] = g; c[2] = b; }
+    float& operator[](int i) { return c[i]; }
+    float operator[](int i) const { return c[i]; }
+    void ToXYZ(float xyz[3]) const { // Enigma/Spectrum.h:28-32
+        xyz[0] = 0.412453f * c[0] + 0.357580f * c[1] + 0.180423f * c[2];
+        xyz[1] = 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2];
+        xyz[2] = 0.019334f * c[0] + 0.119193f * c[1] + 0.950227f * c[2];
+    }
+private:
+    float c[3];
+};
+inline void XYZToRGB(const float xyz[3], float rgb[3]) { // Enigma/Spectrum.h:22-26
+    rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+    rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+    rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+
+// ---- filters (Enigma/Filter.h, Enigma/Filter.cpp:8-32) ----
+class Filter {
+public:
+    Filter(const Vector2f& r) : m_radius(r), m_invRadius(1.0f / r.x, 1.0f / r.y) {}
+    virtual ~Filter() {}
+    virtual float Evaluate(const Vector2f& xy) const = 0;
+    const Vector2f m_radius, m_invRadius;
+};
+class BoxFilter : public Filter { public: BoxFilter(const Vector2f& r) : Filter(r) {} float Evaluate(const Vector2f&) const override { return 1.f; } };
+class TriangleFilter : public Filter {
+public:
+    TriangleFilter(const Vector2f& r) : Filter(r) {}
+    float Evaluate(const Vector2f& p) const override { return std::max((float)0, m_radius.x - std::abs(p.x)) * std::max((float)0, m_radius.y - std::abs(p.y)); }
+};
+class GaussianFilter : public Filter {
+public:
+    GaussianFilter(const Vector2f& r, float a) : Filter(r), m_alpha(a), m_expX(expf(-a * r.x * r.x)), m_expY(expf(-a * r.y * r.y)) {}
+    float Evaluate(const Vector2f& p) const override { return G(p.x, m_expX) * G(p.y, m_expY); }
+private:
+    float G(float d, float e) const { return std::max(0.f, float(expf(-m_alpha * d * d) - e)); }
+    const float m_alpha, m_expX, m_expY;
+};
+
+// ---- film (Enigma/Film.h, Enigma/Film.cpp) ----
+struct FilmTilePixel { Spectrum contribSum = 0.f; float filterWeightSum = 0.f; };
+
+class FilmTile {
+public:
+    FilmTile(const BBox2i& pixelBounds) : m_pixelBounds(pixelBounds), m_pixels(std::max(0, pixelBounds.area())) {}
+    FilmTilePixel& GetPixel(const Vector2i& p) {
+        int width = m_pixelBounds.m_max.x - m_pixelBounds.m_min.x;
+        return m_pixels[(p.x - m_pixelBounds.m_min.x) + (p.y - m_pixelBounds.m_min.y) * width];
+    }
+    BBox2i GetPixelBounds() const { return m_pixelBounds; }
+private:
+    const BBox2i m_pixelBounds;
+    std::vector<FilmTilePixel> m_pixels;
+};
+
+class Film {
+public:
+    Film(const Vector2i& resolution, const BBox2f& cropWindow, std::unique_ptr<Filter> filter, float diagonal, const std::string& filename,
+         float scale, float maxSampleLuminance = InfinityF32)
+        : m_fullResolution(resolution), m_diagonal(diagonal * .001f), m_filter(std::move(filter)), m_filename(filename), m_scale(scale),
+          m_maxSampleLuminance(maxSampleLuminance) {
+        m_croppedPixelBounds = BBox2i(Vector2i((int)std::ceil(resolution.x * cropWindow.m_min.x), (int)std::ceil(resolution.y * cropWindow.m_min.y)),
+                                      Vector2i((int)std::ceil(resolution.x * cropWindow.m_max.x), (int)std::ceil(resolution.y * cropWindow.m_max.y)));
+        m_pixels.assign((size_t)std::max(0, m_croppedPixelBounds.area()), Pixel());
+        int offset = 0; // Enigma/Film.cpp:61-70
+        for (int y = 0; y < filterTableWidth; ++y)
+            for (int x = 0; x < filterTableWidth; ++x, ++offset) {
+                Vector2f p((x + 0.5f) * m_filter->m_radius.x / filterTableWidth, (y + 0.5f) * m_filter->m_radius.y / filterTableWidth);
+                m_filterTable[offset] = m_filter->Evaluate(p);
+            }
+    }
+    BBox2i GetSampleBounds() const { // Enigma/Film.cpp:73-81
+        float mnx = (float)m_croppedPixelBounds.m_min.x + 0.5f - m_filter->m_radius.x, mny = (float)m_croppedPixelBounds.m_min.y + 0.5f - m_filter->m_radius.y;
+        float mxx = (float)m_croppedPixelBounds.m_max.x - 0.5f + m_filter->m_radius.x, mxy = (float)m_croppedPixelBounds.m_max.y - 0.5f + m_filter->m_radius.y;
+        return BBox2i(Vector2i((int)std::floor(mnx), (int)std::floor(mny)), Vector2i((int)std::ceil(mxx), (int)std::ceil(mxy)));
+    }
+    std::unique_ptr<FilmTile> GetFilmTile(const BBox2i& sampleBounds) { // Enigma/Film.cpp:92-99
+        int p0x = (int)std::ceil((float)sampleBounds.m_min.x - 0.5f - m_filter->m_radius.x), p0y = (int)std::ceil((float)sampleBounds.m_min.y - 0.5f - m_filter->m_radius.y);
+        int p1x = (int)std::floor((float)sampleBounds.m_max.x - 0.5f + m_filter->m_radius.x) + 1, p1y = (int)std::floor((float)sampleBounds.m_max.y - 0.5f + m_filter->m_radius.y) + 1;
+        BBox2i b(Vector2i(std::max(p0x, m_croppedPixelBounds.m_min.x), std::max(p0y, m_croppedPixelBounds.m_min.y)),
+                 Vector2i(std::min(p1x, m_croppedPixelBounds.m_max.x), std::min(p1y, m_croppedPixelBounds.m_max.y)));
+        return std::unique_ptr<FilmTile>(new FilmTile(b));
+    }
+    void MergeFilmTile(std::unique_ptr<FilmTile> tile) { // Enigma/Film.cpp:101-125
+        const BBox2i b = tile->GetPixelBounds();
+        for (int y = b.m_min.y; y < b.m_max.y; ++y)
+            for (int x = b.m_min.x; x < b.m_max.x; ++x) {
+                const FilmTilePixel& tp = tile->GetPixel(Vector2i(x, y));
+                Pixel& mp = GetPixel(Vector2i(x, y));
+                float xyz[3];
+                tp.contribSum.ToXYZ(xyz);
+                for (int i = 0; i < 3; ++i) mp.xyz[i] += xyz[i];
+                mp.filterWeightSum += tp.filterWeightSum;
+            }
+    }
+    // Enigma/Film.cpp:157-209.  Keeps the RGB image (m_rgb) and writes a PFM when a file name is set;
+    // the reference's TGA/EXR writers (Enigma/IO.cpp) are outside this path.
+    virtual void WriteImage(float splatScale) {
+        (void)splatScale; // PathIntegrator adds no splats
+        const BBox2i& b = m_croppedPixelBounds;
+        m_rgb.assign((size_t)3 * std::max(0, b.area()), 0.f);
+        int offset = 0;
+        for (int y = b.m_min.y; y < b.m_max.y; ++y)
+            for (int x = b.m_min.x; x < b.m_max.x; ++x, ++offset) {
+                Pixel& pixel = GetPixel(Vector2i(x, y));
+                float* rgb = &m_rgb[3 * (size_t)offset];
+                XYZToRGB(pixel.xyz, rgb);
+                float w = pixel.filterWeightSum;
+                if (w != 0) { float invWt = (float)1 / w; for (int c = 0; c < 3; ++c) rgb[c] = std::max((float)0, rgb[c] * invWt); }
+                for (int c = 0; c < 3; ++c) rgb[c] *= m_scale;
+            }
+        if (!m_filename.empty()) {
+            int w = b.m_max.x - b.m_min.x, h = b.m_max.y - b.m_min.y;
+            if (FILE* f = fopen(m_filename.c_str(), "wb")) {
+                fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+                for (int y = h - 1; y >= 0; --y) fwrite(&m_rgb[(size_t)3 * y * w], sizeof(float), (size_t)3 * w, f);
+                fclose(f);
+            }
+        }
+    }
+    void Clear() { for (auto& p : m_pixels) p = Pixel(); }
+    const std::vector<float>& GetRGB() const { return m_rgb; }
+    const float* GetFilterTable() const { return m_filterTable; }
+    float GetMaxSampleLuminance() const { return m_maxSampleLuminance; }
+
+    const Vector2i m_fullResolution;
+    const float m_diagonal;
+    std::unique_ptr<Filter> m_filter;
+    const std::string m_filename;
+    BBox2i m_croppedPixelBounds;
+    struct Pixel { float xyz[3] = {0, 0, 0}; float filterWeightSum = 0; };
+    Pixel& GetPixel(const Vector2i& p) {
+        int width = m_croppedPixelBounds.m_max.x - m_croppedPixelBounds.m_min.x;
+        return m_pixels[(p.x - m_croppedPixelBounds.m_min.x) + (p.y - m_croppedPixelBounds.m_min.y) * width];
+    }
+private:
+    static constexpr int filterTableWidth = 16;
+    std::vector<Pixel> m_pixels;
+    float m_filterTable[filterTableWidth * filterTableWidth];
+    const float m_scale, m_maxSampleLuminance;
+    std::vector<float> m_rgb;
+};
+
+// ---- transforms / camera (Enigma/Camera.h:40-76) ----
+class Transform { public: float m_mat[4][4]; Transform() { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m_mat[r][c] = r == c; } };
+
+class Camera {
+public:
+    Camera(const Transform& c2w, float sOpen, float sClose, std::unique_ptr<Film> film)
+        : m_cameraToWorld(c2w), m_shutterOpen(sOpen), m_shutterClose(sClose), m_film(std::move(film)) {}
+    virtual ~Camera() {}
+    const Film& GetFilm() const { return *m_film; }
+    Transform m_cameraToWorld;
+    const float m_shutterOpen, m_shutterClose;
+    std::unique_ptr<Film> m_film;
+};
+class ProjectiveCamera : public Camera {
+public:
+    ProjectiveCamera(const Transform& c2w, const Transform& rasterToCamera, float sopen, float sclose, float lensr, float focald, std::unique_ptr<Film> film)
+        : Camera(c2w, sopen, sclose, std::move(film)), m_rasterToCamera(rasterToCamera), m_lensRadius(lensr), m_focalDistance(focald) {}
+    Transform m_rasterToCamera;
+    float m_lensRadius, m_focalDistance;
+};
+class PerspectiveCamera : public ProjectiveCamera { public: using ProjectiveCamera::ProjectiveCamera; };
+using CameraPtr = std::shared_ptr<Camera>;
+
+// ---- sampler (Enigma/Sampler.h:13-50,143-158) ----
+class Sampler { public: Sampler(int64_t spp) : m_samplesPerPixel(spp) {} virtual ~Sampler() {} const int64_t m_samplesPerPixel; };
+class SobolSampler : public Sampler {
+public:
+    static int64_t RoundUpPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+    SobolSampler(int64_t samplesPerPixel, const BBox2i& sampleBounds) : Sampler(RoundUpPow2(samplesPerPixel)), m_sampleBounds(sampleBounds) {
+        m_resolution = (int)RoundUpPow2(std::max(sampleBounds.m_max.x - sampleBounds.m_min.x, sampleBounds.m_max.y - sampleBounds.m_min.y));
+        m_log2Resolution = 0;
+        while ((1 << m_log2Resolution) < m_resolution) ++m_log2Resolution;
+    }
+    const BBox2i m_sampleBounds;
+    int m_resolution, m_log2Resolution;
+};
+using SamplerPtr = std::shared_ptr<Sampler>;
+
+// ---- scene registry ----
+struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexIndices
+    int m_nTriangles = 0, m_nVertices = 0;
+    std::vector<int> m_vertexIndices;
+    std::vector<Vector3f> m_p;
+    int materialIndex = 0;          // registry index of the bound material
+    bool reverseOrientation = false;
+    bool emissive = false;          // an AreaLightSource was active when the shape was created
+    Spectrum Le = 0.f;
+    bool twoSided = false;
+};
+
+class Scene {
+public:
+    // Registry calls: the equivalent of hooking MakeShapes / MakeMaterial / MakeLight (Enigma/Api.cpp:843-932).
+    int AddMaterial(const EnigmaMaterial& m) { m_materials.push_back(m); return (int)m_materials.size() - 1; }
+    // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
+    void AddTriangleMesh(const TriangleMesh& mesh) { m_meshes.push_back(mesh); }
+    void AddPointLight(const Vector3f& from, const Spectrum& I) { PointLightRec r{from, I, NextLightOrder()}; m_pointLights.push_back(r); }
+    int getNumLights() const {
+        int n = (int)m_pointLights.size();
+        for (auto& m : m_meshes) if (m.emissive) n += m.m_nTriangles;
+        return n;
+    }
+    struct PointLightRec { Vector3f from; Spectrum I; int order; };
+    std::vector<TriangleMesh> m_meshes;
+    std::vector<EnigmaMaterial> m_materials;
+    std::vector<PointLightRec> m_pointLights;
+private:
+    int NextLightOrder() const { return (int)m_meshes.size(); } // point lights keep their place among the meshes' lights
+};
+
+// ---- integrators (Enigma/Integrator.h:35-70) ----
+class Integrator {
+public:
+    virtual ~Integrator() {}
+    virtual void Render(const Scene& scene) = 0;
+    virtual const CameraPtr& GetCamera() const = 0;
+};
+
+class SamplerIntegrator : public Integrator {
+public:
+    SamplerIntegrator(const CameraPtr& camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds)
+        : m_camera(camera), m_sampler(sampler), m_pixelBounds(pixelBounds) {}
+    virtual void Preprocess(const Scene&, Sampler&) {}
+    const BBox2i& GetPixelBounds() const { return m_pixelBounds; }
+    const SamplerPtr& GetSampler() const { return m_sampler; }
+    const CameraPtr& GetCamera() const override { return m_camera; }
+protected:
+    CameraPtr m_camera;
+private:
+    std::shared_ptr<Sampler> m_sampler;
+    const BBox2i m_pixelBounds;
+};
+
+// PathIntegrator whose Render runs on the MI355X (constructor arguments: Enigma/PathIntegrator.cpp:30-39).
+class GpuPathIntegrator : public SamplerIntegrator {
+public:
+    GpuPathIntegrator(int maxDepth, std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds,
+                      float rrThreshold = 1, const std::string& lightSampleStrategy = "spatial", int device = 0)
+        : SamplerIntegrator(camera, sampler, pixelBounds), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
+          m_lightSampleStrategy(lightSampleStrategy), m_device(device) {}
+
+    // Errors: the reference prints and continues (Enigma/Error.h:5-10); a failing GPU call cannot
+    // "continue", so it throws std::runtime_error carrying enigma_last_error().
+    void Render(const Scene& scene) override {
+        EnigmaCtx* h = nullptr;
+        if (enigma_ctx_create(m_device, &h) != ENIGMA_OK) throw std::runtime_error("enigma_ctx_create failed: no HIP device");
+        struct Guard { EnigmaCtx* h; ~Guard() { enigma_ctx_destroy(h); } } guard{h};
+        auto check = [&](int rc) { if (rc != ENIGMA_OK) throw std::runtime_error(std::string("enigma: ") + enigma_last_error(h)); };
+        // flatten the registry
+        std::vector<float> verts; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight; std::vector<EnigmaLight> lights;
+        size_t pl = 0;
+        auto flushPointLights = [&](int upTo) {
+            for (; pl < scene.m_pointLights.size() && scene.m_pointLights[pl].order <= upTo; ++pl) {
+                EnigmaLight l{}; l.type = ENIGMA_LIGHT_POINT;
+                const auto& r = scene.m_pointLights[pl];
+                l.pos[0] = r.from.x; l.pos[1] = r.from.y; l.pos[2] = r.from.z; l.L[0] = r.I[0]; l.L[1] = r.I[1]; l.L[2] = r.I[2];
+                lights.push_back(l);
+            }
+        };
+        for (size_t mi = 0; mi < scene.m_meshes.size(); ++mi) {
+            flushPointLights((int)mi);
+            const TriangleMesh& m = scene.m_meshes[mi];
+            uint32_t base = (uint32_t)(verts.size() / 3);
+            for (const Vector3f& p : m.m_p) { verts.push_back(p.x); verts.push_back(p.y); verts.push_back(p.z); }
+            for (int t = 0; t < m.m_nTriangles; ++t) {
+                for (int k = 0; k < 3; ++k) idx.push_back(base + (uint32_t)m.m_vertexIndices[3 * t + k]);
+                triMat.push_back((uint32_t)m.materialIndex);
+                triFlags.push_back(m.reverseOrientation ? ENIGMA_TRI_FLIP_NORMAL : 0u);
+                if (m.emissive) {
+                    EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA; l.triangle = (uint32_t)triMat.size() - 1; l.two_sided = m.twoSided;
+                    l.L[0] = m.Le[0]; l.L[1] = m.Le[1]; l.L[2] = m.Le[2];
+                    triLight.push_back((int32_t)lights.size());
+                    lights.push_back(l);
+                } else triLight.push_back(-1);
+            }
+        }
+        flushPointLights(std::numeric_limits<int>::max());
+        EnigmaSceneDesc sd{};
+        sd.n_vertices = (uint32_t)(verts.size() / 3); sd.n_triangles = (uint32_t)triMat.size();
+        sd.vertices = verts.data(); sd.indices = idx.data(); sd.tri_material = triMat.data(); sd.tri_light = triLight.data(); sd.tri_flags = triFlags.data();
+        sd.n_materials = (uint32_t)scene.m_materials.size(); sd.materials = scene.m_materials.data();
+        sd.n_lights = (uint32_t)lights.size(); sd.lights = lights.data();
+        check(enigma_scene_upload(h, &sd));
+
+        const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());
+        if (!cam) throw std::runtime_error("GpuPathIntegrator needs a PerspectiveCamera");
+        EnigmaCameraDesc cd{};
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { cd.raster_to_camera[4 * r + c] = cam->m_rasterToCamera.m_mat[r][c]; cd.camera_to_world[4 * r + c] = cam->m_cameraToWorld.m_mat[r][c]; }
+        cd.lens_radius = cam->m_lensRadius; cd.focal_distance = cam->m_focalDistance;
+        check(enigma_camera_set(h, &cd));
+
+        Film& film = *m_camera->m_film;
+        EnigmaFilmDesc fd{};
+        fd.full_resolution[0] = film.m_fullResolution.x; fd.full_resolution[1] = film.m_fullResolution.y;
+        const BBox2i& cb = film.m_croppedPixelBounds;
+        fd.cropped_pixel_bounds[0] = cb.m_min.x; fd.cropped_pixel_bounds[1] = cb.m_min.y; fd.cropped_pixel_bounds[2] = cb.m_max.x; fd.cropped_pixel_bounds[3] = cb.m_max.y;
+        fd.filter_radius[0] = film.m_filter->m_radius.x; fd.filter_radius[1] = film.m_filter->m_radius.y;
+        std::copy(film.GetFilterTable(), film.GetFilterTable() + 256, fd.filter_table);
+        fd.max_sample_luminance = film.GetMaxSampleLuminance();
+        check(enigma_film_config(h, &fd));
+
+        const SobolSampler* sob = dynamic_cast<const SobolSampler*>(GetSampler().get());
+        if (!sob) throw std::runtime_error("GpuPathIntegrator needs a SobolSampler");
+        EnigmaIntegratorDesc id{};
+        id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
+        if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
+        else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
+        else if (lights.size() == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
+        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
+        const BBox2i& pb = GetPixelBounds();
+        id.pixel_bounds[0] = pb.m_min.x; id.pixel_bounds[1] = pb.m_min.y; id.pixel_bounds[2] = pb.m_max.x; id.pixel_bounds[3] = pb.m_max.y;
+        id.samples_per_pixel = sob->m_samplesPerPixel;
+        id.sample_bounds[0] = sob->m_sampleBounds.m_min.x; id.sample_bounds[1] = sob->m_sampleBounds.m_min.y;
+        id.sample_bounds[2] = sob->m_sampleBounds.m_max.x; id.sample_bounds[3] = sob->m_sampleBounds.m_max.y;
+        check(enigma_integrator_config(h, &id));
+
+        check(enigma_render(h, 0, sob->m_samplesPerPixel));
+
+        // deposit: one FilmTile over the cropped bounds, then the reference's own merge + write
+        std::vector<float> rgbw((size_t)4 * std::max(0, cb.area()));
+        check(enigma_film_read(h, rgbw.data(), rgbw.size()));
+        std::unique_ptr<FilmTile> tile(new FilmTile(cb));
+        size_t o = 0;
+        for (int y = cb.m_min.y; y < cb.m_max.y; ++y)
+            for (int x = cb.m_min.x; x < cb.m_max.x; ++x, o += 4) {
+                FilmTilePixel& px = tile->GetPixel(Vector2i(x, y));
+                px.contribSum = Spectrum(rgbw[o], rgbw[o + 1], rgbw[o + 2]);
+                px.filterWeightSum = rgbw[o + 3];
+            }
+        film.MergeFilmTile(std::move(tile));
+        film.WriteImage(1.0f / sob->m_samplesPerPixel);
+        check(enigma_get_stats(h, &m_stats));
+    }
+    const EnigmaStats& GetStats() const { return m_stats; }
+private:
+    const int m_maxDepth;
+    const float m_rrThreshold;
+    const std::string m_lightSampleStrategy;
+    const int m_device;
+    EnigmaStats m_stats{};
+};
+
+} // namespace RayTrace
