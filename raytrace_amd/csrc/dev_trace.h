@@ -114,58 +114,76 @@ DEV void nodeBoxes(const float4* n, F3* lo0, F3* hi0, F3* lo1, F3* hi1, int* c0,
 
 // Per-lane traversal stack in LDS: entry (level, lane) lives at stack[level * STRIDE + lane], so a
 // lane always uses LDS bank (lane % 32) whatever its depth -- conflict free for the two 32-lane
-// groups of ds_read_b32 / ds_write_b32.
+// groups of ds_read_b32 / ds_write_b32.  The closest-hit stack keeps the far child's entry distance
+// beside its reference (second plane at +STACK*STRIDE words): a popped node whose entry distance is
+// no longer below the current hit distance is dropped without being fetched -- the same decision
+// the reference takes when it visits the node (tMin < ray.m_maxT, Enigma/BBox.h:294).
+constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (nTris < 2^28)
+
 template <int STACK, int STRIDE>
-DEV Hit traceClosest(const DevScene& sc, F3 o, F3 d, float tMax, uint32_t* stack) {
+DEV int popClosest(const uint32_t* stack, int& sp, float tMax) {
+    while (sp > 0) {
+        --sp;
+        float te = __uint_as_float(stack[(STACK + sp) * STRIDE]);
+        if (te < tMax) return (int)stack[sp * STRIDE];
+    }
+    return kTraverseDone;
+}
+
+// "while-while" traversal: lanes descend inner nodes until each holds a leaf (or is done), then the
+// wave tests triangles together, so the expensive triangle code runs with most lanes active.
+template <int STACK, int STRIDE>
+DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* stack) {
     RaySetup r = setupRay(o, d);
     Hit h; h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
     int cur = 0, sp = 0;
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
-            nodeBoxes(sc.nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
+            nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
             bool h0 = slabTest(r, h.t, lo0, hi0, &t0);
             bool h1 = slabTest(r, h.t, lo1, hi1, &t1);
             if (h0 && h1) {
                 bool swp = t1 < t0;
                 int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
-                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)farC; ++sp; }
+                float farT = swp ? t0 : t1;
+                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)farC; stack[(STACK + sp) * STRIDE] = __float_as_uint(farT); ++sp; }
                 cur = nearC;
             } else if (h0) cur = c0;
             else if (h1) cur = c1;
-            else { if (sp == 0) break; --sp; cur = (int)stack[sp * STRIDE]; }
-        } else {
-            uint32_t leaf = ~(uint32_t)cur;
-            uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const float4* tp = sc.tris + (size_t)(first + i) * 3;
-                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                float t, b0, b1, b2;
-                if (triangleTest(r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) {
-                    // degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
-                    F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
-                    F3 dpdu = (p1 - p2) - (p0 - p2);           // see shading: -dp02 + dp12
-                    F3 dpdv = -(p1 - p2);
-                    bool ok = true;
-                    if (lengthSqr(cross(dpdu, dpdv)) == 0) ok = lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
-                    if (ok) { h.t = t; h.tri = (int)(first + i); h.b0 = b0; h.b1 = b1; h.b2 = b2; }
-                }
-            }
-            if (sp == 0) break;
-            --sp; cur = (int)stack[sp * STRIDE];
+            else cur = popClosest<STACK, STRIDE>(stack, sp, h.t);
         }
+        if (cur == kTraverseDone) break;
+        uint32_t leaf = ~(uint32_t)cur;
+        uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4* tp = tris + (size_t)(first + i) * 3;
+            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float t, b0, b1, b2;
+            if (triangleTest(r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) {
+                // degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
+                F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
+                F3 dpdu = (p1 - p2) - (p0 - p2);
+                F3 dpdv = -(p1 - p2);
+                bool ok = true;
+                if (lengthSqr(cross(dpdu, dpdv)) == 0) ok = lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
+                if (ok) { h.t = t; h.tri = (int)(first + i); h.b0 = b0; h.b1 = b1; h.b2 = b2; }
+            }
+        }
+        cur = popClosest<STACK, STRIDE>(stack, sp, h.t);
     }
     return h;
 }
 
+// Any-hit (Scene::intersectP): no ordering, first accepted triangle ends the walk.
 template <int STACK, int STRIDE>
-DEV bool traceAny(const DevScene& sc, F3 o, F3 d, float tMax, uint32_t* stack) {
+DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* stack) {
     RaySetup r = setupRay(o, d);
     int cur = 0, sp = 0;
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
-            nodeBoxes(sc.nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
+            nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
             bool h0 = slabTest(r, tMax, lo0, hi0, &t0);
             bool h1 = slabTest(r, tMax, lo1, hi1, &t1);
             if (h0 && h1) {
@@ -173,19 +191,20 @@ DEV bool traceAny(const DevScene& sc, F3 o, F3 d, float tMax, uint32_t* stack) {
                 cur = c0;
             } else if (h0) cur = c0;
             else if (h1) cur = c1;
-            else { if (sp == 0) break; --sp; cur = (int)stack[sp * STRIDE]; }
-        } else {
-            uint32_t leaf = ~(uint32_t)cur;
-            uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const float4* tp = sc.tris + (size_t)(first + i) * 3;
-                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                float t, b0, b1, b2;
-                if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) return true; // Triangle::intersectP
-            }
-            if (sp == 0) break;
-            --sp; cur = (int)stack[sp * STRIDE];
+            else if (sp > 0) { --sp; cur = (int)stack[sp * STRIDE]; }
+            else cur = kTraverseDone;
         }
+        if (cur == kTraverseDone) break;
+        uint32_t leaf = ~(uint32_t)cur;
+        uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4* tp = tris + (size_t)(first + i) * 3;
+            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float t, b0, b1, b2;
+            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) return true; // Triangle::intersectP
+        }
+        if (sp > 0) { --sp; cur = (int)stack[sp * STRIDE]; }
+        else cur = kTraverseDone;
     }
     return false;
 }

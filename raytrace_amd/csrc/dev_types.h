@@ -42,6 +42,7 @@ struct DevScene {
     float lightFuncInt;
     int nLights;
     uint32_t nTris;
+    uint32_t nNodes;
 };
 
 struct DevCamera {

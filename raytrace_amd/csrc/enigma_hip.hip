@@ -207,9 +207,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     // BVH + triangle reorder
     auto t0 = std::chrono::steady_clock::now();
     enigma::BvhResult bvh;
-    enigma::build_bvh(s->vertices, s->indices, s->n_triangles, 4, &bvh);
+    uint32_t maxLeaf = 4;
+    if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
+    enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
     h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (bvh.maxDepth > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (64)", bvh.maxDepth);
+    if (bvh.maxDepth > 32) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (32)", bvh.maxDepth);
     h->bvhDepth = bvh.maxDepth;
     h->bvhNodes = (uint32_t)bvh.nodes.size();
     std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
@@ -272,7 +274,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->scene.lights = h->lights.p;
     h->scene.primId = h->primId.p;
     h->scene.nLights = (int)s->n_lights;
-    h->scene.nTris = s->n_triangles;
+    h->scene.nTris = std::max(1u, s->n_triangles);
+    h->scene.nNodes = (uint32_t)bvh.nodes.size();
     h->lightDistDirty = true;
     h->haveScene = true;
     return ENIGMA_OK;
@@ -403,7 +406,11 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
     return ENIGMA_OK;
 }
 
-template <int STACK>
+// Scenes up to this many bytes of nodes + triangles are traversed out of LDS (see stageSceneToLds).
+static constexpr size_t kLdsSceneBytes = 32 * 1024;
+static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 4 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
+
+template <int STACK, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -415,7 +422,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur];
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
+    k_intersect_closest<STACK, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -426,12 +433,12 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, shq, ctr);
-        k_mis<STACK><<<gridTrace, kBlock, 0, s>>>(h->scene, P, misq, ctr);
+        k_shadow_mis<STACK, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
     }
 }
 
-static int stackFor(uint32_t depth) { return depth <= 16 ? 16 : depth <= 24 ? 24 : depth <= 32 ? 32 : depth <= 48 ? 48 : 64; }
+// two LDS planes of STACK x 256 words per block (node reference + entry distance): 64 KB static LDS caps STACK at 32
+static int stackFor(uint32_t depth) { return depth <= 12 ? 12 : depth <= 16 ? 16 : depth <= 24 ? 24 : 32; }
 
 extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (!h) return ENIGMA_E_INVALID;
@@ -449,6 +456,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     const int stack = stackFor(h->bvhDepth);
+    const bool ldsScene = stack == 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -466,7 +474,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
             uint32_t nPaths = nPixels * ks;
             int gridAll = (int)((nPaths + kBlock - 1) / kBlock);
-            int ldsBlocks = std::max(1, (160 * 1024) / (stack * kBlock * 4));
+            int ldsBlocks = std::max(1, (int)((160 * 1024) / (2 * stack * kBlock * 4 + (ldsScene ? sceneLdsBytes(h) : 0))));
             int gridTrace = std::min(gridAll, cus * std::min(ldsBlocks, 8));
             int gridShade = std::min(gridAll, cus * 8);
             k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p);
@@ -478,12 +486,13 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                switch (stack) {
-                case 16: launchBounce<16>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                case 24: launchBounce<24>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                case 32: launchBounce<32>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                case 48: launchBounce<48>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                default: launchBounce<64>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                if (ldsScene) { // small scenes have shallow trees: stack 12 always suffices (checked above)
+                    launchBounce<12, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1);
+                } else switch (stack) {
+                case 12: launchBounce<12, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 16: launchBounce<16, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 24: launchBounce<24, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                default: launchBounce<32, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
                 }
                 h->stats.intersect_launches++;
             }
@@ -639,11 +648,10 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
     if (e == hipSuccess) {
         int grid = (int)((n + kBlock - 1) / kBlock);
         switch (stackFor(h->bvhDepth)) {
+        case 12: k_debug_intersect<12><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
         case 16: k_debug_intersect<16><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
         case 24: k_debug_intersect<24><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        case 32: k_debug_intersect<32><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        case 48: k_debug_intersect<48><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        default: k_debug_intersect<64><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
+        default: k_debug_intersect<32><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
         }
         e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost);

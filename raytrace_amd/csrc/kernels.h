@@ -109,6 +109,18 @@ DEV uint32_t waveFetch(uint32_t* cursor) {
     return __shfl(base, 0);
 }
 
+// ---------------------------------------------------------------- LDS-resident scene
+// Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
+// into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
+// instead of 64 divergent 16-byte requests per wave-instruction through the texture-address path,
+// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 4 float4 each][tris: 3 float4 each].
+DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
+    const uint32_t nN = sc.nNodes * 4u, nT = sc.nTris * 3u;
+    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[nN + i] = sc.tris[i];
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- geometry at a hit
 struct HitGeom { F3 p, pError, n, dpdu; int matIdx, lightIdx; };
 
@@ -170,10 +182,14 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
 struct MatQueues { uint32_t* q[MK_COUNT]; };
 
-template <int STACK>
+template <int STACK, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr) {
-    __shared__ uint32_t stack[STACK * kBlock];
+    __shared__ uint32_t stack[2 * STACK * kBlock];
+    extern __shared__ float4 sceneLds[];
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
     const uint32_t count = countPtr ? *countPtr : countImm;
     uint32_t* myStack = stack + threadIdx.x;
     for (;;) {
@@ -186,11 +202,11 @@ __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPa
         if (active) {
             p = queue ? queue[i] : i;
             F3 o = xyz(P.rayO[p]), d = xyz(P.rayD[p]);
-            Hit h = traceClosest<STACK, kBlock>(sc, o, d, EDEV_INF, myStack);
+            Hit h = traceClosest<STACK, kBlock>(nodes, tris, o, d, EDEV_INF, myStack);
             uint32_t st = P.state[p];
             uint32_t bounces = stBounces(st);
             if (h.tri >= 0) {
-                const float4* tp = sc.tris + (size_t)h.tri * 3;
+                const float4* tp = tris + (size_t)h.tri * 3;
                 float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                 int lightIdx = __float_as_int(v2.w);
                 uint32_t mw = __float_as_uint(v1.w);
@@ -410,42 +426,38 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
     }
 }
 
-// VisibilityTester::Unoccluded for the shadow queue: unoccluded rays add their contribution.
-template <int STACK>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue q, DevCounters* ctr) {
-    __shared__ uint32_t stack[STACK * kBlock];
-    const uint32_t count = ctr->shadowCount;
+// Shadow rays and BSDF-sampled MIS rays of one bounce in ONE launch: work items [0, shadowCount) are
+// VisibilityTester::Unoccluded queries (any-hit; unoccluded rays add their contribution), items
+// [shadowCount, shadowCount + misCount) are the MIS rays of EstimateDirect (closest hit must be the
+// sampled light's triangle).  Waves fetch 64 items at a time, so a wave is (almost always) all of one kind.
+template <int STACK, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, DevRayQueue shq, DevRayQueue misq, DevCounters* ctr) {
+    __shared__ uint32_t stack[2 * STACK * kBlock];
+    extern __shared__ float4 sceneLds[];
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
+    const uint32_t nShadow = ctr->shadowCount, count = nShadow + ctr->misCount;
     uint32_t* myStack = stack + threadIdx.x;
     for (;;) {
         uint32_t base = waveFetch(&ctr->workNext[1]);
         if (base >= count) break;
         uint32_t i = base + (threadIdx.x & 63u);
-        if (i < count) {
-            float4 o = q.o[i], d = q.d[i];
-            if (!traceAny<STACK, kBlock>(sc, xyz(o), xyz(d), d.w, myStack)) {
+        if (i >= count) continue;
+        if (i < nShadow) {
+            float4 o = shq.o[i], d = shq.d[i];
+            if (!traceAny<STACK, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
                 uint32_t p = __float_as_uint(o.w);
-                float4 w = q.w[i], L = P.L[p];
-                P.L[p] = make_float4(L.x + w.x, L.y + w.y, L.z + w.z, 0.f);
+                float4 w = shq.w[i];
+                float* L = reinterpret_cast<float*>(P.L + p);
+                atomicAdd(L + 0, w.x); atomicAdd(L + 1, w.y); atomicAdd(L + 2, w.z);
             }
-        }
-    }
-}
-
-// The BSDF-sampled ray of EstimateDirect: closest hit must be the sampled light's triangle.
-template <int STACK>
-__global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue q, DevCounters* ctr) {
-    __shared__ uint32_t stack[STACK * kBlock];
-    const uint32_t count = ctr->misCount;
-    uint32_t* myStack = stack + threadIdx.x;
-    for (;;) {
-        uint32_t base = waveFetch(&ctr->workNext[2]);
-        if (base >= count) break;
-        uint32_t i = base + (threadIdx.x & 63u);
-        if (i < count) {
-            float4 o = q.o[i], d = q.d[i];
-            Hit h = traceClosest<STACK, kBlock>(sc, xyz(o), xyz(d), EDEV_INF, myStack);
+        } else {
+            uint32_t j = i - nShadow;
+            float4 o = misq.o[j], d = misq.d[j];
+            Hit h = traceClosest<STACK, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, myStack);
             if (h.tri >= 0) {
-                const float4* tp = sc.tris + (size_t)h.tri * 3;
+                const float4* tp = tris + (size_t)h.tri * 3;
                 float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                 int lightIdx = __float_as_int(v2.w);
                 if (lightIdx == __float_as_int(d.w)) { // lightIsect.m_primitive->getAreaLight() == &light
@@ -453,9 +465,10 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
                     F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
                     if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
                         uint32_t p = __float_as_uint(o.w);
-                        float4 w = q.w[i], L = P.L[p];
+                        float4 w = misq.w[j];
                         F3 add = xyz(w) * F3(lt.L[0], lt.L[1], lt.L[2]);
-                        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+                        float* L = reinterpret_cast<float*>(P.L + p);
+                        atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
                     }
                 }
             }
@@ -515,7 +528,7 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
     } else if (phase == 1) {
         ctr->raysShadow += ctr->shadowCount;
         ctr->raysMis += ctr->misCount;
-        ctr->workNext[1] = 0; ctr->workNext[2] = 0;
+        ctr->workNext[1] = 0;
     }
 }
 
@@ -544,16 +557,16 @@ __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int3
 template <int STACK>
 __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
                                                             uint32_t* primOut, float* tOut, float* baryOut) {
-    __shared__ uint32_t stack[STACK * kBlock];
+    __shared__ uint32_t stack[2 * STACK * kBlock];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
     F3 o(r[0], r[1], r[2]), d(r[3], r[4], r[5]);
     if (anyHit) {
-        triOut[i] = traceAny<STACK, kBlock>(sc, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
+        triOut[i] = traceAny<STACK, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
         return;
     }
-    Hit h = traceClosest<STACK, kBlock>(sc, o, d, r[6], stack + threadIdx.x);
+    Hit h = traceClosest<STACK, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
     int orig = -1;
     if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
     triOut[i] = orig;
