@@ -93,11 +93,14 @@ struct DevRayQueue {  // shadow rays and BSDF-sampled MIS rays
     float4* w;        // contribution to add to the path's L (shadow) or weight of Le (MIS)
 };
 
+// Queue tails are bumped with device-scope atomics by every block of a launch.  Atomics on one
+// 128-byte line are served one after the other by a single L2 channel, so each tail gets a line of
+// its own: tails that share a line queue up behind each other even though they are different words.
+struct alignas(128) DevTail { uint32_t v; uint32_t pad[31]; };
 struct DevCounters {
-    uint32_t extCount[2];       // extension-ray queue sizes (current, next)
-    uint32_t matCount[MK_COUNT];
-    uint32_t shadowCount, misCount;
-    uint32_t workNext[4];       // dynamic work-fetch cursors of the traversal kernels
+    DevTail extCount[2];        // extension-ray queue sizes (current, next)
+    DevTail matCount[MK_COUNT];
+    DevTail shadowCount, misCount;
     unsigned long long raysClosest, raysShadow, raysMis, samples;
 };
 

@@ -412,7 +412,7 @@ static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNode
 
 template <int STACK, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
-                         int gridShade, hipEvent_t e0, hipEvent_t e1) {
+                         int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
     uint32_t cur = (uint32_t)bounce & 1u;
     hipStream_t s = h->stream;
@@ -420,7 +420,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     MatQueues mq;
     for (int k = 0; k < MK_COUNT; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
-    const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur];
+    const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
     k_intersect_closest<STACK, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
     (void)hipEventRecord(e1, s);
@@ -433,7 +433,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow_mis<STACK, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
+        k_shadow_mis<STACK, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
     }
 }
 
@@ -474,8 +474,10 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
             uint32_t nPaths = nPixels * ks;
             int gridAll = (int)((nPaths + kBlock - 1) / kBlock);
-            int ldsBlocks = std::max(1, (int)((160 * 1024) / (2 * stack * kBlock * 4 + (ldsScene ? sceneLdsBytes(h) : 0))));
-            int gridTrace = std::min(gridAll, cus * std::min(ldsBlocks, 8));
+            // traversal grids: enough blocks that the hardware dispatcher balances rays of very different cost,
+            // few enough that launches late in a pass (short queues) do not drown in empty blocks
+            int gridTrace = std::min((int)((nPaths + kTraceChunk - 1) / kTraceChunk), cus * 32);
+            int gridShadow = std::min(2 * gridAll, cus * 64);
             int gridShade = std::min(gridAll, cus * 8);
             k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p);
             for (int b = 0; b <= h->integ.maxDepth; ++b) {
@@ -487,12 +489,12 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
                 if (ldsScene) { // small scenes have shallow trees: stack 12 always suffices (checked above)
-                    launchBounce<12, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1);
+                    launchBounce<12, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 } else switch (stack) {
-                case 12: launchBounce<12, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                case 16: launchBounce<16, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                case 24: launchBounce<24, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
-                default: launchBounce<32, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShade, e0, e1); break;
+                case 12: launchBounce<12, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
+                case 16: launchBounce<16, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
+                case 24: launchBounce<24, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
+                default: launchBounce<32, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
                 }
                 h->stats.intersect_launches++;
             }

@@ -89,26 +89,6 @@ DEV uint32_t blockReserve(bool pred, uint32_t* counter, uint32_t* lds /* kWavesP
     __syncthreads(); // lds is reused by the next reservation
     return slot;
 }
-// Wave-wide append for kernels whose waves run independent work loops.
-DEV uint32_t waveReserve(bool pred, uint32_t* counter) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return 0;
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    return base + prefix;
-}
-// Next 64 work items for this wave (dynamic fetch keeps the CUs busy while rays of very
-// different cost share a launch).  Every wave leaves its loop when the cursor passes count.
-DEV uint32_t waveFetch(uint32_t* cursor) {
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, 64u);
-    return __shfl(base, 0);
-}
-
 // ---------------------------------------------------------------- LDS-resident scene
 // Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
 // into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
@@ -182,56 +162,90 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
 struct MatQueues { uint32_t* q[MK_COUNT]; };
 
+// A block owns chunks of kTraceItems x 256 consecutive queue positions (chunk c -> block c mod gridDim).
+// After tracing a chunk it bins the surviving paths by material kind with ONE tail bump per kind and
+// block: per-wave ballots -> LDS -> block totals, so a launch of R rays issues R / 1024 atomics per
+// tail instead of one per wave and kind.
+constexpr int kTraceItems = 4;
+constexpr uint32_t kTraceChunk = kBlock * kTraceItems;
+
 template <int STACK, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr) {
     __shared__ uint32_t stack[2 * STACK * kBlock];
+    __shared__ uint32_t binCnt[MK_COUNT * kWavesPerBlock];
+    __shared__ uint32_t binBase[MK_COUNT];
     extern __shared__ float4 sceneLds[];
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
-    const uint32_t count = countPtr ? *countPtr : countImm;
     uint32_t* myStack = stack + threadIdx.x;
-    for (;;) {
-        uint32_t base = waveFetch(&ctr->workNext[0]);
-        if (base >= count) break;
-        uint32_t i = base + (threadIdx.x & 63u);
-        bool active = i < count;
-        int kind = -1;
-        uint32_t p = 0;
-        if (active) {
-            p = queue ? queue[i] : i;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
+        uint32_t kinds = 0; // 4 bits per item: material kind + 1, 0 = path ended here
+#pragma unroll 1
+        for (int it = 0; it < kTraceItems; ++it) {
+            uint32_t i = chunk + it * kBlock + threadIdx.x;
+            if (i >= count) continue;
+            uint32_t p = queue ? queue[i] : i;
             F3 o = xyz(P.rayO[p]), d = xyz(P.rayD[p]);
             Hit h = traceClosest<STACK, kBlock>(nodes, tris, o, d, EDEV_INF, myStack);
+            if (h.tri < 0) continue;
             uint32_t st = P.state[p];
             uint32_t bounces = stBounces(st);
-            if (h.tri >= 0) {
-                const float4* tp = tris + (size_t)h.tri * 3;
-                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                int lightIdx = __float_as_int(v2.w);
-                uint32_t mw = __float_as_uint(v1.w);
-                if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
-                    const DevLight& lt = sc.lights[lightIdx];
-                    F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
-                    if (lt.twoSided || dot(n, -d) > 0) {
-                        float4 L = P.L[p], be = P.beta[p];
-                        F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
-                        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
-                    }
-                }
-                if ((int)bounces < I.maxDepth) {
-                    kind = (int)sc.materials[mw & 0x7fffffffu].kind;
-                    P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
-                    P.hitTri[p] = h.tri;
+            const float4* tp = tris + (size_t)h.tri * 3;
+            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            int lightIdx = __float_as_int(v2.w);
+            uint32_t mw = __float_as_uint(v1.w);
+            if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
+                const DevLight& lt = sc.lights[lightIdx];
+                F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
+                if (lt.twoSided || dot(n, -d) > 0) {
+                    float4 L = P.L[p], be = P.beta[p];
+                    F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                    P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
                 }
             }
+            if ((int)bounces < I.maxDepth) {
+                kinds |= (sc.materials[mw & 0x7fffffffu].kind + 1u) << (4 * it);
+                P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
+                P.hitTri[p] = h.tri;
+            }
         }
+        // ---- bin the chunk: order inside a material queue is wave, item, lane
 #pragma unroll
         for (int k = 0; k < MK_COUNT; ++k) {
-            bool mine = kind == k;
-            uint32_t slot = waveReserve(mine, &ctr->matCount[k]);
-            if (mine) mq.q[k][slot] = p;
+            uint32_t c = 0;
+#pragma unroll
+            for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot(((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
+            if (lane == 0) binCnt[k * kWavesPerBlock + wid] = c;
         }
+        __syncthreads();
+        if (threadIdx.x < MK_COUNT) {
+            uint32_t total = 0;
+            for (int w = 0; w < kWavesPerBlock; ++w) total += binCnt[threadIdx.x * kWavesPerBlock + w];
+            binBase[threadIdx.x] = total ? atomicAdd(&ctr->matCount[threadIdx.x].v, total) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MK_COUNT; ++k) {
+            uint32_t off = binBase[k];
+            for (uint32_t w = 0; w < wid; ++w) off += binCnt[k * kWavesPerBlock + w];
+#pragma unroll
+            for (int it = 0; it < kTraceItems; ++it) {
+                bool mine = ((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u;
+                unsigned long long mask = __ballot(mine);
+                if (mine) {
+                    uint32_t i = chunk + it * kBlock + threadIdx.x;
+                    mq.q[k][off + __popcll(mask & lanesBelow)] = queue ? queue[i] : i;
+                }
+                off += __popcll(mask);
+            }
+        }
+        __syncthreads(); // binCnt / binBase are rewritten by the next chunk
     }
 }
 
@@ -256,7 +270,7 @@ template <int MK>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
-    const uint32_t count = ctr->matCount[MK];
+    const uint32_t count = ctr->matCount[MK].v;
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
@@ -409,19 +423,19 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             }
         }
         uint32_t s;
-        s = blockReserve(pushShadow, &ctr->shadowCount, lds);
+        s = blockReserve(pushShadow, &ctr->shadowCount.v, lds);
         if (pushShadow) {
             shq.o[s] = mk4(shO, __uint_as_float(p));
             shq.d[s] = mk4(shD, 1 - kShadowEpsilon);
             shq.w[s] = mk4(shW, 0.f);
         }
-        s = blockReserve(pushMis, &ctr->misCount, lds);
+        s = blockReserve(pushMis, &ctr->misCount.v, lds);
         if (pushMis) {
             misq.o[s] = mk4(miO, __uint_as_float(p));
             misq.d[s] = mk4(miD, __int_as_float(miLight));
             misq.w[s] = mk4(miW, 0.f);
         }
-        s = blockReserve(pushNext, &ctr->extCount[nextIdx], lds);
+        s = blockReserve(pushNext, &ctr->extCount[nextIdx].v, lds);
         if (pushNext) nextQueue[s] = p;
     }
 }
@@ -429,21 +443,18 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
 // Shadow rays and BSDF-sampled MIS rays of one bounce in ONE launch: work items [0, shadowCount) are
 // VisibilityTester::Unoccluded queries (any-hit; unoccluded rays add their contribution), items
 // [shadowCount, shadowCount + misCount) are the MIS rays of EstimateDirect (closest hit must be the
-// sampled light's triangle).  Waves fetch 64 items at a time, so a wave is (almost always) all of one kind.
+// sampled light's triangle).  Blocks stride over 256-item chunks, so a wave is (almost always) all of one kind.
 template <int STACK, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, DevRayQueue shq, DevRayQueue misq, DevCounters* ctr) {
     __shared__ uint32_t stack[2 * STACK * kBlock];
     extern __shared__ float4 sceneLds[];
+    const uint32_t nShadow = ctr->shadowCount.v, count = nShadow + ctr->misCount.v;
+    if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
-    const uint32_t nShadow = ctr->shadowCount, count = nShadow + ctr->misCount;
     uint32_t* myStack = stack + threadIdx.x;
-    for (;;) {
-        uint32_t base = waveFetch(&ctr->workNext[1]);
-        if (base >= count) break;
-        uint32_t i = base + (threadIdx.x & 63u);
-        if (i >= count) continue;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         if (i < nShadow) {
             float4 o = shq.o[i], d = shq.d[i];
             if (!traceAny<STACK, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
@@ -515,20 +526,18 @@ __global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, ui
     });
 }
 
-// Between stages: account rays, reset the queues the next stage fills, rewind work cursors.
+// Between stages: account rays, reset the queues the next stage fills.
 // phase 0: before a bounce's k_intersect_closest.  phase 1: after the shade kernels.  phase 2: after shadow/mis.
 __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t countImm, int useImm) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (phase == 0) {
-        ctr->raysClosest += useImm ? countImm : ctr->extCount[curIdx];
-        for (int k = 0; k < MK_COUNT; ++k) ctr->matCount[k] = 0;
-        ctr->workNext[0] = 0;
-        ctr->extCount[curIdx ^ 1u] = 0;
-        ctr->shadowCount = 0; ctr->misCount = 0;
+        ctr->raysClosest += useImm ? countImm : ctr->extCount[curIdx].v;
+        for (int k = 0; k < MK_COUNT; ++k) ctr->matCount[k].v = 0;
+        ctr->extCount[curIdx ^ 1u].v = 0;
+        ctr->shadowCount.v = 0; ctr->misCount.v = 0;
     } else if (phase == 1) {
-        ctr->raysShadow += ctr->shadowCount;
-        ctr->raysMis += ctr->misCount;
-        ctr->workNext[1] = 0;
+        ctr->raysShadow += ctr->shadowCount.v;
+        ctr->raysMis += ctr->misCount.v;
     }
 }
 
