@@ -112,31 +112,57 @@ DEV void nodeBoxes(const float4* n, F3* lo0, F3* hi0, F3* lo1, F3* hi1, int* c0,
     *c0 = __float_as_int(q3.x); *c1 = __float_as_int(q3.y);
 }
 
-// Per-lane traversal stack in LDS: entry (level, lane) lives at stack[level * STRIDE + lane], so a
-// lane always uses LDS bank (lane % 32) whatever its depth -- conflict free for the two 32-lane
-// groups of ds_read_b32 / ds_write_b32.  The closest-hit stack keeps the far child's entry distance
-// beside its reference (second plane at +STACK*STRIDE words): a popped node whose entry distance is
-// no longer below the current hit distance is dropped without being fetched -- the same decision
-// the reference takes when it visits the node (tMin < ray.m_maxT, Enigma/BBox.h:294).
+// Per-lane traversal stack.  The first LDSN levels live in LDS: entry (level, lane) at
+// stack[level * STRIDE + lane], so a lane always uses LDS bank (lane % 32) whatever its depth --
+// conflict free for the two 32-lane groups of ds_read_b32 / ds_write_b32.  Levels LDSN .. LDSN+OVF-1
+// spill to a per-lane private array (scratch memory); with near-child-first descent almost no ray
+// gets that deep, so LDS per block -- and with it occupancy -- no longer grows with the tree depth.
+// The closest-hit stack keeps the far child's entry distance beside its reference (second plane at
+// +LDSN*STRIDE words): a popped node whose entry distance is no longer below the current hit distance
+// is dropped without being fetched -- the same decision the reference takes when it visits the node
+// (tMin < ray.m_maxT, Enigma/BBox.h:294).
 constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (nTris < 2^28)
 
-template <int STACK, int STRIDE>
-DEV int popClosest(const uint32_t* stack, int& sp, float tMax) {
-    while (sp > 0) {
-        --sp;
-        float te = __uint_as_float(stack[(STACK + sp) * STRIDE]);
-        if (te < tMax) return (int)stack[sp * STRIDE];
+template <int LDSN, int OVF, int STRIDE, bool DIST>
+struct LaneStack {
+    uint32_t* lds;
+    int sp;
+    uint32_t ovN[OVF > 0 ? OVF : 1];
+    float ovT[(OVF > 0 && DIST) ? OVF : 1];
+    DEV explicit LaneStack(uint32_t* column) : lds(column), sp(0) {}
+    DEV void push(int node, float t) {
+        if (sp < LDSN) {
+            lds[sp * STRIDE] = (uint32_t)node;
+            if (DIST) lds[(LDSN + sp) * STRIDE] = __float_as_uint(t);
+            ++sp;
+        } else if (OVF > 0 && sp < LDSN + OVF) {
+            ovN[sp - LDSN] = (uint32_t)node;
+            if (DIST) ovT[sp - LDSN] = t;
+            ++sp;
+        }
     }
-    return kTraverseDone;
-}
+    // next node whose entry distance is still below tMax (any node when !DIST), or kTraverseDone
+    DEV int pop(float tMax) {
+        while (sp > 0) {
+            --sp;
+            if (OVF > 0 && sp >= LDSN) {
+                if (!DIST || ovT[sp - LDSN] < tMax) return (int)ovN[sp - LDSN];
+            } else {
+                if (!DIST || __uint_as_float(lds[(LDSN + sp) * STRIDE]) < tMax) return (int)lds[sp * STRIDE];
+            }
+        }
+        return kTraverseDone;
+    }
+};
 
 // "while-while" traversal: lanes descend inner nodes until each holds a leaf (or is done), then the
 // wave tests triangles together, so the expensive triangle code runs with most lanes active.
-template <int STACK, int STRIDE>
-DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* stack) {
+template <int LDSN, int OVF, int STRIDE>
+DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
     RaySetup r = setupRay(o, d);
     Hit h; h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
-    int cur = 0, sp = 0;
+    LaneStack<LDSN, OVF, STRIDE, true> st(column);
+    int cur = 0;
     for (;;) {
         while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
@@ -145,13 +171,11 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
             bool h1 = slabTest(r, h.t, lo1, hi1, &t1);
             if (h0 && h1) {
                 bool swp = t1 < t0;
-                int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
-                float farT = swp ? t0 : t1;
-                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)farC; stack[(STACK + sp) * STRIDE] = __float_as_uint(farT); ++sp; }
-                cur = nearC;
+                st.push(swp ? c0 : c1, swp ? t0 : t1);
+                cur = swp ? c1 : c0;
             } else if (h0) cur = c0;
             else if (h1) cur = c1;
-            else cur = popClosest<STACK, STRIDE>(stack, sp, h.t);
+            else cur = st.pop(h.t);
         }
         if (cur == kTraverseDone) break;
         uint32_t leaf = ~(uint32_t)cur;
@@ -170,29 +194,27 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
                 if (ok) { h.t = t; h.tri = (int)(first + i); h.b0 = b0; h.b1 = b1; h.b2 = b2; }
             }
         }
-        cur = popClosest<STACK, STRIDE>(stack, sp, h.t);
+        cur = st.pop(h.t);
     }
     return h;
 }
 
 // Any-hit (Scene::intersectP): no ordering, first accepted triangle ends the walk.
-template <int STACK, int STRIDE>
-DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* stack) {
+template <int LDSN, int OVF, int STRIDE>
+DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
     RaySetup r = setupRay(o, d);
-    int cur = 0, sp = 0;
+    LaneStack<LDSN, OVF, STRIDE, false> st(column);
+    int cur = 0;
     for (;;) {
         while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
             nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
             bool h0 = slabTest(r, tMax, lo0, hi0, &t0);
             bool h1 = slabTest(r, tMax, lo1, hi1, &t1);
-            if (h0 && h1) {
-                if (sp < STACK) { stack[sp * STRIDE] = (uint32_t)c1; ++sp; }
-                cur = c0;
-            } else if (h0) cur = c0;
+            if (h0 && h1) { st.push(c1, 0.f); cur = c0; }
+            else if (h0) cur = c0;
             else if (h1) cur = c1;
-            else if (sp > 0) { --sp; cur = (int)stack[sp * STRIDE]; }
-            else cur = kTraverseDone;
+            else cur = st.pop(0.f);
         }
         if (cur == kTraverseDone) break;
         uint32_t leaf = ~(uint32_t)cur;
@@ -203,8 +225,7 @@ DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMa
             float t, b0, b1, b2;
             if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) return true; // Triangle::intersectP
         }
-        if (sp > 0) { --sp; cur = (int)stack[sp * STRIDE]; }
-        else cur = kTraverseDone;
+        cur = st.pop(0.f);
     }
     return false;
 }

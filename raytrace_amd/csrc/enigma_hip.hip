@@ -211,7 +211,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
     enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
     h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (bvh.maxDepth > 32) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (32)", bvh.maxDepth);
+    if (bvh.maxDepth > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (64)", bvh.maxDepth);
     h->bvhDepth = bvh.maxDepth;
     h->bvhNodes = (uint32_t)bvh.nodes.size();
     std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
@@ -410,7 +410,7 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
 static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 4 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
 
-template <int STACK, bool LDS_SCENE>
+template <int LDSN, int OVF, int MLDSN, int MOVF, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -422,7 +422,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<STACK, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -433,12 +433,9 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow_mis<STACK, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
+        k_shadow_mis<LDSN, OVF, MLDSN, MOVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
     }
 }
-
-// two LDS planes of STACK x 256 words per block (node reference + entry distance): 64 KB static LDS caps STACK at 32
-static int stackFor(uint32_t depth) { return depth <= 12 ? 12 : depth <= 16 ? 16 : depth <= 24 ? 24 : 32; }
 
 extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (!h) return ENIGMA_E_INVALID;
@@ -455,8 +452,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
-    const int stack = stackFor(h->bvhDepth);
-    const bool ldsScene = stack == 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 16 levels in LDS + scratch spill
+    const bool ldsScene = h->bvhDepth <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -488,14 +485,9 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (ldsScene) { // small scenes have shallow trees: stack 12 always suffices (checked above)
-                    launchBounce<12, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                } else switch (stack) {
-                case 12: launchBounce<12, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
-                case 16: launchBounce<16, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
-                case 24: launchBounce<24, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
-                default: launchBounce<32, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1); break;
-                }
+                if (ldsScene) launchBounce<12, 0, 12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (h->bvhDepth <= 16) launchBounce<16, 0, 8, 8, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else launchBounce<16, 48, 8, 56, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
             }
             k_film_splat<<<gridAll, kBlock, 0, h->stream>>>(P, h->film, nPaths);
@@ -649,12 +641,10 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
     if (e == hipSuccess) e = dPrim.alloc(n);
     if (e == hipSuccess) {
         int grid = (int)((n + kBlock - 1) / kBlock);
-        switch (stackFor(h->bvhDepth)) {
-        case 12: k_debug_intersect<12><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        case 16: k_debug_intersect<16><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        case 24: k_debug_intersect<24><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        default: k_debug_intersect<32><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p); break;
-        }
+        // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
+        if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
+        else if (h->bvhDepth <= 16) k_debug_intersect<16, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
+        else k_debug_intersect<16, 48><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
         e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost);
         if (e == hipSuccess && !anyHit) {

@@ -169,10 +169,10 @@ struct MatQueues { uint32_t* q[MK_COUNT]; };
 constexpr int kTraceItems = 4;
 constexpr uint32_t kTraceChunk = kBlock * kTraceItems;
 
-template <int STACK, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr) {
-    __shared__ uint32_t stack[2 * STACK * kBlock];
+    __shared__ uint32_t stack[2 * LDSN * kBlock];
     __shared__ uint32_t binCnt[MK_COUNT * kWavesPerBlock];
     __shared__ uint32_t binBase[MK_COUNT];
     extern __shared__ float4 sceneLds[];
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPa
             if (i >= count) continue;
             uint32_t p = queue ? queue[i] : i;
             F3 o = xyz(P.rayO[p]), d = xyz(P.rayD[p]);
-            Hit h = traceClosest<STACK, kBlock>(nodes, tris, o, d, EDEV_INF, myStack);
+            Hit h = traceClosest<LDSN, OVF, kBlock>(nodes, tris, o, d, EDEV_INF, myStack);
             if (h.tri < 0) continue;
             uint32_t st = P.state[p];
             uint32_t bounces = stBounces(st);
@@ -444,9 +444,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
 // VisibilityTester::Unoccluded queries (any-hit; unoccluded rays add their contribution), items
 // [shadowCount, shadowCount + misCount) are the MIS rays of EstimateDirect (closest hit must be the
 // sampled light's triangle).  Blocks stride over 256-item chunks, so a wave is (almost always) all of one kind.
-template <int STACK, bool LDS_SCENE>
+// The (rare) MIS rays walk with MLDSN two-plane levels carved out of the same LDS columns.
+template <int LDSN, int OVF, int MLDSN, int MOVF, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, DevRayQueue shq, DevRayQueue misq, DevCounters* ctr) {
-    __shared__ uint32_t stack[2 * STACK * kBlock];
+    __shared__ uint32_t stack[(LDSN > 2 * MLDSN ? LDSN : 2 * MLDSN) * kBlock];
     extern __shared__ float4 sceneLds[];
     const uint32_t nShadow = ctr->shadowCount.v, count = nShadow + ctr->misCount.v;
     if (blockIdx.x * kBlock >= count) return;
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, 
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         if (i < nShadow) {
             float4 o = shq.o[i], d = shq.d[i];
-            if (!traceAny<STACK, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
+            if (!traceAny<LDSN, OVF, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
                 uint32_t p = __float_as_uint(o.w);
                 float4 w = shq.w[i];
                 float* L = reinterpret_cast<float*>(P.L + p);
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, 
         } else {
             uint32_t j = i - nShadow;
             float4 o = misq.o[j], d = misq.d[j];
-            Hit h = traceClosest<STACK, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, myStack);
+            Hit h = traceClosest<MLDSN, MOVF, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, myStack);
             if (h.tri >= 0) {
                 const float4* tp = tris + (size_t)h.tri * 3;
                 float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
@@ -563,19 +564,19 @@ __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int3
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
     outPfilm[2 * (size_t)i] = fx; outPfilm[2 * (size_t)i + 1] = fy;
 }
-template <int STACK>
+template <int LDSN, int OVF>
 __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
                                                             uint32_t* primOut, float* tOut, float* baryOut) {
-    __shared__ uint32_t stack[2 * STACK * kBlock];
+    __shared__ uint32_t stack[2 * LDSN * kBlock];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
     F3 o(r[0], r[1], r[2]), d(r[3], r[4], r[5]);
     if (anyHit) {
-        triOut[i] = traceAny<STACK, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
+        triOut[i] = traceAny<LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
         return;
     }
-    Hit h = traceClosest<STACK, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
+    Hit h = traceClosest<LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
     int orig = -1;
     if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
     triOut[i] = orig;

@@ -141,6 +141,35 @@ def test_hits_bit_exact_random_rays_many_lights_and_mesh():
         r.close(); o.close()
 
 
+def test_traversal_stack_spill_path_gives_identical_hits():
+    """Deep trees keep 16 stack levels in LDS and spill the rest to scratch.  With only two LDS
+    levels (debug knob) nearly every ray spills; hits must not change by a bit."""
+    rng = np.random.RandomState(33)
+    sc, cam = scenes.big_mesh(grid=96, sphere_level=4, n_spheres=4), scenes.big_mesh_camera(64, 64)
+    film = scenes.film_desc(64, 64)
+    integ = scenes.integrator_desc(film, 16)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    P = np.stack([rng.randint(0, 64, 2000), rng.randint(0, 64, 2000)], axis=1).astype(np.int32)
+    rays, _ = o.camera_rays(P, rng.randint(0, 16, 2000).astype(np.int64))
+    rays7 = common.rays_from_camera(rays)
+    base = r.intersect(rays7)
+    hit = base["tri"] >= 0
+    org = rays[hit, :3] + rays[hit, 3:6] * (base["t"][hit, None] * 0.999)
+    sec = np.concatenate([org, rng.normal(size=org.shape), rng.uniform(0.5, 400.0, size=(org.shape[0], 1))], axis=1).astype(np.float32)
+    base_sec, base_any = r.intersect(sec), r.intersect_any(sec)
+    os.environ["ENIGMA_DEBUG_TINY_STACK"] = "1"
+    try:
+        tiny, tiny_sec, tiny_any = r.intersect(rays7), r.intersect(sec), r.intersect_any(sec)
+    finally:
+        del os.environ["ENIGMA_DEBUG_TINY_STACK"]
+    for a, b in ((base, tiny), (base_sec, tiny_sec)):
+        assert np.array_equal(a["tri"], b["tri"]) and np.array_equal(u32(a["t"]), u32(b["t"])) and np.array_equal(u32(a["bary"]), u32(b["bary"]))
+    assert np.array_equal(base_any, tiny_any)
+    _hit_check(r, o, sec)
+    r.close(); o.close()
+
+
 def test_degenerate_rays():
     r, o = pair(common.cornell_setup(res=32, spp=4))
     rays = np.array([
