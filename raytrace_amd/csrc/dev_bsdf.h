@@ -3,7 +3,7 @@
 // Replaces the arena-allocated BxDF object graph (Enigma/BxDF.cpp:843-985 BSDF;
 // :729-732 Lambertian; :1075-1121 MicrofacetReflection; :1007-1073 MicrofacetTransmission;
 // :1124-1158 FresnelSpecular; :453-503 Fresnel terms; Enigma/MicrofacetDist.cpp:165-328
-// Trowbridge-Reitz) with a POD of at most two lobes held in registers.  Formulas keep the
+// Trowbridge-Reitz) with a POD of at most two lobes held in registers; the lobe kinds are compile-time per material kind.  Formulas keep the
 // reference's operation order and its deviations from pbrt:
 //  * the local frame's z axis is the GEOMETRIC normal (BxDF.cpp:872-882);
 //  * FresnelSpecular scales its reflection by T, not R (BxDF.cpp:1135);
@@ -16,14 +16,11 @@ namespace edev {
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
 enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR };
 
-DEV int lobeType(int k) {
-    switch (k) {
-    case LOBE_LAMBERT: return BSDF_REFLECTION | BSDF_DIFFUSE;
-    case LOBE_MICRO_REFL_CONDUCTOR:
-    case LOBE_MICRO_REFL_DIELECTRIC: return BSDF_REFLECTION | BSDF_GLOSSY;
-    case LOBE_MICRO_TRANS: return BSDF_TRANSMISSION | BSDF_GLOSSY;
-    default: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
-    }
+DEV constexpr int lobeType(int k) {
+    return k == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
+         : (k == LOBE_MICRO_REFL_CONDUCTOR || k == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
+         : k == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
+         : (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
 }
 
 // ---- BxDF.h:28-106 helpers ----
@@ -158,10 +155,22 @@ DEV F3 cosineSampleHemisphere(float ux, float uy) {
 }
 
 // ---- the per-hit BSDF ----
+// The lobes a material can own are fixed by its kind, in the order Material::computeScatteringFunctions
+// adds them; which of them exist at a hit (non-black colours) is run-time.  Keeping the lobe kind a
+// compile-time function of (material kind, slot) lets every switch below fold away per shade kernel
+// and keeps the struct in registers (no run-time indexed members).
+template <int MK, int I> struct LobeOf { static constexpr int kind = -1; };
+template <> struct LobeOf<MK_MATTE, 0> { static constexpr int kind = LOBE_LAMBERT; };
+template <> struct LobeOf<MK_METAL, 0> { static constexpr int kind = LOBE_MICRO_REFL_CONDUCTOR; };
+template <> struct LobeOf<MK_GLASS_SMOOTH, 0> { static constexpr int kind = LOBE_FRESNEL_SPECULAR; };
+template <> struct LobeOf<MK_GLASS_ROUGH, 0> { static constexpr int kind = LOBE_MICRO_REFL_DIELECTRIC; };
+template <> struct LobeOf<MK_GLASS_ROUGH, 1> { static constexpr int kind = LOBE_MICRO_TRANS; };
+template <> struct LobeOf<MK_PLASTIC, 0> { static constexpr int kind = LOBE_LAMBERT; };
+template <> struct LobeOf<MK_PLASTIC, 1> { static constexpr int kind = LOBE_MICRO_REFL_DIELECTRIC; };
+
 struct Bsdf {
-    int n;                 // number of lobes (0..2)
-    int kind[2];
-    F3 col[2];             // R / T / Kd / Ks (glass smooth: col[0] = R, col[1] = T)
+    bool has0, has1;       // slot present at this hit
+    F3 col0, col1;         // R / T / Kd / Ks of the slot (glass smooth: col0 = R, col1 = T, one lobe)
     F3 cEta, cK;           // conductor eta, k
     float ax, ay;          // shared microfacet distribution of the material
     float eta;             // BSDF::m_eta (glass index, else 1)
@@ -180,53 +189,57 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 dpdu, Bsdf* b) {
     b->ng = ng;
     b->ss = normalize(dpdu);
     b->ts = cross(ng, b->ss);
-    b->n = 0;
     b->eta = 1.f;
     b->ax = m.alphax; b->ay = m.alphay;
-    F3 c0(m.c0[0], m.c0[1], m.c0[2]), c1(m.c1[0], m.c1[1], m.c1[2]);
-    bool has0 = m.flags & 1u, has1 = m.flags & 2u;
-    if (MK == MK_MATTE) {
-        if (has0) { b->kind[0] = LOBE_LAMBERT; b->col[0] = c0; b->n = 1; }
-    } else if (MK == MK_METAL) {
-        b->kind[0] = LOBE_MICRO_REFL_CONDUCTOR; b->col[0] = F3(1.f); b->cEta = c0; b->cK = c1; b->n = 1;
+    b->col0 = F3(m.c0[0], m.c0[1], m.c0[2]); b->col1 = F3(m.c1[0], m.c1[1], m.c1[2]);
+    b->cEta = F3(0.f); b->cK = F3(0.f);
+    b->dEtaI = 1.f; b->dEtaT = 1.f;
+    bool nb0 = m.flags & 1u, nb1 = m.flags & 2u;
+    b->has0 = nb0; b->has1 = false;
+    if (MK == MK_METAL) {
+        b->cEta = b->col0; b->cK = b->col1; b->col0 = F3(1.f); b->has0 = true;
     } else if (MK == MK_GLASS_SMOOTH) {
-        b->eta = m.eta;
-        if (has0 || has1) { b->kind[0] = LOBE_FRESNEL_SPECULAR; b->col[0] = c0; b->col[1] = c1; b->dEtaI = 1.f; b->dEtaT = m.eta; b->n = 1; }
+        b->eta = m.eta; b->dEtaT = m.eta;
+        b->has0 = nb0 || nb1;
     } else if (MK == MK_GLASS_ROUGH) {
-        b->eta = m.eta;
-        b->dEtaI = 1.f; b->dEtaT = m.eta;
-        if (has0) { b->kind[b->n] = LOBE_MICRO_REFL_DIELECTRIC; b->col[b->n] = c0; b->n++; }
-        if (has1) { b->kind[b->n] = LOBE_MICRO_TRANS; b->col[b->n] = c1; b->n++; }
-    } else { // plastic: FresnelDielectric(1.5f, 1.f), Material.cpp:244
+        b->eta = m.eta; b->dEtaT = m.eta;
+        b->has1 = nb1;
+    } else if (MK == MK_PLASTIC) { // FresnelDielectric(1.5f, 1.f), Material.cpp:244
         b->dEtaI = 1.5f; b->dEtaT = 1.f;
-        if (has0) { b->kind[b->n] = LOBE_LAMBERT; b->col[b->n] = c0; b->n++; }
-        if (has1) { b->kind[b->n] = LOBE_MICRO_REFL_DIELECTRIC; b->col[b->n] = c1; b->n++; }
+        b->has1 = nb1;
     }
 }
 
-DEV bool lobeMatches(int kind, int flags) { int t = lobeType(kind); return (t & flags) == t; }
-DEV int numComponents(const Bsdf& b, int flags) {
-    int c = 0;
-    for (int i = 0; i < 2; ++i) if (i < b.n && lobeMatches(b.kind[i], flags)) ++c;
-    return c;
+DEV constexpr bool lobeMatches(int kind, int flags) {
+    int t = kind == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
+          : (kind == LOBE_MICRO_REFL_CONDUCTOR || kind == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
+          : kind == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
+          : kind == LOBE_FRESNEL_SPECULAR ? (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR) : 0;
+    return kind >= 0 && (t & flags) == t;
 }
+// slot I of material kind MK exists at this hit and matches flags
+template <int MK, int I>
+DEV bool lobeOn(const Bsdf& b, int flags) { return lobeMatches(LobeOf<MK, I>::kind, flags) && (I == 0 ? b.has0 : b.has1); }
+template <int MK>
+DEV int numComponents(const Bsdf& b, int flags) { return (lobeOn<MK, 0>(b, flags) ? 1 : 0) + (lobeOn<MK, 1>(b, flags) ? 1 : 0); }
 
-DEV F3 microReflF(const Bsdf& b, int i, F3 wo, F3 wi) { // BxDF.cpp:1084-1100
+template <int KIND>
+DEV F3 microReflF(const Bsdf& b, F3 col, F3 wo, F3 wi) { // BxDF.cpp:1084-1100
     float cosThetaO = absCosTheta(wo), cosThetaI = absCosTheta(wi);
     F3 wh = wi + wo;
     if (cosThetaI == 0 || cosThetaO == 0) return F3(0.f);
     if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3(0.f);
     wh = normalize(wh);
     float c = dot(wi, faceForward(wh, F3(0, 0, 1)));
-    F3 F = (b.kind[i] == LOBE_MICRO_REFL_CONDUCTOR) ? frConductor(fabsf(c), b.cEta, b.cK) : F3(frDielectric(c, b.dEtaI, b.dEtaT));
-    return b.col[i] * trD(b.ax, b.ay, wh) * trG(b.ax, b.ay, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    F3 F = (KIND == LOBE_MICRO_REFL_CONDUCTOR) ? frConductor(fabsf(c), b.cEta, b.cK) : F3(frDielectric(c, b.dEtaI, b.dEtaT));
+    return col * trD(b.ax, b.ay, wh) * trG(b.ax, b.ay, wo, wi) * F / (4 * cosThetaI * cosThetaO);
 }
 DEV float microReflPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1116-1121
     if (!sameHemisphere(wo, wi)) return 0;
     F3 wh = normalize(wo + wi);
     return trPdf(b.ax, b.ay, wo, wh) / (4 * dot(wo, wh));
 }
-DEV F3 microTransF(const Bsdf& b, int i, F3 wo, F3 wi) { // BxDF.cpp:1018-1043 (radiance transport)
+DEV F3 microTransF(const Bsdf& b, F3 col, F3 wo, F3 wi) { // BxDF.cpp:1018-1043 (radiance transport)
     if (sameHemisphere(wo, wi)) return F3(0.f);
     float cosThetaO = cosTheta(wo), cosThetaI = cosTheta(wi);
     if (cosThetaI == 0 || cosThetaO == 0) return F3(0.f);
@@ -239,7 +252,7 @@ DEV F3 microTransF(const Bsdf& b, int i, F3 wo, F3 wi) { // BxDF.cpp:1018-1043 (
     float factor = 1 / eta;
     float s = fabsf(trD(b.ax, b.ay, wh) * trG(b.ax, b.ay, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                     (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
-    return (F3(1.f) - F3(F)) * b.col[i] * s;
+    return (F3(1.f) - F3(F)) * col * s;
 }
 DEV float microTransPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1059-1073
     if (sameHemisphere(wo, wi)) return 0;
@@ -251,125 +264,132 @@ DEV float microTransPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1059-1073
     return trPdf(b.ax, b.ay, wo, wh) * dwh_dwi;
 }
 
-DEV F3 lobeF(const Bsdf& b, int i, F3 wo, F3 wi) {
-    switch (b.kind[i]) {
-    case LOBE_LAMBERT: return b.col[i] * kInvPi;
-    case LOBE_MICRO_REFL_CONDUCTOR:
-    case LOBE_MICRO_REFL_DIELECTRIC: return microReflF(b, i, wo, wi);
-    case LOBE_MICRO_TRANS: return microTransF(b, i, wo, wi);
-    default: return F3(0.f);
-    }
+template <int KIND>
+DEV F3 lobeF(const Bsdf& b, F3 col, F3 wo, F3 wi) {
+    if (KIND == LOBE_LAMBERT) return col * kInvPi;
+    if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) return microReflF<KIND>(b, col, wo, wi);
+    if (KIND == LOBE_MICRO_TRANS) return microTransF(b, col, wo, wi);
+    return F3(0.f);
 }
-DEV float lobePdf(const Bsdf& b, int i, F3 wo, F3 wi) {
-    switch (b.kind[i]) {
-    case LOBE_LAMBERT: return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF.cpp:568-571
-    case LOBE_MICRO_REFL_CONDUCTOR:
-    case LOBE_MICRO_REFL_DIELECTRIC: return microReflPdf(b, wo, wi);
-    case LOBE_MICRO_TRANS: return microTransPdf(b, wo, wi);
-    default: return 0.f;
-    }
+template <int KIND>
+DEV float lobePdf(const Bsdf& b, F3 wo, F3 wi) {
+    if (KIND == LOBE_LAMBERT) return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF.cpp:568-571
+    if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) return microReflPdf(b, wo, wi);
+    if (KIND == LOBE_MICRO_TRANS) return microTransPdf(b, wo, wi);
+    return 0.f;
 }
 // BxDF::sample_f of one lobe.  Returns f; *pdf stays 0 when the lobe fails to sample.
-DEV F3 lobeSample(const Bsdf& b, int i, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
-    switch (b.kind[i]) {
-    case LOBE_LAMBERT: { // BxDF.cpp:529-536
+template <int KIND>
+DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
+    if (KIND == LOBE_LAMBERT) { // BxDF.cpp:529-536
         *wi = cosineSampleHemisphere(u0, u1);
         if (wo.z < 0.f) wi->z *= -1.f;
-        *pdf = lobePdf(b, i, wo, *wi);
-        return lobeF(b, i, wo, *wi);
-    }
-    case LOBE_MICRO_REFL_CONDUCTOR:
-    case LOBE_MICRO_REFL_DIELECTRIC: { // BxDF.cpp:1102-1114
+        *pdf = lobePdf<KIND>(b, wo, *wi);
+        return lobeF<KIND>(b, col, wo, *wi);
+    } else if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) { // BxDF.cpp:1102-1114
         if (wo.z == 0) return F3(0.f);
         F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
         if (dot(wo, wh) < 0) return F3(0.f);
         *wi = reflect(wo, wh);
         if (!sameHemisphere(wo, *wi)) return F3(0.f);
         *pdf = trPdf(b.ax, b.ay, wo, wh) / (4 * dot(wo, wh));
-        return microReflF(b, i, wo, *wi);
-    }
-    case LOBE_MICRO_TRANS: { // BxDF.cpp:1045-1056
+        return microReflF<KIND>(b, col, wo, *wi);
+    } else if (KIND == LOBE_MICRO_TRANS) { // BxDF.cpp:1045-1056
         if (wo.z == 0) return F3(0.f);
         F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
         if (dot(wo, wh) < 0) return F3(0.f);
         float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
         if (!refract(wo, wh, eta, wi)) return F3(0.f);
         *pdf = microTransPdf(b, wo, *wi);
-        return microTransF(b, i, wo, *wi);
-    }
-    default: { // FresnelSpecular, BxDF.cpp:1124-1158; col[0] = R (unused by the reference), col[1] = T
+        return microTransF(b, col, wo, *wi);
+    } else if (KIND == LOBE_FRESNEL_SPECULAR) { // BxDF.cpp:1124-1158; col0 = R (unused by the reference), col1 = T
         float F = frDielectric(cosTheta(wo), b.dEtaI, b.dEtaT);
         if (u0 < F) {
             *wi = F3(-wo.x, -wo.y, wo.z);
             *sampledType = BSDF_SPECULAR | BSDF_REFLECTION;
             *pdf = F;
-            return (b.col[1] * F) / absCosTheta(*wi);
+            return (b.col1 * F) / absCosTheta(*wi);
         } else {
             bool entering = cosTheta(wo) > 0;
             float etaI = entering ? b.dEtaI : b.dEtaT;
             float etaT = entering ? b.dEtaT : b.dEtaI;
             if (!refract(wo, faceForward(F3(0, 0, 1), wo), etaI / etaT, wi)) return F3(0.f);
-            F3 ft = b.col[1] * (1 - F);
+            F3 ft = b.col1 * (1 - F);
             ft *= (etaI * etaI) / (etaT * etaT);
             *sampledType = BSDF_SPECULAR | BSDF_TRANSMISSION;
             *pdf = 1 - F;
             return ft / absCosTheta(*wi);
         }
     }
-    }
+    return F3(0.f);
 }
 
+// sum of lobe f over the slots matching flags on the side (reflection / transmission) of the pair
+template <int MK, int I>
+DEV F3 sideF(const Bsdf& b, F3 wo, F3 wi, int flags, bool refl) {
+    constexpr int K = LobeOf<MK, I>::kind;
+    if (!lobeOn<MK, I>(b, flags)) return F3(0.f);
+    constexpr int t = lobeType(K < 0 ? 0 : K);
+    if ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION))) return lobeF<K>(b, I == 0 ? b.col0 : b.col1, wo, wi);
+    return F3(0.f);
+}
 // BSDF::f, BxDF.cpp:972-985
+template <int MK>
 DEV F3 bsdfF(const Bsdf& b, F3 woW, F3 wiW, int flags) {
     F3 wi = toLocal(b, wiW), wo = toLocal(b, woW);
     if (wo.z == 0) return F3(0.f);
     bool refl = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
     F3 f(0.f);
-    for (int i = 0; i < 2; ++i)
-        if (i < b.n && lobeMatches(b.kind[i], flags)) {
-            int t = lobeType(b.kind[i]);
-            if ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION))) f += lobeF(b, i, wo, wi);
-        }
+    f += sideF<MK, 0>(b, wo, wi, flags, refl);
+    f += sideF<MK, 1>(b, wo, wi, flags, refl);
     return f;
 }
 // BSDF::Pdf, BxDF.cpp:954-970
+template <int MK>
 DEV float bsdfPdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {
-    if (b.n == 0) return 0.f;
+    if (!b.has0 && !b.has1) return 0.f;
     F3 wo = toLocal(b, woW), wi = toLocal(b, wiW);
     float pdf = 0.f; int matching = 0;
-    for (int i = 0; i < 2; ++i)
-        if (i < b.n && lobeMatches(b.kind[i], flags)) { ++matching; pdf += lobePdf(b, i, wo, wi); }
+    if (lobeOn<MK, 0>(b, flags)) { ++matching; pdf += lobePdf<LobeOf<MK, 0>::kind>(b, wo, wi); }
+    if (lobeOn<MK, 1>(b, flags)) { ++matching; pdf += lobePdf<LobeOf<MK, 1>::kind>(b, wo, wi); }
     return matching > 0 ? pdf / matching : 0.f;
 }
 // BSDF::sample_f, BxDF.cpp:885-952.  *pdf == 0 or a black return mean "no sample".
+template <int MK>
 DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf, int flags, int* sampledType) {
+    constexpr int K0 = LobeOf<MK, 0>::kind, K1 = LobeOf<MK, 1>::kind;
     *pdf = 0; *sampledType = 0;
-    int matching = numComponents(b, flags);
+    bool on0 = lobeOn<MK, 0>(b, flags), on1 = lobeOn<MK, 1>(b, flags);
+    int matching = (on0 ? 1 : 0) + (on1 ? 1 : 0);
     if (matching == 0) return F3(0.f);
     int comp = min((int)floorf(u0 * matching), matching - 1);
-    int sel = -1, count = comp;
-    for (int i = 0; i < 2; ++i)
-        if (sel < 0 && i < b.n && lobeMatches(b.kind[i], flags) && count-- == 0) sel = i;
+    bool pick1 = on1 && (!on0 || comp == 1); // the comp-th matching slot
     float ur0 = smin(u0 * matching - comp, kOneMinusEpsilon);
     F3 wo = toLocal(b, woW), wi(0.f);
     if (wo.z == 0) return F3(0.f);
-    *sampledType = lobeType(b.kind[sel]);
-    F3 f = lobeSample(b, sel, wo, ur0, u1, &wi, pdf, sampledType);
+    F3 f;
+    bool specular;
+    if (pick1) {
+        *sampledType = lobeType(K1 < 0 ? 0 : K1);
+        specular = (lobeType(K1 < 0 ? 0 : K1) & BSDF_SPECULAR) != 0;
+        f = lobeSample<K1>(b, b.col1, wo, ur0, u1, &wi, pdf, sampledType);
+    } else {
+        *sampledType = lobeType(K0);
+        specular = (lobeType(K0) & BSDF_SPECULAR) != 0;
+        f = lobeSample<K0>(b, b.col0, wo, ur0, u1, &wi, pdf, sampledType);
+    }
     if (*pdf == 0) { *sampledType = 0; return F3(0.f); }
     *wiW = toWorld(b, wi);
-    bool specular = (lobeType(b.kind[sel]) & BSDF_SPECULAR) != 0;
-    if (!specular && matching > 1)
-        for (int i = 0; i < 2; ++i)
-            if (i != sel && i < b.n && lobeMatches(b.kind[i], flags)) *pdf += lobePdf(b, i, wo, wi);
+    if (!specular && matching > 1) {
+        if (pick1) *pdf += lobePdf<K0>(b, wo, wi);
+        else *pdf += lobePdf<K1>(b, wo, wi);
+    }
     if (matching > 1) *pdf /= matching;
     if (!specular) {
         bool refl = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
         f = F3(0.f);
-        for (int i = 0; i < 2; ++i)
-            if (i < b.n && lobeMatches(b.kind[i], flags)) {
-                int t = lobeType(b.kind[i]);
-                if ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION))) f += lobeF(b, i, wo, wi);
-            }
+        f += sideF<MK, 0>(b, wo, wi, flags, refl);
+        f += sideF<MK, 1>(b, wo, wi, flags, refl);
     }
     return f;
 }

@@ -87,10 +87,14 @@ struct DevPaths {
     float2* pfilm;    // CameraSample::m_image
 };
 
-struct DevRayQueue {  // shadow rays and BSDF-sampled MIS rays
-    float4* o;        // o.xyz, bits(path index)
-    float4* d;        // d.xyz, bits(light index) (MIS) / tMax (shadow)
-    float4* w;        // contribution to add to the path's L (shadow) or weight of Le (MIS)
+// Shadow rays and BSDF-sampled MIS rays.  The ray itself is stored at the slot of its path (written the
+// moment the shade kernel has it, so nothing stays live in registers); idx is the compact list of
+// paths that have one this bounce.
+struct DevRayQueue {
+    float4* o;        // [path] o.xyz, unused
+    float4* d;        // [path] d.xyz, bits(light index) (MIS) / tMax (shadow)
+    float4* w;        // [path] contribution to add to the path's L (shadow) or weight of Le (MIS)
+    uint32_t* idx;    // [0, count) path indices
 };
 
 // Queue tails are bumped with device-scope atomics by every block of a launch.  Atomics on one

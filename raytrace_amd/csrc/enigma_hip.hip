@@ -81,6 +81,7 @@ struct EnigmaCtx {
     // wavefront state
     size_t capacity = 0;
     DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, shW, miO, miD, miW;
+    DevBuf<uint32_t> shIdx, miIdx;
     DevBuf<int32_t> hitTri;
     DevBuf<uint32_t> pixel, state, extQ[2], matQ[MK_COUNT];
     DevBuf<float2> pfilm;
@@ -134,7 +135,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release(); h->hitTri.release();
     h->pixel.release(); h->state.release(); h->extQ[0].release(); h->extQ[1].release();
     for (auto& q : h->matQ) q.release();
-    h->pfilm.release(); h->counters.release();
+    h->pfilm.release(); h->counters.release(); h->shIdx.release(); h->miIdx.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -396,6 +397,8 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
     DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit, &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
     for (auto* b : f4) HIPCHK(h, b->alloc(n));
     HIPCHK(h, h->hitTri.alloc(n));
+    HIPCHK(h, h->shIdx.alloc(n));
+    HIPCHK(h, h->miIdx.alloc(n));
     HIPCHK(h, h->pixel.alloc(n));
     HIPCHK(h, h->state.alloc(n));
     HIPCHK(h, h->pfilm.alloc(n));
@@ -466,7 +469,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax); if (rc) return rc; }
         DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->hitTri.p, h->pixel.p, h->state.p, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p}, misq{h->miO.p, h->miD.p, h->miW.p};
+        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p, h->shIdx.p}, misq{h->miO.p, h->miD.p, h->miW.p, h->miIdx.p};
         for (int64_t s0 = 0; s0 < cn; s0 += k) {
             uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
             uint32_t nPaths = nPixels * ks;

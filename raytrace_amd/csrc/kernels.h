@@ -89,6 +89,27 @@ DEV uint32_t blockReserve(bool pred, uint32_t* counter, uint32_t* lds /* kWavesP
     __syncthreads(); // lds is reused by the next reservation
     return slot;
 }
+// Three block-wide appends (shadow, MIS, next-bounce queues) behind one pair of barriers.  lds holds
+// 2 x 16 words; callers alternate the half per loop iteration so no third barrier is needed.
+DEV void blockReserve3(bool a, bool b, bool c, uint32_t* ca, uint32_t* cb, uint32_t* cc, uint32_t* lds, uint32_t* sa, uint32_t* sb, uint32_t* sc) {
+    unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
+    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { lds[wid] = __popcll(ma); lds[4 + wid] = __popcll(mb); lds[8 + wid] = __popcll(mc); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t total = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) total += lds[threadIdx.x * 4 + w];
+        uint32_t* ctr = threadIdx.x == 0 ? ca : (threadIdx.x == 1 ? cb : cc);
+        lds[12 + threadIdx.x] = total ? atomicAdd(ctr, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t oa = lds[12], ob = lds[13], oc = lds[14];
+    for (uint32_t w = 0; w < wid; ++w) { oa += lds[w]; ob += lds[4 + w]; oc += lds[8 + w]; }
+    *sa = oa + __popcll(ma & below); *sb = ob + __popcll(mb & below); *sc = oc + __popcll(mc & below);
+}
+static_assert(kWavesPerBlock == 4, "blockReserve3 lays its counts out for four waves");
+
 // ---------------------------------------------------------------- LDS-resident scene
 // Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
 // into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
@@ -269,16 +290,15 @@ DEV float powerHeuristic(float fPdf, float gPdf) { float f = 1 * fPdf, g = 1 * g
 template <int MK>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
-    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    __shared__ uint32_t lds[32];
     const uint32_t count = ctr->matCount[MK].v;
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
-    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+    uint32_t parity = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock, parity ^= 16u) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;
         bool pushShadow = false, pushMis = false, pushNext = false;
         uint32_t p = 0;
-        F3 shO(0.f), shD(0.f), shW(0.f), miO(0.f), miD(0.f), miW(0.f);
-        int miLight = 0;
         if (active) {
             p = matQueue[i];
             F3 d = xyz(P.rayD[p]);
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
 
             // ---- UniformSampleOneLight (Enigma/Integrator.cpp:71-92) ----
-            if (numComponents(bsdf, kNonSpecular) > 0 && sc.nLights > 0) {
+            if (numComponents<MK>(bsdf, kNonSpecular) > 0 && sc.nLights > 0) {
                 float pick;
                 int lightNum = sampleDiscrete(sc, sampleDimension(S, px, py, slot, dim), &pick);
                 dim += 1;
@@ -346,17 +366,18 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                         Li = F3(lt.L[0], lt.L[1], lt.L[2]) / lengthSqr(lp - g.p);
                     }
                     if (lightPdf > 0 && !isBlack(Li)) {
-                        F3 f = bsdfF(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
-                        float scatteringPdf = bsdfPdf(bsdf, woN, wi, kNonSpecular);
+                        F3 f = bsdfF<MK>(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
+                        float scatteringPdf = bsdfPdf<MK>(bsdf, woN, wi, kNonSpecular);
                         if (!isBlack(f)) {
                             // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
                             F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
                             F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
-                            shO = origin; shD = target - origin;
                             F3 Ld;
                             if (lt.type == 0) Ld = f * Li / lightPdf;
                             else Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
-                            shW = beta * (Ld / pick);
+                            shq.o[p] = mk4(origin, 0.f);
+                            shq.d[p] = mk4(target - origin, 1 - kShadowEpsilon);
+                            shq.w[p] = mk4(beta * (Ld / pick), 0.f);
                             pushShadow = true;
                         }
                     }
@@ -364,7 +385,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     if (lt.type == 1) {
                         F3 wi2(0.f);
                         float scatPdf2; int sampledType;
-                        F3 f2 = bsdfSample(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
+                        F3 f2 = bsdfSample<MK>(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
                         f2 = f2 * absdot(wi2, ns);
                         if (!isBlack(f2) && scatPdf2 > 0) {
                             // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
@@ -380,9 +401,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                             }
                             if (lightPdf2 != 0) {
                                 float weight = powerHeuristic(scatPdf2, lightPdf2);
-                                miO = o2; miD = wi2;
-                                miW = beta * ((f2 * weight / scatPdf2) / pick);
-                                miLight = lightNum;
+                                misq.o[p] = mk4(o2, 0.f);
+                                misq.d[p] = mk4(wi2, __int_as_float(lightNum));
+                                misq.w[p] = mk4(beta * ((f2 * weight / scatPdf2) / pick), 0.f);
                                 pushMis = true;
                             }
                         }
@@ -395,7 +416,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             float pdf; int flags;
             float u0 = sampleDimension(S, px, py, slot, dim), u1 = sampleDimension(S, px, py, slot, dim + 1);
             dim += 2;
-            F3 f = bsdfSample(bsdf, wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+            F3 f = bsdfSample<MK>(bsdf, wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
             if (!(isBlack(f) || pdf == 0.f)) {
                 beta *= f * absdot(wi, ns) / pdf;
                 uint32_t spec = (flags & BSDF_SPECULAR) ? 1u : 0u;
@@ -422,21 +443,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                 }
             }
         }
-        uint32_t s;
-        s = blockReserve(pushShadow, &ctr->shadowCount.v, lds);
-        if (pushShadow) {
-            shq.o[s] = mk4(shO, __uint_as_float(p));
-            shq.d[s] = mk4(shD, 1 - kShadowEpsilon);
-            shq.w[s] = mk4(shW, 0.f);
-        }
-        s = blockReserve(pushMis, &ctr->misCount.v, lds);
-        if (pushMis) {
-            misq.o[s] = mk4(miO, __uint_as_float(p));
-            misq.d[s] = mk4(miD, __int_as_float(miLight));
-            misq.w[s] = mk4(miW, 0.f);
-        }
-        s = blockReserve(pushNext, &ctr->extCount[nextIdx].v, lds);
-        if (pushNext) nextQueue[s] = p;
+        uint32_t sSh, sMi, sNx;
+        blockReserve3(pushShadow, pushMis, pushNext, &ctr->shadowCount.v, &ctr->misCount.v, &ctr->extCount[nextIdx].v, lds + parity, &sSh, &sMi, &sNx);
+        if (pushShadow) shq.idx[sSh] = p;
+        if (pushMis) misq.idx[sMi] = p;
+        if (pushNext) nextQueue[sNx] = p;
     }
 }
 
@@ -457,16 +468,15 @@ __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, 
     uint32_t* myStack = stack + threadIdx.x;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         if (i < nShadow) {
-            float4 o = shq.o[i], d = shq.d[i];
+            uint32_t p = shq.idx[i];
+            float4 o = shq.o[p], d = shq.d[p], w = shq.w[p];
             if (!traceAny<LDSN, OVF, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
-                uint32_t p = __float_as_uint(o.w);
-                float4 w = shq.w[i];
                 float* L = reinterpret_cast<float*>(P.L + p);
                 atomicAdd(L + 0, w.x); atomicAdd(L + 1, w.y); atomicAdd(L + 2, w.z);
             }
         } else {
-            uint32_t j = i - nShadow;
-            float4 o = misq.o[j], d = misq.d[j];
+            uint32_t p = misq.idx[i - nShadow];
+            float4 o = misq.o[p], d = misq.d[p];
             Hit h = traceClosest<MLDSN, MOVF, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, myStack);
             if (h.tri >= 0) {
                 const float4* tp = tris + (size_t)h.tri * 3;
@@ -476,8 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, 
                     const DevLight& lt = sc.lights[lightIdx];
                     F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
                     if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
-                        uint32_t p = __float_as_uint(o.w);
-                        float4 w = misq.w[j];
+                        float4 w = misq.w[p];
                         F3 add = xyz(w) * F3(lt.L[0], lt.L[1], lt.L[2]);
                         float* L = reinterpret_cast<float*>(P.L + p);
                         atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
