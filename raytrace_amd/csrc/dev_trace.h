@@ -126,10 +126,10 @@ constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (
 template <int LDSN, int OVF, int STRIDE, bool DIST>
 struct LaneStack {
     uint32_t* lds;
+    uint32_t* ovN;   // spill arrays live in the caller's frame as objects of their own: inside this struct
+    float* ovT;      // their run-time indexing would drag every other member into scratch memory with them
     int sp;
-    uint32_t ovN[OVF > 0 ? OVF : 1];
-    float ovT[(OVF > 0 && DIST) ? OVF : 1];
-    DEV explicit LaneStack(uint32_t* column) : lds(column), sp(0) {}
+    DEV LaneStack(uint32_t* column, uint32_t* spillNodes, float* spillDist) : lds(column), ovN(spillNodes), ovT(spillDist), sp(0) {}
     DEV void push(int node, float t) {
         if (sp < LDSN) {
             lds[sp * STRIDE] = (uint32_t)node;
@@ -155,15 +155,26 @@ struct LaneStack {
     }
 };
 
-// "while-while" traversal: lanes descend inner nodes until each holds a leaf (or is done), then the
-// wave tests triangles together, so the expensive triangle code runs with most lanes active.
+// "while-while" traversal in rounds: in one round the lanes of a wave descend inner nodes until each
+// holds a leaf (or is done), then the wave tests the leaves' triangles together, so the expensive
+// triangle code runs with most lanes active.  The walkers keep a ray's whole traversal state, which
+// lets a kernel hand a finished lane a new ray between rounds instead of idling it until the slowest
+// ray of the wave is through.
 template <int LDSN, int OVF, int STRIDE>
-DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
-    RaySetup r = setupRay(o, d);
-    Hit h; h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
-    LaneStack<LDSN, OVF, STRIDE, true> st(column);
-    int cur = 0;
-    for (;;) {
+struct ClosestWalker {
+    RaySetup r;
+    Hit h;
+    int cur;
+    LaneStack<LDSN, OVF, STRIDE, true> st;
+    DEV ClosestWalker(uint32_t* column, uint32_t* spillNodes, float* spillDist) : cur(kTraverseDone), st(column, spillNodes, spillDist) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
+    DEV void start(F3 o, F3 d, float tMax) {
+        r = setupRay(o, d);
+        h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
+        st.sp = 0;
+        cur = 0;
+    }
+    DEV bool done() const { return cur == kTraverseDone; }
+    DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
             nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
@@ -177,7 +188,7 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
             else if (h1) cur = c1;
             else cur = st.pop(h.t);
         }
-        if (cur == kTraverseDone) break;
+        if (cur == kTraverseDone) return;
         uint32_t leaf = ~(uint32_t)cur;
         uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
         for (uint32_t i = 0; i < cnt; ++i) {
@@ -196,16 +207,26 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
         }
         cur = st.pop(h.t);
     }
-    return h;
-}
+};
 
 // Any-hit (Scene::intersectP): no ordering, first accepted triangle ends the walk.
 template <int LDSN, int OVF, int STRIDE>
-DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
-    RaySetup r = setupRay(o, d);
-    LaneStack<LDSN, OVF, STRIDE, false> st(column);
-    int cur = 0;
-    for (;;) {
+struct AnyWalker {
+    RaySetup r;
+    float tMax;
+    int cur;
+    bool occluded;
+    LaneStack<LDSN, OVF, STRIDE, false> st;
+    DEV AnyWalker(uint32_t* column, uint32_t* spillNodes) : tMax(0.f), cur(kTraverseDone), occluded(false), st(column, spillNodes, nullptr) {}
+    DEV void start(F3 o, F3 d, float tMaxRay) {
+        r = setupRay(o, d);
+        tMax = tMaxRay;
+        occluded = false;
+        st.sp = 0;
+        cur = 0;
+    }
+    DEV bool done() const { return cur == kTraverseDone; }
+    DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
             F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
             nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
@@ -216,18 +237,35 @@ DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMa
             else if (h1) cur = c1;
             else cur = st.pop(0.f);
         }
-        if (cur == kTraverseDone) break;
+        if (cur == kTraverseDone) return;
         uint32_t leaf = ~(uint32_t)cur;
         uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
         for (uint32_t i = 0; i < cnt; ++i) {
             const float4* tp = tris + (size_t)(first + i) * 3;
             float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
             float t, b0, b1, b2;
-            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) return true; // Triangle::intersectP
+            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) occluded = true; // Triangle::intersectP
         }
-        cur = st.pop(0.f);
+        cur = occluded ? kTraverseDone : st.pop(0.f);
     }
-    return false;
+};
+
+template <int LDSN, int OVF, int STRIDE>
+DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    float spillDist[OVF > 0 ? OVF : 1];
+    ClosestWalker<LDSN, OVF, STRIDE> w(column, spillNodes, spillDist);
+    w.start(o, d, tMax);
+    while (!w.done()) w.round(nodes, tris);
+    return w.h;
+}
+template <int LDSN, int OVF, int STRIDE>
+DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    AnyWalker<LDSN, OVF, STRIDE> w(column, spillNodes);
+    w.start(o, d, tMax);
+    while (!w.done()) w.round(nodes, tris);
+    return w.occluded;
 }
 
 } // namespace edev

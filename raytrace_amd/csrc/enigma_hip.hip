@@ -59,6 +59,8 @@ struct EnigmaCtx {
     std::vector<DevLight> hostLights;
     std::vector<float> lightPower; // Light::Power().y() per light
     bool kindPresent[MK_COUNT] = {false, false, false, false, false};
+    bool haveAreaLights = false;
+    uint32_t refillIdle = 16;
     DevScene scene{};
     uint32_t bvhDepth = 0, bvhNodes = 0;
     double msBvhBuild = 0;
@@ -235,6 +237,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
     h->hostLights.assign(s->n_lights, DevLight());
+    h->haveAreaLights = false;
     h->lightPower.assign(s->n_lights, 0.f);
     const float PI = 3.1415926535897932384f;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
@@ -246,6 +249,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
             if (l.triangle >= s->n_triangles) return h->fail(ENIGMA_E_INVALID, "light %u: triangle out of range", i);
             if (s->tri_light[l.triangle] != (int32_t)i) return h->fail(ENIGMA_E_INVALID, "light %u: triangle %u does not point back at it", i, l.triangle);
+            h->haveAreaLights = true;
             d.type = 1; d.tri = newPos[l.triangle]; d.twoSided = l.two_sided ? 1u : 0u;
             const float* a = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle]];
             const float* b = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle + 1]];
@@ -413,7 +417,7 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
 static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 4 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
 
-template <int LDSN, int OVF, int MLDSN, int MOVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -425,7 +429,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr, h->refillIdle);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -436,7 +440,8 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow_mis<LDSN, OVF, MLDSN, MOVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, misq, ctr);
+        k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
@@ -456,6 +461,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 16 levels in LDS + scratch spill
+    if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
     const bool ldsScene = h->bvhDepth <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
@@ -477,7 +483,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             // traversal grids: enough blocks that the hardware dispatcher balances rays of very different cost,
             // few enough that launches late in a pass (short queues) do not drown in empty blocks
             int gridTrace = std::min((int)((nPaths + kTraceChunk - 1) / kTraceChunk), cus * 32);
-            int gridShadow = std::min(2 * gridAll, cus * 64);
+            int gridShadow = std::min(gridAll, cus * 4); // MIS rays: few per bounce
             int gridShade = std::min(gridAll, cus * 8);
             k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p);
             for (int b = 0; b <= h->integ.maxDepth; ++b) {
@@ -488,9 +494,9 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (ldsScene) launchBounce<12, 0, 12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (h->bvhDepth <= 16) launchBounce<16, 0, 8, 8, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else launchBounce<16, 48, 8, 56, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (h->bvhDepth <= 16) launchBounce<16, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else launchBounce<16, 48, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
             }
             k_film_splat<<<gridAll, kBlock, 0, h->stream>>>(P, h->film, nPaths);

@@ -183,60 +183,108 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
 struct MatQueues { uint32_t* q[MK_COUNT]; };
 
-// A block owns chunks of kTraceItems x 256 consecutive queue positions (chunk c -> block c mod gridDim).
-// After tracing a chunk it bins the surviving paths by material kind with ONE tail bump per kind and
-// block: per-wave ballots -> LDS -> block totals, so a launch of R rays issues R / 1024 atomics per
-// tail instead of one per wave and kind.
-constexpr int kTraceItems = 4;
-constexpr uint32_t kTraceChunk = kBlock * kTraceItems;
+// A block owns chunks of kTraceChunk consecutive queue positions (chunk c -> block c mod gridDim) and
+// treats a chunk as a pool of rays: a wave whose lanes have finished their rays (kRefillIdle of them,
+// or all) writes those rays' results and hands the idle lanes the next rays of the pool, so lanes do
+// not sit out the slowest ray of their wave.  The pool cursor is an LDS atomic; nothing global is
+// bumped per wave.  After the chunk the block bins the surviving paths by material kind with ONE
+// tail bump per kind and block (per-wave ballots -> LDS -> block totals).
+constexpr uint32_t kTraceChunk = 512;
+constexpr int kTraceItems = kTraceChunk / kBlock;
+
+constexpr uint32_t kNoRay = 0xffffffffu;
+
+// lanes in idleMask take consecutive pool positions; returns this lane's position (valid for idle lanes)
+DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t* baseOut) {
+    uint32_t lane = threadIdx.x & 63u;
+    int leader = __ffsll((long long)idleMask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(poolNext, (uint32_t)__popcll(idleMask));
+    base = __shfl(base, leader);
+    *baseOut = base;
+    return base + __popcll(idleMask & ((1ull << lane) - 1ull));
+}
 
 template <int LDSN, int OVF, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
-                                                              const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr) {
+                                                              const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle) {
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     __shared__ uint32_t binCnt[MK_COUNT * kWavesPerBlock];
     __shared__ uint32_t binBase[MK_COUNT];
+    __shared__ uint32_t poolNext;
+    __shared__ uint8_t kindOf[kTraceChunk]; // material kind + 1 of the path at a pool position, 0 = path ended
     extern __shared__ float4 sceneLds[];
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    float spillDist[OVF > 0 ? OVF : 1];
     const uint32_t count = countPtr ? *countPtr : countImm;
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
-    uint32_t* myStack = stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
-        uint32_t kinds = 0; // 4 bits per item: material kind + 1, 0 = path ended here
-#pragma unroll 1
-        for (int it = 0; it < kTraceItems; ++it) {
-            uint32_t i = chunk + it * kBlock + threadIdx.x;
-            if (i >= count) continue;
-            uint32_t p = queue ? queue[i] : i;
-            F3 o = xyz(P.rayO[p]), d = xyz(P.rayD[p]);
-            Hit h = traceClosest<LDSN, OVF, kBlock>(nodes, tris, o, d, EDEV_INF, myStack);
-            if (h.tri < 0) continue;
-            uint32_t st = P.state[p];
-            uint32_t bounces = stBounces(st);
-            const float4* tp = tris + (size_t)h.tri * 3;
-            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-            int lightIdx = __float_as_int(v2.w);
-            uint32_t mw = __float_as_uint(v1.w);
-            if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
-                const DevLight& lt = sc.lights[lightIdx];
-                F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
-                if (lt.twoSided || dot(n, -d) > 0) {
-                    float4 L = P.L[p], be = P.beta[p];
-                    F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
-                    P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+        const uint32_t chunkCount = min(kTraceChunk, count - chunk);
+        if (threadIdx.x == 0) poolNext = 0;
+        __syncthreads();
+        ClosestWalker<LDSN, OVF, kBlock> w(stack + threadIdx.x, spillNodes, spillDist);
+        uint32_t pos = kNoRay, p = 0;
+        bool exhausted = false;
+        for (;;) {
+            bool idle = w.done();
+            unsigned long long idleMask = __ballot(idle);
+            uint32_t nIdle = __popcll(idleMask);
+            if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
+                if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
+                    uint32_t kind = 0;
+                    const Hit& h = w.h;
+                    if (h.tri >= 0) {
+                        uint32_t st = P.state[p];
+                        uint32_t bounces = stBounces(st);
+                        const float4* tp = tris + (size_t)h.tri * 3;
+                        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                        int lightIdx = __float_as_int(v2.w);
+                        uint32_t mw = __float_as_uint(v1.w);
+                        if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
+                            const DevLight& lt = sc.lights[lightIdx];
+                            F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
+                            if (lt.twoSided || dot(n, -w.r.d) > 0) {
+                                float4 L = P.L[p], be = P.beta[p];
+                                F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                                P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+                            }
+                        }
+                        if ((int)bounces < I.maxDepth) {
+                            kind = sc.materials[mw & 0x7fffffffu].kind + 1u;
+                            P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
+                            P.hitTri[p] = h.tri;
+                        }
+                    }
+                    kindOf[pos] = (uint8_t)kind;
+                    pos = kNoRay;
                 }
+                if (!exhausted) {
+                    uint32_t base;
+                    uint32_t mine = poolTake(&poolNext, idleMask, &base);
+                    if (idle && mine < chunkCount) {
+                        pos = mine;
+                        p = queue ? queue[chunk + mine] : chunk + mine;
+                        w.start(xyz(P.rayO[p]), xyz(P.rayD[p]), EDEV_INF);
+                    }
+                    exhausted = base + nIdle >= chunkCount;
+                }
+                if (__ballot(!w.done()) == 0) break;
             }
-            if ((int)bounces < I.maxDepth) {
-                kinds |= (sc.materials[mw & 0x7fffffffu].kind + 1u) << (4 * it);
-                P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
-                P.hitTri[p] = h.tri;
-            }
+            w.round(nodes, tris);
         }
+        __syncthreads();
         // ---- bin the chunk: order inside a material queue is wave, item, lane
+        uint32_t kinds = 0; // 4 bits per item
+#pragma unroll
+        for (int it = 0; it < kTraceItems; ++it) {
+            uint32_t j = it * kBlock + threadIdx.x;
+            kinds |= (j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
+        }
 #pragma unroll
         for (int k = 0; k < MK_COUNT; ++k) {
             uint32_t c = 0;
@@ -247,14 +295,14 @@ __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPa
         __syncthreads();
         if (threadIdx.x < MK_COUNT) {
             uint32_t total = 0;
-            for (int w = 0; w < kWavesPerBlock; ++w) total += binCnt[threadIdx.x * kWavesPerBlock + w];
+            for (int w2 = 0; w2 < kWavesPerBlock; ++w2) total += binCnt[threadIdx.x * kWavesPerBlock + w2];
             binBase[threadIdx.x] = total ? atomicAdd(&ctr->matCount[threadIdx.x].v, total) : 0u;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < MK_COUNT; ++k) {
             uint32_t off = binBase[k];
-            for (uint32_t w = 0; w < wid; ++w) off += binCnt[k * kWavesPerBlock + w];
+            for (uint32_t w2 = 0; w2 < wid; ++w2) off += binCnt[k * kWavesPerBlock + w2];
 #pragma unroll
             for (int it = 0; it < kTraceItems; ++it) {
                 bool mine = ((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u;
@@ -266,7 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPa
                 off += __popcll(mask);
             }
         }
-        __syncthreads(); // binCnt / binBase are rewritten by the next chunk
+        __syncthreads(); // binCnt / binBase / kindOf / poolNext are rewritten by the next chunk
     }
 }
 
@@ -451,48 +499,85 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
     }
 }
 
-// Shadow rays and BSDF-sampled MIS rays of one bounce in ONE launch: work items [0, shadowCount) are
-// VisibilityTester::Unoccluded queries (any-hit; unoccluded rays add their contribution), items
-// [shadowCount, shadowCount + misCount) are the MIS rays of EstimateDirect (closest hit must be the
-// sampled light's triangle).  Blocks stride over 256-item chunks, so a wave is (almost always) all of one kind.
-// The (rare) MIS rays walk with MLDSN two-plane levels carved out of the same LDS columns.
-template <int LDSN, int OVF, int MLDSN, int MOVF, bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) k_shadow_mis(DevScene sc, DevPaths P, DevRayQueue shq, DevRayQueue misq, DevCounters* ctr) {
-    __shared__ uint32_t stack[(LDSN > 2 * MLDSN ? LDSN : 2 * MLDSN) * kBlock];
+// VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
+// contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
+template <int LDSN, int OVF, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
+    __shared__ uint32_t stack[LDSN * kBlock];
+    __shared__ uint32_t poolNext;
     extern __shared__ float4 sceneLds[];
-    const uint32_t nShadow = ctr->shadowCount.v, count = nShadow + ctr->misCount.v;
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    const uint32_t count = ctr->shadowCount.v;
+    if (blockIdx.x * kTraceChunk >= count) return;
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
+    for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
+        const uint32_t chunkCount = min(kTraceChunk, count - chunk);
+        if (threadIdx.x == 0) poolNext = 0;
+        __syncthreads();
+        AnyWalker<LDSN, OVF, kBlock> w(stack + threadIdx.x, spillNodes);
+        uint32_t p = kNoRay;
+        bool exhausted = false;
+        for (;;) {
+            bool idle = w.done();
+            unsigned long long idleMask = __ballot(idle);
+            uint32_t nIdle = __popcll(idleMask);
+            if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
+                if (idle && p != kNoRay) {
+                    if (!w.occluded) {
+                        float4 c = shq.w[p];
+                        float* L = reinterpret_cast<float*>(P.L + p);
+                        atomicAdd(L + 0, c.x); atomicAdd(L + 1, c.y); atomicAdd(L + 2, c.z);
+                    }
+                    p = kNoRay;
+                }
+                if (!exhausted) {
+                    uint32_t base;
+                    uint32_t mine = poolTake(&poolNext, idleMask, &base);
+                    if (idle && mine < chunkCount) {
+                        p = shq.idx[chunk + mine];
+                        float4 o = shq.o[p], d = shq.d[p];
+                        w.start(xyz(o), xyz(d), d.w);
+                    }
+                    exhausted = base + nIdle >= chunkCount;
+                }
+                if (__ballot(!w.done()) == 0) break;
+            }
+            w.round(nodes, tris);
+        }
+        __syncthreads(); // poolNext is rewritten by the next chunk
+    }
+}
+
+// The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
+// the sampled light's triangle.  Few rays per bounce (only those that hit the light's own triangle
+// are queued), one per lane.
+template <int LDSN, int OVF, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
+    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    extern __shared__ float4 sceneLds[];
+    const uint32_t count = ctr->misCount.v;
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
-    uint32_t* myStack = stack + threadIdx.x;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-        if (i < nShadow) {
-            uint32_t p = shq.idx[i];
-            float4 o = shq.o[p], d = shq.d[p], w = shq.w[p];
-            if (!traceAny<LDSN, OVF, kBlock>(nodes, tris, xyz(o), xyz(d), d.w, myStack)) {
-                float* L = reinterpret_cast<float*>(P.L + p);
-                atomicAdd(L + 0, w.x); atomicAdd(L + 1, w.y); atomicAdd(L + 2, w.z);
-            }
-        } else {
-            uint32_t p = misq.idx[i - nShadow];
-            float4 o = misq.o[p], d = misq.d[p];
-            Hit h = traceClosest<MLDSN, MOVF, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, myStack);
-            if (h.tri >= 0) {
-                const float4* tp = tris + (size_t)h.tri * 3;
-                float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                int lightIdx = __float_as_int(v2.w);
-                if (lightIdx == __float_as_int(d.w)) { // lightIsect.m_primitive->getAreaLight() == &light
-                    const DevLight& lt = sc.lights[lightIdx];
-                    F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
-                    if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
-                        float4 w = misq.w[p];
-                        F3 add = xyz(w) * F3(lt.L[0], lt.L[1], lt.L[2]);
-                        float* L = reinterpret_cast<float*>(P.L + p);
-                        atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
-                    }
-                }
-            }
+        uint32_t p = misq.idx[i];
+        float4 o = misq.o[p], d = misq.d[p];
+        Hit h = traceClosest<LDSN, OVF, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
+        if (h.tri < 0) continue;
+        const float4* tp = tris + (size_t)h.tri * 3;
+        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        int lightIdx = __float_as_int(v2.w);
+        if (lightIdx != __float_as_int(d.w)) continue; // lightIsect.m_primitive->getAreaLight() == &light
+        const DevLight& lt = sc.lights[lightIdx];
+        F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
+        if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
+            float4 c = misq.w[p];
+            F3 add = xyz(c) * F3(lt.L[0], lt.L[1], lt.L[2]);
+            float* L = reinterpret_cast<float*>(P.L + p);
+            atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
         }
     }
 }
