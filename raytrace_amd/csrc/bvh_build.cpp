@@ -119,14 +119,17 @@ struct Builder {
     }
 };
 
-void setChildBox(BvhNode& n, int which, const Box& b) {
-    if (which == 0) {
-        n.lo0[0] = b.lo[0]; n.lo0[1] = b.lo[1]; n.lo0[2] = b.lo[2]; n.hi0x = b.hi[0];
-        n.hi0yz[0] = b.hi[1]; n.hi0yz[1] = b.hi[2];
-    } else {
-        n.lo1xy[0] = b.lo[0]; n.lo1xy[1] = b.lo[1]; n.lo1z = b.lo[2];
-        n.hi1[0] = b.hi[0]; n.hi1[1] = b.hi[1]; n.hi1[2] = b.hi[2];
+void clearNode(Bvh4Node& n) {
+    memset(&n, 0, sizeof(n));
+    for (int c = 0; c < 4; ++c) {
+        n.lox[c] = n.loy[c] = n.loz[c] = FLT_MAX;
+        n.hix[c] = n.hiy[c] = n.hiz[c] = -FLT_MAX;
+        n.child[c] = kEmptyChild;
     }
+}
+void setChildBox(Bvh4Node& n, int c, const Box& b) {
+    n.lox[c] = b.lo[0]; n.loy[c] = b.lo[1]; n.loz[c] = b.lo[2];
+    n.hix[c] = b.hi[0]; n.hiy[c] = b.hi[1]; n.hiz[c] = b.hi[2];
 }
 
 } // namespace
@@ -143,12 +146,10 @@ void build_bvh(const float* vertices, const uint32_t* indices, uint32_t nTris, u
     for (uint32_t t = 0; t < nTris; ++t) out->triOrder[t] = t;
     out->nodes.clear();
     out->maxDepth = 1;
-    Box empty;
+    out->stackNeed = 3;
     if (nTris == 0) {
-        BvhNode n;
-        memset(&n, 0, sizeof(n));
-        setChildBox(n, 0, empty); setChildBox(n, 1, empty);
-        n.child0 = n.child1 = ~0; // leaf (first 0, count 1) behind a box nothing can hit
+        Bvh4Node n;
+        clearNode(n);
         out->nodes.push_back(n);
         for (int a = 0; a < 3; ++a) { out->rootLo[a] = 0; out->rootHi[a] = 0; }
         return;
@@ -159,41 +160,53 @@ void build_bvh(const float* vertices, const uint32_t* indices, uint32_t nTris, u
     for (int a = 0; a < 3; ++a) { out->rootLo[a] = B.nodes[root].box.lo[a]; out->rootHi[a] = B.nodes[root].box.hi[a]; }
     auto leafRef = [](const TmpNode& n) -> int32_t { return ~(int32_t)((n.first << 3) | (n.count - 1)); };
     if (B.nodes[root].left < 0) { // whole scene is one leaf
-        BvhNode n;
-        memset(&n, 0, sizeof(n));
-        setChildBox(n, 0, B.nodes[root].box); setChildBox(n, 1, empty);
-        n.child0 = leafRef(B.nodes[root]);
-        n.child1 = n.child0;
+        Bvh4Node n;
+        clearNode(n);
+        setChildBox(n, 0, B.nodes[root].box);
+        n.child[0] = leafRef(B.nodes[root]);
         out->nodes.push_back(n);
         return;
     }
-    // flatten inner nodes in depth-first preorder (explicit stack; depth tracked for the traversal stack)
+    // Collapse to four children per node: start from the two children of a binary inner node and keep
+    // replacing the inner child with the largest box by its own two children.  Nodes are emitted in
+    // depth-first preorder (explicit stack; depth tracked for the traversal stack bound).
     struct Item { int tmp; int outIndex; uint32_t depth; };
     std::vector<Item> stack;
-    out->nodes.reserve(B.nodes.size() / 2 + 1);
+    out->nodes.reserve(B.nodes.size() / 3 + 1);
     out->nodes.emplace_back();
     stack.push_back({root, 0, 1});
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();
         out->maxDepth = std::max(out->maxDepth, it.depth);
-        const TmpNode& t = B.nodes[it.tmp];
-        BvhNode n;
-        memset(&n, 0, sizeof(n));
-        const TmpNode& l = B.nodes[t.left];
-        const TmpNode& r = B.nodes[t.right];
-        setChildBox(n, 0, l.box);
-        setChildBox(n, 1, r.box);
-        int rightSlot = -1;
-        if (l.left < 0) n.child0 = leafRef(l);
-        else { n.child0 = (int32_t)out->nodes.size(); out->nodes.emplace_back(); }
-        if (r.left < 0) n.child1 = leafRef(r);
-        else { n.child1 = (int32_t)out->nodes.size(); out->nodes.emplace_back(); rightSlot = n.child1; }
+        int kids[4] = {B.nodes[it.tmp].left, B.nodes[it.tmp].right, -1, -1};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1;
+            float bestArea = -1.f;
+            for (int c = 0; c < nk; ++c) {
+                const TmpNode& k = B.nodes[kids[c]];
+                if (k.left >= 0 && k.box.area() > bestArea) { bestArea = k.box.area(); best = c; }
+            }
+            if (best < 0) break;
+            int opened = kids[best];
+            kids[best] = B.nodes[opened].left;
+            kids[nk++] = B.nodes[opened].right;
+        }
+        Bvh4Node n;
+        clearNode(n);
+        int slots[4] = {-1, -1, -1, -1};
+        for (int c = 0; c < nk; ++c) {
+            const TmpNode& k = B.nodes[kids[c]];
+            setChildBox(n, c, k.box);
+            if (k.left < 0) n.child[c] = leafRef(k);
+            else { n.child[c] = (int32_t)out->nodes.size(); slots[c] = n.child[c]; out->nodes.emplace_back(); }
+        }
         out->nodes[it.outIndex] = n;
-        // push right first so the left subtree is laid out next
-        if (rightSlot >= 0) stack.push_back({t.right, rightSlot, it.depth + 1});
-        if (l.left >= 0) stack.push_back({t.left, n.child0, it.depth + 1});
+        for (int c = nk - 1; c >= 0; --c) // first child's subtree is laid out next
+            if (slots[c] >= 0) stack.push_back({kids[c], slots[c], it.depth + 1});
     }
+    out->stackNeed = 3 * out->maxDepth;
 }
 
 } // namespace enigma

@@ -105,11 +105,21 @@ DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, flo
 
 struct Hit { int tri; float t, b0, b1, b2; };
 
-DEV void nodeBoxes(const float4* n, F3* lo0, F3* hi0, F3* lo1, F3* hi1, int* c0, int* c1) {
-    float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-    *lo0 = F3(q0.x, q0.y, q0.z); *hi0 = F3(q0.w, q1.x, q1.y);
-    *lo1 = F3(q1.z, q1.w, q2.x); *hi1 = F3(q2.y, q2.z, q2.w);
-    *c0 = __float_as_int(q3.x); *c1 = __float_as_int(q3.y);
+// One 4-wide node (see bvh_build.h): child boxes in structure-of-arrays form, seven float4 loads.
+struct Node4 { float4 lox, loy, loz, hix, hiy, hiz; int c0, c1, c2, c3; };
+DEV Node4 loadNode4(const float4* n) {
+    Node4 q;
+    q.lox = n[0]; q.loy = n[1]; q.loz = n[2]; q.hix = n[3]; q.hiy = n[4]; q.hiz = n[5];
+    float4 ch = n[6];
+    q.c0 = __float_as_int(ch.x); q.c1 = __float_as_int(ch.y); q.c2 = __float_as_int(ch.z); q.c3 = __float_as_int(ch.w);
+    return q;
+}
+// compare-exchange of (entry distance, child) pairs: afterwards ta <= tb
+DEV void orderPair(float& ta, int& ca, float& tb, int& cb) {
+    bool s = tb < ta;
+    float tl = s ? tb : ta, th = s ? ta : tb;
+    int cl = s ? cb : ca, chh = s ? ca : cb;
+    ta = tl; tb = th; ca = cl; cb = chh;
 }
 
 // Per-lane traversal stack.  The first LDSN levels live in LDS: entry (level, lane) at
@@ -121,7 +131,7 @@ DEV void nodeBoxes(const float4* n, F3* lo0, F3* hi0, F3* lo1, F3* hi1, int* c0,
 // +LDSN*STRIDE words): a popped node whose entry distance is no longer below the current hit distance
 // is dropped without being fetched -- the same decision the reference takes when it visits the node
 // (tMin < ray.m_maxT, Enigma/BBox.h:294).
-constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (nTris < 2^28)
+constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (nTris < 2^28); also the unused-slot marker of a node
 
 template <int LDSN, int OVF, int STRIDE, bool DIST>
 struct LaneStack {
@@ -176,17 +186,21 @@ struct ClosestWalker {
     DEV bool done() const { return cur == kTraverseDone; }
     DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
-            F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
-            nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
-            bool h0 = slabTest(r, h.t, lo0, hi0, &t0);
-            bool h1 = slabTest(r, h.t, lo1, hi1, &t1);
-            if (h0 && h1) {
-                bool swp = t1 < t0;
-                st.push(swp ? c0 : c1, swp ? t0 : t1);
-                cur = swp ? c1 : c0;
-            } else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else cur = st.pop(h.t);
+            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            // children the ray misses (or unused slots) get entry distance +inf and sort to the back
+            float t0, t1, t2, t3;
+            if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
+            if (!(q.c1 != kTraverseDone && slabTest(r, h.t, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &t1))) t1 = EDEV_INF;
+            if (!(q.c2 != kTraverseDone && slabTest(r, h.t, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &t2))) t2 = EDEV_INF;
+            if (!(q.c3 != kTraverseDone && slabTest(r, h.t, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &t3))) t3 = EDEV_INF;
+            orderPair(t0, q.c0, t1, q.c1); orderPair(t2, q.c2, t3, q.c3);
+            orderPair(t0, q.c0, t2, q.c2); orderPair(t1, q.c1, t3, q.c3);
+            orderPair(t1, q.c1, t2, q.c2);
+            if (t0 == EDEV_INF) { cur = st.pop(h.t); continue; }
+            if (t3 != EDEV_INF) st.push(q.c3, t3); // far to near, so the nearest pending child pops first
+            if (t2 != EDEV_INF) st.push(q.c2, t2);
+            if (t1 != EDEV_INF) st.push(q.c1, t1);
+            cur = q.c0;
         }
         if (cur == kTraverseDone) return;
         uint32_t leaf = ~(uint32_t)cur;
@@ -228,14 +242,18 @@ struct AnyWalker {
     DEV bool done() const { return cur == kTraverseDone; }
     DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
-            F3 lo0, hi0, lo1, hi1; int c0, c1; float t0, t1;
-            nodeBoxes(nodes + (size_t)cur * 4, &lo0, &hi0, &lo1, &hi1, &c0, &c1);
-            bool h0 = slabTest(r, tMax, lo0, hi0, &t0);
-            bool h1 = slabTest(r, tMax, lo1, hi1, &t1);
-            if (h0 && h1) { st.push(c1, 0.f); cur = c0; }
-            else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else cur = st.pop(0.f);
+            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            float te;
+            bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
+            bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
+            bool h2 = q.c2 != kTraverseDone && slabTest(r, tMax, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &te);
+            bool h3 = q.c3 != kTraverseDone && slabTest(r, tMax, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &te);
+            int next = kTraverseDone;
+            if (h3) next = q.c3;
+            if (h2) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c2; }
+            if (h1) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c1; }
+            if (h0) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c0; }
+            cur = (next != kTraverseDone) ? next : st.pop(0.f);
         }
         if (cur == kTraverseDone) return;
         uint32_t leaf = ~(uint32_t)cur;

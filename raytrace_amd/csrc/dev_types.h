@@ -32,7 +32,7 @@ struct DevLight {           // 48 bytes
 //   v1 = {p1.xyz, bits(material index | flip << 31)}
 //   v2 = {p2.xyz, bits(light index or -1)}
 struct DevScene {
-    const float4* nodes;        // BVH nodes, 4 float4 each
+    const float4* nodes;        // 4-wide BVH nodes, 8 float4 each
     const float4* tris;         // triangles in BVH order, 3 float4 each
     const DevMaterial* materials;
     const DevLight* lights;

@@ -62,7 +62,7 @@ struct EnigmaCtx {
     bool haveAreaLights = false;
     uint32_t refillIdle = 16;
     DevScene scene{};
-    uint32_t bvhDepth = 0, bvhNodes = 0;
+    uint32_t bvhDepth = 0, bvhNodes = 0, bvhStack = 0;
     double msBvhBuild = 0;
 
     // camera / film / integrator
@@ -214,8 +214,9 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
     enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
     h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (bvh.maxDepth > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (64)", bvh.maxDepth);
+    if (bvh.stackNeed > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH needs %u traversal stack entries (limit 64)", bvh.stackNeed);
     h->bvhDepth = bvh.maxDepth;
+    h->bvhStack = bvh.stackNeed;
     h->bvhNodes = (uint32_t)bvh.nodes.size();
     std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> newPos(s->n_triangles);
@@ -231,8 +232,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             triData[(size_t)k * 3 + v] = make_float4(p[0], p[1], p[2], wf);
         }
     }
-    std::vector<float4> nodeData(bvh.nodes.size() * 4);
-    memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::BvhNode));
+    std::vector<float4> nodeData(bvh.nodes.size() * 8);
+    memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh4Node));
     std::vector<uint32_t> prim(std::max(1u, s->n_triangles));
     for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
@@ -415,7 +416,7 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
 
 // Scenes up to this many bytes of nodes + triangles are traversed out of LDS (see stageSceneToLds).
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
-static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 4 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
+static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 8 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
 
 template <int LDSN, int OVF, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
@@ -460,9 +461,9 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
-    // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 16 levels in LDS + scratch spill
+    // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
-    const bool ldsScene = h->bvhDepth <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    const bool ldsScene = h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -495,8 +496,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
                 if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (h->bvhDepth <= 16) launchBounce<16, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else launchBounce<16, 48, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else launchBounce<12, 52, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
             }
             k_film_splat<<<gridAll, kBlock, 0, h->stream>>>(P, h->film, nPaths);
@@ -652,8 +653,8 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
         int grid = (int)((n + kBlock - 1) / kBlock);
         // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
         if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
-        else if (h->bvhDepth <= 16) k_debug_intersect<16, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
-        else k_debug_intersect<16, 48><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
+        else if (h->bvhStack <= 12) k_debug_intersect<12, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
+        else k_debug_intersect<12, 52><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
         e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost);
         if (e == hipSuccess && !anyHit) {

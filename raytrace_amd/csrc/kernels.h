@@ -114,9 +114,9 @@ static_assert(kWavesPerBlock == 4, "blockReserve3 lays its counts out for four w
 // Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
 // into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
 // instead of 64 divergent 16-byte requests per wave-instruction through the texture-address path,
-// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 4 float4 each][tris: 3 float4 each].
+// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 8 float4 each][tris: 3 float4 each].
 DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
-    const uint32_t nN = sc.nNodes * 4u, nT = sc.nTris * 3u;
+    const uint32_t nN = sc.nNodes * 8u, nT = sc.nTris * 3u;
     for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[i] = sc.nodes[i];
     for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[nN + i] = sc.tris[i];
     __syncthreads();
@@ -206,7 +206,7 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 }
 
 template <int LDSN, int OVF, bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
+__global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle) {
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     __shared__ uint32_t binCnt[MK_COUNT * kWavesPerBlock];
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_closest(DevScene sc, DevPa
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 4u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];

@@ -35,14 +35,12 @@ uint32_t hc_bvh(const float* v, const uint32_t* idx, uint32_t nT, uint32_t maxLe
     std::vector<int> seen(nT, 0);
     uint32_t violations = 0, bad = 0, covered = 0;
     for (size_t ni = 0; ni < R.nodes.size(); ++ni) {
-        const BvhNode& n = R.nodes[ni];
-        float lo[2][3] = {{n.lo0[0], n.lo0[1], n.lo0[2]}, {n.lo1xy[0], n.lo1xy[1], n.lo1z}};
-        float hi[2][3] = {{n.hi0x, n.hi0yz[0], n.hi0yz[1]}, {n.hi1[0], n.hi1[1], n.hi1[2]}};
-        int32_t ch[2] = {n.child0, n.child1};
-        for (int c = 0; c < 2; ++c) {
-            if (ch[c] >= 0) { if ((size_t)ch[c] >= R.nodes.size() || (size_t)ch[c] <= ni) ++bad; continue; }
-            if (lo[c][0] > hi[c][0]) continue; // empty padding child
-            uint32_t leaf = ~(uint32_t)ch[c], first = leaf >> 3, cnt = (leaf & 7) + 1;
+        const Bvh4Node& n = R.nodes[ni];
+        for (int c = 0; c < 4; ++c) {
+            float lo[3] = {n.lox[c], n.loy[c], n.loz[c]}, hi[3] = {n.hix[c], n.hiy[c], n.hiz[c]};
+            if (n.child[c] == kEmptyChild) { if (!(lo[0] > hi[0])) ++bad; continue; } // unused slot: inverted box
+            if (n.child[c] >= 0) { if ((size_t)n.child[c] >= R.nodes.size() || (size_t)n.child[c] <= ni) ++bad; continue; }
+            uint32_t leaf = ~(uint32_t)n.child[c], first = leaf >> 3, cnt = (leaf & 7) + 1;
             if (first + cnt > nT || cnt > maxLeaf) { ++bad; continue; }
             for (uint32_t k = first; k < first + cnt; ++k) {
                 uint32_t t = R.triOrder[k];
@@ -50,7 +48,7 @@ uint32_t hc_bvh(const float* v, const uint32_t* idx, uint32_t nT, uint32_t maxLe
                 for (int vtx = 0; vtx < 3; ++vtx)
                     for (int a = 0; a < 3; ++a) {
                         float p = v[3 * (size_t)idx[3 * (size_t)t + vtx] + a];
-                        if (p < lo[c][a] || p > hi[c][a]) ++violations;
+                        if (p < lo[a] || p > hi[a]) ++violations;
                     }
             }
         }

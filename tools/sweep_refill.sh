@@ -1,1 +1,1 @@
-for r in 32 16; do echo "refill $r"; ENIGMA_REFILL_IDLE=$r timeout -k 10 200 python3 tools/prof_render.py bigmesh 2 || exit 1; ENIGMA_REFILL_IDLE=$r timeout -k 10 100 python3 tools/prof_render.py microfacet 3 || exit 1; done
+timeout -k 10 200 python3 tools/prof_render.py bigmesh 2 && timeout -k 10 100 python3 tools/prof_render.py microfacet 3 && timeout -k 10 100 python3 tools/prof_render.py manylights 3
