@@ -165,11 +165,14 @@ struct LaneStack {
     }
 };
 
-// "while-while" traversal in rounds: in one round the lanes of a wave descend inner nodes until each
-// holds a leaf (or is done), then the wave tests the leaves' triangles together, so the expensive
-// triangle code runs with most lanes active.  The walkers keep a ray's whole traversal state, which
-// lets a kernel hand a finished lane a new ray between rounds instead of idling it until the slowest
-// ray of the wave is through.
+// Traversal in wave-wide steps.  A lane is either at an inner node, at a leaf triangle, or done.  Each
+// step the wave does ONE kind of work -- a node step for the lanes at inner nodes, or one triangle test
+// for the lanes at leaves -- whichever has more lanes waiting; the others sit the step out.  With 64
+// incoherent rays per wave this keeps at least half of the unfinished lanes busy in every step, where
+// "descend until every lane has a leaf, then test leaves" leaves most lanes waiting for the slowest.
+// Each ray still sees its own nodes and triangles in the same depth-first order.  The walkers keep a
+// ray's whole traversal state, which lets a kernel hand a finished lane a new ray between steps.
+// A leaf in progress is held in cur as ~((next triangle << 3) | (triangles left - 1)).
 template <int LDSN, int OVF, int STRIDE>
 struct ClosestWalker {
     RaySetup r;
@@ -184,8 +187,11 @@ struct ClosestWalker {
         cur = 0;
     }
     DEV bool done() const { return cur == kTraverseDone; }
-    DEV void round(const float4* nodes, const float4* tris) {
-        while (cur >= 0) {
+    DEV void step(const float4* nodes, const float4* tris) {
+        const bool atNode = cur >= 0;
+        const bool atLeaf = cur < 0 && cur != kTraverseDone;
+        if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
+            if (!atNode) return;
             Node4 q = loadNode4(nodes + (size_t)cur * 8);
             // children the ray misses (or unused slots) get entry distance +inf and sort to the back
             float t0, t1, t2, t3;
@@ -196,8 +202,46 @@ struct ClosestWalker {
             orderPair(t0, q.c0, t1, q.c1); orderPair(t2, q.c2, t3, q.c3);
             orderPair(t0, q.c0, t2, q.c2); orderPair(t1, q.c1, t3, q.c3);
             orderPair(t1, q.c1, t2, q.c2);
-            if (t0 == EDEV_INF) { cur = st.pop(h.t); continue; }
+            if (t0 == EDEV_INF) { cur = st.pop(h.t); return; }
             if (t3 != EDEV_INF) st.push(q.c3, t3); // far to near, so the nearest pending child pops first
+            if (t2 != EDEV_INF) st.push(q.c2, t2);
+            if (t1 != EDEV_INF) st.push(q.c1, t1);
+            cur = q.c0;
+        } else {
+            if (!atLeaf) return;
+            uint32_t leaf = ~(uint32_t)cur;
+            uint32_t tri = leaf >> 3, left = leaf & 7u;
+            const float4* tp = tris + (size_t)tri * 3;
+            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float t, b0, b1, b2;
+            if (triangleTest(r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) {
+                // degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
+                F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
+                F3 dpdu = (p1 - p2) - (p0 - p2);
+                F3 dpdv = -(p1 - p2);
+                bool ok = true;
+                if (lengthSqr(cross(dpdu, dpdv)) == 0) ok = lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
+                if (ok) { h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2; }
+            }
+            cur = left ? (int)~(((tri + 1u) << 3) | (left - 1u)) : st.pop(h.t);
+        }
+    }
+    // The other schedule ("while-while"): descend until every lane of the wave holds a leaf (or is done),
+    // then test the leaves.  Cheaper per step (no votes); better when rays of a wave stay together, as they
+    // do in the shallow tree of a scene small enough to be traversed out of LDS.
+    DEV void round(const float4* nodes, const float4* tris) {
+        while (cur >= 0) {
+            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            float t0, t1, t2, t3;
+            if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
+            if (!(q.c1 != kTraverseDone && slabTest(r, h.t, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &t1))) t1 = EDEV_INF;
+            if (!(q.c2 != kTraverseDone && slabTest(r, h.t, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &t2))) t2 = EDEV_INF;
+            if (!(q.c3 != kTraverseDone && slabTest(r, h.t, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &t3))) t3 = EDEV_INF;
+            orderPair(t0, q.c0, t1, q.c1); orderPair(t2, q.c2, t3, q.c3);
+            orderPair(t0, q.c0, t2, q.c2); orderPair(t1, q.c1, t3, q.c3);
+            orderPair(t1, q.c1, t2, q.c2);
+            if (t0 == EDEV_INF) { cur = st.pop(h.t); continue; }
+            if (t3 != EDEV_INF) st.push(q.c3, t3);
             if (t2 != EDEV_INF) st.push(q.c2, t2);
             if (t1 != EDEV_INF) st.push(q.c1, t1);
             cur = q.c0;
@@ -210,7 +254,6 @@ struct ClosestWalker {
             float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
             float t, b0, b1, b2;
             if (triangleTest(r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) {
-                // degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
                 F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
                 F3 dpdu = (p1 - p2) - (p0 - p2);
                 F3 dpdv = -(p1 - p2);
@@ -221,6 +264,7 @@ struct ClosestWalker {
         }
         cur = st.pop(h.t);
     }
+    template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
 // Any-hit (Scene::intersectP): no ordering, first accepted triangle ends the walk.
@@ -240,7 +284,35 @@ struct AnyWalker {
         cur = 0;
     }
     DEV bool done() const { return cur == kTraverseDone; }
-    DEV void round(const float4* nodes, const float4* tris) {
+    DEV void step(const float4* nodes, const float4* tris) {
+        const bool atNode = cur >= 0;
+        const bool atLeaf = cur < 0 && cur != kTraverseDone;
+        if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
+            if (!atNode) return;
+            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            float te;
+            bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
+            bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
+            bool h2 = q.c2 != kTraverseDone && slabTest(r, tMax, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &te);
+            bool h3 = q.c3 != kTraverseDone && slabTest(r, tMax, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &te);
+            int next = kTraverseDone;
+            if (h3) next = q.c3;
+            if (h2) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c2; }
+            if (h1) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c1; }
+            if (h0) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c0; }
+            cur = (next != kTraverseDone) ? next : st.pop(0.f);
+        } else {
+            if (!atLeaf) return;
+            uint32_t leaf = ~(uint32_t)cur;
+            uint32_t tri = leaf >> 3, left = leaf & 7u;
+            const float4* tp = tris + (size_t)tri * 3;
+            float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float t, b0, b1, b2;
+            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) { occluded = true; cur = kTraverseDone; } // Triangle::intersectP
+            else cur = left ? (int)~(((tri + 1u) << 3) | (left - 1u)) : st.pop(0.f);
+        }
+    }
+    DEV void round(const float4* nodes, const float4* tris) { // see ClosestWalker::round
         while (cur >= 0) {
             Node4 q = loadNode4(nodes + (size_t)cur * 8);
             float te;
@@ -262,10 +334,11 @@ struct AnyWalker {
             const float4* tp = tris + (size_t)(first + i) * 3;
             float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
             float t, b0, b1, b2;
-            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) occluded = true; // Triangle::intersectP
+            if (triangleTest(r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) occluded = true;
         }
         cur = occluded ? kTraverseDone : st.pop(0.f);
     }
+    template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
 template <int LDSN, int OVF, int STRIDE>
@@ -274,7 +347,7 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
     float spillDist[OVF > 0 ? OVF : 1];
     ClosestWalker<LDSN, OVF, STRIDE> w(column, spillNodes, spillDist);
     w.start(o, d, tMax);
-    while (!w.done()) w.round(nodes, tris);
+    while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
     return w.h;
 }
 template <int LDSN, int OVF, int STRIDE>
@@ -282,7 +355,7 @@ DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMa
     uint32_t spillNodes[OVF > 0 ? OVF : 1];
     AnyWalker<LDSN, OVF, STRIDE> w(column, spillNodes);
     w.start(o, d, tMax);
-    while (!w.done()) w.round(nodes, tris);
+    while (__ballot(!w.done()) != 0) w.step(nodes, tris);
     return w.occluded;
 }
 

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
                 }
                 if (__ballot(!w.done()) == 0) break;
             }
-            w.round(nodes, tris);
+            w.template advance<LDS_SCENE>(nodes, tris);
         }
         __syncthreads();
         // ---- bin the chunk: order inside a material queue is wave, item, lane
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
                 }
                 if (__ballot(!w.done()) == 0) break;
             }
-            w.round(nodes, tris);
+            w.template advance<LDS_SCENE>(nodes, tris);
         }
         __syncthreads(); // poolNext is rewritten by the next chunk
     }
