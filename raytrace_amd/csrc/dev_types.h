@@ -18,6 +18,8 @@ struct DevMaterial {        // 64 bytes
     float pad2[4];
 };
 
+static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
+
 struct DevLight {           // 48 bytes
     uint32_t type;          // 0 point, 1 diffuse area
     uint32_t tri;           // area: triangle position in the device (BVH) order
@@ -27,9 +29,11 @@ struct DevLight {           // 48 bytes
     float pos[3]; float pad1;
 };
 
+static_assert(sizeof(DevLight) == 48, "k_shade copies lights as three float4");
+
 // One triangle, 48 bytes, three float4 loads:
 //   v0 = {p0.xyz, bits(original triangle index)}
-//   v1 = {p1.xyz, bits(material index | flip << 31)}
+//   v1 = {p1.xyz, bits(material index [0:24) | material kind [24:27) | flip << 31)}
 //   v2 = {p2.xyz, bits(light index or -1)}
 struct DevScene {
     const float4* nodes;        // 4-wide BVH nodes, 8 float4 each
@@ -43,6 +47,7 @@ struct DevScene {
     int nLights;
     uint32_t nTris;
     uint32_t nNodes;
+    uint32_t nMaterials;
 };
 
 struct DevCamera {

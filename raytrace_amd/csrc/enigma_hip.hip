@@ -151,6 +151,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
     if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
     if (s->n_materials == 0 && s->n_triangles) return h->fail(ENIGMA_E_INVALID, "no materials");
+    if (s->n_materials >= (1u << 24)) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 2^24 materials");
     for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
         if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
@@ -224,7 +225,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         uint32_t t = bvh.triOrder[k];
         newPos[t] = k;
         uint32_t flip = (s->tri_flags && (s->tri_flags[t] & ENIGMA_TRI_FLIP_NORMAL)) ? 1u : 0u;
-        uint32_t w[3] = {t, s->tri_material[t] | (flip << 31), (uint32_t)s->tri_light[t]};
+        uint32_t w[3] = {t, s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | (flip << 31), (uint32_t)s->tri_light[t]};
         for (int v = 0; v < 3; ++v) {
             const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
             float wf;
@@ -282,6 +283,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->scene.nLights = (int)s->n_lights;
     h->scene.nTris = std::max(1u, s->n_triangles);
     h->scene.nNodes = (uint32_t)bvh.nodes.size();
+    h->scene.nMaterials = s->n_materials;
     h->lightDistDirty = true;
     h->haveScene = true;
     return ENIGMA_OK;
@@ -418,6 +420,11 @@ static int ensureCapacity(EnigmaCtx* h, size_t n) {
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
 static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 8 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
 
+// triangles + materials + lights + light distribution, as k_shade stages them
+static size_t shadeLdsBytes(const EnigmaCtx* h) {
+    return ((size_t)h->scene.nTris * 3 + (size_t)h->scene.nMaterials * 4 + (size_t)h->scene.nLights * 3) * sizeof(float4) + (2 * (size_t)h->scene.nLights + 1) * sizeof(float);
+}
+
 template <int LDSN, int OVF, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
@@ -434,11 +441,11 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
-    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC><<<gridShade, kBlock, 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
@@ -463,7 +470,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
-    const bool ldsScene = h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    const bool ldsScene = h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;

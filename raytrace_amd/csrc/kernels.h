@@ -123,6 +123,11 @@ DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
 }
 
 // ---------------------------------------------------------------- geometry at a hit
+// second triangle word: material index [0:24) | material kind [24:27) | flip-normal [31]
+DEV uint32_t triMaterial(uint32_t mw) { return mw & 0xffffffu; }
+DEV uint32_t triKind(uint32_t mw) { return (mw >> 24) & 7u; }
+DEV bool triFlip(uint32_t mw) { return (mw >> 31) != 0; }
+
 struct HitGeom { F3 p, pError, n, dpdu; int matIdx, lightIdx; };
 
 DEV F3 triNormal(F3 p0, F3 p1, F3 p2, bool flip) { // Enigma/TriangleMesh.cpp:287-289
@@ -130,13 +135,13 @@ DEV F3 triNormal(F3 p0, F3 p1, F3 p2, bool flip) { // Enigma/TriangleMesh.cpp:28
     return flip ? -n : n;
 }
 // Triangle::intersect after the hit test, Enigma/TriangleMesh.cpp:226-289 (default uvs, no normals)
-DEV HitGeom hitGeometry(const DevScene& sc, int tri, float b0, float b1, float b2) {
-    const float4* tp = sc.tris + (size_t)tri * 3;
+DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b2) {
+    const float4* tp = tris + (size_t)tri * 3;
     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
     F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
     uint32_t mw = __float_as_uint(v1.w);
     HitGeom g;
-    g.matIdx = (int)(mw & 0x7fffffffu);
+    g.matIdx = (int)triMaterial(mw);
     g.lightIdx = __float_as_int(v2.w);
     F3 dp02 = p0 - p2, dp12 = p1 - p2;
     F3 dpdu = dp12 - dp02;
@@ -151,7 +156,7 @@ DEV HitGeom hitGeometry(const DevScene& sc, int tri, float b0, float b1, float b
     float zAbsSum = (fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z));
     g.pError = gammaf(7) * F3(xAbsSum, yAbsSum, zAbsSum);
     g.p = b0 * p0 + b1 * p1 + b2 * p2;
-    g.n = triNormal(p0, p1, p2, (mw >> 31) != 0);
+    g.n = triNormal(p0, p1, p2, triFlip(mw));
     return g;
 }
 
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
                         uint32_t mw = __float_as_uint(v1.w);
                         if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
                             const DevLight& lt = sc.lights[lightIdx];
-                            F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (mw >> 31) != 0);
+                            F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
                             if (lt.twoSided || dot(n, -w.r.d) > 0) {
                                 float4 L = P.L[p], be = P.beta[p];
                                 F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
@@ -255,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
                             }
                         }
                         if ((int)bounces < I.maxDepth) {
-                            kind = sc.materials[mw & 0x7fffffffu].kind + 1u;
+                            kind = triKind(mw) + 1u;
                             P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
                             P.hitTri[p] = h.tri;
                         }
@@ -319,27 +324,56 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
 }
 
 // Distribution1D::SampleDiscrete, Enigma/MonteCarlo.h:61-69 (std::upper_bound on the cdf)
-DEV int sampleDiscrete(const DevScene& sc, float u, float* pdf) {
-    int n = sc.nLights;
+DEV int sampleDiscrete(const float* lightCdf, const float* lightFunc, float lightFuncInt, int n, float u, float* pdf) {
     int lo = 0, len = n + 1; // first element > u in cdf[0..n]
     while (len > 0) {
         int half = len >> 1;
-        if (!(u < sc.lightCdf[lo + half])) { lo += half + 1; len -= half + 1; }
+        if (!(u < lightCdf[lo + half])) { lo += half + 1; len -= half + 1; }
         else len = half;
     }
     int offset = max(0, lo - 1);
     offset = min(offset, n - 1); // unreachable for u < 1 (cdf[n] == 1); keeps the read in bounds
-    *pdf = sc.lightFunc[offset] / (sc.lightFuncInt * n);
+    *pdf = lightFunc[offset] / (lightFuncInt * n);
     return offset;
 }
 
 DEV float powerHeuristic(float fPdf, float gPdf) { float f = 1 * fPdf, g = 1 * gPdf; return (f * f) / (f * f + g * g); }
 
-template <int MK>
+// For scenes small enough (LDS_SCENE) the block first copies triangles, materials, lights and the light
+// distribution into LDS: the chain hit triangle -> material -> light -> light triangle is then four LDS
+// reads instead of four dependent trips to L2/HBM per path.
+template <int MK, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
+    extern __shared__ float4 sceneLds[];
     const uint32_t count = ctr->matCount[MK].v;
+    if (blockIdx.x * kBlock >= count) return;
+    const float4* tris = sc.tris;
+    const DevMaterial* materials = sc.materials;
+    const DevLight* lights = sc.lights;
+    const float* lightCdf = sc.lightCdf;
+    const float* lightFunc = sc.lightFunc;
+    if (LDS_SCENE) {
+        const uint32_t nT = sc.nTris * 3u, nM = sc.nMaterials * 4u, nL = (uint32_t)sc.nLights * 3u;
+        float4* ldsMat = sceneLds + nT;
+        float4* ldsLight = ldsMat + nM;
+        float* ldsCdf = reinterpret_cast<float*>(ldsLight + nL);
+        float* ldsFunc = ldsCdf + sc.nLights + 1;
+        const float4* gMat = reinterpret_cast<const float4*>(sc.materials);
+        const float4* gLight = reinterpret_cast<const float4*>(sc.lights);
+        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) sceneLds[i] = sc.tris[i];
+        for (uint32_t i = threadIdx.x; i < nM; i += kBlock) ldsMat[i] = gMat[i];
+        for (uint32_t i = threadIdx.x; i < nL; i += kBlock) ldsLight[i] = gLight[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights + 1u; i += kBlock) ldsCdf[i] = sc.lightCdf[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights; i += kBlock) ldsFunc[i] = sc.lightFunc[i];
+        __syncthreads();
+        tris = sceneLds;
+        materials = reinterpret_cast<const DevMaterial*>(ldsMat);
+        lights = reinterpret_cast<const DevLight*>(ldsLight);
+        lightCdf = ldsCdf;
+        lightFunc = ldsFunc;
+    }
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     uint32_t parity = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock, parity ^= 16u) {
@@ -359,32 +393,32 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             float4 bv = P.beta[p];
             F3 beta = xyz(bv);
             float etaScale = bv.w;
-            HitGeom g = hitGeometry(sc, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
-            makeBsdf<MK>(sc.materials[g.matIdx], g.n, g.dpdu, &bsdf);
+            makeBsdf<MK>(materials[g.matIdx], g.n, g.dpdu, &bsdf);
             F3 ns = g.n; // shading normal == geometric normal (no per-vertex normals)
             F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
 
             // ---- UniformSampleOneLight (Enigma/Integrator.cpp:71-92) ----
             if (numComponents<MK>(bsdf, kNonSpecular) > 0 && sc.nLights > 0) {
                 float pick;
-                int lightNum = sampleDiscrete(sc, sampleDimension(S, px, py, slot, dim), &pick);
+                int lightNum = sampleDiscrete(lightCdf, lightFunc, sc.lightFuncInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
                 dim += 1;
                 if (pick != 0) {
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
-                    const DevLight& lt = sc.lights[lightNum];
+                    const DevLight& lt = lights[lightNum];
                     // ---- EstimateDirect: light sampling (Enigma/Integrator.cpp:104-148) ----
                     F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
                     float lightPdf = 0.f;
                     F3 q0(0.f), q1(0.f), q2(0.f);
                     bool lflip = false;
                     if (lt.type == 1) {
-                        const float4* tp = sc.tris + (size_t)lt.tri * 3;
+                        const float4* tp = tris + (size_t)lt.tri * 3;
                         float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
                         q0 = xyz(a0); q1 = xyz(a1); q2 = xyz(a2);
-                        lflip = (__float_as_uint(a1.w) >> 31) != 0;
+                        lflip = triFlip(__float_as_uint(a1.w));
                         // Triangle::sample (Enigma/TriangleMesh.cpp:604-632)
                         float su1 = sqrtf(ulx);
                         float tb0 = 1.f - su1, tb1 = uly * su1;
@@ -518,6 +552,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
         __syncthreads();
         AnyWalker<LDSN, OVF, kBlock> w(stack + threadIdx.x, spillNodes);
         uint32_t p = kNoRay;
+        float4 contrib = make_float4(0.f, 0.f, 0.f, 0.f); // fetched with the ray: no dependent load when the ray is through
         bool exhausted = false;
         for (;;) {
             bool idle = w.done();
@@ -526,9 +561,8 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && p != kNoRay) {
                     if (!w.occluded) {
-                        float4 c = shq.w[p];
                         float* L = reinterpret_cast<float*>(P.L + p);
-                        atomicAdd(L + 0, c.x); atomicAdd(L + 1, c.y); atomicAdd(L + 2, c.z);
+                        atomicAdd(L + 0, contrib.x); atomicAdd(L + 1, contrib.y); atomicAdd(L + 2, contrib.z);
                     }
                     p = kNoRay;
                 }
@@ -538,6 +572,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
                     if (idle && mine < chunkCount) {
                         p = shq.idx[chunk + mine];
                         float4 o = shq.o[p], d = shq.d[p];
+                        contrib = shq.w[p];
                         w.start(xyz(o), xyz(d), d.w);
                     }
                     exhausted = base + nIdle >= chunkCount;
@@ -572,7 +607,7 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
         int lightIdx = __float_as_int(v2.w);
         if (lightIdx != __float_as_int(d.w)) continue; // lightIsect.m_primitive->getAreaLight() == &light
         const DevLight& lt = sc.lights[lightIdx];
-        F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), (__float_as_uint(v1.w) >> 31) != 0);
+        F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(__float_as_uint(v1.w)));
         if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
             float4 c = misq.w[p];
             F3 add = xyz(c) * F3(lt.L[0], lt.L[1], lt.L[2]);
