@@ -507,7 +507,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                 else launchBounce<12, 52, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
             }
-            k_film_splat<<<gridAll, kBlock, 0, h->stream>>>(P, h->film, nPaths);
+            k_film_splat<<<(nPixels + kBlock - 1) / kBlock, kBlock, 0, h->stream>>>(P, h->film, h->integ, nPixels, ks);
             HIPCHK(h, hipGetLastError());
         }
         HIPCHK(h, hipStreamSynchronize(h->stream)); // the constant table is re-uploaded per chunk

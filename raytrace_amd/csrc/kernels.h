@@ -636,24 +636,43 @@ DEV void filmFootprint(const DevFilm& F, float fx, float fy, SINK sink) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, uint32_t nPaths) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nPaths) return;
-    F3 L = xyz(P.L[i]);
-    // Enigma/Integrator.cpp:284-292
-    float y = luminance(L);
-    if (isnan(L.x) || isnan(L.y) || isnan(L.z)) L = F3(0.f);
-    else if ((double)y < -1e-5) L = F3(0.f);
-    else if (isinf(y)) L = F3(0.f);
-    float2 pf = P.pfilm[i];
-    float ly = luminance(L);
-    if (ly > F.maxSampleLuminance) L = L * (F.maxSampleLuminance / ly);
+// One thread per pixel of the render region walks the pass's sample numbers of that pixel (path
+// slot * nPixels + pixel).  Contributions that land on the thread's own pixel -- all of them for the
+// default half-pixel box filter, bar samples exactly on a pixel edge -- are summed in registers and
+// added once; the rest go out as atomics.  The film sees one atomic set per pixel and pass instead of
+// one per sample.
+__global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, DevIntegrator I, uint32_t nPixels, uint32_t nSlots) {
+    uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= nPixels) return;
+    const int ownX = I.rx0 + (int)(pix % (uint32_t)I.rw), ownY = I.ry0 + (int)(pix / (uint32_t)I.rw);
     const int width = F.x1 - F.x0;
-    filmFootprint(F, pf.x, pf.y, [&](int x, int yy, float w) {
-        float* px = reinterpret_cast<float*>(F.pixels + ((size_t)(yy - F.y0) * width + (x - F.x0)));
-        F3 c = L * 1.f * w; // L * sampleWeight * filterWeight
-        atomicAdd(px + 0, c.x); atomicAdd(px + 1, c.y); atomicAdd(px + 2, c.z); atomicAdd(px + 3, w);
-    });
+    F3 acc(0.f);
+    float accW = 0.f;
+    bool any = false;
+    for (uint32_t s = 0; s < nSlots; ++s) {
+        size_t i = (size_t)s * nPixels + pix;
+        F3 L = xyz(P.L[i]);
+        // Enigma/Integrator.cpp:284-292
+        float y = luminance(L);
+        if (isnan(L.x) || isnan(L.y) || isnan(L.z)) L = F3(0.f);
+        else if ((double)y < -1e-5) L = F3(0.f);
+        else if (isinf(y)) L = F3(0.f);
+        float2 pf = P.pfilm[i];
+        float ly = luminance(L);
+        if (ly > F.maxSampleLuminance) L = L * (F.maxSampleLuminance / ly);
+        filmFootprint(F, pf.x, pf.y, [&](int x, int yy, float w) {
+            F3 c = L * 1.f * w; // L * sampleWeight * filterWeight
+            if (x == ownX && yy == ownY) { acc += c; accW += w; any = true; }
+            else {
+                float* px = reinterpret_cast<float*>(F.pixels + ((size_t)(yy - F.y0) * width + (x - F.x0)));
+                atomicAdd(px + 0, c.x); atomicAdd(px + 1, c.y); atomicAdd(px + 2, c.z); atomicAdd(px + 3, w);
+            }
+        });
+    }
+    if (any && ownX >= F.x0 && ownX < F.x1 && ownY >= F.y0 && ownY < F.y1) {
+        float* px = reinterpret_cast<float*>(F.pixels + ((size_t)(ownY - F.y0) * width + (ownX - F.x0)));
+        atomicAdd(px + 0, acc.x); atomicAdd(px + 1, acc.y); atomicAdd(px + 2, acc.z); atomicAdd(px + 3, accW);
+    }
 }
 
 // Between stages: account rays, reset the queues the next stage fills.
