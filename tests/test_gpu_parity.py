@@ -142,7 +142,7 @@ def test_hits_bit_exact_random_rays_many_lights_and_mesh():
 
 
 def test_traversal_stack_spill_path_gives_identical_hits():
-    """Deep trees keep 16 stack levels in LDS and spill the rest to scratch.  With only two LDS
+    """Deep trees keep 12 stack levels in LDS and spill the rest to scratch.  With only two LDS
     levels (debug knob) nearly every ray spills; hits must not change by a bit."""
     rng = np.random.RandomState(33)
     sc, cam = scenes.big_mesh(grid=96, sphere_level=4, n_spheres=4), scenes.big_mesh_camera(64, 64)
@@ -342,6 +342,44 @@ def test_full_size_film_invariants_1080p():
     assert np.allclose(ra.resolve(r.film()), img, rtol=1e-4, atol=1e-5)
     # a 270p slice of the same job agrees with the oracle
     r.close()
+
+
+def test_full_size_big_mesh_1080p():
+    """The >= 1 M triangle configuration at its full size (1,179,662 triangles, 1920x1080 sampler).  The whole
+    film is checked through invariants; a 192x108 window of the same job (pixel bounds, full-size Sobol indices,
+    full scene) is compared with the oracle pixel by pixel."""
+    sc = scenes.big_mesh()
+    assert sc.indices.shape[0] >= 1 << 20
+    cam = scenes.big_mesh_camera(1920, 1080)
+    film = scenes.film_desc(1920, 1080)
+    integ = scenes.integrator_desc(film, 1024)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    assert r.stats()["bvh_nodes"] > 100000
+    r.render(0, 2)
+    f = r.film()
+    st = r.stats()
+    assert st["camera_samples"] == 1920 * 1080 * 2
+    assert f[..., 3].min() >= 2 and f[..., 3].sum() - 2 * 1920 * 1080 < 0.01 * 2 * 1920 * 1080
+    assert np.isfinite(f).all() and f[..., :3].min() >= 0
+    assert (f[..., :3].sum(axis=2) > 0).mean() > 0.9            # closed sky box + overhead light: almost no black pixels
+    whole = ra.resolve(f)
+    r.clear(); r.render(0, 1); r.render(1, 2)
+    assert np.allclose(ra.resolve(r.film()), whole, rtol=1e-4, atol=1e-5)
+    # window of the same job against the oracle (min.x == min.y: see the tile-row rule in test_pixel_bounds_and_crop_window)
+    integ_w = scenes.integrator_desc(film, 1024)
+    integ_w.pixel_bounds[:] = [600, 600, 792, 708]
+    r.set_integrator(integ_w)
+    r.clear(); r.render(0, 2)
+    o = orc.Oracle(sc, cam, film, integ_w)
+    o.render(0, 2, threads=16)
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])
+    win = (slice(600, 708), slice(600, 792))
+    a, b = r.image()[win], o.image()[win]
+    assert np.allclose(whole[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)   # the window is a piece of the whole job
+    assert common.mean_relative_error(a, b) < 0.01
+    assert np.median(np.abs(a - b) / np.maximum(b, 1e-3)) < 1e-5
+    r.close(); o.close()
 
 
 def test_error_conventions():
