@@ -62,7 +62,8 @@ typedef struct EnigmaLight {
     uint32_t type;      /* ENIGMA_LIGHT_* */
     uint32_t triangle;  /* area light: index of its triangle */
     uint32_t two_sided; /* area light: twosided flag */
-    uint32_t pad;
+    uint32_t n_samples; /* Light::m_nSamples ("samples"/"nsamples", default 1; 0 means 1): read only by
+                           DirectLightingIntegrator's UniformSampleAll strategy (Enigma/DirectLightingIntegrator.cpp:76-77) */
     float L[3];         /* area: emitted radiance Lemission; point: intensity I */
     float pos[3];       /* point light: world position */
 } EnigmaLight;
@@ -122,6 +123,18 @@ typedef struct EnigmaIntegratorDesc {
     int32_t sample_bounds[4];   /* SobolSampler::m_sampleBounds = Film::GetSampleBounds() */
 } EnigmaIntegratorDesc;
 
+enum { ENIGMA_DL_SAMPLE_ALL = 0, ENIGMA_DL_SAMPLE_ONE = 1 };
+
+/* DirectLightingIntegrator + SobolSampler parameters (Enigma/DirectLightingIntegrator.cpp:30-35,
+ * 89-114; Enigma/Sampler.cpp:211-222). */
+typedef struct EnigmaDirectLightingDesc {
+    int32_t max_depth;          /* "maxdepth", default 5: depth limit of the specular recursion */
+    int32_t strategy;           /* ENIGMA_DL_SAMPLE_*: "strategy" all (default) | one */
+    int32_t pixel_bounds[4];
+    int64_t samples_per_pixel;
+    int32_t sample_bounds[4];
+} EnigmaDirectLightingDesc;
+
 typedef struct EnigmaStats {
     uint64_t camera_samples;  /* camera samples started */
     uint64_t rays_closest;    /* Scene::intersect equivalents: path rays */
@@ -152,6 +165,15 @@ int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* film);
 /* Replaces CreatePathIntegrator + SobolSampler construction + PathIntegrator::Preprocess
  * (Enigma/PathIntegrator.cpp:41-44,182-201; Enigma/Sampler.cpp:211-222). */
 int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* integ);
+/* Replaces CreateDirectLightingIntegrator + SobolSampler construction +
+ * DirectLightingIntegrator::Preprocess (Enigma/DirectLightingIntegrator.cpp:71-114): the sample arrays
+ * Preprocess requests become reserved Sobol' dimensions.  enigma_render then runs
+ * DirectLightingIntegrator::Li (:37-69) with UniformSampleAllLights / UniformSampleOneLight
+ * (Enigma/Integrator.cpp:42-92) and SpecularReflect / SpecularTransmit (:329-444).  The integrator
+ * configured last is the one enigma_render runs.  ENIGMA_E_UNSUPPORTED where the reference itself is
+ * undefined: strategy "all" reading past the sample arrays it requested (a smooth glass with both Kr and
+ * Kt branches the recursion, Enigma/Sampler.cpp:62-69), or more than 1024 Sobol' dimensions. */
+int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLightingDesc* integ);
 
 /* Replaces the tile loop of SamplerIntegrator::Render (Enigma/Integrator.cpp:239-320)
  * for sample numbers [sample_begin, sample_end) of every pixel; accumulates into the

@@ -68,8 +68,11 @@ struct BBox2i { Vec2i mn, mx; };
 
 struct CameraSample { Vec2 image; Vec2 lens; float time = 0; };
 
-// Sampler.cpp:139-245 (GlobalSampler + SobolSampler; no sample arrays are requested
-// by PathIntegrator, so m_arrayEndDim == s_arrayStartDim == 5).
+// Sampler.cpp:22-83,139-245 (Sampler + GlobalSampler + SobolSampler).  PathIntegrator requests no sample
+// arrays (m_arrayEndDim == s_arrayStartDim == 5); DirectLightingIntegrator::Preprocess requests 2D arrays.
+// GlobalSampler::StartPixel fills every requested array for all samples of the pixel (Sampler.cpp:170-180):
+// entry j of array i is SampleDimension(GetIndexForSample(j), dim_i).  Here an entry is computed when it
+// is handed out, which gives the same values without the per-pixel fill.
 struct SobolSampler {
     int64_t samplesPerPixel;
     BBox2i sampleBounds;
@@ -80,6 +83,10 @@ struct SobolSampler {
     int64_t intervalSampleIndex = 0;
     static const int arrayStartDim = 5;
     int arrayEndDim = 5;
+    std::vector<int> samples2DArraySizes;   // Request2DArray, Sampler.cpp:46-51
+    size_t array1DOffset = 0, array2DOffset = 0;
+    std::vector<Vec2> arrayScratch[2];
+    bool readPastArrays = false;            // the reference would index m_sampleArray2D out of range
 
     SobolSampler(int64_t spp, const BBox2i& sb) : samplesPerPixel(RoundUpPow2((uint32_t)spp)), sampleBounds(sb) {
         int dx = sb.mx.x - sb.mn.x, dy = sb.mx.y - sb.mn.y;
@@ -98,21 +105,41 @@ struct SobolSampler {
         }
         return s;
     }
+    void Request2DArray(int n) { samples2DArraySizes.push_back(n); }
+    // Sampler.cpp:62-69.  The guard compares m_array1DOffset (never advanced: nothing asks for 1D arrays)
+    // with the number of 2D arrays, so it fires only when no 2D array was requested at all; past the
+    // last requested array the reference indexes out of range (flagged here, nullptr returned).
+    const Vec2* Get2DArray(int n) {
+        if (array1DOffset == samples2DArraySizes.size()) return nullptr;
+        if (array2DOffset >= samples2DArraySizes.size()) { readPastArrays = true; return nullptr; }
+        size_t i = array2DOffset++;
+        int dim = arrayStartDim + 2 * (int)i;
+        std::vector<Vec2>& out = arrayScratch[i & 1]; // uLightArray and uScatteringArray are alive together
+        out.resize(n);
+        for (int k = 0; k < n; ++k) {
+            int64_t idx = GetIndexForSample(currentPixelSampleIndex * n + k);
+            out[k] = Vec2(SampleDimension(idx, dim), SampleDimension(idx, dim + 1));
+        }
+        return out.data();
+    }
     void StartPixel(const Vec2i& p) {
         currentPixel = p;
         currentPixelSampleIndex = 0;
+        array1DOffset = array2DOffset = 0;
         dimension = 0;
         intervalSampleIndex = GetIndexForSample(0);
-        arrayEndDim = arrayStartDim;
+        arrayEndDim = arrayStartDim + 2 * (int)samples2DArraySizes.size();
     }
     bool StartNextSample() {
         dimension = 0;
         intervalSampleIndex = GetIndexForSample(currentPixelSampleIndex + 1);
+        array1DOffset = array2DOffset = 0;
         return ++currentPixelSampleIndex < samplesPerPixel;
     }
     bool SetSampleNumber(int64_t n) {
         dimension = 0;
         intervalSampleIndex = GetIndexForSample(n);
+        array1DOffset = array2DOffset = 0;
         currentPixelSampleIndex = n;
         return currentPixelSampleIndex < samplesPerPixel;
     }
@@ -1365,6 +1392,7 @@ struct Distribution1D { // MonteCarlo.h:15-84
 };
 
 struct Light {
+    int nSamples = 1; // Light::m_nSamples
     int flags; // 1 = delta position, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
     bool IsDelta() const { return (flags & 1) || (flags & 2); } // Lights.h:15-18
@@ -1528,6 +1556,78 @@ struct PathIntegrator {
     }
 };
 
+// Integrator.cpp:42-69
+static Spectrum UniformSampleAllLights(const SurfaceInteraction& it, const BSDF& bsdf, const Scene& scene, SobolSampler& sampler,
+                                       const std::vector<int>& nLightSamples) {
+    Spectrum L(0.f);
+    for (size_t i = 0; i < scene.lights.size(); ++i) {
+        const Light& light = scene.lights[i];
+        int nSamples = nLightSamples[i];
+        const Vec2* uLightArray = sampler.Get2DArray(nSamples);
+        const Vec2* uScatteringArray = sampler.Get2DArray(nSamples);
+        if (!uLightArray || !uScatteringArray) {
+            Vec2 uLight = sampler.Get2D();
+            Vec2 uScattering = sampler.Get2D();
+            L += EstimateDirect(it, bsdf, uScattering, light, uLight, scene);
+        } else {
+            Spectrum Ld(0.f);
+            for (int k = 0; k < nSamples; ++k) Ld += EstimateDirect(it, bsdf, uScatteringArray[k], light, uLightArray[k], scene);
+            L += Ld / (float)nSamples;
+        }
+    }
+    return L;
+}
+
+// DirectLightingIntegrator.cpp:37-87 with SamplerIntegrator::SpecularReflect / SpecularTransmit
+// (Integrator.cpp:329-444; the ray-differential blocks feed texture filtering only and are not restated).
+struct DirectLightingIntegrator {
+    int maxDepth = 5;
+    int strategy = ENIGMA_DL_SAMPLE_ALL;
+    std::vector<int> nLightSamples;
+    // Preprocess: RoundCount is the identity for every sampler on this path (Sampler.h default)
+    void Preprocess(const Scene& scene, SobolSampler& sampler) {
+        nLightSamples.clear();
+        if (strategy != ENIGMA_DL_SAMPLE_ALL) return;
+        for (const Light& l : scene.lights) nLightSamples.push_back(l.nSamples);
+        for (int i = 0; i < maxDepth; ++i)
+            for (size_t j = 0; j < scene.lights.size(); ++j) {
+                sampler.Request2DArray(nLightSamples[j]);
+                sampler.Request2DArray(nLightSamples[j]);
+            }
+    }
+    Spectrum Li(const Ray& ray, const Scene& scene, SobolSampler& sampler, int depth) const {
+        Spectrum L(0.f);
+        SurfaceInteraction isect;
+        if (tl_counters) { tl_counters->rays_closest++; tl_counters->kind = 0; }
+        if (!scene.intersect(ray, &isect)) return L; // light->Le(ray) is zero for point and area lights
+        // allowMultipleLobes defaults to false here (Interaction.h:68): smooth glass = two specular lobes
+        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false));
+        Vec3 wo = isect.wo;
+        L += Le(scene, isect, wo);
+        if (scene.lights.size() > 0) {
+            if (strategy == ENIGMA_DL_SAMPLE_ALL) L += UniformSampleAllLights(isect, *bsdf, scene, sampler, nLightSamples);
+            else L += UniformSampleOneLight(isect, *bsdf, scene, sampler, nullptr);
+        }
+        if (depth + 1 < maxDepth) {
+            L += SpecularBounce(isect, *bsdf, scene, sampler, depth, BSDF_REFLECTION | BSDF_SPECULAR);
+            L += SpecularBounce(isect, *bsdf, scene, sampler, depth, BSDF_TRANSMISSION | BSDF_SPECULAR);
+        }
+        return L;
+    }
+    Spectrum SpecularBounce(const SurfaceInteraction& isect, const BSDF& bsdf, const Scene& scene, SobolSampler& sampler, int depth, int type) const {
+        Vec3 wo = isect.wo, wi;
+        float pdf = 0;
+        int sampledType = 0;
+        Spectrum f = bsdf.sample_f(wo, &wi, sampler.Get2D(), &pdf, type, &sampledType);
+        const Vec3& ns = isect.shading.n;
+        if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+            Ray rd = isect.SpawnRay(wi);
+            return f * Li(rd, scene, sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+        }
+        return Spectrum(0.f);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // The oracle context: scene + camera + film + integrator, and the Render loop
 // ---------------------------------------------------------------------------
@@ -1536,6 +1636,9 @@ struct Oracle {
     PerspectiveCamera camera;
     std::unique_ptr<Film> film;
     PathIntegrator integrator;
+    DirectLightingIntegrator direct;
+    bool useDirect = false;
+    std::atomic<bool> readPastArrays{false};
     EnigmaIntegratorDesc idesc;
     std::string error;
     Counters totals;
@@ -1567,6 +1670,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
             if (t >= total) break;
             Vec2i curTile(t % nTiles.x, t / nTiles.x);
             SobolSampler tileSampler(O.idesc.samples_per_pixel, sampleBounds);
+            if (O.useDirect) { DirectLightingIntegrator pre = O.direct; pre.Preprocess(O.scene, tileSampler); } // the clone carries the array requests
             int x0 = sampleBounds.mn.x + curTile.x * TileSize;
             int x1 = std::min(x0 + TileSize, sampleBounds.mx.x);
             int y0 = sampleBounds.mn.x + curTile.y * TileSize; // sic: min.x (Integrator.cpp:254)
@@ -1588,7 +1692,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
                         float rayWeight = O.camera.GenerateRay(cameraSample, &ray);
                         tl_counters->samples++;
                         Spectrum L(0.f);
-                        if (rayWeight > 0) L = O.integrator.Li(ray, O.scene, tileSampler);
+                        if (rayWeight > 0) L = O.useDirect ? O.direct.Li(ray, O.scene, tileSampler, 0) : O.integrator.Li(ray, O.scene, tileSampler);
                         if (L.HasNaNs()) L = Spectrum(0.f);
                         else if (L.y() < -1e-5) L = Spectrum(0.f);
                         else if (std::isinf(L.y())) L = Spectrum(0.f);
@@ -1605,6 +1709,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
                     } while (tileSampler.StartNextSample() && tileSampler.currentPixelSampleIndex < sampleEnd);
                 }
             done[t] = std::move(filmTile);
+            if (tileSampler.readPastArrays) O.readPastArrays = true;
         }
         tl_counters = nullptr;
     };
@@ -1669,6 +1774,7 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         Light& L = sc.lights[i];
         L.index = (int)i;
         L.I_or_L = Spectrum(l.L[0], l.L[1], l.L[2]);
+        L.nSamples = l.n_samples ? (int)l.n_samples : 1;
         if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
             L.flags = 4; L.shape = &sc.tris[l.triangle]; L.twoSided = l.two_sided != 0; L.area = L.shape->area();
         } else { L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]); }
@@ -1692,6 +1798,7 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     Oracle& O = h->o;
     O.idesc = *d;
     O.integrator.maxDepth = d->max_depth; O.integrator.rrThreshold = d->rr_threshold;
+    O.useDirect = false;
     // CreateLightSampleDistribution (LightDist.cpp:20-38) + ComputeLightPowerDistribution (Integrator.cpp:30-38)
     size_t n = O.scene.lights.size();
     O.integrator.lightDistrib.reset();
@@ -1703,6 +1810,21 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     }
     return 0;
 }
+int oracle_direct_lighting_config(OracleCtx* h, const EnigmaDirectLightingDesc* d) {
+    Oracle& O = h->o;
+    O.idesc.max_depth = d->max_depth;
+    memcpy(O.idesc.pixel_bounds, d->pixel_bounds, sizeof(d->pixel_bounds));
+    O.idesc.samples_per_pixel = d->samples_per_pixel;
+    memcpy(O.idesc.sample_bounds, d->sample_bounds, sizeof(d->sample_bounds));
+    O.direct.maxDepth = d->max_depth;
+    O.direct.strategy = d->strategy;
+    O.direct.nLightSamples.clear();
+    for (const Light& l : O.scene.lights) O.direct.nLightSamples.push_back(l.nSamples);
+    O.useDirect = true;
+    return 0;
+}
+// 1 if a render since the last call read past the sample arrays the integrator requested (undefined in the reference)
+int oracle_read_past_arrays(OracleCtx* h) { bool v = h->o.readPastArrays.exchange(false); return v ? 1 : 0; }
 int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_threads, int want_moments) {
     {   // the tile loop starts its rows at sampleBounds.m_min.x (Integrator.cpp:254); with min.x < min.y it would
         // visit pixels above the sample bounds, whose Sobol' pixel offsets are negative: undefined in the reference

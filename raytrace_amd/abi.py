@@ -6,6 +6,7 @@ import numpy as np
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_DIFFUSE_AREA = 0, 1
 LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
+DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
 
 
@@ -17,7 +18,7 @@ class EnigmaMaterial(C.Structure):
 
 
 class EnigmaLight(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("triangle", C.c_uint32), ("two_sided", C.c_uint32), ("pad", C.c_uint32),
+    _fields_ = [("type", C.c_uint32), ("triangle", C.c_uint32), ("two_sided", C.c_uint32), ("n_samples", C.c_uint32),
                 ("L", C.c_float * 3), ("pos", C.c_float * 3)]
 
 
@@ -44,6 +45,11 @@ class EnigmaFilmDesc(C.Structure):
 class EnigmaIntegratorDesc(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
                 ("pixel_bounds", C.c_int32 * 4), ("samples_per_pixel", C.c_int64), ("sample_bounds", C.c_int32 * 4)]
+
+
+class EnigmaDirectLightingDesc(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("strategy", C.c_int32), ("pixel_bounds", C.c_int32 * 4),
+                ("samples_per_pixel", C.c_int64), ("sample_bounds", C.c_int32 * 4)]
 
 
 class EnigmaStats(C.Structure):
@@ -134,18 +140,20 @@ def plastic(kd, ks, roughness=0.1, remap=True):
     return m
 
 
-def area_light(triangle, L, two_sided=False):
+def area_light(triangle, L, two_sided=False, n_samples=1):
     l = EnigmaLight()
     l.type = LIGHT_DIFFUSE_AREA
     l.triangle = triangle
     l.two_sided = 1 if two_sided else 0
+    l.n_samples = n_samples
     l.L[:] = L
     return l
 
 
-def point_light(pos, I):
+def point_light(pos, I, n_samples=1):
     l = EnigmaLight()
     l.type = LIGHT_POINT
+    l.n_samples = n_samples
     l.pos[:] = pos
     l.L[:] = I
     return l

@@ -14,12 +14,14 @@
 namespace edev {
 
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR };
+enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR, LOBE_SPEC_REFL, LOBE_SPEC_TRANS };
 
 DEV constexpr int lobeType(int k) {
     return k == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
          : (k == LOBE_MICRO_REFL_CONDUCTOR || k == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
          : k == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
+         : k == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
+         : k == LOBE_SPEC_TRANS ? (BSDF_TRANSMISSION | BSDF_SPECULAR)
          : (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
 }
 
@@ -165,6 +167,9 @@ template <> struct LobeOf<MK_METAL, 0> { static constexpr int kind = LOBE_MICRO_
 template <> struct LobeOf<MK_GLASS_SMOOTH, 0> { static constexpr int kind = LOBE_FRESNEL_SPECULAR; };
 template <> struct LobeOf<MK_GLASS_ROUGH, 0> { static constexpr int kind = LOBE_MICRO_REFL_DIELECTRIC; };
 template <> struct LobeOf<MK_GLASS_ROUGH, 1> { static constexpr int kind = LOBE_MICRO_TRANS; };
+// smooth glass without allowMultipleLobes (DirectLightingIntegrator): two specular lobes, Material.cpp:204-218
+template <> struct LobeOf<MK_DL_GLASS, 0> { static constexpr int kind = LOBE_SPEC_REFL; };
+template <> struct LobeOf<MK_DL_GLASS, 1> { static constexpr int kind = LOBE_SPEC_TRANS; };
 template <> struct LobeOf<MK_PLASTIC, 0> { static constexpr int kind = LOBE_LAMBERT; };
 template <> struct LobeOf<MK_PLASTIC, 1> { static constexpr int kind = LOBE_MICRO_REFL_DIELECTRIC; };
 
@@ -201,7 +206,7 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 dpdu, Bsdf* b) {
     } else if (MK == MK_GLASS_SMOOTH) {
         b->eta = m.eta; b->dEtaT = m.eta;
         b->has0 = nb0 || nb1;
-    } else if (MK == MK_GLASS_ROUGH) {
+    } else if (MK == MK_GLASS_ROUGH || MK == MK_DL_GLASS) {
         b->eta = m.eta; b->dEtaT = m.eta;
         b->has1 = nb1;
     } else if (MK == MK_PLASTIC) { // FresnelDielectric(1.5f, 1.f), Material.cpp:244
@@ -214,6 +219,8 @@ DEV constexpr bool lobeMatches(int kind, int flags) {
     int t = kind == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
           : (kind == LOBE_MICRO_REFL_CONDUCTOR || kind == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
           : kind == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
+          : kind == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
+          : kind == LOBE_SPEC_TRANS ? (BSDF_TRANSMISSION | BSDF_SPECULAR)
           : kind == LOBE_FRESNEL_SPECULAR ? (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR) : 0;
     return kind >= 0 && (t & flags) == t;
 }
@@ -302,6 +309,19 @@ DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, floa
         if (!refract(wo, wh, eta, wi)) return F3(0.f);
         *pdf = microTransPdf(b, wo, *wi);
         return microTransF(b, col, wo, *wi);
+    } else if (KIND == LOBE_SPEC_REFL) { // SpecularReflection::sample_f with FresnelDielectric(1, eta), BxDF.cpp:674-679,649-659
+        *pdf = 1.0f;
+        *wi = F3(-wo.x, -wo.y, wo.z);
+        return (F3(frDielectric(cosTheta(wo), b.dEtaI, b.dEtaT)) * col) / absCosTheta(*wi);
+    } else if (KIND == LOBE_SPEC_TRANS) { // SpecularTransmission::sample_f, BxDF.cpp:705-722 (radiance transport)
+        bool entering = cosTheta(wo) > 0;
+        float etaI = entering ? b.dEtaI : b.dEtaT;
+        float etaT = entering ? b.dEtaT : b.dEtaI;
+        if (!refract(wo, faceForward(F3(0, 0, 1), wo), etaI / etaT, wi)) return F3(0.f);
+        *pdf = 1;
+        F3 ft = col * (F3(1.f) - F3(frDielectric(cosTheta(*wi), b.dEtaI, b.dEtaT)));
+        ft *= (etaI * etaI) / (etaT * etaT);
+        return ft / absCosTheta(*wi);
     } else if (KIND == LOBE_FRESNEL_SPECULAR) { // BxDF.cpp:1124-1158; col0 = R (unused by the reference), col1 = T
         float F = frDielectric(cosTheta(wo), b.dEtaI, b.dEtaT);
         if (u0 < F) {

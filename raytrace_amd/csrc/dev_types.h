@@ -7,7 +7,9 @@ namespace edev {
 // Material kinds the shade kernels are sorted by.  ENIGMA_MAT_GLASS splits by roughness at
 // upload: a smooth glass is one FresnelSpecular lobe (allowMultipleLobes is always true on the
 // PathIntegrator path, Enigma/PathIntegrator.cpp:89, Enigma/Material.cpp:190-194).
-enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4, MK_COUNT = 5 };
+enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4, MK_COUNT = 5,
+                          MK_DL_GLASS = 6 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
+constexpr int kQueueKinds = MK_COUNT + 1; // one queue per material kind + (DirectLightingIntegrator) paths that resume a pending branch
 
 struct DevMaterial {        // 64 bytes
     uint32_t kind;          // MatKind
@@ -25,7 +27,7 @@ struct DevLight {           // 48 bytes
     uint32_t tri;           // area: triangle position in the device (BVH) order
     uint32_t twoSided;
     float area;             // Triangle::area() (Enigma/TriangleMesh.cpp:438-446)
-    float L[3]; float pad0;
+    float L[3]; uint32_t nSamples;  // Light::m_nSamples (DirectLightingIntegrator, strategy all)
     float pos[3]; float pad1;
 };
 
@@ -68,15 +70,35 @@ struct DevSampler {
     const uint32_t* tx;         // [nDims][res] pixel-x XOR table
     const uint32_t* ty;         // [nDims][res]
     const uint32_t* sampleConst;// [samples in flight][nDims]
+    const uint32_t* bitConst;   // [nDims][kSampleBits]: constant of sample number 1 << b (the constant is linear in the bits)
+    unsigned long long sampleBase; // sample number of slot 0
     uint32_t res, nDims;
     int sbx0, sby0;             // sample bounds origin
     float resolutionF;          // (float)m_resolution
 };
 
+constexpr int kSampleBits = 40;
+
 struct DevIntegrator {
     int maxDepth;
     float rrThreshold;
     int rx0, ry0, rw, rh;       // render region = sample bounds clipped to pixel bounds
+    // DirectLightingIntegrator
+    int dlStrategy;             // ENIGMA_DL_SAMPLE_*
+    int arrayEndDim;            // GlobalSampler::m_arrayEndDim: first dimension after the sample arrays
+    int raysPerPath;            // shadow (and MIS) ray slots per path: sum of the lights' sample counts, or 1
+    int pendingLevels;          // pending-branch stack entries per path (maxDepth - 1, at least 1)
+};
+
+// DirectLightingIntegrator per-path state: the recursion Li -> SpecularReflect -> Li ... -> SpecularTransmit
+// (Enigma/Integrator.cpp:329-444) is walked depth first; a node's transmission branch waits on this stack
+// while its reflection subtree runs, because the sampler dimensions it consumes follow that subtree's.
+struct DevDirect {
+    uint32_t* arrayOff;   // Sampler::m_array2DOffset
+    uint32_t* pendCount;
+    float4* pendO;        // [path][level] o.xyz, valid (1) / placeholder that only consumes its Get2D (0)
+    float4* pendD;        // d.xyz, depth of the child
+    float4* pendB;        // throughput of the child
 };
 
 // Per-path state, structure of arrays (float4 where the fields travel together).
@@ -99,7 +121,8 @@ struct DevRayQueue {
     float4* o;        // [path] o.xyz, unused
     float4* d;        // [path] d.xyz, bits(light index) (MIS) / tMax (shadow)
     float4* w;        // [path] contribution to add to the path's L (shadow) or weight of Le (MIS)
-    uint32_t* idx;    // [0, count) path indices
+    uint32_t* idx;    // [0, count) ray slots (= path index * perPath + ray of the path)
+    uint32_t perPath; // 1 for PathIntegrator
 };
 
 // Queue tails are bumped with device-scope atomics by every block of a launch.  Atomics on one
@@ -108,7 +131,7 @@ struct DevRayQueue {
 struct alignas(128) DevTail { uint32_t v; uint32_t pad[31]; };
 struct DevCounters {
     DevTail extCount[2];        // extension-ray queue sizes (current, next)
-    DevTail matCount[MK_COUNT];
+    DevTail matCount[kQueueKinds];
     DevTail shadowCount, misCount;
     unsigned long long raysClosest, raysShadow, raysMis, samples;
 };

@@ -79,13 +79,20 @@ struct EnigmaCtx {
     DevBuf<uint32_t> tx, ty, sampleConst;
     DevSampler sampler{};
     bool lightDistDirty = true;
+    // DirectLightingIntegrator
+    bool useDirect = false, directDirty = true;
+    EnigmaDirectLightingDesc directDesc{};
+    bool glassBranches = false, glassSpecular = false; // a smooth glass with Kr and Kt / with either
+    DevBuf<uint32_t> bitConst, arrayOff, pendCount;
+    DevBuf<float4> pendO, pendD, pendB;
+    size_t rayCapacity = 0, pendCapacity = 0;
 
     // wavefront state
     size_t capacity = 0;
     DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, shW, miO, miD, miW;
     DevBuf<uint32_t> shIdx, miIdx;
     DevBuf<int32_t> hitTri;
-    DevBuf<uint32_t> pixel, state, extQ[2], matQ[MK_COUNT];
+    DevBuf<uint32_t> pixel, state, extQ[2], matQ[kQueueKinds];
     DevBuf<float2> pfilm;
     DevBuf<DevCounters> counters;
 
@@ -138,6 +145,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     h->pixel.release(); h->state.release(); h->extQ[0].release(); h->extQ[1].release();
     for (auto& q : h->matQ) q.release();
     h->pfilm.release(); h->counters.release(); h->shIdx.release(); h->miIdx.release();
+    h->bitConst.release(); h->arrayOff.release(); h->pendCount.release(); h->pendO.release(); h->pendD.release(); h->pendB.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -161,6 +169,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     // materials (Enigma/Material.cpp:76-255 parameter evaluation with constant textures)
     std::vector<DevMaterial> mats(s->n_materials);
     for (int k = 0; k < MK_COUNT; ++k) h->kindPresent[k] = false;
+    h->glassBranches = h->glassSpecular = false;
     auto clamp01inf = [](float v) { return v < 0.f ? 0.f : v; }; // Spectrum::Clamp(0, inf)
     auto remap = [](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
         r = std::max(r, (float)1e-3);
@@ -205,6 +214,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f;
         bool nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
         d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
+        if (d.kind == MK_GLASS_SMOOTH && (nb0 || nb1)) h->glassSpecular = true;
+        if (d.kind == MK_GLASS_SMOOTH && nb0 && nb1) h->glassBranches = true;
         h->kindPresent[d.kind] = true;
         mats[i] = d;
     }
@@ -240,6 +251,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
     h->hostLights.assign(s->n_lights, DevLight());
     h->haveAreaLights = false;
+    h->directDirty = true;
     h->lightPower.assign(s->n_lights, 0.f);
     const float PI = 3.1415926535897932384f;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
@@ -247,6 +259,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         DevLight d;
         memset(&d, 0, sizeof(d));
         for (int c = 0; c < 3; ++c) { d.L[c] = l.L[c]; d.pos[c] = l.pos[c]; }
+        d.nSamples = l.n_samples ? l.n_samples : 1u;
         const float YW[3] = {0.212671f, 0.715160f, 0.072169f};
         if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
             if (l.triangle >= s->n_triangles) return h->fail(ENIGMA_E_INVALID, "light %u: triangle out of range", i);
@@ -330,32 +343,33 @@ extern "C" int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* f) {
     return enigma_film_clear(h);
 }
 
-extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
-    if (!h || !d) return ENIGMA_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
-    if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
-    if (d->samples_per_pixel <= 0 || d->samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
-    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
-        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
-    const int32_t* sb = d->sample_bounds;
+// SobolSampler construction + the pixels the tile loop visits; shared by both integrators.
+static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32_t* sb, const int32_t* pixel_bounds, uint32_t nDims) {
+    if (samples_per_pixel <= 0 || samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
     int dx = sb[2] - sb[0], dy = sb[3] - sb[1];
     if (dx <= 0 || dy <= 0) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
-    h->integDesc = *d;
     // SobolSampler ctor, Enigma/Sampler.cpp:211-222
-    h->spp = (int64_t)roundUpPow2((uint32_t)d->samples_per_pixel);
+    h->spp = (int64_t)roundUpPow2((uint32_t)samples_per_pixel);
     h->resolution = roundUpPow2((uint32_t)std::max(dx, dy));
     h->log2Res = (uint32_t)log2Int((float)h->resolution);
     if ((1u << h->log2Res) != h->resolution) return h->fail(ENIGMA_E_INVALID, "Log2Int(resolution) is inexact for %u", h->resolution);
-    // dimensions a path can consume: 5 (camera) + per bounce 1+2+2 (light) + 2 (BSDF) + 1 (roulette)
-    uint32_t nDims = 5u + 8u * (uint32_t)d->max_depth;
-    if (nDims > (uint32_t)enigma::kNumSobolDimensions) return h->fail(ENIGMA_E_INVALID, "max_depth needs %u Sobol dimensions (> 1024)", nDims);
+    if (nDims > (uint32_t)enigma::kNumSobolDimensions) return h->fail(ENIGMA_E_INVALID, "the integrator needs %u Sobol dimensions (> 1024)", nDims);
     if (nDims > 1023u) return h->fail(ENIGMA_E_INVALID, "dimension cursor overflow");
     h->nDims = nDims;
     enigma::SobolPixelTables T;
     enigma::build_pixel_tables(h->log2Res, nDims, &T);
     HIPCHK(h, h->tx.upload(T.tx));
     HIPCHK(h, h->ty.upload(T.ty));
-    h->sampler.tx = h->tx.p; h->sampler.ty = h->ty.p;
+    // constant of sample number 1 << b per dimension; sample numbers stay below 2^(52 - 2 log2Res), the width of the
+    // Sobol' matrices (Enigma/SamplerInclude.h:2627-2637 reads one matrix column per index bit)
+    std::vector<uint32_t> bits((size_t)nDims * kSampleBits, 0u), tmp(nDims);
+    int usable = std::min<int>(kSampleBits, 52 - 2 * (int)h->log2Res);
+    for (int b = 0; b < usable; ++b) {
+        enigma::sample_constants(h->log2Res, 1ull << b, nDims, tmp.data());
+        for (uint32_t d = 0; d < nDims; ++d) bits[(size_t)d * kSampleBits + b] = tmp[d];
+    }
+    HIPCHK(h, h->bitConst.upload(bits));
+    h->sampler.tx = h->tx.p; h->sampler.ty = h->ty.p; h->sampler.bitConst = h->bitConst.p;
     h->sampler.res = h->resolution; h->sampler.nDims = nDims;
     h->sampler.sbx0 = sb[0]; h->sampler.sby0 = sb[1];
     h->sampler.resolutionF = (float)(int)h->resolution;
@@ -366,14 +380,85 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
                                                           "start above the sample bounds; its result is undefined");
     int nTilesY = (dy + 31) / 32;
     int tileY0 = sb[0], tileY1 = std::min(sb[0] + nTilesY * 32, sb[3]);
-    int rx0 = std::max(sb[0], d->pixel_bounds[0]), ry0 = std::max(tileY0, d->pixel_bounds[1]);
-    int rx1 = std::min(sb[2], d->pixel_bounds[2]), ry1 = std::min(tileY1, d->pixel_bounds[3]);
-    h->integ.maxDepth = d->max_depth;
-    h->integ.rrThreshold = d->rr_threshold;
+    int rx0 = std::max(sb[0], pixel_bounds[0]), ry0 = std::max(tileY0, pixel_bounds[1]);
+    int rx1 = std::min(sb[2], pixel_bounds[2]), ry1 = std::min(tileY1, pixel_bounds[3]);
     h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
     if (dx > 65535 || dy > 65535) return h->fail(ENIGMA_E_INVALID, "sample bounds wider than 65535");
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
+    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
+    // dimensions a path can consume: 5 (camera) + per bounce 1+2+2 (light) + 2 (BSDF) + 1 (roulette)
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u + 8u * (uint32_t)d->max_depth);
+    if (rc) return rc;
+    h->integDesc = *d;
+    h->integ.maxDepth = d->max_depth;
+    h->integ.rrThreshold = d->rr_threshold;
+    h->integ.raysPerPath = 1;
     h->lightDistDirty = true;
+    h->useDirect = false;
     h->haveInteg = true;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLightingDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (d->max_depth < 0 || d->max_depth > 30) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
+    if (d->strategy != ENIGMA_DL_SAMPLE_ALL && d->strategy != ENIGMA_DL_SAMPLE_ONE) return h->fail(ENIGMA_E_INVALID, "unknown strategy %d", d->strategy);
+    if (d->samples_per_pixel <= 0 || d->samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
+    if (d->sample_bounds[2] <= d->sample_bounds[0] || d->sample_bounds[3] <= d->sample_bounds[1]) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
+    h->directDesc = *d;
+    h->integDesc.max_depth = d->max_depth;
+    memcpy(h->integDesc.pixel_bounds, d->pixel_bounds, sizeof(d->pixel_bounds));
+    memcpy(h->integDesc.sample_bounds, d->sample_bounds, sizeof(d->sample_bounds));
+    h->integDesc.samples_per_pixel = d->samples_per_pixel;
+    h->useDirect = true;
+    h->directDirty = true; // finished against the scene at render time (Preprocess needs the lights)
+    h->haveInteg = true;
+    // the sampler part does not depend on the scene: report its errors now
+    return configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u);
+}
+
+// DirectLightingIntegrator::Preprocess against the current scene (Enigma/DirectLightingIntegrator.cpp:71-87): the
+// 2 x lights x maxDepth sample arrays become the reserved dimensions [5, arrayEndDim).
+static int finishDirectLighting(EnigmaCtx* h) {
+    const EnigmaDirectLightingDesc& d = h->directDesc;
+    const uint32_t nLights = (uint32_t)h->hostLights.size();
+    uint32_t nArrays = 0, raysPerPath = 1, maxN = 1;
+    if (d.strategy == ENIGMA_DL_SAMPLE_ALL) {
+        nArrays = 2u * nLights * (uint32_t)d.max_depth;
+        raysPerPath = 0;
+        for (const DevLight& l : h->hostLights) { raysPerPath += l.nSamples; maxN = std::max(maxN, l.nSamples); }
+        raysPerPath = std::max(1u, raysPerPath);
+        // Li evaluations of one camera sample exceed maxDepth only if the recursion branches; the reference then indexes
+        // m_sampleArray2D past its end (Get2DArray's guard tests the wrong offset, Enigma/Sampler.cpp:62-69)
+        if (h->glassBranches && d.max_depth >= 2 && nLights > 0)
+            return h->fail(ENIGMA_E_UNSUPPORTED, "strategy 'all' with a smooth glass that has both Kr and Kt: the reference reads past the sample "
+                                                 "arrays it requested (undefined); use strategy 'one'");
+    }
+    // Li evaluations (nodes) per camera sample: 1 without specular lobes, a chain with one, a binary tree with two
+    uint64_t nodes = !h->glassSpecular ? 1 : (!h->glassBranches ? (uint64_t)std::max(1, d.max_depth) : ((1ull << std::min(d.max_depth, 20)) - 1));
+    uint64_t nDims = 5ull + 2ull * nArrays + nodes * (d.strategy == ENIGMA_DL_SAMPLE_ONE ? 9ull : 4ull);
+    if (nDims > (uint64_t)enigma::kNumSobolDimensions)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "DirectLightingIntegrator needs %llu Sobol dimensions here (%u sample arrays); the reference has 1024",
+                       (unsigned long long)nDims, nArrays);
+    if ((uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res)))
+        return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the Sobol' index width", maxN, (long long)h->spp);
+    int rc = configureSampler(h, d.samples_per_pixel, d.sample_bounds, d.pixel_bounds, (uint32_t)nDims);
+    if (rc) return rc;
+    h->integ.maxDepth = d.max_depth;
+    h->integ.rrThreshold = 0.f;
+    h->integ.dlStrategy = d.strategy;
+    h->integ.arrayEndDim = 5 + 2 * (int)nArrays;
+    h->integ.raysPerPath = (int)raysPerPath;
+    h->integ.pendingLevels = std::max(1, d.max_depth - 1);
+    h->directDirty = false;
     return ENIGMA_OK;
 }
 
@@ -399,13 +484,27 @@ static int buildLightDistribution(EnigmaCtx* h) {
     return ENIGMA_OK;
 }
 
-static int ensureCapacity(EnigmaCtx* h, size_t n) {
+// n paths, each with raysPerPath shadow/MIS ray slots and (DirectLightingIntegrator) pendingLevels stack entries
+static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pendingLevels) {
+    if (n * raysPerPath > h->rayCapacity) {
+        DevBuf<float4>* r4[] = {&h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+        for (auto* b : r4) HIPCHK(h, b->alloc(n * raysPerPath));
+        HIPCHK(h, h->shIdx.alloc(n * raysPerPath));
+        HIPCHK(h, h->miIdx.alloc(n * raysPerPath));
+        h->rayCapacity = n * raysPerPath;
+    }
+    if (n * pendingLevels > h->pendCapacity) {
+        HIPCHK(h, h->pendO.alloc(n * pendingLevels));
+        HIPCHK(h, h->pendD.alloc(n * pendingLevels));
+        HIPCHK(h, h->pendB.alloc(n * pendingLevels));
+        h->pendCapacity = n * pendingLevels;
+    }
     if (n <= h->capacity) return ENIGMA_OK;
-    DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit, &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+    DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit};
     for (auto* b : f4) HIPCHK(h, b->alloc(n));
     HIPCHK(h, h->hitTri.alloc(n));
-    HIPCHK(h, h->shIdx.alloc(n));
-    HIPCHK(h, h->miIdx.alloc(n));
+    HIPCHK(h, h->arrayOff.alloc(n));
+    HIPCHK(h, h->pendCount.alloc(n));
     HIPCHK(h, h->pixel.alloc(n));
     HIPCHK(h, h->state.alloc(n));
     HIPCHK(h, h->pfilm.alloc(n));
@@ -433,11 +532,11 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     hipStream_t s = h->stream;
     k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, bounce == 0 ? 1 : 0);
     MatQueues mq;
-    for (int k = 0; k < MK_COUNT; ++k) mq.q[k] = h->matQ[k].p;
+    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr, h->refillIdle);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, false><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -453,18 +552,55 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     }
 }
 
+// One step of the depth-first walk of DirectLightingIntegrator::Li's recursion for every path in flight:
+// trace the current rays, shade the hits (direct lighting + the specular children), resume pending branches
+// of the paths that missed, then the shadow and MIS rays of this step.
+template <int LDSN, int OVF, bool LDS_SCENE>
+static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths,
+                             int step, int gridTrace, int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
+    DevCounters* ctr = h->counters.p;
+    uint32_t cur = (uint32_t)step & 1u;
+    hipStream_t s = h->stream;
+    k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, step == 0 ? 1 : 0);
+    MatQueues mq;
+    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
+    const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
+    const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
+    (void)hipEventRecord(e0, s);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, true><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr,
+                                                                                                                 h->refillIdle, D.pendCount);
+    (void)hipEventRecord(e1, s);
+    uint32_t* nextQ = h->extQ[cur ^ 1u].p;
+    const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
+    k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
+    if (h->scene.nLights > 0) {
+        k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+    }
+}
+
 extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (!h) return ENIGMA_E_INVALID;
     if (!h->haveScene || !h->haveCamera || !h->haveFilm || !h->haveInteg) return h->fail(ENIGMA_E_STATE, "scene, camera, film and integrator must be configured before render");
     if (sample_begin < 0 || sample_end < sample_begin || sample_end > h->spp) return h->fail(ENIGMA_E_INVALID, "sample range [%lld, %lld) outside [0, %lld)", (long long)sample_begin, (long long)sample_end, (long long)h->spp);
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->useDirect && h->directDirty) { int rc = finishDirectLighting(h); if (rc) return rc; }
     if (h->lightDistDirty) { int rc = buildLightDistribution(h); if (rc) return rc; }
     auto wall0 = std::chrono::steady_clock::now();
     const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
     h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
     // passes of k sample numbers over all pixels, ~8M paths in flight (capped by the 12-bit sample slot)
-    const size_t targetPaths = (size_t)8 << 20;
+    const bool direct = h->useDirect;
+    const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
+    // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
+    const size_t targetPaths = std::max<size_t>((size_t)1 << 16, ((size_t)8 << 20) / std::max<size_t>(1, (raysPerPath + pendingLevels) / 4));
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
@@ -480,10 +616,13 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         for (int64_t s = 0; s < cn; ++s) enigma::sample_constants(h->log2Res, (uint64_t)(sample_begin + c0 + s), h->nDims, &consts[(size_t)s * h->nDims]);
         HIPCHK(h, h->sampleConst.upload(consts));
         h->sampler.sampleConst = h->sampleConst.p;
+        h->sampler.sampleBase = (unsigned long long)(sample_begin + c0);
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
-        { int rc = ensureCapacity(h, passPathsMax); if (rc) return rc; }
+        { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
         DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->hitTri.p, h->pixel.p, h->state.p, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p, h->shIdx.p}, misq{h->miO.p, h->miD.p, h->miW.p, h->miIdx.p};
+        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p, h->shIdx.p, (uint32_t)raysPerPath}, misq{h->miO.p, h->miD.p, h->miW.p, h->miIdx.p, (uint32_t)raysPerPath};
+        DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
         for (int64_t s0 = 0; s0 < cn; s0 += k) {
             uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
             uint32_t nPaths = nPixels * ks;
@@ -493,8 +632,29 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             int gridTrace = std::min((int)((nPaths + kTraceChunk - 1) / kTraceChunk), cus * 32);
             int gridShadow = std::min(gridAll, cus * 4); // MIS rays: few per bounce
             int gridShade = std::min(gridAll, cus * 8);
-            k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p);
-            for (int b = 0; b <= h->integ.maxDepth; ++b) {
+            k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
+                                                          direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
+            // DirectLightingIntegrator: one step per level of the recursion still alive; the host reads the number of
+            // continuing paths after each step (a camera sample is a chain of <= maxDepth steps, or a tree with glass)
+            for (int step = 0; direct; ++step) {
+                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
+                while (h->evPool.size() < need) {
+                    hipEvent_t e;
+                    HIPCHK(h, hipEventCreate(&e));
+                    h->evPool.push_back(e);
+                }
+                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
+                if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                else launchDirectStep<12, 52, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                h->stats.intersect_launches++;
+                uint32_t alive = 0;
+                HIPCHK(h, hipMemcpyAsync(&alive, &h->counters.p->extCount[(step & 1) ^ 1].v, sizeof(alive), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (alive == 0) break;
+                if (step > (1 << 20)) return h->fail(ENIGMA_E_DEVICE, "DirectLightingIntegrator walk did not terminate");
+            }
+            for (int b = 0; !direct && b <= h->integ.maxDepth; ++b) {
                 size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
                 while (h->evPool.size() < need) {
                     hipEvent_t e;

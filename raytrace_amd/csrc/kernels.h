@@ -42,6 +42,16 @@ DEV float sampleDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uin
     return s;
 }
 
+// Sample of an arbitrary sample number of the pixel (the entries of GlobalSampler's sample arrays,
+// Enigma/Sampler.cpp:170-180, are samples of OTHER sample numbers of the same pixel): the per-sample
+// constant is GF(2)-linear in the bits of the sample number, so it is XORed together from per-bit constants.
+DEV float sampleDimensionOf(const DevSampler& S, uint32_t relx, uint32_t rely, unsigned long long sampleNum, uint32_t dim) {
+    uint32_t v = S.tx[(size_t)dim * S.res + relx] ^ S.ty[(size_t)dim * S.res + rely];
+    for (int b = 0; sampleNum != 0 && b < kSampleBits; ++b, sampleNum >>= 1)
+        if (sampleNum & 1ull) v ^= S.bitConst[(size_t)dim * kSampleBits + b];
+    return smin((float)v * 0x1p-32f, kOneMinusEpsilon); // dims >= 2 only
+}
+
 // ---------------------------------------------------------------- camera
 DEV F3 xfPoint(const float* m, F3 p) { // Transform::transformPoint, Enigma/Transform.h:36-45
     float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
@@ -162,7 +172,7 @@ DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b
 
 // ---------------------------------------------------------------- kernels
 __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, DevCamera C, DevIntegrator I, uint32_t nPaths, uint32_t nPixels,
-                                                     uint32_t slotBase, DevCounters* ctr) {
+                                                     uint32_t slotBase, DevCounters* ctr, uint32_t firstDim, DevDirect D) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nPaths) return;
     uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
@@ -180,13 +190,14 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
     P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.beta[i] = make_float4(1.f, 1.f, 1.f, 1.f);
     P.pixel[i] = relx | (rely << 16);
-    P.state[i] = packState(slot, 5u, 0u, 0u);
+    P.state[i] = packState(slot, firstDim, 0u, 0u); // 5 after GetCameraSample; DirectLightingIntegrator skips its sample arrays
     P.pfilm[i] = make_float2(fx, fy);
+    if (D.arrayOff) { D.arrayOff[i] = 0; D.pendCount[i] = 0; }
     if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
 }
 
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
-struct MatQueues { uint32_t* q[MK_COUNT]; };
+struct MatQueues { uint32_t* q[kQueueKinds]; };
 
 // A block owns chunks of kTraceChunk consecutive queue positions (chunk c -> block c mod gridDim) and
 // treats a chunk as a pool of rays: a wave whose lanes have finished their rays (kRefillIdle of them,
@@ -210,12 +221,16 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
     return base + __popcll(idleMask & ((1ull << lane) - 1ull));
 }
 
-template <int LDSN, int OVF, bool LDS_SCENE>
+// DL: the head of DirectLightingIntegrator::Li instead (Enigma/DirectLightingIntegrator.cpp:41-55): emitted
+// radiance is added at every hit, every hit is shaded, and a path that misses resumes a pending branch.
+template <int LDSN, int OVF, bool LDS_SCENE, bool DL>
 __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
-                                                              const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle) {
+                                                              const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
+                                                              const uint32_t* pendCount) {
+    constexpr int NK = DL ? kQueueKinds : MK_COUNT;
     __shared__ uint32_t stack[2 * LDSN * kBlock];
-    __shared__ uint32_t binCnt[MK_COUNT * kWavesPerBlock];
-    __shared__ uint32_t binBase[MK_COUNT];
+    __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];
+    __shared__ uint32_t binBase[kQueueKinds];
     __shared__ uint32_t poolNext;
     __shared__ uint8_t kindOf[kTraceChunk]; // material kind + 1 of the path at a pool position, 0 = path ended
     extern __shared__ float4 sceneLds[];
@@ -250,7 +265,7 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
                         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                         int lightIdx = __float_as_int(v2.w);
                         uint32_t mw = __float_as_uint(v1.w);
-                        if ((bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
+                        if ((DL || bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
                             const DevLight& lt = sc.lights[lightIdx];
                             F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
                             if (lt.twoSided || dot(n, -w.r.d) > 0) {
@@ -259,12 +274,12 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
                                 P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
                             }
                         }
-                        if ((int)bounces < I.maxDepth) {
+                        if (DL || (int)bounces < I.maxDepth) {
                             kind = triKind(mw) + 1u;
                             P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
                             P.hitTri[p] = h.tri;
                         }
-                    }
+                    } else if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
                     kindOf[pos] = (uint8_t)kind;
                     pos = kNoRay;
                 }
@@ -291,21 +306,21 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
             kinds |= (j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
         }
 #pragma unroll
-        for (int k = 0; k < MK_COUNT; ++k) {
+        for (int k = 0; k < NK; ++k) {
             uint32_t c = 0;
 #pragma unroll
             for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot(((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
             if (lane == 0) binCnt[k * kWavesPerBlock + wid] = c;
         }
         __syncthreads();
-        if (threadIdx.x < MK_COUNT) {
+        if (threadIdx.x < NK) {
             uint32_t total = 0;
             for (int w2 = 0; w2 < kWavesPerBlock; ++w2) total += binCnt[threadIdx.x * kWavesPerBlock + w2];
             binBase[threadIdx.x] = total ? atomicAdd(&ctr->matCount[threadIdx.x].v, total) : 0u;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < MK_COUNT; ++k) {
+        for (int k = 0; k < NK; ++k) {
             uint32_t off = binBase[k];
             for (uint32_t w2 = 0; w2 < wid; ++w2) off += binCnt[k * kWavesPerBlock + w2];
 #pragma unroll
@@ -339,9 +354,133 @@ DEV int sampleDiscrete(const float* lightCdf, const float* lightFunc, float ligh
 
 DEV float powerHeuristic(float fPdf, float gPdf) { float f = 1 * fPdf, g = 1 * gPdf; return (f * f) / (f * f + g * g); }
 
+// EstimateDirect for a surface interaction (Enigma/Integrator.cpp:94-204, handleMedia = specular = false),
+// up to the two rays it traces: the shadow ray of the light sample (Ld = its contribution if unoccluded)
+// and the BSDF-sampled ray (miF = f * weight / scatteringPdf, multiplies the light's Le if the closest hit
+// is the light's own triangle).  The caller scales both by throughput / light-choice pdf and queues them.
+struct DirectSample {
+    bool shadow, mis;
+    F3 shO, shD, Ld;
+    F3 miO, miD, miF;
+};
+template <int MK>
+DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
+                                float ulx, float uly, float usx, float usy) {
+    const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
+    DirectSample r;
+    r.shadow = false; r.mis = false;
+    // ---- light sampling (Enigma/Integrator.cpp:104-148) ----
+    F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
+    float lightPdf = 0.f;
+    F3 q0(0.f), q1(0.f), q2(0.f);
+    bool lflip = false;
+    if (lt.type == 1) {
+        const float4* tp = tris + (size_t)lt.tri * 3;
+        float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+        q0 = xyz(a0); q1 = xyz(a1); q2 = xyz(a2);
+        lflip = triFlip(__float_as_uint(a1.w));
+        // Triangle::sample (Enigma/TriangleMesh.cpp:604-632)
+        float su1 = sqrtf(ulx);
+        float tb0 = 1.f - su1, tb1 = uly * su1;
+        lp = tb0 * q0 + tb1 * q1 + (1 - tb0 - tb1) * q2;
+        ln = normalize(cross(q1 - q0, q2 - q0));
+        if (lflip) ln = ln * -1.f;
+        lpErr = gammaf(6) * (fabs3(tb0 * q0) + fabs3(tb1 * q1) + fabs3((1 - tb0 - tb1) * q2));
+        lightPdf = 1 / lt.area;
+        // Shape::sample(ref, u) (Enigma/Shape.cpp:54-69)
+        F3 w = lp - g.p;
+        if (lengthSqr(w) == 0) lightPdf = 0;
+        else {
+            w = normalize(w);
+            lightPdf *= lengthSqr(g.p - lp) / absdot(ln, -w);
+            if (isinf(lightPdf)) lightPdf = 0.f;
+        }
+        // DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
+        if (lightPdf == 0 || lengthSqr(lp - g.p) == 0) lightPdf = 0;
+        else {
+            wi = normalize(lp - g.p);
+            if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+        }
+    } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124)
+        lp = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
+        wi = normalize(lp - g.p);
+        lightPdf = 1.f;
+        Li = F3(lt.L[0], lt.L[1], lt.L[2]) / lengthSqr(lp - g.p);
+    }
+    if (lightPdf > 0 && !isBlack(Li)) {
+        F3 f = bsdfF<MK>(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
+        float scatteringPdf = bsdfPdf<MK>(bsdf, woN, wi, kNonSpecular);
+        if (!isBlack(f)) {
+            // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
+            F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
+            F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
+            if (lt.type == 0) r.Ld = f * Li / lightPdf;
+            else r.Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
+            r.shO = origin; r.shD = target - origin;
+            r.shadow = true;
+        }
+    }
+    // ---- BSDF sampling (Enigma/Integrator.cpp:150-199) ----
+    if (lt.type == 1) {
+        F3 wi2(0.f);
+        float scatPdf2; int sampledType;
+        F3 f2 = bsdfSample<MK>(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
+        f2 = f2 * absdot(wi2, ns);
+        if (!isBlack(f2) && scatPdf2 > 0) {
+            // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
+            F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
+            RaySetup rs = setupRay(o2, wi2);
+            float lt_t, lb0, lb1, lb2;
+            float lightPdf2 = 0.f;
+            if (triangleTest(rs, EDEV_INF, q0, q1, q2, &lt_t, &lb0, &lb1, &lb2)) {
+                F3 pl = lb0 * q0 + lb1 * q1 + lb2 * q2;
+                F3 nl = normalize(cross(q0 - q2, q1 - q2));
+                lightPdf2 = lengthSqr(g.p - pl) / (absdot(nl, -wi2) * lt.area);
+                if (isinf(lightPdf2)) lightPdf2 = 0.f;
+            }
+            if (lightPdf2 != 0) {
+                float weight = powerHeuristic(scatPdf2, lightPdf2);
+                r.miO = o2; r.miD = wi2;
+                r.miF = f2 * weight / scatPdf2;
+                r.mis = true;
+            }
+        }
+    }
+    return r;
+}
+
 // For scenes small enough (LDS_SCENE) the block first copies triangles, materials, lights and the light
 // distribution into LDS: the chain hit triangle -> material -> light -> light triangle is then four LDS
 // reads instead of four dependent trips to L2/HBM per path.
+// (a macro, not a function: the pointers must be visibly derived from the __shared__ array for the
+// compiler to address them as LDS)
+#define ENIGMA_STAGE_SHADE_TABLES                                                                                        \
+    const float4* tris = sc.tris;                                                                                        \
+    const DevMaterial* materials = sc.materials;                                                                         \
+    const DevLight* lights = sc.lights;                                                                                  \
+    const float* lightCdf = sc.lightCdf;                                                                                 \
+    const float* lightFunc = sc.lightFunc;                                                                               \
+    if (LDS_SCENE) {                                                                                                     \
+        const uint32_t nT = sc.nTris * 3u, nM = sc.nMaterials * 4u, nL = (uint32_t)sc.nLights * 3u;                      \
+        float4* ldsMat = sceneLds + nT;                                                                                  \
+        float4* ldsLight = ldsMat + nM;                                                                                  \
+        float* ldsCdf = reinterpret_cast<float*>(ldsLight + nL);                                                         \
+        float* ldsFunc = ldsCdf + sc.nLights + 1;                                                                        \
+        const float4* gMat = reinterpret_cast<const float4*>(sc.materials);                                              \
+        const float4* gLight = reinterpret_cast<const float4*>(sc.lights);                                               \
+        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) sceneLds[i] = sc.tris[i];                                    \
+        for (uint32_t i = threadIdx.x; i < nM; i += kBlock) ldsMat[i] = gMat[i];                                         \
+        for (uint32_t i = threadIdx.x; i < nL; i += kBlock) ldsLight[i] = gLight[i];                                     \
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights + 1u; i += kBlock) ldsCdf[i] = sc.lightCdf[i];           \
+        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights; i += kBlock) ldsFunc[i] = sc.lightFunc[i];              \
+        __syncthreads();                                                                                                 \
+        tris = sceneLds;                                                                                                 \
+        materials = reinterpret_cast<const DevMaterial*>(ldsMat);                                                        \
+        lights = reinterpret_cast<const DevLight*>(ldsLight);                                                            \
+        lightCdf = ldsCdf;                                                                                               \
+        lightFunc = ldsFunc;                                                                                             \
+    }
+
 template <int MK, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
@@ -349,31 +488,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
     extern __shared__ float4 sceneLds[];
     const uint32_t count = ctr->matCount[MK].v;
     if (blockIdx.x * kBlock >= count) return;
-    const float4* tris = sc.tris;
-    const DevMaterial* materials = sc.materials;
-    const DevLight* lights = sc.lights;
-    const float* lightCdf = sc.lightCdf;
-    const float* lightFunc = sc.lightFunc;
-    if (LDS_SCENE) {
-        const uint32_t nT = sc.nTris * 3u, nM = sc.nMaterials * 4u, nL = (uint32_t)sc.nLights * 3u;
-        float4* ldsMat = sceneLds + nT;
-        float4* ldsLight = ldsMat + nM;
-        float* ldsCdf = reinterpret_cast<float*>(ldsLight + nL);
-        float* ldsFunc = ldsCdf + sc.nLights + 1;
-        const float4* gMat = reinterpret_cast<const float4*>(sc.materials);
-        const float4* gLight = reinterpret_cast<const float4*>(sc.lights);
-        for (uint32_t i = threadIdx.x; i < nT; i += kBlock) sceneLds[i] = sc.tris[i];
-        for (uint32_t i = threadIdx.x; i < nM; i += kBlock) ldsMat[i] = gMat[i];
-        for (uint32_t i = threadIdx.x; i < nL; i += kBlock) ldsLight[i] = gLight[i];
-        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights + 1u; i += kBlock) ldsCdf[i] = sc.lightCdf[i];
-        for (uint32_t i = threadIdx.x; i < (uint32_t)sc.nLights; i += kBlock) ldsFunc[i] = sc.lightFunc[i];
-        __syncthreads();
-        tris = sceneLds;
-        materials = reinterpret_cast<const DevMaterial*>(ldsMat);
-        lights = reinterpret_cast<const DevLight*>(ldsLight);
-        lightCdf = ldsCdf;
-        lightFunc = ldsFunc;
-    }
+    ENIGMA_STAGE_SHADE_TABLES
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     uint32_t parity = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock, parity ^= 16u) {
@@ -408,87 +523,18 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
-                    const DevLight& lt = lights[lightNum];
-                    // ---- EstimateDirect: light sampling (Enigma/Integrator.cpp:104-148) ----
-                    F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
-                    float lightPdf = 0.f;
-                    F3 q0(0.f), q1(0.f), q2(0.f);
-                    bool lflip = false;
-                    if (lt.type == 1) {
-                        const float4* tp = tris + (size_t)lt.tri * 3;
-                        float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                        q0 = xyz(a0); q1 = xyz(a1); q2 = xyz(a2);
-                        lflip = triFlip(__float_as_uint(a1.w));
-                        // Triangle::sample (Enigma/TriangleMesh.cpp:604-632)
-                        float su1 = sqrtf(ulx);
-                        float tb0 = 1.f - su1, tb1 = uly * su1;
-                        lp = tb0 * q0 + tb1 * q1 + (1 - tb0 - tb1) * q2;
-                        ln = normalize(cross(q1 - q0, q2 - q0));
-                        if (lflip) ln = ln * -1.f;
-                        lpErr = gammaf(6) * (fabs3(tb0 * q0) + fabs3(tb1 * q1) + fabs3((1 - tb0 - tb1) * q2));
-                        lightPdf = 1 / lt.area;
-                        // Shape::sample(ref, u) (Enigma/Shape.cpp:54-69)
-                        F3 w = lp - g.p;
-                        if (lengthSqr(w) == 0) lightPdf = 0;
-                        else {
-                            w = normalize(w);
-                            lightPdf *= lengthSqr(g.p - lp) / absdot(ln, -w);
-                            if (isinf(lightPdf)) lightPdf = 0.f;
-                        }
-                        // DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
-                        if (lightPdf == 0 || lengthSqr(lp - g.p) == 0) lightPdf = 0;
-                        else {
-                            wi = normalize(lp - g.p);
-                            if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
-                        }
-                    } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124)
-                        lp = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
-                        wi = normalize(lp - g.p);
-                        lightPdf = 1.f;
-                        Li = F3(lt.L[0], lt.L[1], lt.L[2]) / lengthSqr(lp - g.p);
+                    DirectSample ds = estimateDirect<MK>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    if (ds.shadow) {
+                        shq.o[p] = mk4(ds.shO, 0.f);
+                        shq.d[p] = mk4(ds.shD, 1 - kShadowEpsilon);
+                        shq.w[p] = mk4(beta * (ds.Ld / pick), 0.f);
+                        pushShadow = true;
                     }
-                    if (lightPdf > 0 && !isBlack(Li)) {
-                        F3 f = bsdfF<MK>(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
-                        float scatteringPdf = bsdfPdf<MK>(bsdf, woN, wi, kNonSpecular);
-                        if (!isBlack(f)) {
-                            // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
-                            F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
-                            F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
-                            F3 Ld;
-                            if (lt.type == 0) Ld = f * Li / lightPdf;
-                            else Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
-                            shq.o[p] = mk4(origin, 0.f);
-                            shq.d[p] = mk4(target - origin, 1 - kShadowEpsilon);
-                            shq.w[p] = mk4(beta * (Ld / pick), 0.f);
-                            pushShadow = true;
-                        }
-                    }
-                    // ---- EstimateDirect: BSDF sampling (Enigma/Integrator.cpp:150-199) ----
-                    if (lt.type == 1) {
-                        F3 wi2(0.f);
-                        float scatPdf2; int sampledType;
-                        F3 f2 = bsdfSample<MK>(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
-                        f2 = f2 * absdot(wi2, ns);
-                        if (!isBlack(f2) && scatPdf2 > 0) {
-                            // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
-                            F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
-                            RaySetup rs = setupRay(o2, wi2);
-                            float lt_t, lb0, lb1, lb2;
-                            float lightPdf2 = 0.f;
-                            if (triangleTest(rs, EDEV_INF, q0, q1, q2, &lt_t, &lb0, &lb1, &lb2)) {
-                                F3 pl = lb0 * q0 + lb1 * q1 + lb2 * q2;
-                                F3 nl = normalize(cross(q0 - q2, q1 - q2));
-                                lightPdf2 = lengthSqr(g.p - pl) / (absdot(nl, -wi2) * lt.area);
-                                if (isinf(lightPdf2)) lightPdf2 = 0.f;
-                            }
-                            if (lightPdf2 != 0) {
-                                float weight = powerHeuristic(scatPdf2, lightPdf2);
-                                misq.o[p] = mk4(o2, 0.f);
-                                misq.d[p] = mk4(wi2, __int_as_float(lightNum));
-                                misq.w[p] = mk4(beta * ((f2 * weight / scatPdf2) / pick), 0.f);
-                                pushMis = true;
-                            }
-                        }
+                    if (ds.mis) {
+                        misq.o[p] = mk4(ds.miO, 0.f);
+                        misq.d[p] = mk4(ds.miD, __int_as_float(lightNum));
+                        misq.w[p] = mk4(beta * (ds.miF / pick), 0.f);
+                        pushMis = true;
                     }
                 }
             }
@@ -533,6 +579,203 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
     }
 }
 
+// ---------------------------------------------------------------- DirectLightingIntegrator
+// Block-wide append of a COUNT of entries per thread to three queues (shadow rays, MIS rays, continuing
+// paths) behind one pair of barriers: wave-inclusive scans by shuffle, wave totals through LDS, one
+// atomic per block and queue.  lds: 16 words.
+DEV void blockReserveCounts(uint32_t na, uint32_t nb, uint32_t nc, uint32_t* ca, uint32_t* cb, uint32_t* cc, uint32_t* lds,
+                            uint32_t* sa, uint32_t* sb, uint32_t* sc) {
+    uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t ia = na, ib = nb, ic = nc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t ta = __shfl_up(ia, d), tb = __shfl_up(ib, d), tc = __shfl_up(ic, d);
+        if ((int)lane >= d) { ia += ta; ib += tb; ic += tc; }
+    }
+    if (lane == 63u) { lds[wid] = ia; lds[4 + wid] = ib; lds[8 + wid] = ic; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t total = 0;
+        for (int w = 0; w < kWavesPerBlock; ++w) total += lds[threadIdx.x * 4 + w];
+        uint32_t* ctr = threadIdx.x == 0 ? ca : (threadIdx.x == 1 ? cb : cc);
+        lds[12 + threadIdx.x] = total ? atomicAdd(ctr, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t oa = lds[12], ob = lds[13], oc = lds[14];
+    for (uint32_t w = 0; w < wid; ++w) { oa += lds[w]; ob += lds[4 + w]; oc += lds[8 + w]; }
+    *sa = oa + ia - na; *sb = ob + ib - nb; *sc = oc + ic - nc;
+}
+
+// Resume the innermost pending branch of a path whose current branch has ended: every pending entry
+// stands for a SpecularTransmit call the recursion has yet to make (one Get2D each); placeholders of
+// nodes without a transmission lobe only consume their two dimensions.  Returns false when the stack
+// runs empty (the camera sample is complete).
+DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrator& I, uint32_t p, uint32_t slot, uint32_t dim) {
+    uint32_t cnt = D.pendCount[p];
+    bool found = false;
+    while (cnt > 0 && !found) {
+        --cnt;
+        dim += 2;
+        size_t e = (size_t)p * I.pendingLevels + cnt;
+        float4 o = D.pendO[e];
+        if (o.w != 0.f) {
+            float4 d = D.pendD[e], b = D.pendB[e];
+            P.rayO[p] = make_float4(o.x, o.y, o.z, 0.f);
+            P.rayD[p] = make_float4(d.x, d.y, d.z, 0.f);
+            P.beta[p] = make_float4(b.x, b.y, b.z, 1.f);
+            P.state[p] = packState(slot, dim, (uint32_t)d.w, 0u);
+            found = true;
+        }
+    }
+    D.pendCount[p] = cnt;
+    return found;
+}
+
+// The body of DirectLightingIntegrator::Li at a hit (Enigma/DirectLightingIntegrator.cpp:49-68) for the paths
+// of one material kind: direct lighting from all lights (sample arrays) or one uniformly chosen light,
+// then SpecularReflect / SpecularTransmit.  Smooth glass carries two specular lobes here (allowMultipleLobes
+// is false on this path).  A path's shadow / MIS rays go to its raysPerPath ray slots, packed from slot 0.
+template <int MK, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevDirect D, DevRayQueue shq,
+                                                         DevRayQueue misq, const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx,
+                                                         DevCounters* ctr) {
+    constexpr int MKD = (MK == MK_GLASS_SMOOTH) ? (int)MK_DL_GLASS : MK;
+    __shared__ uint32_t lds[32];
+    extern __shared__ float4 sceneLds[];
+    const uint32_t count = ctr->matCount[MK].v;
+    if (blockIdx.x * kBlock >= count) return;
+    ENIGMA_STAGE_SHADE_TABLES
+    (void)lightCdf; (void)lightFunc;
+    uint32_t parity = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock, parity ^= 16u) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        uint32_t nShadow = 0, nMis = 0, nNext = 0;
+        uint32_t p = 0;
+        if (active) {
+            p = matQueue[i];
+            F3 d = xyz(P.rayD[p]);
+            float4 hv = P.hit[p];
+            int tri = P.hitTri[p];
+            uint32_t st = P.state[p];
+            uint32_t slot = stSlot(st), dim = stDim(st), depth = stBounces(st);
+            uint32_t pix = P.pixel[p];
+            uint32_t px = pix & 0xffffu, py = pix >> 16;
+            F3 beta = xyz(P.beta[p]);
+            HitGeom g = hitGeometry(tris, tri, hv.y, hv.z, hv.w);
+            Bsdf bsdf;
+            makeBsdf<MKD>(materials[g.matIdx], g.n, g.dpdu, &bsdf);
+            F3 ns = g.n;
+            F3 woN = normalize(-d); // isect.m_wo
+            const size_t raySlot0 = (size_t)p * I.raysPerPath;
+            auto emit = [&](const DirectSample& ds, float div, int lightNum) { // div: sample count (all) or light-choice pdf (one)
+                if (ds.shadow) {
+                    size_t q = raySlot0 + nShadow++;
+                    shq.o[q] = mk4(ds.shO, 0.f);
+                    shq.d[q] = mk4(ds.shD, 1 - kShadowEpsilon);
+                    shq.w[q] = mk4(beta * (ds.Ld / div), 0.f);
+                }
+                if (ds.mis) {
+                    size_t q = raySlot0 + nMis++;
+                    misq.o[q] = mk4(ds.miO, 0.f);
+                    misq.d[q] = mk4(ds.miD, __int_as_float(lightNum));
+                    misq.w[q] = mk4(beta * (ds.miF / div), 0.f);
+                }
+            };
+            if (sc.nLights > 0) {
+                if (I.dlStrategy == 0) { // UniformSampleAllLights, Enigma/Integrator.cpp:42-69
+                    uint32_t a = D.arrayOff[p];
+                    const unsigned long long sampleNum = S.sampleBase + slot;
+                    for (int l = 0; l < sc.nLights; ++l) {
+                        const DevLight& lt = lights[l];
+                        const uint32_t n = lt.nSamples;
+                        const uint32_t dimL = 5u + 2u * (a + 2u * (uint32_t)l), dimS = dimL + 2u; // uLightArray, uScatteringArray
+                        for (uint32_t k = 0; k < n; ++k) {
+                            unsigned long long sn = sampleNum * n + k; // entry of the array that belongs to this sample
+                            float ulx = sampleDimensionOf(S, px, py, sn, dimL), uly = sampleDimensionOf(S, px, py, sn, dimL + 1);
+                            float usx = sampleDimensionOf(S, px, py, sn, dimS), usy = sampleDimensionOf(S, px, py, sn, dimS + 1);
+                            DirectSample ds = estimateDirect<MKD>(bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
+                            emit(ds, (float)n, l);
+                        }
+                    }
+                    D.arrayOff[p] = a + 2u * (uint32_t)sc.nLights;
+                } else { // UniformSampleOneLight without a distribution, Enigma/Integrator.cpp:83-91
+                    int nl = sc.nLights;
+                    int lightNum = min((int)(sampleDimension(S, px, py, slot, dim) * nl), nl - 1);
+                    float lightPdf = 1.0f / nl;
+                    float ulx = sampleDimension(S, px, py, slot, dim + 1), uly = sampleDimension(S, px, py, slot, dim + 2);
+                    float usx = sampleDimension(S, px, py, slot, dim + 3), usy = sampleDimension(S, px, py, slot, dim + 4);
+                    dim += 5;
+                    DirectSample ds = estimateDirect<MKD>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    emit(ds, lightPdf, lightNum);
+                }
+            }
+            // ---- SpecularReflect, SpecularTransmit (Enigma/Integrator.cpp:329-444) ----
+            bool haveNext = false;
+            if ((int)depth + 1 < I.maxDepth) {
+                F3 wiR(0.f), wiT(0.f);
+                float pdfR, pdfT; int tyR, tyT;
+                dim += 2; // SpecularReflect's Get2D (a specular lobe ignores the values)
+                F3 fR = bsdfSample<MKD>(bsdf, woN, &wiR, 0.5f, 0.5f, &pdfR, BSDF_REFLECTION | BSDF_SPECULAR, &tyR);
+                bool validR = pdfR > 0.f && !isBlack(fR) && absdot(wiR, ns) != 0.f;
+                F3 fT = bsdfSample<MKD>(bsdf, woN, &wiT, 0.5f, 0.5f, &pdfT, BSDF_TRANSMISSION | BSDF_SPECULAR, &tyT);
+                bool validT = pdfT > 0.f && !isBlack(fT) && absdot(wiT, ns) != 0.f;
+                F3 betaT = validT ? beta * (fT * absdot(wiT, ns) / pdfT) : F3(0.f);
+                F3 oT = validT ? offsetRayOrigin(g.p, g.pError, g.n, wiT) : F3(0.f);
+                if (validR) {
+                    // the transmission branch (or its placeholder) waits until the reflection subtree is through
+                    uint32_t cnt = D.pendCount[p];
+                    size_t e = (size_t)p * I.pendingLevels + cnt;
+                    D.pendO[e] = mk4(oT, validT ? 1.f : 0.f);
+                    D.pendD[e] = mk4(wiT, (float)(depth + 1));
+                    D.pendB[e] = mk4(betaT, 0.f);
+                    D.pendCount[p] = cnt + 1;
+                    P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, wiR), 0.f);
+                    P.rayD[p] = mk4(wiR, 0.f);
+                    P.beta[p] = mk4(beta * (fR * absdot(wiR, ns) / pdfR), 1.f);
+                    P.state[p] = packState(slot, dim, depth + 1, 0u);
+                    haveNext = true;
+                } else {
+                    dim += 2; // SpecularTransmit's Get2D
+                    if (validT) {
+                        P.rayO[p] = mk4(oT, 0.f);
+                        P.rayD[p] = mk4(wiT, 0.f);
+                        P.beta[p] = mk4(betaT, 1.f);
+                        P.state[p] = packState(slot, dim, depth + 1, 0u);
+                        haveNext = true;
+                    }
+                }
+            }
+            if (!haveNext) haveNext = resumePending(P, D, I, p, slot, dim);
+            nNext = haveNext ? 1u : 0u;
+        }
+        uint32_t sSh, sMi, sNx;
+        blockReserveCounts(nShadow, nMis, nNext, &ctr->shadowCount.v, &ctr->misCount.v, &ctr->extCount[nextIdx].v, lds + parity, &sSh, &sMi, &sNx);
+        for (uint32_t j = 0; j < nShadow; ++j) shq.idx[sSh + j] = p * (uint32_t)I.raysPerPath + j;
+        for (uint32_t j = 0; j < nMis; ++j) misq.idx[sMi + j] = p * (uint32_t)I.raysPerPath + j;
+        if (nNext) nextQueue[sNx] = p;
+    }
+}
+
+// Paths whose ray left the scene while branches are pending (queue MK_COUNT of k_intersect_closest<DL>).
+__global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegrator I, DevDirect D, const uint32_t* queue, uint32_t* nextQueue,
+                                                           uint32_t nextIdx, DevCounters* ctr) {
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    const uint32_t count = ctr->matCount[MK_COUNT].v;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool found = false;
+        uint32_t p = 0;
+        if (i < count) {
+            p = queue[i];
+            uint32_t st = P.state[p];
+            found = resumePending(P, D, I, p, stSlot(st), stDim(st));
+        }
+        uint32_t s = blockReserve(found, &ctr->extCount[nextIdx].v, lds);
+        if (found) nextQueue[s] = p;
+    }
+}
+
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
 template <int LDSN, int OVF, bool LDS_SCENE>
@@ -561,7 +804,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && p != kNoRay) {
                     if (!w.occluded) {
-                        float* L = reinterpret_cast<float*>(P.L + p);
+                        float* L = reinterpret_cast<float*>(P.L + p / shq.perPath);
                         atomicAdd(L + 0, contrib.x); atomicAdd(L + 1, contrib.y); atomicAdd(L + 2, contrib.z);
                     }
                     p = kNoRay;
@@ -611,7 +854,7 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
         if (lt.twoSided || dot(n, -xyz(d)) > 0) { // lightIsect.Le(-wi)
             float4 c = misq.w[p];
             F3 add = xyz(c) * F3(lt.L[0], lt.L[1], lt.L[2]);
-            float* L = reinterpret_cast<float*>(P.L + p);
+            float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
             atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
         }
     }
@@ -681,7 +924,7 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (phase == 0) {
         ctr->raysClosest += useImm ? countImm : ctr->extCount[curIdx].v;
-        for (int k = 0; k < MK_COUNT; ++k) ctr->matCount[k].v = 0;
+        for (int k = 0; k < kQueueKinds; ++k) ctr->matCount[k].v = 0;
         ctr->extCount[curIdx ^ 1u].v = 0;
         ctr->shadowCount.v = 0; ctr->misCount.v = 0;
     } else if (phase == 1) {

@@ -120,6 +120,18 @@ def integrator_desc(film, spp, max_depth=5, rr_threshold=1.0, light_strategy=abi
     return d
 
 
+def direct_lighting_desc(film, spp, max_depth=5, strategy=abi.DL_SAMPLE_ALL, pixel_bounds=None):
+    """CreateDirectLightingIntegrator (Enigma/DirectLightingIntegrator.cpp:89-114)."""
+    d = abi.EnigmaDirectLightingDesc()
+    sb = sample_bounds(film)
+    d.max_depth = max_depth
+    d.strategy = strategy
+    d.pixel_bounds[:] = sb if pixel_bounds is None else pixel_bounds
+    d.samples_per_pixel = spp
+    d.sample_bounds[:] = sb
+    return d
+
+
 # ----------------------------------------------------------------------------- mesh helpers
 class MeshBuilder:
     def __init__(self):

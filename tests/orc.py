@@ -53,13 +53,24 @@ class Oracle:
         self._chk(self.L.oracle_scene_upload(self.h, C.byref(d), 1 if split_method == "hlbvh" else 0, max_node_prims))
         self._chk(self.L.oracle_camera_set(self.h, C.byref(camera)))
         self._chk(self.L.oracle_film_config(self.h, C.byref(film)))
-        self._chk(self.L.oracle_integrator_config(self.h, C.byref(integ)))
+        self.set_integrator(integ)
         b = film.cropped_pixel_bounds
         self.w, self.hgt = b[2] - b[0], b[3] - b[1]
 
     def _chk(self, rc):
         if rc != 0:
             raise RuntimeError(self.L.oracle_last_error(self.h).decode())
+
+    def set_integrator(self, integ):
+        if isinstance(integ, abi.EnigmaDirectLightingDesc):
+            self._chk(self.L.oracle_direct_lighting_config(self.h, C.byref(integ)))
+        else:
+            self._chk(self.L.oracle_integrator_config(self.h, C.byref(integ)))
+        self.integ = integ
+
+    def read_past_arrays(self):
+        """True if a render since the last call read past the integrator's sample arrays (undefined in the reference)."""
+        return bool(self.L.oracle_read_past_arrays(self.h))
 
     def close(self):
         if self.h:
