@@ -283,13 +283,13 @@ private:
     const BBox2i m_pixelBounds;
 };
 
-// PathIntegrator whose Render runs on the MI355X (constructor arguments: Enigma/PathIntegrator.cpp:30-39).
-class GpuPathIntegrator : public SamplerIntegrator {
+// SamplerIntegrator whose Render runs on the MI355X: flattens the scene, hands camera, film and sampler state
+// to the library, renders, and deposits the device film through the reference's own MergeFilmTile / WriteImage.
+// Subclasses configure the integrator proper.
+class GpuSamplerIntegrator : public SamplerIntegrator {
 public:
-    GpuPathIntegrator(int maxDepth, std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds,
-                      float rrThreshold = 1, const std::string& lightSampleStrategy = "spatial", int device = 0)
-        : SamplerIntegrator(camera, sampler, pixelBounds), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
-          m_lightSampleStrategy(lightSampleStrategy), m_device(device) {}
+    GpuSamplerIntegrator(std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds, int device)
+        : SamplerIntegrator(camera, sampler, pixelBounds), m_device(device) {}
 
     // Errors: the reference prints and continues (Enigma/Error.h:5-10); a failing GPU call cannot
     // "continue", so it throws std::runtime_error carrying enigma_last_error().
@@ -335,7 +335,7 @@ public:
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());
-        if (!cam) throw std::runtime_error("GpuPathIntegrator needs a PerspectiveCamera");
+        if (!cam) throw std::runtime_error("the GPU integrators need a PerspectiveCamera");
         EnigmaCameraDesc cd{};
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { cd.raster_to_camera[4 * r + c] = cam->m_rasterToCamera.m_mat[r][c]; cd.camera_to_world[4 * r + c] = cam->m_cameraToWorld.m_mat[r][c]; }
         cd.lens_radius = cam->m_lensRadius; cd.focal_distance = cam->m_focalDistance;
@@ -352,19 +352,8 @@ public:
         check(enigma_film_config(h, &fd));
 
         const SobolSampler* sob = dynamic_cast<const SobolSampler*>(GetSampler().get());
-        if (!sob) throw std::runtime_error("GpuPathIntegrator needs a SobolSampler");
-        EnigmaIntegratorDesc id{};
-        id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
-        if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
-        else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
-        else if (lights.size() == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
-        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
-        const BBox2i& pb = GetPixelBounds();
-        id.pixel_bounds[0] = pb.m_min.x; id.pixel_bounds[1] = pb.m_min.y; id.pixel_bounds[2] = pb.m_max.x; id.pixel_bounds[3] = pb.m_max.y;
-        id.samples_per_pixel = sob->m_samplesPerPixel;
-        id.sample_bounds[0] = sob->m_sampleBounds.m_min.x; id.sample_bounds[1] = sob->m_sampleBounds.m_min.y;
-        id.sample_bounds[2] = sob->m_sampleBounds.m_max.x; id.sample_bounds[3] = sob->m_sampleBounds.m_max.y;
-        check(enigma_integrator_config(h, &id));
+        if (!sob) throw std::runtime_error("the GPU integrators need a SobolSampler");
+        check(ConfigureIntegrator(h, lights.size(), *sob));
 
         check(enigma_render(h, 0, sob->m_samplesPerPixel));
 
@@ -384,12 +373,62 @@ public:
         check(enigma_get_stats(h, &m_stats));
     }
     const EnigmaStats& GetStats() const { return m_stats; }
+protected:
+    virtual int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) = 0;
+    template <class DESC> void FillSamplerFields(DESC& id, const SobolSampler& sob) const {
+        const BBox2i& pb = GetPixelBounds();
+        id.pixel_bounds[0] = pb.m_min.x; id.pixel_bounds[1] = pb.m_min.y; id.pixel_bounds[2] = pb.m_max.x; id.pixel_bounds[3] = pb.m_max.y;
+        id.samples_per_pixel = sob.m_samplesPerPixel;
+        id.sample_bounds[0] = sob.m_sampleBounds.m_min.x; id.sample_bounds[1] = sob.m_sampleBounds.m_min.y;
+        id.sample_bounds[2] = sob.m_sampleBounds.m_max.x; id.sample_bounds[3] = sob.m_sampleBounds.m_max.y;
+    }
+private:
+    const int m_device;
+    EnigmaStats m_stats{};
+};
+
+// PathIntegrator on the GPU (constructor arguments: Enigma/PathIntegrator.cpp:30-39).
+class GpuPathIntegrator : public GpuSamplerIntegrator {
+public:
+    GpuPathIntegrator(int maxDepth, std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds,
+                      float rrThreshold = 1, const std::string& lightSampleStrategy = "spatial", int device = 0)
+        : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
+          m_lightSampleStrategy(lightSampleStrategy) {}
+protected:
+    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) override {
+        EnigmaIntegratorDesc id{};
+        id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
+        if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
+        else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
+        else if (nLights == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
+        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
+        FillSamplerFields(id, sob);
+        return enigma_integrator_config(h, &id);
+    }
 private:
     const int m_maxDepth;
     const float m_rrThreshold;
     const std::string m_lightSampleStrategy;
-    const int m_device;
-    EnigmaStats m_stats{};
+};
+
+// DirectLightingIntegrator on the GPU (constructor arguments: Enigma/DirectLightingIntegrator.cpp:30-35).
+class GpuDirectLightingIntegrator : public GpuSamplerIntegrator {
+public:
+    enum class eLightStrategy { UniformSampleAll, UniformSampleOne }; // Enigma/DirectLightingIntegrator.h
+    GpuDirectLightingIntegrator(eLightStrategy strategy, int maxDepth, std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler,
+                                const BBox2i& pixelBounds, int device = 0)
+        : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_strategy(strategy), m_maxDepth(maxDepth) {}
+protected:
+    int ConfigureIntegrator(EnigmaCtx* h, size_t, const SobolSampler& sob) override {
+        EnigmaDirectLightingDesc id{};
+        id.max_depth = m_maxDepth;
+        id.strategy = m_strategy == eLightStrategy::UniformSampleAll ? ENIGMA_DL_SAMPLE_ALL : ENIGMA_DL_SAMPLE_ONE;
+        FillSamplerFields(id, sob);
+        return enigma_direct_lighting_config(h, &id);
+    }
+private:
+    const eLightStrategy m_strategy;
+    const int m_maxDepth;
 };
 
 } // namespace RayTrace

@@ -1,10 +1,11 @@
 // Host driver written against the mirrored reference interface (enigma_host.h): loads a flat scene
-// file, builds Film / PerspectiveCamera / SobolSampler / Scene / GpuPathIntegrator the way
+// file, builds Film / PerspectiveCamera / SobolSampler / Scene / GpuPathIntegrator (or GpuDirectLightingIntegrator) the way
 // RenderOptions::MakeIntegrator + MakeScene do (Enigma/Api.cpp:1170-1254), calls
 // integrator->Render(scene) like Enigma/Main.h:245, and writes the film's RGB as raw floats.
 //
 //   enigma_render <scene.bin> <out.f32>
-// scene.bin (little endian): "ESC1", then int32 {xres, yres, spp, maxDepth, lightStrategy(0 uniform,1 power),
+// scene.bin (little endian): "ESC1", then int32 {xres, yres, spp, maxDepth, integrator (PathIntegrator: 0 uniform / 1 power
+//   light distribution; DirectLightingIntegrator: 2 strategy all / 3 strategy one),
 //   nVerts, nTris, nMaterials}, float {rrThreshold, lensRadius, focalDistance}, float[16] rasterToCamera,
 //   float[16] cameraToWorld, float[nVerts*3], int32[nTris*3], int32[nTris] material,
 //   int32[nTris] emissive flag, float[nTris*3] Le, EnigmaMaterial[nMaterials].
@@ -62,7 +63,13 @@ int main(int argc, char** argv) {
         t = e;
     }
     // integrator (CreatePathIntegrator: pixelBounds = film sample bounds, Enigma/PathIntegrator.cpp:187)
-    std::unique_ptr<Integrator> integrator(new GpuPathIntegrator(maxDepth, camera, sampler, filmPtr->GetSampleBounds(), fl[0], strat ? "power" : "uniform"));
+    // (CreateDirectLightingIntegrator: the same pixel bounds, Enigma/DirectLightingIntegrator.cpp:104)
+    std::unique_ptr<GpuSamplerIntegrator> integrator;
+    if (strat >= 2)
+        integrator.reset(new GpuDirectLightingIntegrator(strat == 2 ? GpuDirectLightingIntegrator::eLightStrategy::UniformSampleAll
+                                                                    : GpuDirectLightingIntegrator::eLightStrategy::UniformSampleOne,
+                                                         maxDepth, camera, sampler, filmPtr->GetSampleBounds()));
+    else integrator.reset(new GpuPathIntegrator(maxDepth, camera, sampler, filmPtr->GetSampleBounds(), fl[0], strat ? "power" : "uniform"));
     try {
         integrator->Render(scene);
     } catch (const std::exception& e) {
@@ -72,7 +79,7 @@ int main(int argc, char** argv) {
     const std::vector<float>& rgb = filmPtr->GetRGB();
     std::ofstream o(argv[2], std::ios::binary);
     o.write(reinterpret_cast<const char*>(rgb.data()), rgb.size() * sizeof(float));
-    const EnigmaStats& st = static_cast<GpuPathIntegrator*>(integrator.get())->GetStats();
+    const EnigmaStats& st = integrator->GetStats();
     std::cout << "rendered " << xres << "x" << yres << " spp " << spp << " rays " << (st.rays_closest + st.rays_shadow + st.rays_mis) << " in " << st.ms_render << " ms\n";
     return 0;
 }

@@ -2,6 +2,8 @@
 DirectLightingIntegrator::Li's recursion against the CPU oracle on the same scenes and sample numbers.
 Same bars as the PathIntegrator tests: images within 1 % mean relative error (north-star bound), the
 much tighter agreement identical samples actually give, and identical ray counts (same control flow)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ import raytrace_amd as ra
 from raytrace_amd import abi, scenes
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _pair(sc, cam, film, integ):
@@ -121,4 +124,25 @@ def test_direct_lighting_refuses_what_the_reference_leaves_undefined():
     with pytest.raises(ra.EnigmaError) as e:
         r.render(0, 4)
     assert e.value.code == -4
+    r.close()
+
+
+def test_direct_lighting_matches_golden_fixture():
+    g = np.load(os.path.join(GOLD, "direct_lighting64_16spp.npz"))
+    sc, cam, film, _ = common.cornell_setup(res=64, spp=16, variant="microfacet")
+    sc.lights[0].n_samples = 2
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=5, strategy=abi.DL_SAMPLE_ALL))
+    r.render(0, 16)
+    assert common.mean_relative_error(r.image(), g["all_rgb"]) < 1e-4
+    st = r.stats()
+    got = np.array([st["camera_samples"], st["rays_closest"], st["rays_shadow"], st["rays_mis"]], dtype=np.int64)
+    assert np.all(np.abs(got - g["all_rays"]) <= np.maximum(3, 1e-4 * g["all_rays"]))
+    r.close()
+    sc, cam, film, _ = common.cornell_setup(res=64, spp=16, variant="specular")
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=4, strategy=abi.DL_SAMPLE_ONE))
+    r.render(0, 16)
+    assert common.mean_relative_error(r.image(), g["one_rgb"]) < 1e-3
+    st = r.stats()
+    got = np.array([st["camera_samples"], st["rays_closest"], st["rays_shadow"], st["rays_mis"]], dtype=np.int64)
+    assert np.all(np.abs(got - g["one_rays"]) <= np.maximum(3, 1e-3 * g["one_rays"]))
     r.close()

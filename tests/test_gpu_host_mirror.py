@@ -10,7 +10,7 @@ import pytest
 
 import common
 import orc
-from raytrace_amd import abi
+from raytrace_amd import abi, scenes
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,6 +49,23 @@ def test_host_mirror_renders_like_the_reference_path(tmp_path, variant):
     assert p.returncode == 0, p.stderr
     img = np.fromfile(out_file, dtype=np.float32).reshape(res, res, 3)
     o = orc.Oracle(sc, cam, film, integ)
+    o.render(0, spp, threads=4)
+    assert common.mean_relative_error(img, o.image()) < 1e-4
+    o.close()
+
+
+@pytest.mark.parametrize("strategy,code", [(abi.DL_SAMPLE_ALL, 2), (abi.DL_SAMPLE_ONE, 3)])
+def test_host_mirror_direct_lighting(tmp_path, strategy, code):
+    """GpuDirectLightingIntegrator behind the mirrored SamplerIntegrator::Render."""
+    assert os.path.exists(EXE), "raytrace_amd/enigma_render is not built (make -C raytrace_amd/csrc)"
+    res, spp = 48, 8
+    sc, cam, film, _ = common.cornell_setup(res=res, spp=spp, variant="microfacet")
+    scene_file, out_file = str(tmp_path / "scene.bin"), str(tmp_path / "out.f32")
+    write_scene(scene_file, sc, cam, res, res, spp, 3, code)
+    p = subprocess.run([EXE, scene_file, out_file], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    img = np.fromfile(out_file, dtype=np.float32).reshape(res, res, 3)
+    o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, spp, max_depth=3, strategy=strategy))
     o.render(0, spp, threads=4)
     assert common.mean_relative_error(img, o.image()) < 1e-4
     o.close()

@@ -209,3 +209,46 @@ def test_film_footprint_edge_rule():
     assert pix[1, 0].tolist() == [10, 20] and pix[2, 0].tolist() == [0, 0]
     assert np.all(w[0, :4] == 1.0)
     o.close()
+
+
+# ------------------------------------------------------------------ DirectLightingIntegrator (oracle only, CPU)
+def test_direct_lighting_oracle_reproduces_its_golden_fixture():
+    g = np.load(os.path.join(GOLD, "direct_lighting64_16spp.npz"))
+    sc, cam, film, _ = common.cornell_setup(res=64, spp=16, variant="microfacet")
+    sc.lights[0].n_samples = 2
+    o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=5, strategy=abi.DL_SAMPLE_ALL))
+    o.render(0, 16, threads=4)
+    s = o.stats()
+    assert np.array_equal(o.image(), g["all_rgb"])
+    assert [s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]] == g["all_rays"].tolist()
+    assert not o.read_past_arrays()
+    o.close()
+
+
+def test_direct_lighting_strategies_and_path_depth_one_agree_in_expectation():
+    """UniformSampleAll, UniformSampleOne and PathIntegrator(maxdepth 1) all estimate emitted + direct light."""
+    sc, cam, film, pinteg = common.cornell_setup(res=24, spp=256, variant="diffuse", max_depth=1)
+    means = []
+    for integ in (scenes.direct_lighting_desc(film, 256, strategy=abi.DL_SAMPLE_ALL),
+                  scenes.direct_lighting_desc(film, 256, strategy=abi.DL_SAMPLE_ONE), pinteg):
+        o = orc.Oracle(sc, cam, film, integ)
+        o.render(0, 256, threads=8)
+        means.append(o.image().mean(axis=(0, 1)))
+        o.close()
+    for m in means[1:]:
+        assert np.allclose(m, means[0], rtol=0.02)
+
+
+def test_direct_lighting_sample_arrays_are_samples_of_other_sample_numbers():
+    """Entry k of a size-n array for sample s is the Sobol' sample of sample number s*n + k in the array's
+    dimensions (GlobalSampler::StartPixel, Enigma/Sampler.cpp:170-180): with n = 1 the arrays are plain dimensions
+    5.., so strategy all with one sample per light consumes dims (5,6 | 7,8) for light 0 and (9,10 | 11,12) for light 1."""
+    sc, cam, film, _ = common.cornell_setup(res=16, spp=8, variant="diffuse")
+    a = scenes.direct_lighting_desc(film, 8, max_depth=1, strategy=abi.DL_SAMPLE_ALL)
+    o = orc.Oracle(sc, cam, film, a)
+    o.render(0, 8, threads=1)
+    s = o.stats()
+    assert s["rays_closest"] == 16 * 16 * 8                # depth 1: no specular children
+    assert s["rays_shadow"] <= 2 * s["rays_closest"]       # at most one shadow ray per light and hit
+    assert not o.read_past_arrays()
+    o.close()

@@ -92,7 +92,32 @@ def images():
         o.close()
     np.savez_compressed(os.path.join(G, "cornell64_64spp.npz"), **out)
 
+def direct_lighting_images():
+    """DirectLightingIntegrator: strategy all (two lights, 2 + 1 samples) and strategy one through smooth glass."""
+    from raytrace_amd import abi, scenes
+    out = {}
+    sc, cam, film, _ = common.cornell_setup(res=64, spp=16, variant="microfacet")
+    sc.lights[0].n_samples = 2
+    o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=5, strategy=abi.DL_SAMPLE_ALL))
+    o.render(0, 16, threads=8)
+    s = o.stats()
+    out["all_rgb"] = o.image()
+    out["all_rays"] = np.array([s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]], dtype=np.int64)
+    o.close()
+    sc, cam, film, _ = common.cornell_setup(res=64, spp=16, variant="specular")
+    o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=4, strategy=abi.DL_SAMPLE_ONE))
+    o.render(0, 16, threads=8)
+    s = o.stats()
+    out["one_rgb"] = o.image()
+    out["one_rays"] = np.array([s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]], dtype=np.int64)
+    o.close()
+    np.savez_compressed(os.path.join(G, "direct_lighting64_16spp.npz"), **out)
+
+
 if __name__ == "__main__":
-    sobol_and_camera(); primary_hits(); film_footprints(); bsdf_points(); images()
+    if len(sys.argv) > 1 and sys.argv[1] == "direct":
+        direct_lighting_images()
+    else:
+        sobol_and_camera(); primary_hits(); film_footprints(); bsdf_points(); images(); direct_lighting_images()
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
