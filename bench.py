@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--variant", default="microfacet",
                     help="workload: microfacet (Cornell, configs[1], the default) | diffuse | specular | bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3])")
+    ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one"],
+                    help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=2, help="sample numbers per pixel the CPU baseline renders")
     args = ap.parse_args()
@@ -69,7 +71,13 @@ def main():
         scene, camera, cam_small, label = scenes.cornell_box(args.variant), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (%s)" % args.variant
     film = scenes.film_desc(XRES, YRES, "box")
     total_spp = pow2_at_least(max(1024, (K + 1) * N * SPP_PER_STEP + SPP_PER_STEP))
-    integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
+    if args.integrator == "path":
+        integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
+        integ_label = "PathIntegrator maxdepth 5, Sobol, box filter, power light sampling"
+    else:
+        strat = abi.DL_SAMPLE_ALL if args.integrator == "direct-all" else abi.DL_SAMPLE_ONE
+        integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
+        integ_label = "DirectLightingIntegrator maxdepth 5 strategy %s, Sobol, box filter" % ("all" if strat == abi.DL_SAMPLE_ALL else "one")
     r = ra.Renderer(local_rank).configure(scene, camera, film, integ)
     film_t = distributed.film_tensor(r, dev)
 
@@ -126,14 +134,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s 1920x1080, PathIntegrator maxdepth 5, Sobol, box filter, power light sampling; "
-                                   "%d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, SPP_PER_STEP),
+            "config": {"workload": "%s 1920x1080, %s; "
+                                   "%d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
                        "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP, "parallelism": "spp-shard x%d + RCCL film reduce" % N},
             "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
         }
         # --- algorithmic bytes per ray from the reference traversal (HLBVH, <=127 prims per leaf) on a small sample
         small = scenes.film_desc(480, 270, "box")
-        o_small = orc.Oracle(scene, cam_small, small, scenes.integrator_desc(small, 16), fast=True)
+        o_small = orc.Oracle(scene, cam_small, small, scenes.integrator_desc(small, 16) if args.integrator == "path" else
+                             scenes.direct_lighting_desc(small, 16, max_depth=5, strategy=integ.strategy), fast=True)
         o_small.render(0, 1, threads=min(16, os.cpu_count() or 1))
         so = o_small.stats()
         n_nodes = so["nodes_closest"] / max(1, so["rays_closest"])
