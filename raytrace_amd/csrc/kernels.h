@@ -804,8 +804,13 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && p != kNoRay) {
                     if (!w.occluded) {
-                        float* L = reinterpret_cast<float*>(P.L + p / shq.perPath);
-                        atomicAdd(L + 0, contrib.x); atomicAdd(L + 1, contrib.y); atomicAdd(L + 2, contrib.z);
+                        if (shq.perPath == 1) { // the path's only ray in this kernel: nobody else touches its L
+                            float4 L = P.L[p];
+                            P.L[p] = make_float4(L.x + contrib.x, L.y + contrib.y, L.z + contrib.z, 0.f);
+                        } else {
+                            float* L = reinterpret_cast<float*>(P.L + p / shq.perPath);
+                            atomicAdd(L + 0, contrib.x); atomicAdd(L + 1, contrib.y); atomicAdd(L + 2, contrib.z);
+                        }
                     }
                     p = kNoRay;
                 }
