@@ -173,7 +173,8 @@ struct LaneStack {
 // Each ray still sees its own nodes and triangles in the same depth-first order.  The walkers keep a
 // ray's whole traversal state, which lets a kernel hand a finished lane a new ray between steps.
 // A leaf in progress is held in cur as ~((next triangle << 3) | (triangles left - 1)).
-template <int LDSN, int OVF, int STRIDE>
+// NS: float4s between consecutive nodes (8 in HBM; 9 in the LDS copy, which staggers the nodes over the banks)
+template <int LDSN, int OVF, int STRIDE, int NS = 8>
 struct ClosestWalker {
     RaySetup r;
     Hit h;
@@ -192,7 +193,7 @@ struct ClosestWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
-            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS);
             // children the ray misses (or unused slots) get entry distance +inf and sort to the back
             float t0, t1, t2, t3;
             if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
@@ -231,7 +232,7 @@ struct ClosestWalker {
     // do in the shallow tree of a scene small enough to be traversed out of LDS.
     DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
-            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS);
             float t0, t1, t2, t3;
             if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
             if (!(q.c1 != kTraverseDone && slabTest(r, h.t, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &t1))) t1 = EDEV_INF;
@@ -268,7 +269,7 @@ struct ClosestWalker {
 };
 
 // Any-hit (Scene::intersectP): no ordering, first accepted triangle ends the walk.
-template <int LDSN, int OVF, int STRIDE>
+template <int LDSN, int OVF, int STRIDE, int NS = 8>
 struct AnyWalker {
     RaySetup r;
     float tMax;
@@ -289,7 +290,7 @@ struct AnyWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
-            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS);
             float te;
             bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
             bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
@@ -314,7 +315,7 @@ struct AnyWalker {
     }
     DEV void round(const float4* nodes, const float4* tris) { // see ClosestWalker::round
         while (cur >= 0) {
-            Node4 q = loadNode4(nodes + (size_t)cur * 8);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS);
             float te;
             bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
             bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
@@ -341,11 +342,11 @@ struct AnyWalker {
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
-template <int LDSN, int OVF, int STRIDE>
+template <int LDSN, int OVF, int STRIDE, int NS = 8>
 DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
     uint32_t spillNodes[OVF > 0 ? OVF : 1];
     float spillDist[OVF > 0 ? OVF : 1];
-    ClosestWalker<LDSN, OVF, STRIDE> w(column, spillNodes, spillDist);
+    ClosestWalker<LDSN, OVF, STRIDE, NS> w(column, spillNodes, spillDist);
     w.start(o, d, tMax);
     while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
     return w.h;

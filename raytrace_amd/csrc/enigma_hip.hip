@@ -517,7 +517,7 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
 
 // Scenes up to this many bytes of nodes + triangles are traversed out of LDS (see stageSceneToLds).
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
-static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * 8 + (size_t)h->scene.nTris * 3) * sizeof(float4); }
+static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * kLdsNodePitch + (size_t)h->scene.nTris * 3) * sizeof(float4); }
 
 // triangles + materials + lights + light distribution, as k_shade stages them
 static size_t shadeLdsBytes(const EnigmaCtx* h) {

@@ -124,11 +124,14 @@ static_assert(kWavesPerBlock == 4, "blockReserve3 lays its counts out for four w
 // Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
 // into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
 // instead of 64 divergent 16-byte requests per wave-instruction through the texture-address path,
-// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 8 float4 each][tris: 3 float4 each].
+// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 9 float4 apart][tris: 3 float4 each].
+// Nodes sit 9 float4 apart in LDS (144 bytes = 36 banks): lanes at different nodes then read from
+// different banks, where a 128-byte pitch would put every other node on the same ones.
+constexpr uint32_t kLdsNodePitch = 9;
 DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
     const uint32_t nN = sc.nNodes * 8u, nT = sc.nTris * 3u;
-    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[i] = sc.nodes[i];
-    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[nN + i] = sc.tris[i];
+    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[(i >> 3) * kLdsNodePitch + (i & 7u)] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[sc.nNodes * kLdsNodePitch + i] = sc.tris[i];
     __syncthreads();
 }
 
@@ -240,14 +243,14 @@ __global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, De
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        ClosestWalker<LDSN, OVF, kBlock> w(stack + threadIdx.x, spillNodes, spillDist);
+        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
         uint32_t pos = kNoRay, p = 0;
         bool exhausted = false;
         for (;;) {
@@ -788,12 +791,12 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        AnyWalker<LDSN, OVF, kBlock> w(stack + threadIdx.x, spillNodes);
+        AnyWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes);
         uint32_t p = kNoRay;
         float4 contrib = make_float4(0.f, 0.f, 0.f, 0.f); // fetched with the ray: no dependent load when the ray is through
         bool exhausted = false;
@@ -844,11 +847,11 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * 8u; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
-        Hit h = traceClosest<LDSN, OVF, kBlock>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
+        Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
         if (h.tri < 0) continue;
         const float4* tp = tris + (size_t)h.tri * 3;
         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
