@@ -60,6 +60,29 @@ DEV bool slabTest(const RaySetup& r, float tMaxRay, F3 lo, F3 hi, float* tEntry)
     return (tMin < tMaxRay) && (tMax > 0);
 }
 
+// The same test with the near / far plane of each axis already picked (the picks depend on the ray only,
+// so the traversal fetches "near x of four children" straight from the node instead of selecting per child).
+DEV bool slabTestNF(const RaySetup& r, float tMaxRay, float nx, float ny, float nz, float fx, float fy, float fz, float* tEntry) {
+    constexpr float kRobust = 1 + 2 * gammaf(3);
+    float tMin = (nx - r.o.x) * r.invDir.x;
+    float tMax = (fx - r.o.x) * r.invDir.x;
+    float tyMin = (ny - r.o.y) * r.invDir.y;
+    float tyMax = (fy - r.o.y) * r.invDir.y;
+    tMax *= kRobust;
+    tyMax *= kRobust;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = (nz - r.o.z) * r.invDir.z;
+    float tzMax = (fz - r.o.z) * r.invDir.z;
+    tzMax *= kRobust;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    *tEntry = tMin;
+    return (tMin < tMaxRay) && (tMax > 0);
+}
+
 // Triangle::intersects, Enigma/TriangleMesh.cpp:491-602.
 DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o) {
     F3 p0t = permuteK(p0 - r.o, r.kz0, r.kz1);
@@ -106,10 +129,13 @@ DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, flo
 struct Hit { int tri; float t, b0, b1, b2; };
 
 // One 4-wide node (see bvh_build.h): child boxes in structure-of-arrays form, seven float4 loads.
-struct Node4 { float4 lox, loy, loz, hix, hiy, hiz; int c0, c1, c2, c3; };
-DEV Node4 loadNode4(const float4* n) {
+// Planes come out as near / far along the ray: the float4 index of "near x" is 0 or 3 by the sign of d.x, etc.
+struct Node4 { float4 nx, ny, nz, fx, fy, fz; int c0, c1, c2, c3; };
+DEV Node4 loadNode4(const float4* n, const RaySetup& r) {
     Node4 q;
-    q.lox = n[0]; q.loy = n[1]; q.loz = n[2]; q.hix = n[3]; q.hiy = n[4]; q.hiz = n[5];
+    const int ox = r.negX ? 3 : 0, oy = r.negY ? 3 : 0, oz = r.negZ ? 3 : 0;
+    q.nx = n[ox]; q.ny = n[1 + oy]; q.nz = n[2 + oz];
+    q.fx = n[3 - ox]; q.fy = n[4 - oy]; q.fz = n[5 - oz];
     float4 ch = n[6];
     q.c0 = __float_as_int(ch.x); q.c1 = __float_as_int(ch.y); q.c2 = __float_as_int(ch.z); q.c3 = __float_as_int(ch.w);
     return q;
@@ -193,13 +219,13 @@ struct ClosestWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
-            Node4 q = loadNode4(nodes + (size_t)cur * NS);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             // children the ray misses (or unused slots) get entry distance +inf and sort to the back
             float t0, t1, t2, t3;
-            if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
-            if (!(q.c1 != kTraverseDone && slabTest(r, h.t, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &t1))) t1 = EDEV_INF;
-            if (!(q.c2 != kTraverseDone && slabTest(r, h.t, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &t2))) t2 = EDEV_INF;
-            if (!(q.c3 != kTraverseDone && slabTest(r, h.t, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &t3))) t3 = EDEV_INF;
+            if (!(q.c0 != kTraverseDone && slabTestNF(r, h.t, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &t0))) t0 = EDEV_INF;
+            if (!(q.c1 != kTraverseDone && slabTestNF(r, h.t, q.nx.y, q.ny.y, q.nz.y, q.fx.y, q.fy.y, q.fz.y, &t1))) t1 = EDEV_INF;
+            if (!(q.c2 != kTraverseDone && slabTestNF(r, h.t, q.nx.z, q.ny.z, q.nz.z, q.fx.z, q.fy.z, q.fz.z, &t2))) t2 = EDEV_INF;
+            if (!(q.c3 != kTraverseDone && slabTestNF(r, h.t, q.nx.w, q.ny.w, q.nz.w, q.fx.w, q.fy.w, q.fz.w, &t3))) t3 = EDEV_INF;
             orderPair(t0, q.c0, t1, q.c1); orderPair(t2, q.c2, t3, q.c3);
             orderPair(t0, q.c0, t2, q.c2); orderPair(t1, q.c1, t3, q.c3);
             orderPair(t1, q.c1, t2, q.c2);
@@ -232,12 +258,12 @@ struct ClosestWalker {
     // do in the shallow tree of a scene small enough to be traversed out of LDS.
     DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
-            Node4 q = loadNode4(nodes + (size_t)cur * NS);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float t0, t1, t2, t3;
-            if (!(q.c0 != kTraverseDone && slabTest(r, h.t, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &t0))) t0 = EDEV_INF;
-            if (!(q.c1 != kTraverseDone && slabTest(r, h.t, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &t1))) t1 = EDEV_INF;
-            if (!(q.c2 != kTraverseDone && slabTest(r, h.t, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &t2))) t2 = EDEV_INF;
-            if (!(q.c3 != kTraverseDone && slabTest(r, h.t, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &t3))) t3 = EDEV_INF;
+            if (!(q.c0 != kTraverseDone && slabTestNF(r, h.t, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &t0))) t0 = EDEV_INF;
+            if (!(q.c1 != kTraverseDone && slabTestNF(r, h.t, q.nx.y, q.ny.y, q.nz.y, q.fx.y, q.fy.y, q.fz.y, &t1))) t1 = EDEV_INF;
+            if (!(q.c2 != kTraverseDone && slabTestNF(r, h.t, q.nx.z, q.ny.z, q.nz.z, q.fx.z, q.fy.z, q.fz.z, &t2))) t2 = EDEV_INF;
+            if (!(q.c3 != kTraverseDone && slabTestNF(r, h.t, q.nx.w, q.ny.w, q.nz.w, q.fx.w, q.fy.w, q.fz.w, &t3))) t3 = EDEV_INF;
             orderPair(t0, q.c0, t1, q.c1); orderPair(t2, q.c2, t3, q.c3);
             orderPair(t0, q.c0, t2, q.c2); orderPair(t1, q.c1, t3, q.c3);
             orderPair(t1, q.c1, t2, q.c2);
@@ -290,12 +316,12 @@ struct AnyWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
-            Node4 q = loadNode4(nodes + (size_t)cur * NS);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float te;
-            bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
-            bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
-            bool h2 = q.c2 != kTraverseDone && slabTest(r, tMax, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &te);
-            bool h3 = q.c3 != kTraverseDone && slabTest(r, tMax, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &te);
+            bool h0 = q.c0 != kTraverseDone && slabTestNF(r, tMax, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &te);
+            bool h1 = q.c1 != kTraverseDone && slabTestNF(r, tMax, q.nx.y, q.ny.y, q.nz.y, q.fx.y, q.fy.y, q.fz.y, &te);
+            bool h2 = q.c2 != kTraverseDone && slabTestNF(r, tMax, q.nx.z, q.ny.z, q.nz.z, q.fx.z, q.fy.z, q.fz.z, &te);
+            bool h3 = q.c3 != kTraverseDone && slabTestNF(r, tMax, q.nx.w, q.ny.w, q.nz.w, q.fx.w, q.fy.w, q.fz.w, &te);
             int next = kTraverseDone;
             if (h3) next = q.c3;
             if (h2) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c2; }
@@ -315,12 +341,12 @@ struct AnyWalker {
     }
     DEV void round(const float4* nodes, const float4* tris) { // see ClosestWalker::round
         while (cur >= 0) {
-            Node4 q = loadNode4(nodes + (size_t)cur * NS);
+            Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float te;
-            bool h0 = q.c0 != kTraverseDone && slabTest(r, tMax, F3(q.lox.x, q.loy.x, q.loz.x), F3(q.hix.x, q.hiy.x, q.hiz.x), &te);
-            bool h1 = q.c1 != kTraverseDone && slabTest(r, tMax, F3(q.lox.y, q.loy.y, q.loz.y), F3(q.hix.y, q.hiy.y, q.hiz.y), &te);
-            bool h2 = q.c2 != kTraverseDone && slabTest(r, tMax, F3(q.lox.z, q.loy.z, q.loz.z), F3(q.hix.z, q.hiy.z, q.hiz.z), &te);
-            bool h3 = q.c3 != kTraverseDone && slabTest(r, tMax, F3(q.lox.w, q.loy.w, q.loz.w), F3(q.hix.w, q.hiy.w, q.hiz.w), &te);
+            bool h0 = q.c0 != kTraverseDone && slabTestNF(r, tMax, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &te);
+            bool h1 = q.c1 != kTraverseDone && slabTestNF(r, tMax, q.nx.y, q.ny.y, q.nz.y, q.fx.y, q.fy.y, q.fz.y, &te);
+            bool h2 = q.c2 != kTraverseDone && slabTestNF(r, tMax, q.nx.z, q.ny.z, q.nz.z, q.fx.z, q.fy.z, q.fz.z, &te);
+            bool h3 = q.c3 != kTraverseDone && slabTestNF(r, tMax, q.nx.w, q.ny.w, q.nz.w, q.fx.w, q.fy.w, q.fz.w, &te);
             int next = kTraverseDone;
             if (h3) next = q.c3;
             if (h2) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c2; }

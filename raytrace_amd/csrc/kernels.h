@@ -227,7 +227,7 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 // DL: the head of DirectLightingIntegrator::Li instead (Enigma/DirectLightingIntegrator.cpp:41-55): emitted
 // radiance is added at every hit, every hit is shaded, and a path that misses resumes a pending branch.
 template <int LDSN, int OVF, bool LDS_SCENE, bool DL>
-__global__ void __launch_bounds__(kBlock, 5) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
+__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr int NK = DL ? kQueueKinds : MK_COUNT;
