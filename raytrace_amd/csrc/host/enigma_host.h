@@ -238,6 +238,7 @@ struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexI
     bool emissive = false;          // an AreaLightSource was active when the shape was created
     Spectrum Le = 0.f;
     bool twoSided = false;
+    int nSamples = 1;               // Light::m_nSamples of the area lights made for this mesh
 };
 
 class Scene {
@@ -319,7 +320,7 @@ public:
                 triMat.push_back((uint32_t)m.materialIndex);
                 triFlags.push_back(m.reverseOrientation ? ENIGMA_TRI_FLIP_NORMAL : 0u);
                 if (m.emissive) {
-                    EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA; l.triangle = (uint32_t)triMat.size() - 1; l.two_sided = m.twoSided;
+                    EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA; l.triangle = (uint32_t)triMat.size() - 1; l.two_sided = m.twoSided; l.n_samples = (uint32_t)std::max(1, m.nSamples);
                     l.L[0] = m.Le[0]; l.L[1] = m.Le[1]; l.L[2] = m.Le[2];
                     triLight.push_back((int32_t)lights.size());
                     lights.push_back(l);

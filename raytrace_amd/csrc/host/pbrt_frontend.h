@@ -1,0 +1,659 @@
+// Scene-description front end: the reference's pbrt-format parser and pbrt* API for the part of the
+// format the GPU integrators can render, written against the mirrored classes of enigma_host.h.
+//
+// Replaces, for that subset: the tokenizer / directive loop of Enigma/Parser.cpp:1-1140, ParamSet
+// (Enigma/ParameterSet.h:14-175), the API state machine (Enigma/Api.cpp:483-1254: transforms, option block,
+// attribute stack, named materials, shapes, lights, WorldEnd -> MakeIntegrator / MakeScene / Render) and the
+// Create* factories it calls (Film.cpp:330-372, Filter.cpp:38-75, Camera.cpp:385-432, Sampler.cpp:554-559,
+// PathIntegrator.cpp:182-201, DirectLightingIntegrator.cpp:89-114, Material.cpp:594-646, Lights.cpp:742-750,
+// 812-822).  Parameter names and defaults are the reference's.
+//
+// Deliberate divergence: transforms compose as the pbrt format defines them (CTM = CTM * T, points map
+// through the CTM, the camera transform is Inverse(CTM)), evaluated in double and rounded once.  The
+// reference's Transform composition transposes on construction (Enigma/Transform.cpp:295-314) and gives
+// wrong matrices for chained operations; that defect is not reproduced.
+//
+// Outside the subset (textures other than constants, shapes other than trianglemesh, shading normals,
+// spectra other than rgb, object instancing, media, other samplers / cameras / lights / integrators) the
+// front end throws std::runtime_error naming the directive; it never renders something else silently.
+#pragma once
+#include "enigma_host.h"
+
+#include <cctype>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace RayTrace {
+
+// ---------------------------------------------------------------- ParamSet (Enigma/ParameterSet.h:14-175)
+struct ParamSetItem {
+    std::string type, name;
+    std::vector<double> nums;
+    std::vector<std::string> strs;
+    mutable bool lookedUp = false;
+};
+
+class ParamSet {
+public:
+    void Add(const ParamSetItem& it) { m_items.push_back(it); }
+    int FindOneInt(const std::string& n, int d) const { auto* i = find(n, "integer", 1); return i ? (int)i->nums[0] : d; }
+    float FindOneFloat(const std::string& n, float d) const { auto* i = find(n, "float", 1); return i ? (float)i->nums[0] : d; }
+    bool FindOneBool(const std::string& n, bool d) const { auto* i = find(n, "bool", 1); return i ? i->strs[0] == "true" : d; }
+    std::string FindOneString(const std::string& n, const std::string& d) const { auto* i = find(n, "string", 1); return i ? i->strs[0] : d; }
+    Vector3f FindOnePoint3f(const std::string& n, const Vector3f& d) const {
+        auto* i = find(n, "point", 3);
+        return i ? Vector3f((float)i->nums[0], (float)i->nums[1], (float)i->nums[2]) : d;
+    }
+    // rgb / color only: sampled spectra, blackbody and xyz need the CIE tables of Enigma/Spectrum.cpp
+    Spectrum FindOneSpectrum(const std::string& n, const Spectrum& d) const {
+        for (const auto& it : m_items)
+            if (it.name == n && (it.type == "spectrum" || it.type == "blackbody" || it.type == "xyz"))
+                throw std::runtime_error("parameter \"" + it.type + " " + n + "\": only rgb / color values are supported");
+        auto* i = find(n, "rgb", 3);
+        return i ? Spectrum((float)i->nums[0], (float)i->nums[1], (float)i->nums[2]) : d;
+    }
+    bool HasSpectrum(const std::string& n) const { return find(n, "rgb", 3, false) != nullptr; }
+    bool Has(const std::string& n) const { for (const auto& it : m_items) if (it.name == n) return true; return false; }
+    std::vector<int> FindInt(const std::string& n) const {
+        std::vector<int> out;
+        if (auto* i = find(n, "integer", 0)) for (double v : i->nums) out.push_back((int)v);
+        return out;
+    }
+    std::vector<float> FindFloat(const std::string& n) const {
+        std::vector<float> out;
+        if (auto* i = find(n, "float", 0)) for (double v : i->nums) out.push_back((float)v);
+        return out;
+    }
+    std::vector<double> FindPoint3(const std::string& n) const { auto* i = find(n, "point", 0); return i ? i->nums : std::vector<double>(); }
+    std::string FindTexture(const std::string& n) const { auto* i = find(n, "texture", 1, false); return i ? i->strs[0] : ""; }
+    std::vector<std::string> Unused() const { // ReportUnused
+        std::vector<std::string> out;
+        for (const auto& it : m_items) if (!it.lookedUp) out.push_back(it.type + " " + it.name);
+        return out;
+    }
+    const std::vector<ParamSetItem>& Items() const { return m_items; }
+private:
+    static std::string canon(const std::string& t) {
+        if (t == "color") return "rgb";
+        if (t == "point3" || t == "point3f") return "point";
+        if (t == "vector3" || t == "vector3f") return "vector";
+        if (t == "normal3" || t == "normal3f") return "normal";
+        return t;
+    }
+    const ParamSetItem* find(const std::string& n, const std::string& type, size_t minCount, bool mark = true) const {
+        for (const auto& it : m_items)
+            if (it.name == n && canon(it.type) == type) {
+                size_t have = (type == "bool" || type == "string" || type == "texture") ? it.strs.size() : it.nums.size();
+                if (minCount && have < minCount) throw std::runtime_error("parameter \"" + n + "\" has too few values");
+                if (mark) it.lookedUp = true;
+                return &it;
+            }
+        return nullptr;
+    }
+    std::vector<ParamSetItem> m_items;
+};
+
+// ---------------------------------------------------------------- 4x4 algebra in double (Enigma/Transform.h)
+struct Mat4d {
+    double m[4][4];
+    Mat4d() { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m[r][c] = r == c; }
+    Mat4d operator*(const Mat4d& b) const {
+        Mat4d o;
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += m[r][k] * b.m[k][c];
+                o.m[r][c] = s;
+            }
+        return o;
+    }
+    Mat4d Inverse() const { // Gauss-Jordan with full pivoting
+        double a[4][8];
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m[r][c]; a[r][4 + c] = r == c; }
+        for (int col = 0; col < 4; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < 4; ++r) if (std::abs(a[r][col]) > std::abs(a[piv][col])) piv = r;
+            if (a[piv][col] == 0) throw std::runtime_error("singular matrix in transform inversion");
+            if (piv != col) for (int c = 0; c < 8; ++c) std::swap(a[piv][c], a[col][c]);
+            double inv = 1.0 / a[col][col];
+            for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+            for (int r = 0; r < 4; ++r)
+                if (r != col && a[r][col] != 0) {
+                    double f = a[r][col];
+                    for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+                }
+        }
+        Mat4d o;
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) o.m[r][c] = a[r][4 + c];
+        return o;
+    }
+    void Point(const double p[3], double out[3]) const {
+        double x = m[0][0] * p[0] + m[0][1] * p[1] + m[0][2] * p[2] + m[0][3];
+        double y = m[1][0] * p[0] + m[1][1] * p[1] + m[1][2] * p[2] + m[1][3];
+        double z = m[2][0] * p[0] + m[2][1] * p[1] + m[2][2] * p[2] + m[2][3];
+        double w = m[3][0] * p[0] + m[3][1] * p[1] + m[3][2] * p[2] + m[3][3];
+        if (w != 1.0) { x /= w; y /= w; z /= w; }
+        out[0] = x; out[1] = y; out[2] = z;
+    }
+    bool SwapsHandedness() const { // Transform::swapsHandedness: negative determinant of the upper 3x3
+        double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                     m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        return det < 0;
+    }
+    Transform ToFloat() const { Transform t; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) t.m_mat[r][c] = (float)m[r][c]; return t; }
+};
+inline Mat4d TranslateD(double x, double y, double z) { Mat4d t; t.m[0][3] = x; t.m[1][3] = y; t.m[2][3] = z; return t; }
+inline Mat4d ScaleD(double x, double y, double z) { Mat4d t; t.m[0][0] = x; t.m[1][1] = y; t.m[2][2] = z; return t; }
+inline Mat4d RotateD(double deg, double ax, double ay, double az) { // Rotate(theta, axis)
+    double len = std::sqrt(ax * ax + ay * ay + az * az);
+    if (len == 0) throw std::runtime_error("Rotate: zero axis");
+    ax /= len; ay /= len; az /= len;
+    double th = deg * 3.14159265358979323846 / 180.0, s = std::sin(th), c = std::cos(th);
+    Mat4d t;
+    t.m[0][0] = ax * ax + (1 - ax * ax) * c; t.m[0][1] = ax * ay * (1 - c) - az * s; t.m[0][2] = ax * az * (1 - c) + ay * s;
+    t.m[1][0] = ax * ay * (1 - c) + az * s; t.m[1][1] = ay * ay + (1 - ay * ay) * c; t.m[1][2] = ay * az * (1 - c) - ax * s;
+    t.m[2][0] = ax * az * (1 - c) - ay * s; t.m[2][1] = ay * az * (1 - c) + ax * s; t.m[2][2] = az * az + (1 - az * az) * c;
+    return t;
+}
+inline Mat4d LookAtD(const double e[3], const double l[3], const double u[3]) { // world-to-camera, left-handed, +z forward
+    double d[3] = {l[0] - e[0], l[1] - e[1], l[2] - e[2]};
+    double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (dl == 0) throw std::runtime_error("LookAt: eye and look-at point coincide");
+    for (double& v : d) v /= dl;
+    double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    double un[3] = {u[0] / ul, u[1] / ul, u[2] / ul};
+    double r[3] = {un[1] * d[2] - un[2] * d[1], un[2] * d[0] - un[0] * d[2], un[0] * d[1] - un[1] * d[0]};
+    double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (rl == 0) throw std::runtime_error("LookAt: up vector and viewing direction are parallel");
+    for (double& v : r) v /= rl;
+    double nu[3] = {d[1] * r[2] - d[2] * r[1], d[2] * r[0] - d[0] * r[2], d[0] * r[1] - d[1] * r[0]};
+    Mat4d c2w;
+    for (int i = 0; i < 3; ++i) { c2w.m[i][0] = r[i]; c2w.m[i][1] = nu[i]; c2w.m[i][2] = d[i]; c2w.m[i][3] = e[i]; }
+    return c2w.Inverse();
+}
+
+class MitchellFilter : public Filter { // Enigma/Filter.h:78-103
+public:
+    MitchellFilter(const Vector2f& r, float B, float C) : Filter(r), m_B(B), m_C(C) {}
+    float Evaluate(const Vector2f& p) const override { return M1(p.x * m_invRadius.x) * M1(p.y * m_invRadius.y); }
+private:
+    float M1(float x) const {
+        x = std::abs(2 * x);
+        if (x > 1) return ((-m_B - 6 * m_C) * x * x * x + (6 * m_B + 30 * m_C) * x * x + (-12 * m_B - 48 * m_C) * x + (8 * m_B + 24 * m_C)) * (1.f / 6.f);
+        return ((12 - 9 * m_B - 6 * m_C) * x * x * x + (-18 + 12 * m_B + 6 * m_C) * x * x + (6 - 2 * m_B)) * (1.f / 6.f);
+    }
+    const float m_B, m_C;
+};
+
+// ---------------------------------------------------------------- API state (Enigma/Api.h:96-200)
+struct RenderOptions {
+    std::string FilterName = "box", FilmName = "image", SamplerName = "halton", IntegratorName = "path", CameraName = "perspective";
+    ParamSet FilterParams, FilmParams, SamplerParams, IntegratorParams, CameraParams;
+    Mat4d CameraToWorld;
+    bool haveCamera = false;
+};
+
+struct GraphicsState {
+    int currentMaterial = -1; // index into the scene's material registry; -1 = the default matte, made on first use
+    std::string areaLight;
+    ParamSet areaLightParams;
+    bool reverseOrientation = false;
+    std::map<std::string, int> namedMaterials;
+};
+
+// What WorldEnd built: kept so that callers (and tests) can look at it after Render.
+struct FrontEndResult {
+    Scene scene;
+    CameraPtr camera;
+    SamplerPtr sampler;
+    std::unique_ptr<GpuSamplerIntegrator> integrator;
+    std::string integratorName, lightStrategy, filterName;
+    int maxDepth = 5, directStrategy = 0;
+    float rrThreshold = 1.f;
+    BBox2i pixelBounds;
+    std::vector<std::string> warnings;
+};
+
+class PbrtApi {
+public:
+    explicit PbrtApi(bool renderOnWorldEnd = true, int device = 0) : m_render(renderOnWorldEnd), m_device(device) {}
+
+    // ---- transforms (Enigma/Api.cpp:507-586)
+    void pbrtIdentity() { m_ctm = Mat4d(); }
+    void pbrtTranslate(float dx, float dy, float dz) { m_ctm = m_ctm * TranslateD(dx, dy, dz); }
+    void pbrtRotate(float angle, float ax, float ay, float az) { m_ctm = m_ctm * RotateD(angle, ax, ay, az); }
+    void pbrtScale(float sx, float sy, float sz) { m_ctm = m_ctm * ScaleD(sx, sy, sz); }
+    void pbrtLookAt(float ex, float ey, float ez, float lx, float ly, float lz, float ux, float uy, float uz) {
+        double e[3] = {ex, ey, ez}, l[3] = {lx, ly, lz}, u[3] = {ux, uy, uz};
+        m_ctm = m_ctm * LookAtD(e, l, u);
+    }
+    static Mat4d FromColumnMajor(const float tr[16]) { // the file lists matrices column by column
+        Mat4d t;
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) t.m[r][c] = tr[4 * c + r];
+        return t;
+    }
+    void pbrtConcatTransform(const float tr[16]) { m_ctm = m_ctm * FromColumnMajor(tr); }
+    void pbrtTransform(const float tr[16]) { m_ctm = FromColumnMajor(tr); }
+    void pbrtCoordinateSystem(const std::string& name) { m_namedCoordinateSystems[name] = m_ctm; }
+    void pbrtCoordSysTransform(const std::string& name) {
+        auto it = m_namedCoordinateSystems.find(name);
+        if (it != m_namedCoordinateSystems.end()) m_ctm = it->second;
+        else Warn("Couldn't find named coordinate system \"" + name + "\"");
+    }
+
+    // ---- option block (Enigma/Api.cpp:600-641)
+    void pbrtPixelFilter(const std::string& name, const ParamSet& p) { VerifyOptions("PixelFilter"); m_opt.FilterName = name; m_opt.FilterParams = p; }
+    void pbrtFilm(const std::string& type, const ParamSet& p) { VerifyOptions("Film"); m_opt.FilmName = type; m_opt.FilmParams = p; }
+    void pbrtSampler(const std::string& name, const ParamSet& p) { VerifyOptions("Sampler"); m_opt.SamplerName = name; m_opt.SamplerParams = p; }
+    void pbrtAccelerator(const std::string&, const ParamSet&) { VerifyOptions("Accelerator"); } // the device builds its own BVH
+    void pbrtIntegrator(const std::string& name, const ParamSet& p) { VerifyOptions("Integrator"); m_opt.IntegratorName = name; m_opt.IntegratorParams = p; }
+    void pbrtCamera(const std::string& name, const ParamSet& p) {
+        VerifyOptions("Camera");
+        m_opt.CameraName = name; m_opt.CameraParams = p;
+        m_opt.CameraToWorld = m_ctm.Inverse();
+        m_opt.haveCamera = true;
+        m_namedCoordinateSystems["camera"] = m_opt.CameraToWorld;
+    }
+
+    // ---- world block (Enigma/Api.cpp:667-905)
+    void pbrtWorldBegin() {
+        VerifyOptions("WorldBegin");
+        m_inWorld = true;
+        m_ctm = Mat4d();
+        m_namedCoordinateSystems["world"] = m_ctm;
+    }
+    void pbrtAttributeBegin() { VerifyWorld("AttributeBegin"); m_pushedGraphicsStates.push_back(m_gs); m_pushedTransforms.push_back(m_ctm); }
+    void pbrtAttributeEnd() {
+        VerifyWorld("AttributeEnd");
+        if (m_pushedGraphicsStates.empty()) { Warn("Unmatched AttributeEnd encountered. Ignoring it."); return; }
+        m_gs = m_pushedGraphicsStates.back(); m_pushedGraphicsStates.pop_back();
+        m_ctm = m_pushedTransforms.back(); m_pushedTransforms.pop_back();
+    }
+    void pbrtTransformBegin() { VerifyWorld("TransformBegin"); m_pushedTransforms.push_back(m_ctm); }
+    void pbrtTransformEnd() {
+        VerifyWorld("TransformEnd");
+        if (m_pushedTransforms.empty()) { Warn("Unmatched TransformEnd encountered. Ignoring it."); return; }
+        m_ctm = m_pushedTransforms.back(); m_pushedTransforms.pop_back();
+    }
+    void pbrtReverseOrientation() { VerifyWorld("ReverseOrientation"); m_gs.reverseOrientation = !m_gs.reverseOrientation; }
+    void pbrtMaterial(const std::string& name, const ParamSet& p) { VerifyWorld("Material"); m_gs.currentMaterial = MakeMaterial(name, p); }
+    void pbrtMakeNamedMaterial(const std::string& name, const ParamSet& p) {
+        VerifyWorld("MakeNamedMaterial");
+        std::string type = p.FindOneString("type", "");
+        if (type.empty()) throw std::runtime_error("No parameter string \"type\" found in MakeNamedMaterial");
+        m_gs.namedMaterials[name] = MakeMaterial(type, p);
+    }
+    void pbrtNamedMaterial(const std::string& name) {
+        VerifyWorld("NamedMaterial");
+        auto it = m_gs.namedMaterials.find(name);
+        if (it == m_gs.namedMaterials.end()) throw std::runtime_error("NamedMaterial \"" + name + "\" unknown.");
+        m_gs.currentMaterial = it->second;
+    }
+    void pbrtTexture(const std::string& name, const std::string&, const std::string&, const ParamSet&) {
+        throw std::runtime_error("Texture \"" + name + "\": textures are outside the GPU path (constant material parameters only)");
+    }
+    void pbrtLightSource(const std::string& name, const ParamSet& p) {
+        VerifyWorld("LightSource");
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, and diffuse area lights)");
+        Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+        Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
+        // l2w = Translate(P) * lightToWorld, position = l2w(0,0,0) (Enigma/Lights.cpp:742-750,89-95)
+        Mat4d l2w = TranslateD(P.x, P.y, P.z) * m_ctm;
+        double zero[3] = {0, 0, 0}, pos[3];
+        l2w.Point(zero, pos);
+        Spectrum Isc(I[0] * sc[0], I[1] * sc[1], I[2] * sc[2]);
+        m_res->scene.AddPointLight(Vector3f((float)pos[0], (float)pos[1], (float)pos[2]), Isc);
+        NoteUnused("LightSource", p);
+    }
+    void pbrtAreaLightSource(const std::string& name, const ParamSet& p) { VerifyWorld("AreaLightSource"); m_gs.areaLight = name; m_gs.areaLightParams = p; }
+    void pbrtShape(const std::string& name, const ParamSet& p) {
+        VerifyWorld("Shape");
+        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh)");
+        std::vector<int> vi = p.FindInt("indices");
+        std::vector<double> P = p.FindPoint3("P");
+        if (P.empty() || P.size() % 3) throw std::runtime_error("trianglemesh: \"point P\" missing or not a multiple of 3 values");
+        int nVerts = (int)P.size() / 3;
+        if (vi.empty()) {
+            if (nVerts == 3) vi = {0, 1, 2};
+            else throw std::runtime_error("Vertex indices \"indices\" not provided with triangle mesh shape");
+        }
+        if (vi.size() % 3) throw std::runtime_error("trianglemesh: number of indices is not a multiple of 3");
+        for (int v : vi) if (v < 0 || v >= nVerts) throw std::runtime_error("trianglemesh has out-of-bounds vertex index");
+        for (const auto& it : p.Items()) {
+            if (it.name == "N" || it.name == "S") throw std::runtime_error("trianglemesh: shading normals / tangents (\"" + it.name + "\") are not supported");
+            if (it.name == "alpha" || it.name == "shadowalpha") throw std::runtime_error("trianglemesh: alpha textures are not supported");
+            if (it.name == "uv" || it.name == "st") it.lookedUp = true; // parametrisation feeds textures only; materials here are constant
+        }
+        TriangleMesh m;
+        m.m_nTriangles = (int)vi.size() / 3; m.m_nVertices = nVerts;
+        m.m_vertexIndices = vi;
+        m.m_p.reserve(nVerts);
+        for (int i = 0; i < nVerts; ++i) { // TriangleMesh ctor: vertices to world space (Enigma/TriangleMesh.cpp:23-58)
+            double w[3];
+            m_ctm.Point(&P[3 * (size_t)i], w);
+            m.m_p.push_back(Vector3f((float)w[0], (float)w[1], (float)w[2]));
+        }
+        if (m_gs.currentMaterial < 0 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet()); // GraphicsState ctor, Enigma/Api.cpp:992-999
+        m.materialIndex = m_gs.currentMaterial < 0 ? m_defaultMaterial : m_gs.currentMaterial;
+        m.reverseOrientation = m_gs.reverseOrientation ^ m_ctm.SwapsHandedness(); // Enigma/TriangleMesh.cpp:287-289
+        if (!m_gs.areaLight.empty()) {
+            if (m_gs.areaLight != "diffuse" && m_gs.areaLight != "area") throw std::runtime_error("AreaLightSource \"" + m_gs.areaLight + "\" is not supported (diffuse)");
+            const ParamSet& ap = m_gs.areaLightParams; // CreateDiffuseAreaLight, Enigma/Lights.cpp:812-822
+            Spectrum L = ap.FindOneSpectrum("L", Spectrum(1.f)), sc = ap.FindOneSpectrum("scale", Spectrum(1.f));
+            m.emissive = true;
+            m.Le = Spectrum(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]);
+            m.nSamples = ap.FindOneInt("samples", ap.FindOneInt("nsamples", 1));
+            m.twoSided = ap.FindOneBool("twosided", false);
+        }
+        m_res->scene.AddTriangleMesh(m);
+        NoteUnused("Shape", p);
+    }
+    void pbrtObjectBegin(const std::string&) { throw std::runtime_error("ObjectBegin: object instancing is not supported"); }
+    void pbrtMakeNamedMedium(const std::string&, const ParamSet&) { throw std::runtime_error("MakeNamedMedium: participating media are not supported"); }
+
+    // WorldEnd: MakeIntegrator (camera, film, filter, sampler) + MakeScene + Render (Enigma/Api.cpp:1170-1254, 1103-1135)
+    void pbrtWorldEnd() {
+        VerifyWorld("WorldEnd");
+        while (!m_pushedGraphicsStates.empty()) { Warn("Missing end to AttributeBegin"); m_pushedGraphicsStates.pop_back(); m_pushedTransforms.pop_back(); }
+        FrontEndResult& R = *m_res;
+        // filter (Enigma/Filter.cpp:38-75)
+        const ParamSet& fp = m_opt.FilterParams;
+        std::unique_ptr<Filter> filter;
+        if (m_opt.FilterName == "box") filter.reset(new BoxFilter(Vector2f(fp.FindOneFloat("xwidth", 0.5f), fp.FindOneFloat("ywidth", 0.5f))));
+        else if (m_opt.FilterName == "gaussian") {
+            float xw = fp.FindOneFloat("xwidth", 2.f), yw = fp.FindOneFloat("ywidth", 2.f);
+            filter.reset(new GaussianFilter(Vector2f(xw, yw), fp.FindOneFloat("alpha", 2.f)));
+        } else if (m_opt.FilterName == "mitchell") {
+            float xw = fp.FindOneFloat("xwidth", 2.f), yw = fp.FindOneFloat("ywidth", 2.f);
+            float B = fp.FindOneFloat("B", 1.f / 3.f), C = fp.FindOneFloat("C", 1.f / 3.f);
+            filter.reset(new MitchellFilter(Vector2f(xw, yw), B, C));
+        } else if (m_opt.FilterName == "triangle") filter.reset(new TriangleFilter(Vector2f(fp.FindOneFloat("xwidth", 2.f), fp.FindOneFloat("ywidth", 2.f))));
+        else throw std::runtime_error("Filter \"" + m_opt.FilterName + "\" is not supported (box, gaussian, mitchell, triangle)");
+        R.filterName = m_opt.FilterName;
+        // film (Enigma/Film.cpp:330-372)
+        if (m_opt.FilmName != "image") throw std::runtime_error("Film \"" + m_opt.FilmName + "\" unknown.");
+        const ParamSet& flp = m_opt.FilmParams;
+        std::string filename = m_imageFile.empty() ? flp.FindOneString("filename", "") : m_imageFile;
+        int xres = flp.FindOneInt("xresolution", 1280), yres = flp.FindOneInt("yresolution", 720);
+        BBox2f crop;
+        std::vector<float> cr = flp.FindFloat("cropwindow");
+        if (cr.size() == 4) {
+            auto c01 = [](float v) { return std::min(1.f, std::max(0.f, v)); };
+            crop.m_min.x = c01(std::min(cr[0], cr[1])); crop.m_max.x = c01(std::max(cr[0], cr[1]));
+            crop.m_min.y = c01(std::min(cr[2], cr[3])); crop.m_max.y = c01(std::max(cr[2], cr[3]));
+        } else if (!cr.empty()) throw std::runtime_error("\"cropwindow\" expects 4 values");
+        float scale = flp.FindOneFloat("scale", 1.f), diagonal = flp.FindOneFloat("diagonal", 35.f);
+        float maxLum = flp.FindOneFloat("maxsampleluminance", InfinityF32);
+        std::unique_ptr<Film> film(new Film(Vector2i(xres, yres), crop, std::move(filter), diagonal, filename, scale, maxLum));
+        Film* filmPtr = film.get();
+        // camera (Enigma/Camera.cpp:385-432, 80-97)
+        if (m_opt.CameraName != "perspective") throw std::runtime_error("Camera \"" + m_opt.CameraName + "\" is not supported (perspective)");
+        const ParamSet& cp = m_opt.CameraParams;
+        float lensradius = cp.FindOneFloat("lensradius", 0.f), focaldistance = cp.FindOneFloat("focaldistance", 1e30f);
+        float frame = cp.FindOneFloat("frameaspectratio", float(xres) / float(yres));
+        float screen[4];
+        if (frame > 1.f) { screen[0] = -frame; screen[1] = frame; screen[2] = -1.f; screen[3] = 1.f; }
+        else { screen[0] = -1.f; screen[1] = 1.f; screen[2] = -1.f / frame; screen[3] = 1.f / frame; }
+        std::vector<float> sw = cp.FindFloat("screenwindow");
+        if (sw.size() == 4) for (int i = 0; i < 4; ++i) screen[i] = sw[i];
+        float fov = cp.FindOneFloat("fov", 90.f), halffov = cp.FindOneFloat("halffov", -1.f);
+        if (halffov > 0.f) fov = 2.f * halffov;
+        const double n = 1e-2, f = 1000.0;
+        Mat4d persp;
+        persp.m[2][2] = f / (f - n); persp.m[2][3] = -f * n / (f - n); persp.m[3][2] = 1; persp.m[3][3] = 0;
+        double invTan = 1.0 / std::tan((double)fov * 3.14159265358979323846 / 180.0 / 2);
+        Mat4d cameraToScreen = ScaleD(invTan, invTan, 1) * persp;
+        Mat4d screenToRaster = ScaleD(xres, yres, 1) * ScaleD(1.0 / ((double)screen[1] - screen[0]), 1.0 / ((double)screen[2] - screen[3]), 1) *
+                               TranslateD(-(double)screen[0], -(double)screen[3], 0);
+        Mat4d rasterToCamera = cameraToScreen.Inverse() * screenToRaster.Inverse();
+        R.camera.reset(new PerspectiveCamera(m_opt.CameraToWorld.ToFloat(), rasterToCamera.ToFloat(), cp.FindOneFloat("shutteropen", 0.f),
+                                             cp.FindOneFloat("shutterclose", 1.f), lensradius, focaldistance, std::move(film)));
+        // sampler (Enigma/Sampler.cpp:554-559)
+        if (m_opt.SamplerName != "sobol") throw std::runtime_error("Sampler \"" + m_opt.SamplerName + "\" is not supported: the GPU integrators reproduce the sobol sampler");
+        R.sampler.reset(new SobolSampler(m_opt.SamplerParams.FindOneInt("pixelsamples", 16), filmPtr->GetSampleBounds()));
+        // integrator (Enigma/PathIntegrator.cpp:182-201, Enigma/DirectLightingIntegrator.cpp:89-114)
+        const ParamSet& ip = m_opt.IntegratorParams;
+        R.integratorName = m_opt.IntegratorName;
+        R.maxDepth = ip.FindOneInt("maxdepth", 5);
+        BBox2i pixelBounds = filmPtr->GetSampleBounds();
+        std::vector<int> pb = ip.FindInt("pixelbounds");
+        if (pb.size() == 4) { // Intersection(sampleBounds, {{pb[0], pb[2]}, {pb[1], pb[3]}})
+            pixelBounds = BBox2i(Vector2i(std::max(pixelBounds.m_min.x, pb[0]), std::max(pixelBounds.m_min.y, pb[2])),
+                                 Vector2i(std::min(pixelBounds.m_max.x, pb[1]), std::min(pixelBounds.m_max.y, pb[3])));
+        }
+        R.pixelBounds = pixelBounds;
+        if (m_opt.IntegratorName == "path") {
+            R.rrThreshold = ip.FindOneFloat("rrthreshold", 1.f);
+            R.lightStrategy = ip.FindOneString("lightsamplestrategy", "spatial");
+            R.integrator.reset(new GpuPathIntegrator(R.maxDepth, R.camera, R.sampler, pixelBounds, R.rrThreshold, R.lightStrategy, m_device));
+        } else if (m_opt.IntegratorName == "directlighting") {
+            std::string st = ip.FindOneString("strategy", "all");
+            R.directStrategy = st == "one" ? 1 : 0;
+            R.integrator.reset(new GpuDirectLightingIntegrator(st == "one" ? GpuDirectLightingIntegrator::eLightStrategy::UniformSampleOne
+                                                                           : GpuDirectLightingIntegrator::eLightStrategy::UniformSampleAll,
+                                                               R.maxDepth, R.camera, R.sampler, pixelBounds, m_device));
+        } else throw std::runtime_error("Integrator \"" + m_opt.IntegratorName + "\" is not supported (path, directlighting)");
+        for (const char* what : {"Film", "Camera", "Sampler", "Integrator", "PixelFilter"}) {
+            const ParamSet& ps = std::string(what) == "Film" ? flp : std::string(what) == "Camera" ? cp : std::string(what) == "Sampler" ? m_opt.SamplerParams
+                                 : std::string(what) == "Integrator" ? ip : fp;
+            NoteUnused(what, ps);
+        }
+        if (R.scene.getNumLights() == 0) Warn("No light sources defined in scene; rendering a black image.");
+        m_inWorld = false;
+        if (m_render) R.integrator->Render(R.scene);
+    }
+
+    // ---- parsing (Enigma/Parser.cpp)
+    void pbrtParseFile(const std::string& filename) {
+        std::ifstream f(filename);
+        if (!f) throw std::runtime_error("Couldn't open scene file \"" + filename + "\"");
+        std::stringstream ss;
+        ss << f.rdbuf();
+        std::string dir;
+        size_t slash = filename.find_last_of('/');
+        if (slash != std::string::npos) dir = filename.substr(0, slash + 1);
+        Parse(ss.str(), dir);
+    }
+    void pbrtParseString(const std::string& s) { Parse(s, ""); }
+
+    void SetImageFile(const std::string& f) { m_imageFile = f; } // Options::imageFile overrides the Film's filename
+    FrontEndResult& Result() { return *m_res; }
+    std::unique_ptr<FrontEndResult> TakeResult() { return std::move(m_res); }
+
+private:
+    // ---- Create*Material (Enigma/Material.cpp:594-646)
+    static void texGuard(const ParamSet& p, const char* n) {
+        if (!p.FindTexture(n).empty()) throw std::runtime_error(std::string("material parameter \"") + n + "\" refers to a texture; only constant values are supported");
+    }
+    int MakeMaterial(const std::string& name, const ParamSet& p) {
+        EnigmaMaterial m{};
+        for (const char* n : {"Kd", "Ks", "Kr", "Kt", "eta", "k", "sigma", "roughness", "uroughness", "vroughness", "index", "bumpmap"}) texGuard(p, n);
+        if (p.Has("bumpmap")) throw std::runtime_error("bump mapping is not supported");
+        auto put = [](float* dst, const Spectrum& s) { dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; };
+        m.remap_roughness = p.FindOneBool("remaproughness", true) ? 1u : 0u;
+        if (name == "matte" || name == "") {
+            m.type = ENIGMA_MAT_MATTE;
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.5f)));
+            m.sigma = p.FindOneFloat("sigma", 0.f);
+        } else if (name == "metal") {
+            m.type = ENIGMA_MAT_METAL;
+            // the reference's defaults are the sampled copper spectra (Material.cpp:604-605); their RGB needs the CIE tables
+            if (!p.HasSpectrum("eta") || !p.HasSpectrum("k")) throw std::runtime_error("metal: give \"rgb eta\" and \"rgb k\" explicitly (sampled-spectrum defaults are not supported)");
+            put(m.eta, p.FindOneSpectrum("eta", Spectrum(1.f)));
+            put(m.k, p.FindOneSpectrum("k", Spectrum(1.f)));
+            float rough = p.FindOneFloat("roughness", .5f);
+            m.uroughness = p.FindOneFloat("uroughness", rough); // MetalMaterial: u/v fall back to roughness (Material.cpp:121-126)
+            m.vroughness = p.FindOneFloat("vroughness", rough);
+        } else if (name == "glass") {
+            m.type = ENIGMA_MAT_GLASS;
+            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(1.f)));
+            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(1.f)));
+            m.index = p.Has("eta") ? p.FindOneFloat("eta", 1.5f) : p.FindOneFloat("index", 1.5f);
+            m.uroughness = p.FindOneFloat("uroughness", 0.f);
+            m.vroughness = p.FindOneFloat("vroughness", 0.f);
+        } else if (name == "plastic") {
+            m.type = ENIGMA_MAT_PLASTIC;
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
+            m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
+        } else throw std::runtime_error("Material \"" + name + "\" is not supported (matte, metal, glass, plastic)");
+        p.FindOneString("type", ""); // consumed by MakeNamedMaterial
+        NoteUnused("Material", p);
+        return m_res->scene.AddMaterial(m);
+    }
+
+    void VerifyOptions(const char* fn) const { if (m_inWorld) throw std::runtime_error(std::string("Options cannot be set inside world block; \"") + fn + "\" not allowed."); }
+    void VerifyWorld(const char* fn) const { if (!m_inWorld) throw std::runtime_error(std::string("Scene description must be inside world block; \"") + fn + "\" not allowed."); }
+    void Warn(const std::string& w) { m_res->warnings.push_back(w); }
+    void NoteUnused(const char* what, const ParamSet& p) { for (const auto& u : p.Unused()) Warn(std::string(what) + ": parameter \"" + u + "\" not used"); }
+
+    // ---- tokenizer + directive loop
+    struct Tok { std::string s; bool quoted = false; };
+    static std::vector<Tok> Tokenize(const std::string& src) {
+        std::vector<Tok> out;
+        size_t i = 0, n = src.size();
+        while (i < n) {
+            char c = src[i];
+            if (isspace((unsigned char)c)) { ++i; continue; }
+            if (c == '#') { while (i < n && src[i] != '\n') ++i; continue; }
+            if (c == '[' || c == ']') { out.push_back({std::string(1, c), false}); ++i; continue; }
+            if (c == '"') {
+                size_t j = i + 1;
+                std::string s;
+                while (j < n && src[j] != '"') {
+                    if (src[j] == '\n') throw std::runtime_error("unterminated string in scene description");
+                    if (src[j] == '\\' && j + 1 < n) { ++j; s += src[j] == 'n' ? '\n' : src[j] == 't' ? '\t' : src[j]; }
+                    else s += src[j];
+                    ++j;
+                }
+                if (j >= n) throw std::runtime_error("premature EOF inside a string");
+                out.push_back({s, true});
+                i = j + 1;
+                continue;
+            }
+            size_t j = i;
+            while (j < n && !isspace((unsigned char)src[j]) && src[j] != '"' && src[j] != '[' && src[j] != ']' && src[j] != '#') ++j;
+            out.push_back({src.substr(i, j - i), false});
+            i = j;
+        }
+        return out;
+    }
+    static bool IsNumber(const Tok& t) {
+        if (t.quoted || t.s.empty()) return false;
+        char* end = nullptr;
+        strtod(t.s.c_str(), &end);
+        return end && *end == 0;
+    }
+    struct Cursor {
+        const std::vector<Tok>& t; size_t i = 0;
+        bool done() const { return i >= t.size(); }
+        const Tok& peek() const { return t[i]; }
+        Tok next(const char* what) { if (done()) throw std::runtime_error(std::string("premature EOF: expected ") + what); return t[i++]; }
+        float num(const char* d) { Tok k = next("a number"); if (!IsNumber(k)) throw std::runtime_error(std::string(d) + ": expected a number, got \"" + k.s + "\""); return (float)strtod(k.s.c_str(), nullptr); }
+        std::string str(const char* d) { Tok k = next("a quoted string"); if (!k.quoted) throw std::runtime_error(std::string(d) + ": expected a quoted string, got \"" + k.s + "\""); return k.s; }
+    };
+    static ParamSet ParseParams(Cursor& c) {
+        ParamSet ps;
+        while (!c.done() && c.peek().quoted) {
+            std::string decl = c.next("a parameter declaration").s;
+            std::istringstream ds(decl);
+            ParamSetItem it;
+            if (!(ds >> it.type >> it.name)) throw std::runtime_error("parameter \"" + decl + "\" doesn't have a type declaration");
+            static const char* known[] = {"integer", "float", "bool", "string", "point", "point3", "point3f", "point2", "vector", "vector3", "vector3f", "vector2", "normal",
+                                          "normal3", "normal3f", "rgb", "color", "spectrum", "blackbody", "xyz", "texture"};
+            bool ok = false;
+            for (const char* k : known) ok = ok || it.type == k;
+            if (!ok) throw std::runtime_error("Unable to decode type of parameter \"" + decl + "\"");
+            bool bracket = !c.done() && !c.peek().quoted && c.peek().s == "[";
+            if (bracket) c.next("[");
+            bool any = false;
+            while (!c.done()) {
+                const Tok& k = c.peek();
+                if (!k.quoted && k.s == "]") break;
+                if (!bracket && any) break;
+                if (k.quoted) it.strs.push_back(k.s);
+                else if (IsNumber(k)) it.nums.push_back(strtod(k.s.c_str(), nullptr));
+                else if (k.s == "true" || k.s == "false") it.strs.push_back(k.s);
+                else throw std::runtime_error("parameter \"" + decl + "\": unexpected token \"" + k.s + "\"");
+                c.next("a value");
+                any = true;
+            }
+            if (bracket) { Tok e = c.next("]"); if (e.quoted || e.s != "]") throw std::runtime_error("parameter \"" + decl + "\": expected ]"); }
+            if (!any) throw std::runtime_error("parameter \"" + decl + "\" has no values");
+            ps.Add(it);
+        }
+        return ps;
+    }
+    void Parse(const std::string& src, const std::string& dir) {
+        std::vector<Tok> toks = Tokenize(src);
+        Cursor c{toks};
+        auto nums = [&](int n, const char* d, float* out) {
+            bool bracket = !c.done() && !c.peek().quoted && c.peek().s == "[";
+            if (bracket) c.next("[");
+            for (int i = 0; i < n; ++i) out[i] = c.num(d);
+            if (bracket) { Tok e = c.next("]"); if (e.s != "]") throw std::runtime_error(std::string(d) + ": expected ]"); }
+        };
+        while (!c.done()) {
+            Tok t = c.next("a directive");
+            if (t.quoted) throw std::runtime_error("unexpected string \"" + t.s + "\" where a directive was expected");
+            const std::string& d = t.s;
+            float v[16];
+            if (d == "Identity") pbrtIdentity();
+            else if (d == "Translate") { nums(3, "Translate", v); pbrtTranslate(v[0], v[1], v[2]); }
+            else if (d == "Scale") { nums(3, "Scale", v); pbrtScale(v[0], v[1], v[2]); }
+            else if (d == "Rotate") { nums(4, "Rotate", v); pbrtRotate(v[0], v[1], v[2], v[3]); }
+            else if (d == "LookAt") { nums(9, "LookAt", v); pbrtLookAt(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]); }
+            else if (d == "ConcatTransform") { nums(16, "ConcatTransform", v); pbrtConcatTransform(v); }
+            else if (d == "Transform") { nums(16, "Transform", v); pbrtTransform(v); }
+            else if (d == "CoordinateSystem") pbrtCoordinateSystem(c.str("CoordinateSystem"));
+            else if (d == "CoordSysTransform") pbrtCoordSysTransform(c.str("CoordSysTransform"));
+            else if (d == "Camera") { std::string n = c.str("Camera"); pbrtCamera(n, ParseParams(c)); }
+            else if (d == "Film") { std::string n = c.str("Film"); pbrtFilm(n, ParseParams(c)); }
+            else if (d == "Sampler") { std::string n = c.str("Sampler"); pbrtSampler(n, ParseParams(c)); }
+            else if (d == "PixelFilter") { std::string n = c.str("PixelFilter"); pbrtPixelFilter(n, ParseParams(c)); }
+            else if (d == "Integrator" || d == "SurfaceIntegrator") { std::string n = c.str("Integrator"); pbrtIntegrator(n, ParseParams(c)); }
+            else if (d == "Accelerator") { std::string n = c.str("Accelerator"); pbrtAccelerator(n, ParseParams(c)); }
+            else if (d == "WorldBegin") pbrtWorldBegin();
+            else if (d == "WorldEnd") pbrtWorldEnd();
+            else if (d == "AttributeBegin") pbrtAttributeBegin();
+            else if (d == "AttributeEnd") pbrtAttributeEnd();
+            else if (d == "TransformBegin") pbrtTransformBegin();
+            else if (d == "TransformEnd") pbrtTransformEnd();
+            else if (d == "ReverseOrientation") pbrtReverseOrientation();
+            else if (d == "Material") { std::string n = c.str("Material"); pbrtMaterial(n, ParseParams(c)); }
+            else if (d == "MakeNamedMaterial") { std::string n = c.str("MakeNamedMaterial"); pbrtMakeNamedMaterial(n, ParseParams(c)); }
+            else if (d == "NamedMaterial") pbrtNamedMaterial(c.str("NamedMaterial"));
+            else if (d == "LightSource") { std::string n = c.str("LightSource"); pbrtLightSource(n, ParseParams(c)); }
+            else if (d == "AreaLightSource") { std::string n = c.str("AreaLightSource"); pbrtAreaLightSource(n, ParseParams(c)); }
+            else if (d == "Shape") { std::string n = c.str("Shape"); pbrtShape(n, ParseParams(c)); }
+            else if (d == "Texture") { std::string n = c.str("Texture"), ty = c.str("Texture"), cl = c.str("Texture"); pbrtTexture(n, ty, cl, ParseParams(c)); }
+            else if (d == "Include") {
+                std::string inc = c.str("Include");
+                pbrtParseFile((!inc.empty() && inc[0] == '/') ? inc : dir + inc);
+            }
+            else if (d == "ObjectBegin") pbrtObjectBegin(c.str("ObjectBegin"));
+            else if (d == "ObjectEnd" || d == "ObjectInstance") throw std::runtime_error(d + ": object instancing is not supported");
+            else if (d == "MakeNamedMedium") { std::string n = c.str("MakeNamedMedium"); pbrtMakeNamedMedium(n, ParseParams(c)); }
+            else if (d == "MediumInterface") throw std::runtime_error("MediumInterface: participating media are not supported");
+            else if (d == "ActiveTransform" || d == "TransformTimes") throw std::runtime_error(d + ": animated transforms are not supported");
+            else throw std::runtime_error("unknown directive \"" + d + "\"");
+        }
+    }
+
+    bool m_render;
+    int m_device;
+    bool m_inWorld = false;
+    Mat4d m_ctm;
+    std::map<std::string, Mat4d> m_namedCoordinateSystems;
+    RenderOptions m_opt;
+    GraphicsState m_gs;
+    std::vector<GraphicsState> m_pushedGraphicsStates;
+    std::vector<Mat4d> m_pushedTransforms;
+    std::string m_imageFile;
+    int m_defaultMaterial = -1;
+    std::unique_ptr<FrontEndResult> m_res{new FrontEndResult()};
+};
+
+} // namespace RayTrace

@@ -4,12 +4,15 @@
 // integrator->Render(scene) like Enigma/Main.h:245, and writes the film's RGB as raw floats.
 //
 //   enigma_render <scene.bin> <out.f32>
+//   enigma_render <scene.pbrt> [out.pfm | out.f32]      scene description through the pbrt front end (pbrt_frontend.h)
+//   enigma_render --dump <scene.pbrt> <out.json>        parse only (no GPU): what the front end hands to the integrator
 // scene.bin (little endian): "ESC1", then int32 {xres, yres, spp, maxDepth, integrator (PathIntegrator: 0 uniform / 1 power
 //   light distribution; DirectLightingIntegrator: 2 strategy all / 3 strategy one),
 //   nVerts, nTris, nMaterials}, float {rrThreshold, lensRadius, focalDistance}, float[16] rasterToCamera,
 //   float[16] cameraToWorld, float[nVerts*3], int32[nTris*3], int32[nTris] material,
 //   int32[nTris] emissive flag, float[nTris*3] Le, EnigmaMaterial[nMaterials].
 #include "enigma_host.h"
+#include "pbrt_frontend.h"
 
 #include <cstring>
 #include <fstream>
@@ -19,8 +22,92 @@ using namespace RayTrace;
 
 template <class T> static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), sizeof(T) * n); }
 
+static bool endsWith(const std::string& s, const char* suffix) {
+    size_t n = strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+static void dumpJson(const FrontEndResult& R, std::ostream& o) {
+    o.precision(9);
+    auto arr = [&](const float* v, size_t n) { o << "["; for (size_t i = 0; i < n; ++i) o << (i ? "," : "") << (std::isinf(v[i]) ? (v[i] > 0 ? 1e39 : -1e39) : (double)v[i]); o << "]"; };
+    const Film& film = R.camera->GetFilm();
+    const ProjectiveCamera& cam = static_cast<const ProjectiveCamera&>(*R.camera);
+    const SobolSampler& sob = static_cast<const SobolSampler&>(*R.sampler);
+    const BBox2i &cb = film.m_croppedPixelBounds, &sb = sob.m_sampleBounds, &pb = R.pixelBounds;
+    o << "{\"film\":{\"xres\":" << film.m_fullResolution.x << ",\"yres\":" << film.m_fullResolution.y << ",\"cropped\":[" << cb.m_min.x << "," << cb.m_min.y << ","
+      << cb.m_max.x << "," << cb.m_max.y << "],\"filter\":\"" << R.filterName << "\",\"radius\":[" << film.m_filter->m_radius.x << "," << film.m_filter->m_radius.y
+      << "],\"filename\":\"" << film.m_filename << "\",\"max_sample_luminance\":";
+    float msl = film.GetMaxSampleLuminance(); arr(&msl, 1);
+    o << ",\"filter_table\":"; arr(film.GetFilterTable(), 256);
+    o << "},\n\"camera\":{\"c2w\":"; arr(&cam.m_cameraToWorld.m_mat[0][0], 16);
+    o << ",\"r2c\":"; arr(&cam.m_rasterToCamera.m_mat[0][0], 16);
+    o << ",\"lensradius\":"; arr(&cam.m_lensRadius, 1); o << ",\"focaldistance\":"; arr(&cam.m_focalDistance, 1);
+    o << "},\n\"sampler\":{\"spp\":" << sob.m_samplesPerPixel << ",\"sample_bounds\":[" << sb.m_min.x << "," << sb.m_min.y << "," << sb.m_max.x << "," << sb.m_max.y << "]},\n";
+    o << "\"integrator\":{\"name\":\"" << R.integratorName << "\",\"maxdepth\":" << R.maxDepth << ",\"rrthreshold\":" << R.rrThreshold << ",\"lightsamplestrategy\":\""
+      << R.lightStrategy << "\",\"strategy\":" << R.directStrategy << ",\"pixel_bounds\":[" << pb.m_min.x << "," << pb.m_min.y << "," << pb.m_max.x << "," << pb.m_max.y << "]},\n";
+    o << "\"materials\":[";
+    for (size_t i = 0; i < R.scene.m_materials.size(); ++i) {
+        const EnigmaMaterial& m = R.scene.m_materials[i];
+        o << (i ? "," : "") << "{\"type\":" << m.type << ",\"remap\":" << m.remap_roughness << ",\"kd\":"; arr(m.kd, 3);
+        o << ",\"ks\":"; arr(m.ks, 3); o << ",\"kr\":"; arr(m.kr, 3); o << ",\"kt\":"; arr(m.kt, 3); o << ",\"eta\":"; arr(m.eta, 3); o << ",\"k\":"; arr(m.k, 3);
+        o << ",\"sigma\":" << m.sigma << ",\"uroughness\":" << m.uroughness << ",\"vroughness\":" << m.vroughness << ",\"index\":" << m.index << "}";
+    }
+    o << "],\n\"meshes\":[";
+    for (size_t i = 0; i < R.scene.m_meshes.size(); ++i) {
+        const TriangleMesh& m = R.scene.m_meshes[i];
+        o << (i ? ",\n" : "") << "{\"material\":" << m.materialIndex << ",\"reverse\":" << (m.reverseOrientation ? 1 : 0) << ",\"emissive\":" << (m.emissive ? 1 : 0)
+          << ",\"twosided\":" << (m.twoSided ? 1 : 0) << ",\"nsamples\":" << m.nSamples << ",\"Le\":[" << m.Le[0] << "," << m.Le[1] << "," << m.Le[2] << "],\"indices\":[";
+        for (size_t k = 0; k < m.m_vertexIndices.size(); ++k) o << (k ? "," : "") << m.m_vertexIndices[k];
+        o << "],\"P\":[";
+        for (size_t k = 0; k < m.m_p.size(); ++k) o << (k ? "," : "") << m.m_p[k].x << "," << m.m_p[k].y << "," << m.m_p[k].z;
+        o << "]}";
+    }
+    o << "],\n\"point_lights\":[";
+    for (size_t i = 0; i < R.scene.m_pointLights.size(); ++i) {
+        const auto& l = R.scene.m_pointLights[i];
+        o << (i ? "," : "") << "{\"order\":" << l.order << ",\"from\":[" << l.from.x << "," << l.from.y << "," << l.from.z << "],\"I\":[" << l.I[0] << "," << l.I[1] << "," << l.I[2] << "]}";
+    }
+    o << "],\n\"warnings\":[";
+    for (size_t i = 0; i < R.warnings.size(); ++i) {
+        std::string w = R.warnings[i];
+        for (char& ch : w) if (ch == '"' || ch == '\\') ch = '\'';
+        o << (i ? "," : "") << "\"" << w << "\"";
+    }
+    o << "]}\n";
+}
+
+// Scene description file -> front end -> GPU integrator, like pbrtParseFile + pbrtWorldEnd in Enigma/Main.h.
+static int runPbrt(const std::string& scene, const std::string& out, bool dumpOnly) {
+    try {
+        PbrtApi api(!dumpOnly);
+        if (!dumpOnly && endsWith(out, ".pfm")) api.SetImageFile(out);
+        api.pbrtParseFile(scene);
+        FrontEndResult& R = api.Result();
+        if (!R.camera) { std::cerr << "scene description has no WorldEnd\n"; return 1; }
+        for (const std::string& w : R.warnings) std::cerr << "Warning: " << w << "\n";
+        if (dumpOnly) {
+            std::ofstream o(out);
+            dumpJson(R, o);
+            return o ? 0 : 1;
+        }
+        if (!out.empty() && !endsWith(out, ".pfm")) {
+            const std::vector<float>& rgb = R.camera->m_film->GetRGB();
+            std::ofstream o(out, std::ios::binary);
+            o.write(reinterpret_cast<const char*>(rgb.data()), rgb.size() * sizeof(float));
+        }
+        const EnigmaStats& st = R.integrator->GetStats();
+        std::cout << "rendered " << scene << " rays " << (st.rays_closest + st.rays_shadow + st.rays_mis) << " in " << st.ms_render << " ms\n";
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << "Error: " << e.what() << "\n";
+        return 1;
+    }
+}
+
 int main(int argc, char** argv) {
-    if (argc < 3) { std::cerr << "usage: enigma_render scene.bin out.f32\n"; return 2; }
+    if (argc >= 4 && std::string(argv[1]) == "--dump") return runPbrt(argv[2], argv[3], true);
+    if (argc >= 2 && endsWith(argv[1], ".pbrt")) return runPbrt(argv[1], argc >= 3 ? argv[2] : "", false);
+    if (argc < 3) { std::cerr << "usage: enigma_render scene.bin out.f32 | scene.pbrt [out.pfm|out.f32] | --dump scene.pbrt out.json\n"; return 2; }
     std::ifstream f(argv[1], std::ios::binary);
     char magic[4];
     rd(f, magic, 4);

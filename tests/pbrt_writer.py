@@ -1,0 +1,77 @@
+"""Writes a pbrt-format scene description for a SceneArrays scene (test helper for the scene-description
+front end).  One trianglemesh Shape per run of triangles that share material and emission; materials as
+MakeNamedMaterial.  Light order in the file = light order in SceneArrays (lights are created in file order)."""
+import numpy as np
+
+from raytrace_amd import abi
+
+
+def _rgb(name, v):
+    return '"rgb %s" [%.9g %.9g %.9g]' % (name, v[0], v[1], v[2])
+
+
+def material_text(i, m):
+    t = {abi.MAT_MATTE: "matte", abi.MAT_METAL: "metal", abi.MAT_GLASS: "glass", abi.MAT_PLASTIC: "plastic"}[m.type]
+    parts = ['MakeNamedMaterial "m%d" "string type" "%s"' % (i, t)]
+    remap = '"bool remaproughness" "%s"' % ("true" if m.remap_roughness else "false")
+    if t == "matte":
+        parts += [_rgb("Kd", m.kd), '"float sigma" %.9g' % m.sigma]
+    elif t == "metal":
+        parts += [_rgb("eta", m.eta), _rgb("k", m.k), '"float uroughness" %.9g' % m.uroughness, '"float vroughness" %.9g' % m.vroughness, remap]
+    elif t == "glass":
+        parts += [_rgb("Kr", m.kr), _rgb("Kt", m.kt), '"float index" %.9g' % m.index, '"float uroughness" %.9g' % m.uroughness,
+                  '"float vroughness" %.9g' % m.vroughness, remap]
+    else:
+        parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), '"float roughness" %.9g' % m.uroughness, remap]
+    return " ".join(parts)
+
+
+def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
+               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens=""):
+    out = ["# written by tests/pbrt_writer.py",
+           "LookAt %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g" % (tuple(eye) + tuple(look) + tuple(up)),
+           'Camera "perspective" "float fov" %.9g %s' % (fov, lens),
+           'Film "image" "integer xresolution" [%d] "integer yresolution" [%d] %s' % (xres, yres, film_extra),
+           'Sampler "sobol" "integer pixelsamples" %d' % spp, pixel_filter, integrator, "WorldBegin"]
+    if world_prefix:
+        out.append(world_prefix)
+    for i in range(sc.n_materials):
+        out.append(material_text(i, sc.materials[i]))
+    nT = sc.indices.shape[0]
+    # point lights keep their position among the area lights: emit each before the first triangle whose light index is larger
+    point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type == abi.LIGHT_POINT]
+    emitted = 0
+
+    def flush_points(upto):
+        nonlocal emitted
+        while emitted < len(point) and point[emitted][0] < upto:
+            l = point[emitted][1]
+            out.append('LightSource "point" %s "point from" [%.9g %.9g %.9g]' % (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2]))
+            emitted += 1
+    t = 0
+    while t < nT:
+        e = t
+        li = int(sc.tri_light[t])
+        key = lambda k: (int(sc.tri_material[k]), int(sc.tri_light[k]) >= 0,
+                         tuple(sc.lights[sc.tri_light[k]].L) + (sc.lights[sc.tri_light[k]].two_sided, sc.lights[sc.tri_light[k]].n_samples) if sc.tri_light[k] >= 0 else None,
+                         int(sc.tri_flags[k]) if sc.tri_flags is not None else 0)
+        while e < nT and key(e) == key(t) and (li < 0 or int(sc.tri_light[e]) == li + (e - t)):
+            e += 1
+        if li >= 0:
+            flush_points(li)
+        verts = sc.vertices[sc.indices[t:e].reshape(-1)]
+        idx = np.arange(verts.shape[0])
+        out.append("AttributeBegin")
+        out.append('  NamedMaterial "m%d"' % int(sc.tri_material[t]))
+        if sc.tri_flags is not None and int(sc.tri_flags[t]) & 1:
+            out.append("  ReverseOrientation")
+        if li >= 0:
+            l = sc.lights[li]
+            out.append('  AreaLightSource "diffuse" %s "bool twosided" "%s" "integer samples" %d' % (_rgb("L", l.L), "true" if l.two_sided else "false", max(1, l.n_samples)))
+        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' %
+                   (" ".join(str(int(v)) for v in idx), " ".join("%.9g" % float(v) for v in verts.reshape(-1))))
+        out.append("AttributeEnd")
+        t = e
+    flush_points(1 << 30)
+    out.append("WorldEnd")
+    return "\n".join(out) + "\n"
