@@ -596,11 +596,13 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
     h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
-    // passes of k sample numbers over all pixels, ~8M paths in flight (capped by the 12-bit sample slot)
+    // passes of k sample numbers over all pixels, ~32M paths in flight (capped by the 12-bit sample slot)
     const bool direct = h->useDirect;
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
-    const size_t targetPaths = std::max<size_t>((size_t)1 << 16, ((size_t)8 << 20) / std::max<size_t>(1, (raysPerPath + pendingLevels) / 4));
+    size_t basePaths = (size_t)32 << 20; // ~11 GB of path state at 330 B per path; larger launches run closer to the hardware's rates
+    if (const char* e = getenv("ENIGMA_PATHS_IN_FLIGHT")) basePaths = (size_t)atoll(e);
+    const size_t targetPaths = std::max<size_t>((size_t)1 << 16, basePaths / std::max<size_t>(1, (raysPerPath + pendingLevels) / 4));
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
