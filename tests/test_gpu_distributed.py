@@ -1,0 +1,53 @@
+"""The pieces of the multi-GPU path that one GPU can exercise: the torch view of the library's device film is the
+film itself (no copy), RCCL accepts it (memory the library allocated, not torch), and the sample-sharded render +
+sum of films equals the whole render.  The N > 1 reduce itself runs in tests/test_distributed_cpu.py (gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import common
+import raytrace_amd as ra
+from raytrace_amd import distributed
+
+pytestmark = pytest.mark.gpu
+
+
+def test_film_view_aliases_device_film_and_rccl_accepts_it():
+    import torch
+    import torch.distributed as dist
+    sc, cam, film, integ = common.cornell_setup(res=64, spp=16, variant="microfacet")
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    dev = torch.device("cuda", 0)
+    t = distributed.film_tensor(r, dev)
+    assert t.numel() == 64 * 64 * 4 and float(t.abs().sum()) == 0.0
+    r.render(0, 16)
+    torch.cuda.synchronize()
+    whole = r.film()
+    assert np.array_equal(t.cpu().numpy().reshape(64, 64, 4), whole)         # the view sees what the library rendered
+    # two "ranks" on this one GPU: disjoint sample ranges into two films, summed with torch on the device views
+    lo0, hi0 = distributed.shard_range(0, 16, 0, 2)
+    lo1, hi1 = distributed.shard_range(0, 16, 1, 2)
+    assert (lo0, hi0, lo1, hi1) == (0, 8, 8, 16)
+    r2 = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.clear(); r.render(lo0, hi0); r2.render(lo1, hi1)
+    t2 = distributed.film_tensor(r2, dev)
+    t += t2                                                                   # what reduce(SUM) does on rank 0
+    torch.cuda.synchronize()
+    summed = r.film()
+    assert np.array_equal(summed[..., 3], whole[..., 3])
+    assert np.allclose(summed, whole, rtol=1e-5, atol=1e-5)
+    # RCCL on library-owned memory (world size 1: the collective is a no-op copy, but registration and launch happen)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        before = t.clone()
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(t, before)
+    finally:
+        dist.destroy_process_group()
+    r.close(); r2.close()
