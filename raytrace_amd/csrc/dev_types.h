@@ -83,6 +83,7 @@ struct DevIntegrator {
     int maxDepth;
     float rrThreshold;
     int rx0, ry0, rw, rh;       // render region = sample bounds clipped to pixel bounds
+    uint32_t nPixels, slotBase; // rw * rh; sample slot of the pass's first sample number
     // DirectLightingIntegrator
     int dlStrategy;             // ENIGMA_DL_SAMPLE_*
     int arrayEndDim;            // GlobalSampler::m_arrayEndDim: first dimension after the sample arrays
@@ -101,16 +102,15 @@ struct DevDirect {
     float4* pendB;        // throughput of the child
 };
 
-// Per-path state, structure of arrays (float4 where the fields travel together).
+// Per-path state, structure of arrays of float4 so that a kernel touches one 16-byte slot per field group:
+// the sampler cursor travels in the spare word of the ray direction, the hit triangle in the spare word of the
+// hit record, and the pixel / sample slot of a path follow from its index (path = slot * nPixels + pixel).
 struct DevPaths {
     float4* rayO;     // o.xyz, unused
-    float4* rayD;     // d.xyz, unused
+    float4* rayD;     // d.xyz, bits(state): dim[12:22) | bounces or depth[22:30) | specularBounce[30]
     float4* L;        // radiance accumulated so far, unused
     float4* beta;     // throughput rgb, etaScale
-    float4* hit;      // t, b0, b1, b2
-    int32_t* hitTri;  // triangle (device order) or -1
-    uint32_t* pixel;  // x | y << 16, pixel relative to the sample-bounds origin
-    uint32_t* state;  // sampleSlot[0:12) | dim[12:22) | bounces[22:30) | specularBounce[30]
+    float4* hit;      // bits(triangle, device order), b0, b1, b2
     float2* pfilm;    // CameraSample::m_image
 };
 

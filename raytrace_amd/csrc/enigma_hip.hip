@@ -91,8 +91,7 @@ struct EnigmaCtx {
     size_t capacity = 0;
     DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, shW, miO, miD, miW;
     DevBuf<uint32_t> shIdx, miIdx;
-    DevBuf<int32_t> hitTri;
-    DevBuf<uint32_t> pixel, state, extQ[2], matQ[kQueueKinds];
+    DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
     DevBuf<float2> pfilm;
     DevBuf<DevCounters> counters;
 
@@ -141,8 +140,8 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
                             &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
     for (auto* b : f4) b->release();
     h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
-    h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release(); h->hitTri.release();
-    h->pixel.release(); h->state.release(); h->extQ[0].release(); h->extQ[1].release();
+    h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
+    h->extQ[0].release(); h->extQ[1].release();
     for (auto& q : h->matQ) q.release();
     h->pfilm.release(); h->counters.release(); h->shIdx.release(); h->miIdx.release();
     h->bitConst.release(); h->arrayOff.release(); h->pendCount.release(); h->pendO.release(); h->pendD.release(); h->pendB.release();
@@ -502,11 +501,8 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
     if (n <= h->capacity) return ENIGMA_OK;
     DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit};
     for (auto* b : f4) HIPCHK(h, b->alloc(n));
-    HIPCHK(h, h->hitTri.alloc(n));
     HIPCHK(h, h->arrayOff.alloc(n));
     HIPCHK(h, h->pendCount.alloc(n));
-    HIPCHK(h, h->pixel.alloc(n));
-    HIPCHK(h, h->state.alloc(n));
     HIPCHK(h, h->pfilm.alloc(n));
     HIPCHK(h, h->extQ[0].alloc(n));
     HIPCHK(h, h->extQ[1].alloc(n));
@@ -621,13 +617,15 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         h->sampler.sampleBase = (unsigned long long)(sample_begin + c0);
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
-        DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->hitTri.p, h->pixel.p, h->state.p, h->pfilm.p};
+        DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->pfilm.p};
         DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p, h->shIdx.p, (uint32_t)raysPerPath}, misq{h->miO.p, h->miD.p, h->miW.p, h->miIdx.p, (uint32_t)raysPerPath};
         DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
         for (int64_t s0 = 0; s0 < cn; s0 += k) {
             uint32_t ks = (uint32_t)std::min<int64_t>(k, cn - s0);
             uint32_t nPaths = nPixels * ks;
+            h->integ.nPixels = nPixels;
+            h->integ.slotBase = (uint32_t)s0; // kernels take the integrator by value: set before the pass's launches
             int gridAll = (int)((nPaths + kBlock - 1) / kBlock);
             // traversal grids: enough blocks that the hardware dispatcher balances rays of very different cost,
             // few enough that launches late in a pass (short queues) do not drown in empty blocks

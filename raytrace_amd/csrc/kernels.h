@@ -52,6 +52,16 @@ DEV float sampleDimensionOf(const DevSampler& S, uint32_t relx, uint32_t rely, u
     return smin((float)v * 0x1p-32f, kOneMinusEpsilon); // dims >= 2 only
 }
 
+// Pixel (relative to the sample-bounds origin) and sample slot of a path: paths of a pass are numbered
+// slot-major over the pixels of the render region.
+DEV void pathPixel(const DevIntegrator& I, const DevSampler& S, uint32_t p, uint32_t* relx, uint32_t* rely, uint32_t* slot) {
+    uint32_t s = p / I.nPixels, pix = p - s * I.nPixels;
+    uint32_t y = pix / (uint32_t)I.rw, x = pix - y * (uint32_t)I.rw;
+    *relx = (uint32_t)(I.rx0 - S.sbx0) + x;
+    *rely = (uint32_t)(I.ry0 - S.sby0) + y;
+    *slot = I.slotBase + s;
+}
+
 // ---------------------------------------------------------------- camera
 DEV F3 xfPoint(const float* m, F3 p) { // Transform::transformPoint, Enigma/Transform.h:36-45
     float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
@@ -189,11 +199,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
     F3 o, d;
     cameraRay(C, fx, fy, lu, lv, &o, &d);
     P.rayO[i] = mk4(o, 0.f);
-    P.rayD[i] = mk4(d, 0.f);
+    P.rayD[i] = mk4(d, __uint_as_float(packState(0u, firstDim, 0u, 0u))); // 5 after GetCameraSample; DirectLightingIntegrator skips its sample arrays
     P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.beta[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-    P.pixel[i] = relx | (rely << 16);
-    P.state[i] = packState(slot, firstDim, 0u, 0u); // 5 after GetCameraSample; DirectLightingIntegrator skips its sample arrays
     P.pfilm[i] = make_float2(fx, fy);
     if (D.arrayOff) { D.arrayOff[i] = 0; D.pendCount[i] = 0; }
     if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
@@ -251,7 +259,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
         ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
-        uint32_t pos = kNoRay, p = 0;
+        uint32_t pos = kNoRay, p = 0, state = 0;
         bool exhausted = false;
         for (;;) {
             bool idle = w.done();
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                     uint32_t kind = 0;
                     const Hit& h = w.h;
                     if (h.tri >= 0) {
-                        uint32_t st = P.state[p];
+                        uint32_t st = state;
                         uint32_t bounces = stBounces(st);
                         const float4* tp = tris + (size_t)h.tri * 3;
                         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
@@ -279,8 +287,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                         }
                         if (DL || (int)bounces < I.maxDepth) {
                             kind = triKind(mw) + 1u;
-                            P.hit[p] = make_float4(h.t, h.b0, h.b1, h.b2);
-                            P.hitTri[p] = h.tri;
+                            P.hit[p] = make_float4(__int_as_float(h.tri), h.b0, h.b1, h.b2);
                         }
                     } else if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
                     kindOf[pos] = (uint8_t)kind;
@@ -292,7 +299,9 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                     if (idle && mine < chunkCount) {
                         pos = mine;
                         p = queue ? queue[chunk + mine] : chunk + mine;
-                        w.start(xyz(P.rayO[p]), xyz(P.rayD[p]), EDEV_INF);
+                        float4 rd = P.rayD[p];
+                        state = __float_as_uint(rd.w);
+                        w.start(xyz(P.rayO[p]), xyz(rd), EDEV_INF);
                     }
                     exhausted = base + nIdle >= chunkCount;
                 }
@@ -501,13 +510,14 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
         uint32_t p = 0;
         if (active) {
             p = matQueue[i];
-            F3 d = xyz(P.rayD[p]);
+            float4 rdv = P.rayD[p];
+            F3 d = xyz(rdv);
             float4 hv = P.hit[p];
-            int tri = P.hitTri[p];
-            uint32_t st = P.state[p];
-            uint32_t slot = stSlot(st), dim = stDim(st), bounces = stBounces(st);
-            uint32_t pix = P.pixel[p];
-            uint32_t px = pix & 0xffffu, py = pix >> 16; // relative to the sample-bounds origin
+            int tri = __float_as_int(hv.x);
+            uint32_t st = __float_as_uint(rdv.w);
+            uint32_t dim = stDim(st), bounces = stBounces(st);
+            uint32_t px, py, slot; // pixel relative to the sample-bounds origin
+            pathPixel(I, S, p, &px, &py, &slot);
             float4 bv = P.beta[p];
             F3 beta = xyz(bv);
             float etaScale = bv.w;
@@ -567,9 +577,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                 }
                 if (alive) {
                     P.rayO[p] = mk4(no, 0.f);
-                    P.rayD[p] = mk4(wi, 0.f);
+                    P.rayD[p] = mk4(wi, __uint_as_float(packState(0u, dim, bounces + 1, spec)));
                     P.beta[p] = mk4(beta, etaScale);
-                    P.state[p] = packState(slot, dim, bounces + 1, spec);
                     pushNext = true;
                 }
             }
@@ -613,7 +622,7 @@ DEV void blockReserveCounts(uint32_t na, uint32_t nb, uint32_t nc, uint32_t* ca,
 // stands for a SpecularTransmit call the recursion has yet to make (one Get2D each); placeholders of
 // nodes without a transmission lobe only consume their two dimensions.  Returns false when the stack
 // runs empty (the camera sample is complete).
-DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrator& I, uint32_t p, uint32_t slot, uint32_t dim) {
+DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrator& I, uint32_t p, uint32_t dim) {
     uint32_t cnt = D.pendCount[p];
     bool found = false;
     while (cnt > 0 && !found) {
@@ -624,9 +633,8 @@ DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrato
         if (o.w != 0.f) {
             float4 d = D.pendD[e], b = D.pendB[e];
             P.rayO[p] = make_float4(o.x, o.y, o.z, 0.f);
-            P.rayD[p] = make_float4(d.x, d.y, d.z, 0.f);
+            P.rayD[p] = make_float4(d.x, d.y, d.z, __uint_as_float(packState(0u, dim, (uint32_t)d.w, 0u)));
             P.beta[p] = make_float4(b.x, b.y, b.z, 1.f);
-            P.state[p] = packState(slot, dim, (uint32_t)d.w, 0u);
             found = true;
         }
     }
@@ -657,13 +665,14 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
         uint32_t p = 0;
         if (active) {
             p = matQueue[i];
-            F3 d = xyz(P.rayD[p]);
+            float4 rdv = P.rayD[p];
+            F3 d = xyz(rdv);
             float4 hv = P.hit[p];
-            int tri = P.hitTri[p];
-            uint32_t st = P.state[p];
-            uint32_t slot = stSlot(st), dim = stDim(st), depth = stBounces(st);
-            uint32_t pix = P.pixel[p];
-            uint32_t px = pix & 0xffffu, py = pix >> 16;
+            int tri = __float_as_int(hv.x);
+            uint32_t st = __float_as_uint(rdv.w);
+            uint32_t dim = stDim(st), depth = stBounces(st);
+            uint32_t px, py, slot;
+            pathPixel(I, S, p, &px, &py, &slot);
             F3 beta = xyz(P.beta[p]);
             HitGeom g = hitGeometry(tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
@@ -734,22 +743,20 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                     D.pendB[e] = mk4(betaT, 0.f);
                     D.pendCount[p] = cnt + 1;
                     P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, wiR), 0.f);
-                    P.rayD[p] = mk4(wiR, 0.f);
+                    P.rayD[p] = mk4(wiR, __uint_as_float(packState(0u, dim, depth + 1, 0u)));
                     P.beta[p] = mk4(beta * (fR * absdot(wiR, ns) / pdfR), 1.f);
-                    P.state[p] = packState(slot, dim, depth + 1, 0u);
                     haveNext = true;
                 } else {
                     dim += 2; // SpecularTransmit's Get2D
                     if (validT) {
                         P.rayO[p] = mk4(oT, 0.f);
-                        P.rayD[p] = mk4(wiT, 0.f);
+                        P.rayD[p] = mk4(wiT, __uint_as_float(packState(0u, dim, depth + 1, 0u)));
                         P.beta[p] = mk4(betaT, 1.f);
-                        P.state[p] = packState(slot, dim, depth + 1, 0u);
                         haveNext = true;
                     }
                 }
             }
-            if (!haveNext) haveNext = resumePending(P, D, I, p, slot, dim);
+            if (!haveNext) haveNext = resumePending(P, D, I, p, dim);
             nNext = haveNext ? 1u : 0u;
         }
         uint32_t sSh, sMi, sNx;
@@ -771,8 +778,7 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
         uint32_t p = 0;
         if (i < count) {
             p = queue[i];
-            uint32_t st = P.state[p];
-            found = resumePending(P, D, I, p, stSlot(st), stDim(st));
+            found = resumePending(P, D, I, p, stDim(__float_as_uint(P.rayD[p].w)));
         }
         uint32_t s = blockReserve(found, &ctr->extCount[nextIdx].v, lds);
         if (found) nextQueue[s] = p;
