@@ -117,10 +117,14 @@ struct DevPaths {
 // Shadow rays and BSDF-sampled MIS rays.  The ray itself is stored at the slot of its path (written the
 // moment the shade kernel has it, so nothing stays live in registers); idx is the compact list of
 // paths that have one this bounce.
+// A shadow ray (origin, direction to just short of the light sample, contribution) is nine floats; they are
+// packed into two float4 and one float instead of three float4: a = {o.xyz, d.x}, b = {d.y, d.z, w.x, w.y},
+// wz = w.z.  Its tMax is the constant 1 - ShadowEpsilon (Enigma/Interaction.cpp:58-64).
 struct DevRayQueue {
-    float4* o;        // [path] o.xyz, unused
-    float4* d;        // [path] d.xyz, bits(light index) (MIS) / tMax (shadow)
-    float4* w;        // [path] contribution to add to the path's L (shadow) or weight of Le (MIS)
+    float4* o;        // MIS: [slot] o.xyz, unused.                 shadow: a
+    float4* d;        // MIS: [slot] d.xyz, bits(light index).      shadow: b
+    float4* w;        // MIS: [slot] weight of the light's Le.      shadow: unused (nullptr)
+    float* wz;        // shadow only
     uint32_t* idx;    // [0, count) ray slots (= path index * perPath + ray of the path)
     uint32_t perPath; // 1 for PathIntegrator
 };

@@ -89,7 +89,8 @@ struct EnigmaCtx {
 
     // wavefront state
     size_t capacity = 0;
-    DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, shW, miO, miD, miW;
+    DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, miO, miD, miW;
+    DevBuf<float> shWz;
     DevBuf<uint32_t> shIdx, miIdx;
     DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
     DevBuf<float2> pfilm;
@@ -137,8 +138,9 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->rayO, &h->rayD, &h->L, &h->beta, &h->hit,
-                            &h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+                            &h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
     for (auto* b : f4) b->release();
+    h->shWz.release();
     h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
     h->extQ[0].release(); h->extQ[1].release();
@@ -486,8 +488,9 @@ static int buildLightDistribution(EnigmaCtx* h) {
 // n paths, each with raysPerPath shadow/MIS ray slots and (DirectLightingIntegrator) pendingLevels stack entries
 static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pendingLevels) {
     if (n * raysPerPath > h->rayCapacity) {
-        DevBuf<float4>* r4[] = {&h->shO, &h->shD, &h->shW, &h->miO, &h->miD, &h->miW};
+        DevBuf<float4>* r4[] = {&h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
         for (auto* b : r4) HIPCHK(h, b->alloc(n * raysPerPath));
+        HIPCHK(h, h->shWz.alloc(n * raysPerPath));
         HIPCHK(h, h->shIdx.alloc(n * raysPerPath));
         HIPCHK(h, h->miIdx.alloc(n * raysPerPath));
         h->rayCapacity = n * raysPerPath;
@@ -618,7 +621,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
         DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, h->shW.p, h->shIdx.p, (uint32_t)raysPerPath}, misq{h->miO.p, h->miD.p, h->miW.p, h->miIdx.p, (uint32_t)raysPerPath};
+        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath}, misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath};
         DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
         for (int64_t s0 = 0; s0 < cn; s0 += k) {

@@ -461,6 +461,12 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
     return r;
 }
 
+DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
+    q.o[slot] = make_float4(o.x, o.y, o.z, d.x);
+    q.d[slot] = make_float4(d.y, d.z, w.x, w.y);
+    q.wz[slot] = w.z;
+}
+
 // For scenes small enough (LDS_SCENE) the block first copies triangles, materials, lights and the light
 // distribution into LDS: the chain hit triangle -> material -> light -> light triangle is then four LDS
 // reads instead of four dependent trips to L2/HBM per path.
@@ -538,9 +544,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     dim += 4;
                     DirectSample ds = estimateDirect<MK>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
-                        shq.o[p] = mk4(ds.shO, 0.f);
-                        shq.d[p] = mk4(ds.shD, 1 - kShadowEpsilon);
-                        shq.w[p] = mk4(beta * (ds.Ld / pick), 0.f);
+                        storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
                         pushShadow = true;
                     }
                     if (ds.mis) {
@@ -683,9 +687,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             auto emit = [&](const DirectSample& ds, float div, int lightNum) { // div: sample count (all) or light-choice pdf (one)
                 if (ds.shadow) {
                     size_t q = raySlot0 + nShadow++;
-                    shq.o[q] = mk4(ds.shO, 0.f);
-                    shq.d[q] = mk4(ds.shD, 1 - kShadowEpsilon);
-                    shq.w[q] = mk4(beta * (ds.Ld / div), 0.f);
+                    storeShadowRay(shq, q, ds.shO, ds.shD, beta * (ds.Ld / div));
                 }
                 if (ds.mis) {
                     size_t q = raySlot0 + nMis++;
@@ -804,7 +806,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
         __syncthreads();
         AnyWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes);
         uint32_t p = kNoRay;
-        float4 contrib = make_float4(0.f, 0.f, 0.f, 0.f); // fetched with the ray: no dependent load when the ray is through
+        F3 contrib(0.f); // fetched with the ray: no dependent load when the ray is through
         bool exhausted = false;
         for (;;) {
             bool idle = w.done();
@@ -828,9 +830,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
                     uint32_t mine = poolTake(&poolNext, idleMask, &base);
                     if (idle && mine < chunkCount) {
                         p = shq.idx[chunk + mine];
-                        float4 o = shq.o[p], d = shq.d[p];
-                        contrib = shq.w[p];
-                        w.start(xyz(o), xyz(d), d.w);
+                        float4 a = shq.o[p], b = shq.d[p];
+                        contrib = F3(b.z, b.w, shq.wz[p]);
+                        w.start(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), 1 - kShadowEpsilon);
                     }
                     exhausted = base + nIdle >= chunkCount;
                 }
