@@ -54,9 +54,9 @@ typedef struct EnigmaMaterial {
     float index;              /* glass: index of refraction */
 } EnigmaMaterial;
 
-/* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651).
- * One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
-enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1 };
+/* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651), SpotLight (:133-190),
+ * DistantLight (:656-708).  One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
+enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT = 2, ENIGMA_LIGHT_DISTANT = 3 };
 
 typedef struct EnigmaLight {
     uint32_t type;      /* ENIGMA_LIGHT_* */
@@ -64,8 +64,13 @@ typedef struct EnigmaLight {
     uint32_t two_sided; /* area light: twosided flag */
     uint32_t n_samples; /* Light::m_nSamples ("samples"/"nsamples", default 1; 0 means 1): read only by
                            DirectLightingIntegrator's UniformSampleAll strategy (Enigma/DirectLightingIntegrator.cpp:76-77) */
-    float L[3];         /* area: emitted radiance Lemission; point: intensity I */
-    float pos[3];       /* point light: world position */
+    float L[3];         /* area: emitted radiance Lemission; point / spot: intensity I; distant: radiance L */
+    float pos[3];       /* point / spot light: world position m_pos */
+    float dir[3];       /* distant: m_lightDir = lightToWorld.transformVector(from - to); the reference does NOT
+                           normalise it (Enigma/Lights.cpp:656-663) and neither does this library */
+    float cos_total_width;    /* spot: cosf(radians(coneangle)) (Enigma/Lights.cpp:138) */
+    float cos_falloff_start;  /* spot: cosf(radians(coneangle - conedeltaangle)) (Enigma/Lights.cpp:139) */
+    float world_to_light[9];  /* spot: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
 } EnigmaLight;
 
 #define ENIGMA_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness */

@@ -1393,13 +1393,27 @@ struct Distribution1D { // MonteCarlo.h:15-84
 
 struct Light {
     int nSamples = 1; // Light::m_nSamples
-    int flags; // 1 = delta position, 4 = area (Defines.h:236-239)
+    int flags; // 1 = delta position, 2 = delta direction, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
+    bool spot = false; float cosTotalWidth = 0, cosFalloffStart = 0; float w2l[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // SpotLight
+    Vec3 lightDir; float worldRadius = 0; // DistantLight (m_lightDir is not normalised, Lights.cpp:656-663)
     bool IsDelta() const { return (flags & 1) || (flags & 2); } // Lights.h:15-18
+    // SpotLight::Falloff (Lights.cpp:180-190)
+    float Falloff(const Vec3& w) const {
+        Vec3 wl = Normalize(Vec3(w2l[0] * w.x + w2l[1] * w.y + w2l[2] * w.z, w2l[3] * w.x + w2l[4] * w.y + w2l[5] * w.z,
+                                 w2l[6] * w.x + w2l[7] * w.y + w2l[8] * w.z));
+        float cosTheta = wl.z;
+        if (cosTheta < cosTotalWidth) return 0;
+        if (cosTheta >= cosFalloffStart) return 1;
+        float delta = (cosTheta - cosTotalWidth) / (cosFalloffStart - cosTotalWidth);
+        return (delta * delta) * (delta * delta);
+    }
     // DiffuseAreaLight::L (Lights.cpp:575-578)
     Spectrum L(const Interaction& intr, const Vec3& w) const { return (twoSided || Dot(intr.n, w) > 0) ? I_or_L : Spectrum(0.f); }
     Spectrum Power() const {
         if (flags & 4) { float scale = twoSided ? 2.0f : 1.0f; return I_or_L * (area * PI * scale); } // Lights.cpp:647-651
+        if (flags & 2) return I_or_L * PI * worldRadius * worldRadius;                                   // Lights.cpp:705-708
+        if (spot) return I_or_L * 2.f * PI * (1.f - .5f * (cosFalloffStart + cosTotalWidth));            // Lights.cpp:174-178
         return 4.0f * PI * I_or_L;                                                                       // Lights.cpp:126-129
     }
     // Lights.cpp:117-124 / 634-645.  vis endpoints returned in p1.
@@ -1411,10 +1425,18 @@ struct Light {
             *p1 = pShape;
             return L(pShape, -*wi);
         }
+        if (flags & 2) { // DistantLight::Sample_Li (Lights.cpp:696-703)
+            *wi = lightDir;
+            *pdf = 1;
+            Interaction po; po.p = ref.p + lightDir * (2 * worldRadius); po.time = ref.time;
+            *p1 = po;
+            return I_or_L;
+        }
         *wi = Normalize(pos - ref.p);
         *pdf = 1.f;
         Interaction pl; pl.p = pos; pl.time = ref.time;
         *p1 = pl;
+        if (spot) return I_or_L * Falloff(-*wi) / DistanceSqr(pos, ref.p); // SpotLight::Sample_Li (Lights.cpp:165-172)
         return I_or_L / DistanceSqr(pos, ref.p);
     }
     float Pdf_Li(const Interaction& ref, const Vec3& wi) const { return (flags & 4) ? shape->pdf(ref, wi) : 0; }
@@ -1777,9 +1799,29 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         L.nSamples = l.n_samples ? (int)l.n_samples : 1;
         if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
             L.flags = 4; L.shape = &sc.tris[l.triangle]; L.twoSided = l.two_sided != 0; L.area = L.shape->area();
-        } else { L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]); }
+        } else if (l.type == ENIGMA_LIGHT_POINT || l.type == ENIGMA_LIGHT_SPOT) {
+            L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]);
+            if (l.type == ENIGMA_LIGHT_SPOT) {
+                L.spot = true; L.cosTotalWidth = l.cos_total_width; L.cosFalloffStart = l.cos_falloff_start;
+                memcpy(L.w2l, l.world_to_light, sizeof(L.w2l));
+            }
+        } else if (l.type == ENIGMA_LIGHT_DISTANT) {
+            L.flags = 2; L.lightDir = Vec3(l.dir[0], l.dir[1], l.dir[2]);
+        } else { h->o.error = "light type is not restated"; return -4; }
     }
     sc.accel.reset(new BVHAccel(&sc.tris, max_node_prims, split_method == 1 ? SplitMethod::HLBVH : SplitMethod::SAH));
+    {   // Scene::Scene (Scene.cpp:19-30): every light's Preprocess sees the aggregate's world bound;
+        // BBox3::getBoundingSphere (BBox.h:322-326), getCenter (BBox.h:263-265)
+        BBox3 wb;
+        for (const Triangle& t : sc.tris) { BBox3 b = t.worldBound(); wb.addPoint(b.mn); wb.addPoint(b.mx); }
+        float radius = 0.f;
+        if (!sc.tris.empty()) {
+            Vec3 center = (wb.mn * .5f) + (wb.mx * .5f);
+            bool inside = center.x >= wb.mn.x && center.x <= wb.mx.x && center.y >= wb.mn.y && center.y <= wb.mx.y && center.z >= wb.mn.z && center.z <= wb.mx.z;
+            radius = inside ? Length(center - wb.mx) : 0.0f;
+        }
+        for (Light& L : sc.lights) L.worldRadius = radius;
+    }
     return 0;
 }
 int oracle_camera_set(OracleCtx* h, const EnigmaCameraDesc* c) {

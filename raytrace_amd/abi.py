@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
-LIGHT_POINT, LIGHT_DIFFUSE_AREA = 0, 1
+LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT = 0, 1, 2, 3
 LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
@@ -19,7 +19,8 @@ class EnigmaMaterial(C.Structure):
 
 class EnigmaLight(C.Structure):
     _fields_ = [("type", C.c_uint32), ("triangle", C.c_uint32), ("two_sided", C.c_uint32), ("n_samples", C.c_uint32),
-                ("L", C.c_float * 3), ("pos", C.c_float * 3)]
+                ("L", C.c_float * 3), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
+                ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float), ("world_to_light", C.c_float * 9)]
 
 
 class EnigmaSceneDesc(C.Structure):
@@ -156,4 +157,47 @@ def point_light(pos, I, n_samples=1):
     l.n_samples = n_samples
     l.pos[:] = pos
     l.L[:] = I
+    return l
+
+
+def coordinate_system(v1):
+    """CoordinateSystem (Enigma/MathCommon.h:371-382) in float32."""
+    f = np.float32
+    v1 = np.asarray(v1, dtype=f)
+    if abs(v1[0]) > abs(v1[1]):
+        inv = f(1) / np.sqrt(v1[0] * v1[0] + v1[2] * v1[2])
+        v2 = np.array([-v1[2] * inv, 0, v1[0] * inv], dtype=f)
+    else:
+        inv = f(1) / np.sqrt(v1[1] * v1[1] + v1[2] * v1[2])
+        v2 = np.array([0, v1[2] * inv, -v1[1] * inv], dtype=f)
+    v3 = np.array([v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]], dtype=f)
+    return v2, v3
+
+
+def spot_light(pos, to, I, coneangle=30.0, conedeltaangle=5.0, n_samples=1):
+    """CreateSpotLight (Enigma/Lights.cpp:752-771) under an identity CTM: the light looks from pos towards
+    `to`; world-to-light is the rotation whose rows are (du, dv, dir)."""
+    f = np.float32
+    d = np.asarray(to, dtype=f) - np.asarray(pos, dtype=f)
+    d = d / np.sqrt((d * d).sum(dtype=f))
+    du, dv = coordinate_system(d)
+    l = EnigmaLight()
+    l.type = LIGHT_SPOT
+    l.n_samples = n_samples
+    l.pos[:] = pos
+    l.L[:] = I
+    l.cos_total_width = float(np.cos(f(np.radians(f(coneangle)))))
+    l.cos_falloff_start = float(np.cos(f(np.radians(f(coneangle - conedeltaangle)))))
+    l.world_to_light[:] = [float(x) for x in np.concatenate([du, dv, d])]
+    return l
+
+
+def distant_light(frm, to, L, n_samples=1):
+    """CreateDistantLight (Enigma/Lights.cpp:791-799) under an identity CTM: m_lightDir = from - to, kept
+    at whatever length it has."""
+    l = EnigmaLight()
+    l.type = LIGHT_DISTANT
+    l.n_samples = n_samples
+    l.dir[:] = [float(np.float32(a) - np.float32(b)) for a, b in zip(frm, to)]
+    l.L[:] = L
     return l

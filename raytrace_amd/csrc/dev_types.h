@@ -22,16 +22,21 @@ struct DevMaterial {        // 64 bytes
 
 static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
 
-struct DevLight {           // 48 bytes
-    uint32_t type;          // 0 point, 1 diffuse area
+struct DevLight {           // 96 bytes
+    uint32_t type;          // 0 point, 1 diffuse area, 2 spot, 3 distant
     uint32_t tri;           // area: triangle position in the device (BVH) order
     uint32_t twoSided;
     float area;             // Triangle::area() (Enigma/TriangleMesh.cpp:438-446)
     float L[3]; uint32_t nSamples;  // Light::m_nSamples (DirectLightingIntegrator, strategy all)
-    float pos[3]; float pad1;
+    float pos[3];           // point / spot: m_pos.  distant: m_lightDir (not normalised, as in the reference)
+    float cosTotalWidth;    // spot
+    float w2l0[3]; float cosFalloffStart; // spot: rows of the upper 3x3 of m_worldToLight
+    float w2l1[3]; float worldRadius;     // distant: radius of the scene's bounding sphere (Light::Preprocess)
+    float w2l2[3]; float pad;
 };
+constexpr uint32_t kLightVec4 = 6;
 
-static_assert(sizeof(DevLight) == 48, "k_shade copies lights as three float4");
+static_assert(sizeof(DevLight) == kLightVec4 * 16, "k_shade copies lights as float4");
 
 // One triangle, 48 bytes, three float4 loads:
 //   v0 = {p0.xyz, bits(original triangle index)}

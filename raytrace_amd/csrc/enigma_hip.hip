@@ -255,6 +255,20 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->directDirty = true;
     h->lightPower.assign(s->n_lights, 0.f);
     const float PI = 3.1415926535897932384f;
+    // Scene::worldBound() = the union of the primitives' bounds; BBox3::getBoundingSphere (Enigma/BBox.h:322-326)
+    float worldRadius = 0.f;
+    if (s->n_triangles) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = 0; k < (size_t)s->n_triangles * 3; ++k) {
+            const float* p = &s->vertices[3 * (size_t)s->indices[k]];
+            for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], p[c]); hi[c] = std::max(hi[c], p[c]); }
+        }
+        float ctr[3], d2 = 0.f;
+        bool inside = true;
+        for (int c = 0; c < 3; ++c) { ctr[c] = (lo[c] * .5f) + (hi[c] * .5f); inside = inside && ctr[c] >= lo[c] && ctr[c] <= hi[c]; }
+        for (int c = 0; c < 3; ++c) d2 += (ctr[c] - hi[c]) * (ctr[c] - hi[c]);
+        worldRadius = inside ? std::sqrt(d2) : 0.f;
+    }
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const EnigmaLight& l = s->lights[i];
         DevLight d;
@@ -281,6 +295,20 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             d.type = 0;
             float k = 4.0f * PI; // PointLight::Power, Enigma/Lights.cpp:126-129
             h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
+        } else if (l.type == ENIGMA_LIGHT_SPOT) {
+            d.type = 2;
+            d.cosTotalWidth = l.cos_total_width; d.cosFalloffStart = l.cos_falloff_start;
+            for (int c = 0; c < 3; ++c) { d.w2l0[c] = l.world_to_light[c]; d.w2l1[c] = l.world_to_light[3 + c]; d.w2l2[c] = l.world_to_light[6 + c]; }
+            float P[3]; // SpotLight::Power, Enigma/Lights.cpp:174-178, evaluated left to right
+            for (int c = 0; c < 3; ++c) P[c] = d.L[c] * 2.f * PI * (1.f - .5f * (d.cosFalloffStart + d.cosTotalWidth));
+            h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
+        } else if (l.type == ENIGMA_LIGHT_DISTANT) {
+            d.type = 3;
+            for (int c = 0; c < 3; ++c) d.pos[c] = l.dir[c];
+            d.worldRadius = worldRadius;
+            float P[3]; // DistantLight::Power, Enigma/Lights.cpp:705-708: m_L * PI * r * r, evaluated left to right
+            for (int c = 0; c < 3; ++c) P[c] = d.L[c] * PI * worldRadius * worldRadius;
+            h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
         } else return h->fail(ENIGMA_E_UNSUPPORTED, "light type %u is not supported", l.type);
         h->hostLights[i] = d;
     }
@@ -520,7 +548,7 @@ static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNode
 
 // triangles + materials + lights + light distribution, as k_shade stages them
 static size_t shadeLdsBytes(const EnigmaCtx* h) {
-    return ((size_t)h->scene.nTris * 3 + (size_t)h->scene.nMaterials * 4 + (size_t)h->scene.nLights * 3) * sizeof(float4) + (2 * (size_t)h->scene.nLights + 1) * sizeof(float);
+    return ((size_t)h->scene.nTris * 3 + (size_t)h->scene.nMaterials * 4 + (size_t)h->scene.nLights * kLightVec4) * sizeof(float4) + (2 * (size_t)h->scene.nLights + 1) * sizeof(float);
 }
 
 template <int LDSN, int OVF, bool LDS_SCENE>

@@ -247,16 +247,40 @@ public:
     int AddMaterial(const EnigmaMaterial& m) { m_materials.push_back(m); return (int)m_materials.size() - 1; }
     // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
     void AddTriangleMesh(const TriangleMesh& mesh) { m_meshes.push_back(mesh); }
-    void AddPointLight(const Vector3f& from, const Spectrum& I) { PointLightRec r{from, I, NextLightOrder()}; m_pointLights.push_back(r); }
+    // Lights without a shape (point, spot, distant) keep their place among the meshes' area lights.
+    void AddLight(const EnigmaLight& l) { m_lights.push_back(LightRec{l, NextLightOrder()}); }
+    void AddPointLight(const Vector3f& from, const Spectrum& I) { // PointLight(light2world, mi, I): from = light2world(0,0,0)
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_POINT;
+        l.pos[0] = from.x; l.pos[1] = from.y; l.pos[2] = from.z; l.L[0] = I[0]; l.L[1] = I[1]; l.L[2] = I[2];
+        AddLight(l);
+    }
+    // SpotLight(light2world, mi, I, width, fall) (Enigma/Lights.cpp:133-140): position light2world(0,0,0), the cosines
+    // of the two cone angles (degrees), and the upper 3x3 of the inverse for Falloff.
+    void AddSpotLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& I, float width, float fall) {
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_SPOT;
+        for (int c = 0; c < 3; ++c) { l.pos[c] = lightToWorld.m_mat[c][3]; l.L[c] = I[c]; }
+        const float toRad = 3.14159265358979323846f / 180.f;
+        l.cos_total_width = cosf(toRad * width);
+        l.cos_falloff_start = cosf(toRad * fall);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) l.world_to_light[3 * r + c] = worldToLight.m_mat[r][c];
+        AddLight(l);
+    }
+    // DistantLight(light2world, L, dir) (Enigma/Lights.cpp:656-663): m_lightDir = light2world.transformVector(dir), not normalised.
+    void AddDistantLight(const Transform& lightToWorld, const Spectrum& L, const Vector3f& dir) {
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_DISTANT;
+        for (int r = 0; r < 3; ++r) l.dir[r] = lightToWorld.m_mat[r][0] * dir.x + lightToWorld.m_mat[r][1] * dir.y + lightToWorld.m_mat[r][2] * dir.z;
+        for (int c = 0; c < 3; ++c) l.L[c] = L[c];
+        AddLight(l);
+    }
     int getNumLights() const {
-        int n = (int)m_pointLights.size();
+        int n = (int)m_lights.size();
         for (auto& m : m_meshes) if (m.emissive) n += m.m_nTriangles;
         return n;
     }
-    struct PointLightRec { Vector3f from; Spectrum I; int order; };
+    struct LightRec { EnigmaLight light; int order; };
     std::vector<TriangleMesh> m_meshes;
     std::vector<EnigmaMaterial> m_materials;
-    std::vector<PointLightRec> m_pointLights;
+    std::vector<LightRec> m_lights;
 private:
     int NextLightOrder() const { return (int)m_meshes.size(); } // point lights keep their place among the meshes' lights
 };
@@ -303,12 +327,7 @@ public:
         std::vector<float> verts; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight; std::vector<EnigmaLight> lights;
         size_t pl = 0;
         auto flushPointLights = [&](int upTo) {
-            for (; pl < scene.m_pointLights.size() && scene.m_pointLights[pl].order <= upTo; ++pl) {
-                EnigmaLight l{}; l.type = ENIGMA_LIGHT_POINT;
-                const auto& r = scene.m_pointLights[pl];
-                l.pos[0] = r.from.x; l.pos[1] = r.from.y; l.pos[2] = r.from.z; l.L[0] = r.I[0]; l.L[1] = r.I[1]; l.L[2] = r.I[2];
-                lights.push_back(l);
-            }
+            for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) lights.push_back(scene.m_lights[pl].light);
         };
         for (size_t mi = 0; mi < scene.m_meshes.size(); ++mi) {
             flushPointLights((int)mi);

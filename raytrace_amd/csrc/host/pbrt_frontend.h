@@ -296,7 +296,9 @@ public:
     }
     void pbrtLightSource(const std::string& name, const ParamSet& p) {
         VerifyWorld("LightSource");
-        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, and diffuse area lights)");
+        if (name == "spot") { MakeSpotLight(p); NoteUnused("LightSource", p); return; }
+        if (name == "distant") { MakeDistantLight(p); NoteUnused("LightSource", p); return; }
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, and diffuse area lights)");
         Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
         Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
         // l2w = Translate(P) * lightToWorld, position = l2w(0,0,0) (Enigma/Lights.cpp:742-750,89-95)
@@ -306,6 +308,37 @@ public:
         Spectrum Isc(I[0] * sc[0], I[1] * sc[1], I[2] * sc[2]);
         m_res->scene.AddPointLight(Vector3f((float)pos[0], (float)pos[1], (float)pos[2]), Isc);
         NoteUnused("LightSource", p);
+    }
+    // CreateSpotLight (Enigma/Lights.cpp:752-771): light2world = CTM * Translate(from) * inverse(dirToZ), where the rows
+    // of dirToZ are (du, dv, dir) from CoordinateSystem(Normalize(to - from)) in float, as the reference computes them.
+    void MakeSpotLight(const ParamSet& p) {
+        Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+        float coneangle = p.FindOneFloat("coneangle", 30.f), conedelta = p.FindOneFloat("conedeltaangle", 5.f);
+        Vector3f from = p.FindOnePoint3f("from", Vector3f(0, 0, 0)), to = p.FindOnePoint3f("to", Vector3f(0, 0, 1));
+        float dx = to.x - from.x, dy = to.y - from.y, dz = to.z - from.z;
+        float len = std::sqrt(dx * dx + dy * dy + dz * dz);
+        if (len == 0) throw std::runtime_error("LightSource \"spot\": from and to coincide");
+        float dir[3] = {dx / len, dy / len, dz / len}, du[3], dv[3];
+        if (std::fabs(dir[0]) > std::fabs(dir[1])) { // CoordinateSystem, Enigma/MathCommon.h:371-382
+            float inv = 1.f / std::sqrt(dir[0] * dir[0] + dir[2] * dir[2]);
+            du[0] = -dir[2] * inv; du[1] = 0.f; du[2] = dir[0] * inv;
+        } else {
+            float inv = 1.f / std::sqrt(dir[1] * dir[1] + dir[2] * dir[2]);
+            du[0] = 0.f; du[1] = dir[2] * inv; du[2] = -dir[1] * inv;
+        }
+        dv[0] = dir[1] * du[2] - dir[2] * du[1]; dv[1] = dir[2] * du[0] - dir[0] * du[2]; dv[2] = dir[0] * du[1] - dir[1] * du[0];
+        Mat4d dirToZ;
+        for (int c = 0; c < 3; ++c) { dirToZ.m[0][c] = du[c]; dirToZ.m[1][c] = dv[c]; dirToZ.m[2][c] = dir[c]; }
+        Mat4d l2w = m_ctm * TranslateD(from.x, from.y, from.z) * dirToZ.Inverse();
+        Spectrum Isc(I[0] * sc[0], I[1] * sc[1], I[2] * sc[2]);
+        m_res->scene.AddSpotLight(l2w.ToFloat(), l2w.Inverse().ToFloat(), Isc, coneangle, coneangle - conedelta);
+    }
+    // CreateDistantLight (Enigma/Lights.cpp:791-799): dir = from - to, carried through the CTM without normalisation.
+    void MakeDistantLight(const ParamSet& p) {
+        Spectrum L = p.FindOneSpectrum("L", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+        Vector3f from = p.FindOnePoint3f("from", Vector3f(0, 0, 0)), to = p.FindOnePoint3f("to", Vector3f(0, 0, 1));
+        Spectrum Lsc(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]);
+        m_res->scene.AddDistantLight(m_ctm.ToFloat(), Lsc, Vector3f(from.x - to.x, from.y - to.y, from.z - to.z));
     }
     void pbrtAreaLightSource(const std::string& name, const ParamSet& p) { VerifyWorld("AreaLightSource"); m_gs.areaLight = name; m_gs.areaLightParams = p; }
     void pbrtShape(const std::string& name, const ParamSet& p) {

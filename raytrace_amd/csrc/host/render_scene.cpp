@@ -62,10 +62,13 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         for (size_t k = 0; k < m.m_p.size(); ++k) o << (k ? "," : "") << m.m_p[k].x << "," << m.m_p[k].y << "," << m.m_p[k].z;
         o << "]}";
     }
-    o << "],\n\"point_lights\":[";
-    for (size_t i = 0; i < R.scene.m_pointLights.size(); ++i) {
-        const auto& l = R.scene.m_pointLights[i];
-        o << (i ? "," : "") << "{\"order\":" << l.order << ",\"from\":[" << l.from.x << "," << l.from.y << "," << l.from.z << "],\"I\":[" << l.I[0] << "," << l.I[1] << "," << l.I[2] << "]}";
+    o << "],\n\"lights\":[";
+    for (size_t i = 0; i < R.scene.m_lights.size(); ++i) {
+        const EnigmaLight& l = R.scene.m_lights[i].light;
+        o << (i ? "," : "") << "{\"order\":" << R.scene.m_lights[i].order << ",\"type\":" << l.type << ",\"from\":"; arr(l.pos, 3);
+        o << ",\"I\":"; arr(l.L, 3); o << ",\"dir\":"; arr(l.dir, 3);
+        o << ",\"cos_total_width\":"; arr(&l.cos_total_width, 1); o << ",\"cos_falloff_start\":"; arr(&l.cos_falloff_start, 1);
+        o << ",\"world_to_light\":"; arr(l.world_to_light, 9); o << "}";
     }
     o << "],\n\"warnings\":[";
     for (size_t i = 0; i < R.warnings.size(); ++i) {

@@ -413,11 +413,30 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
             wi = normalize(lp - g.p);
             if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
         }
-    } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124)
+    } else if (lt.type == 3) { // DistantLight::Sample_Li (Enigma/Lights.cpp:696-703): wi = m_lightDir as stored
+        wi = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
+        lightPdf = 1.f;
+        lp = g.p + wi * (2 * lt.worldRadius);
+        Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+    } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124), SpotLight::Sample_Li (:165-172)
         lp = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
         wi = normalize(lp - g.p);
         lightPdf = 1.f;
-        Li = F3(lt.L[0], lt.L[1], lt.L[2]) / lengthSqr(lp - g.p);
+        Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+        if (lt.type == 2) { // SpotLight::Falloff(-wi) (Enigma/Lights.cpp:180-190)
+            F3 w = -wi;
+            F3 wl = normalize(F3(lt.w2l0[0] * w.x + lt.w2l0[1] * w.y + lt.w2l0[2] * w.z, lt.w2l1[0] * w.x + lt.w2l1[1] * w.y + lt.w2l1[2] * w.z,
+                                 lt.w2l2[0] * w.x + lt.w2l2[1] * w.y + lt.w2l2[2] * w.z));
+            float cosTheta = wl.z, fall;
+            if (cosTheta < lt.cosTotalWidth) fall = 0.f;
+            else if (cosTheta >= lt.cosFalloffStart) fall = 1.f;
+            else {
+                float delta = (cosTheta - lt.cosTotalWidth) / (lt.cosFalloffStart - lt.cosTotalWidth);
+                fall = (delta * delta) * (delta * delta);
+            }
+            Li = Li * fall;
+        }
+        Li = Li / lengthSqr(lp - g.p);
     }
     if (lightPdf > 0 && !isBlack(Li)) {
         F3 f = bsdfF<MK>(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
@@ -426,7 +445,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
             // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
             F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
             F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
-            if (lt.type == 0) r.Ld = f * Li / lightPdf;
+            if (lt.type != 1) r.Ld = f * Li / lightPdf; // IsDeltaLight
             else r.Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
             r.shO = origin; r.shD = target - origin;
             r.shadow = true;
@@ -479,7 +498,7 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
     const float* lightCdf = sc.lightCdf;                                                                                 \
     const float* lightFunc = sc.lightFunc;                                                                               \
     if (LDS_SCENE) {                                                                                                     \
-        const uint32_t nT = sc.nTris * 3u, nM = sc.nMaterials * 4u, nL = (uint32_t)sc.nLights * 3u;                      \
+        const uint32_t nT = sc.nTris * 3u, nM = sc.nMaterials * 4u, nL = (uint32_t)sc.nLights * kLightVec4;                      \
         float4* ldsMat = sceneLds + nT;                                                                                  \
         float4* ldsLight = ldsMat + nM;                                                                                  \
         float* ldsCdf = reinterpret_cast<float*>(ldsLight + nL);                                                         \

@@ -173,6 +173,12 @@ class MeshBuilder:
     def add_point_light(self, pos, I):
         self.lights.append(abi.point_light(pos, I))
 
+    def add_spot_light(self, pos, to, I, coneangle=30.0, conedeltaangle=5.0):
+        self.lights.append(abi.spot_light(pos, to, I, coneangle, conedeltaangle))
+
+    def add_distant_light(self, frm, to, L):
+        self.lights.append(abi.distant_light(frm, to, L))
+
     def weld(self):
         """Share identical vertices (keeps triangle order and winding)."""
         v = np.asarray(self.v, dtype=np.float32)
@@ -218,8 +224,10 @@ COPPER_ETA = (0.200, 0.924, 1.102)
 COPPER_K = (3.912, 2.452, 2.142)
 
 
-def cornell_box(variant="diffuse"):
-    """S1 (all matte) or S1m (short block metal, tall block rough glass).  32 triangles, 2 lights."""
+def cornell_box(variant="diffuse", delta_lights=False):
+    """S1 (all matte) or S1m (short block metal, tall block rough glass).  32 triangles, 2 lights.
+    delta_lights: adds a spot light aimed at the short block and a distant light shining in through the
+    open front (its direction deliberately not unit length: the reference never normalises it)."""
     b = MeshBuilder()
     white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
     red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
@@ -245,6 +253,9 @@ def cornell_box(variant="diffuse"):
             outward = np.mean(f, axis=0) * 2 - centre  # a point on the outer side of the face
             b.add_quad(f, m, toward=outward)
     b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
+    if delta_lights:
+        b.add_spot_light((278, 500, 100), (186, 165, 169), (4.0e5, 5.0e5, 6.0e5), coneangle=25.0, conedeltaangle=10.0)
+        b.add_distant_light((0.3, 0.5, -1.1), (0, 0, 0), (1.5, 1.2, 0.9))
     return b.arrays()
 
 

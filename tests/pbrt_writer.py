@@ -1,6 +1,8 @@
 """Writes a pbrt-format scene description for a SceneArrays scene (test helper for the scene-description
 front end).  One trianglemesh Shape per run of triangles that share material and emission; materials as
 MakeNamedMaterial.  Light order in the file = light order in SceneArrays (lights are created in file order)."""
+import math
+
 import numpy as np
 
 from raytrace_amd import abi
@@ -39,14 +41,23 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         out.append(material_text(i, sc.materials[i]))
     nT = sc.indices.shape[0]
     # point lights keep their position among the area lights: emit each before the first triangle whose light index is larger
-    point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type == abi.LIGHT_POINT]
+    point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type != abi.LIGHT_DIFFUSE_AREA]
     emitted = 0
 
     def flush_points(upto):
         nonlocal emitted
         while emitted < len(point) and point[emitted][0] < upto:
             l = point[emitted][1]
-            out.append('LightSource "point" %s "point from" [%.9g %.9g %.9g]' % (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2]))
+            if l.type == abi.LIGHT_POINT:
+                out.append('LightSource "point" %s "point from" [%.9g %.9g %.9g]' % (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2]))
+            elif l.type == abi.LIGHT_SPOT:   # the light looks along the third row of its world-to-light rotation
+                d = [l.world_to_light[6], l.world_to_light[7], l.world_to_light[8]]
+                cone = math.degrees(math.acos(l.cos_total_width))
+                start = math.degrees(math.acos(l.cos_falloff_start))
+                out.append('LightSource "spot" %s "point from" [%.9g %.9g %.9g] "point to" [%.9g %.9g %.9g] "float coneangle" %.9g "float conedeltaangle" %.9g' %
+                           (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2], l.pos[0] + 100 * d[0], l.pos[1] + 100 * d[1], l.pos[2] + 100 * d[2], cone, cone - start))
+            elif l.type == abi.LIGHT_DISTANT:
+                out.append('LightSource "distant" %s "point from" [%.9g %.9g %.9g] "point to" [0 0 0]' % (_rgb("L", l.L), l.dir[0], l.dir[1], l.dir[2]))
             emitted += 1
     t = 0
     while t < nT:

@@ -105,6 +105,18 @@ def test_direct_lighting_many_lights_strategy_one_and_switching_integrators():
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("strategy", [abi.DL_SAMPLE_ALL, abi.DL_SAMPLE_ONE])
+def test_direct_lighting_spot_and_distant_lights(strategy):
+    sc = scenes.cornell_box("diffuse", delta_lights=True)
+    sc.lights[0].n_samples = 2
+    sc.lights[2].n_samples = 3                             # the spot light: a delta light sampled three times under strategy all
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    integ = scenes.direct_lighting_desc(film, 8, max_depth=3, strategy=strategy)
+    r, o = _pair(sc, cam, film, integ)
+    _compare(r, o, 8)
+    r.close(); o.close()
+
+
 def test_direct_lighting_refuses_what_the_reference_leaves_undefined():
     cam, film = scenes.cornell_camera(32, 32), scenes.film_desc(32, 32)
     # strategy all + branching glass: the reference indexes past its sample arrays

@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -88,7 +88,7 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     import pbrt_writer
     assert os.path.exists(EXE), "raytrace_amd/enigma_render is not built (make -C raytrace_amd/csrc)"
     xres, yres, spp = 72, 48, 8
-    sc = scenes.cornell_box(variant)
+    sc = scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
     itext = ('Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"' if integrator == "path"
              else 'Integrator "directlighting" "integer maxdepth" 5 "string strategy" "all"')

@@ -268,6 +268,31 @@ def test_image_parity_many_lights_power_and_uniform():
         r.close(); o.close()
 
 
+@pytest.mark.parametrize("variant,strategy", [("diffuse", abi.LIGHTS_POWER), ("microfacet", abi.LIGHTS_UNIFORM)])
+def test_image_parity_spot_and_distant_lights(variant, strategy):
+    """SpotLight / DistantLight (Enigma/Lights.cpp:133-190,656-708) beside the area light; the distant light's
+    direction is not unit length, as the reference leaves it."""
+    g = np.load(os.path.join(GOLD, "delta_lights64_16spp.npz"))
+    sc = scenes.cornell_box(variant, delta_lights=True)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    integ = scenes.integrator_desc(film, 16, light_strategy=strategy)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(0, 16)
+    o.render(0, 16, threads=8)
+    img = r.image()
+    assert common.mean_relative_error(img, o.image()) < (1e-4 if variant == "diffuse" else 1e-3)
+    assert common.mean_relative_error(img, g[variant + "_rgb"]) < (1e-4 if variant == "diffuse" else 1e-3)
+    so, st = o.stats(), r.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
+    # the delta lights add light: the same scene without them is darker everywhere it matters
+    r2 = ra.Renderer(0).configure(scenes.cornell_box(variant), cam, film, integ)
+    r2.render(0, 16)
+    assert img.mean() > 1.2 * r2.image().mean()
+    r.close(); r2.close(); o.close()
+
+
 def test_image_parity_mesh_scene():
     sc = scenes.big_mesh(grid=128, sphere_level=4, n_spheres=6)
     film = scenes.film_desc(96, 54)

@@ -252,3 +252,89 @@ def test_direct_lighting_sample_arrays_are_samples_of_other_sample_numbers():
     assert s["rays_shadow"] <= 2 * s["rays_closest"]       # at most one shadow ray per light and hit
     assert not o.read_past_arrays()
     o.close()
+
+
+# ------------------------------------------------------------------ SpotLight / DistantLight (oracle only, CPU)
+def _floor_scene(light):
+    b = scenes.MeshBuilder()
+    grey = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)], grey, toward=(0, 1, 0))
+    b.lights.append(light)
+    return b.arrays()
+
+
+def test_spot_light_matches_its_closed_form():
+    """A matte floor under a spot light, direct lighting only: L = Kd/pi * I * falloff(theta) / d^2 * cos(theta)
+    (SpotLight::Sample_Li / Falloff, Enigma/Lights.cpp:165-190)."""
+    h, cone, delta = 10.0, 30.0, 10.0
+    I = np.array([300.0, 200.0, 100.0])
+    sc = _floor_scene(abi.spot_light((0, h, 0), (0, 0, 0), tuple(I), cone, delta))
+    res = 33
+    cam = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, res, res)
+    film = scenes.film_desc(res, res)
+    o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16, max_depth=1, strategy=abi.DL_SAMPLE_ALL))
+    o.render(0, 16, threads=4)
+    img = o.image().astype(np.float64)
+    o.close()
+    half = 40 * math.tan(math.radians(10.0))                       # the image spans [-half, half] on the floor
+    xs = (np.arange(res) + 0.5) / res * 2 * half - half
+    r = np.hypot(xs[None, :], xs[:, None])
+    d2 = r * r + h * h
+    cos_t = h / np.sqrt(d2)
+    ct, cf = math.cos(math.radians(cone)), math.cos(math.radians(cone - delta))
+    falloff = lambda c: np.clip((c - ct) / (cf - ct), 0, 1) ** 4
+    fall = falloff(cos_t)
+    want = (0.5 / math.pi) * fall[..., None] * I[None, None, :] / d2[..., None] * cos_t[..., None]
+    px = half / res                                                 # half a pixel on the floor
+    corner = lambda sx, sy: falloff(h / np.sqrt((np.abs(xs[None, :]) + sx * px) ** 2 + (np.abs(xs[:, None]) + sy * px) ** 2 + h * h))
+    lo, hi = corner(1, 1), corner(-1, -1)                           # falloff at the pixel's outermost / innermost corner
+    smooth = ((lo == 1) & (hi == 1)) | ((lo == 0) & (hi == 0))      # pixels the falloff ring does not cross
+    assert smooth.sum() > res * res // 2
+    assert np.allclose(img[smooth], want[smooth], rtol=0.02, atol=1e-5)
+    assert img[res // 2, res // 2, 0] > 0 and img[0, 0].max() == 0  # lit in the cone, black outside it
+    assert np.abs(img - want).mean() < 0.02 * want.mean() + 1e-6     # falloff ring included, on average
+
+
+def test_distant_light_keeps_the_reference_unnormalised_direction():
+    """DistantLight::Sample_Li hands m_lightDir out as stored (Enigma/Lights.cpp:656-663,696-703): the matte
+    floor sees Kd/pi * L * |lightDir . n|, which scales with the length of from - to; an occluder casts a
+    shadow along the same direction."""
+    L = np.array([2.0, 1.0, 0.5])
+    for scale in (1.0, 2.5):
+        sc = _floor_scene(abi.distant_light((0.3 * scale, 0.8 * scale, 0.1 * scale), (0, 0, 0), tuple(L)))
+        cam = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, 9, 9)
+        film = scenes.film_desc(9, 9)
+        o = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 4, max_depth=1, strategy=abi.DL_SAMPLE_ONE))
+        o.render(0, 4, threads=2)
+        img = o.image().astype(np.float64)
+        o.close()
+        want = (0.5 / math.pi) * L * np.float32(0.8 * scale)
+        assert np.allclose(img, want[None, None, :], rtol=1e-5)
+    # power of a distant light = L * pi * r^2 of the scene's bounding sphere (Enigma/Lights.cpp:705-708): with a
+    # second, much stronger point light the "power" strategy must still pick both with non-zero probability
+    sc = _floor_scene(abi.distant_light((0, 1, 0), (0, 0, 0), (1, 1, 1)))
+    sc2 = scenes.MeshBuilder()
+    g = sc2.add_material(abi.matte((0.5, 0.5, 0.5)))
+    sc2.add_quad([(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)], g, toward=(0, 1, 0))
+    sc2.add_quad([(-2, 5, -2), (-2, 5, 2), (2, 5, 2), (2, 5, -2)], g, toward=(0, 10, 0))   # occluder above the centre
+    sc2.add_distant_light((0, 1, 0), (0, 0, 0), (1, 1, 1))
+    cam = scenes.camera_desc((0, 40, 30), (0, 0, 0), (0, 1, 0), 30.0, 32, 32)
+    film = scenes.film_desc(32, 32)
+    o = orc.Oracle(sc2.arrays(), cam, film, scenes.integrator_desc(film, 4, max_depth=1, light_strategy=abi.LIGHTS_POWER))
+    o.render(0, 4, threads=2)
+    img = o.image()
+    o.close()
+    assert img.max() > 0 and (img.reshape(-1, 3).max(axis=1) == 0).sum() > 10   # lit floor and a hard shadow under the occluder
+    del sc
+
+
+def test_delta_light_oracle_reproduces_its_golden_fixture():
+    g = np.load(os.path.join(GOLD, "delta_lights64_16spp.npz"))
+    sc = scenes.cornell_box("diffuse", delta_lights=True)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 16, light_strategy=abi.LIGHTS_POWER))
+    o.render(0, 16, threads=4)
+    s = o.stats()
+    assert np.array_equal(o.image(), g["diffuse_rgb"])
+    assert [s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]] == g["diffuse_rays"].tolist()
+    o.close()

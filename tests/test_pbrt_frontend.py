@@ -84,9 +84,9 @@ def test_many_lights_keeps_light_order_with_point_lights(tmp_path):
     P, mat, lights = flatten(d)
     assert np.array_equal(P, sc.vertices[sc.indices])
     n_area = sum(1 for l in lights if l is not None)
-    assert n_area + len(d["point_lights"]) == sc.n_lights
+    assert n_area + len(d["lights"]) == sc.n_lights
     pts = [sc.lights[i] for i in range(sc.n_lights) if sc.lights[i].type == abi.LIGHT_POINT]
-    for got, ref in zip(d["point_lights"], pts):
+    for got, ref in zip(d["lights"], pts):
         assert np.array_equal(np.float32(got["from"]), np.float32(list(ref.pos))) and np.array_equal(np.float32(got["I"]), np.float32(list(ref.L)))
 
 
@@ -125,7 +125,7 @@ WorldEnd
     assert m0["reverse"] == 0 and m1["reverse"] == 1
     assert np.allclose(np.array(m1["P"]).reshape(3, 3), [[-1, 0, 0], [0, 1, 0], [0, 0, 1]])
     assert np.allclose(np.array(m2["P"]).reshape(3, 3), [[5, 6, 7], [6, 6, 7], [5, 7, 7]])          # column-major matrix: translation
-    (l,) = d["point_lights"]
+    (l,) = d["lights"]
     assert np.allclose(l["from"], [11, 22, 33]) and np.allclose(l["I"], [4, 6, 8])
     assert d["integrator"]["name"] == "directlighting" and d["integrator"]["strategy"] == 1 and d["integrator"]["maxdepth"] == 3
     assert len(d["materials"]) == 1 and d["materials"][0]["type"] == abi.MAT_MATTE and np.allclose(d["materials"][0]["kd"], 0.5)   # default material
@@ -212,3 +212,38 @@ WorldEnd
     assert np.allclose(red["kd"], [0.65, 0.05, 0.05]) and glass["type"] == abi.MAT_GLASS and np.float32(glass["index"]) == np.float32(1.33)
     assert np.allclose(glass["kt"], 0) and np.allclose(glass["kr"], 1)
     assert np.float32(metal["uroughness"]) == np.float32(0.2) and np.float32(metal["vroughness"]) == np.float32(0.2)
+
+
+def test_spot_and_distant_lights(tmp_path):
+    """CreateSpotLight / CreateDistantLight (Enigma/Lights.cpp:752-771,791-799): a spot light sits at CTM(from) and its
+    world-to-light rotation takes the direction from -> to to +z; a distant light keeps CTM(from - to) unnormalised."""
+    text = '''
+LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" 60
+Film "image" "integer xresolution" 8 "integer yresolution" 8
+Sampler "sobol" "integer pixelsamples" 1
+WorldBegin
+TransformBegin
+  Translate 1 2 3
+  Scale 2 2 2
+  LightSource "spot" "rgb I" [2 3 4] "point from" [0 5 0] "point to" [0 0 0] "float coneangle" 40 "float conedeltaangle" 15
+  LightSource "distant" "rgb L" [1 2 3] "rgb scale" [2 2 2] "point from" [0 3 0] "point to" [0 0 4]
+TransformEnd
+LightSource "spot" "point to" [3 0 4]
+Shape "trianglemesh" "point P" [0 0 0  1 0 0  0 1 0]
+WorldEnd
+'''
+    d = dump(tmp_path, text)
+    spot, dist, spot2 = d["lights"]
+    assert spot["type"] == abi.LIGHT_SPOT and dist["type"] == abi.LIGHT_DISTANT
+    assert np.allclose(spot["from"], [1, 12, 3]) and np.allclose(spot["I"], [2, 3, 4])
+    assert np.isclose(spot["cos_total_width"], np.cos(np.radians(40.0)), atol=1e-6) and np.isclose(spot["cos_falloff_start"], np.cos(np.radians(25.0)), atol=1e-6)
+    w2l = np.array(spot["world_to_light"]).reshape(3, 3)
+    down = w2l @ np.array([0.0, -1.0, 0.0])                 # world direction the light looks along
+    assert np.allclose(down / np.linalg.norm(down), [0, 0, 1], atol=1e-6)
+    assert np.isclose(np.linalg.norm(down), 0.5, atol=1e-6)  # the CTM's scale 2 is inverted, as m_worldToLight would be
+    assert np.allclose(dist["dir"], [0, 6, -8]) and np.allclose(dist["I"], [2, 4, 6])
+    # defaults: from the origin towards `to`, 30 degree cone with a 5 degree falloff band, I = 1
+    assert np.allclose(spot2["from"], [0, 0, 0]) and np.allclose(spot2["I"], [1, 1, 1])
+    assert np.isclose(spot2["cos_total_width"], np.cos(np.radians(30.0)), atol=1e-6) and np.isclose(spot2["cos_falloff_start"], np.cos(np.radians(25.0)), atol=1e-6)
+    assert np.allclose(np.array(spot2["world_to_light"]).reshape(3, 3) @ np.array([0.6, 0.0, 0.8]), [0, 0, 1], atol=1e-6)

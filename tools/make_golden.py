@@ -114,10 +114,27 @@ def direct_lighting_images():
     np.savez_compressed(os.path.join(G, "direct_lighting64_16spp.npz"), **out)
 
 
+def delta_light_images():
+    """PathIntegrator over the Cornell box with a spot and a distant light added (power / uniform light sampling)."""
+    out = {}
+    for variant, strategy in (("diffuse", abi.LIGHTS_POWER), ("microfacet", abi.LIGHTS_UNIFORM)):
+        sc = scenes.cornell_box(variant, delta_lights=True)
+        cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+        o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 16, light_strategy=strategy))
+        o.render(0, 16, threads=8)
+        s = o.stats()
+        out[variant + "_rgb"] = o.image()
+        out[variant + "_rays"] = np.array([s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]], dtype=np.int64)
+        o.close()
+    np.savez_compressed(os.path.join(G, "delta_lights64_16spp.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "direct":
         direct_lighting_images()
+    elif len(sys.argv) > 1 and sys.argv[1] == "delta":
+        delta_light_images()
     else:
-        sobol_and_camera(); primary_hits(); film_footprints(); bsdf_points(); images(); direct_lighting_images()
+        sobol_and_camera(); primary_hits(); film_footprints(); bsdf_points(); images(); direct_lighting_images(); delta_light_images()
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
