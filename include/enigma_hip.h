@@ -75,6 +75,19 @@ typedef struct EnigmaLight {
 
 #define ENIGMA_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness */
 
+/* HomogeneousMedium (Enigma/Medium.cpp:69-108) with its HenyeyGreenstein phase function
+ * (Enigma/MediumInterface.cpp:159-200).  Read by the VolPathIntegrator only. */
+typedef struct EnigmaMedium {
+    float sigma_a[3];
+    float sigma_s[3];
+    float g;
+    uint32_t reserved;
+} EnigmaMedium;
+
+/* tri_material value of a GeometricPrimitive without a material (MakeMaterial "" / "none", Enigma/Api.cpp:135):
+ * a medium boundary the VolPathIntegrator passes through (Enigma/VolPathIntegrator.cpp:105-111). */
+#define ENIGMA_NO_MATERIAL 0xffffffffu
+
 typedef struct EnigmaSceneDesc {
     uint32_t n_vertices;
     uint32_t n_triangles;
@@ -91,6 +104,13 @@ typedef struct EnigmaSceneDesc {
     uint32_t n_lights;
     const EnigmaMaterial* materials;
     const EnigmaLight* lights;    /* in the order of Scene::m_lights */
+    /* GeometricPrimitive::m_mi per triangle (Enigma/Primitive.cpp:155-160): indices into media or -1 (no medium).
+     * Both NULL = no media anywhere.  Camera rays start outside every medium: the reference's
+     * PerspectiveCamera never hands its medium to the ray (Enigma/Camera.cpp:144-192). */
+    uint32_t n_media;
+    const EnigmaMedium* media;
+    const int32_t* tri_medium_inside;
+    const int32_t* tri_medium_outside;
 } EnigmaSceneDesc;
 
 /* PerspectiveCamera state read by GenerateRayDifferential (Enigma/Camera.cpp:144-192):
@@ -179,6 +199,13 @@ int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* integ);
  * undefined: strategy "all" reading past the sample arrays it requested (a smooth glass with both Kr and
  * Kt branches the recursion, Enigma/Sampler.cpp:62-69), or more than 1024 Sobol' dimensions. */
 int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLightingDesc* integ);
+/* Replaces CreateVolPathIntegrator + SobolSampler construction + VolPathIntegrator::Preprocess
+ * (Enigma/VolPathIntegrator.cpp:27-43,179-200).  enigma_render then runs VolPathIntegrator::Li (:45-177):
+ * HomogeneousMedium::Sample / Tr, Henyey-Greenstein scattering, EstimateDirect with handleMedia = true
+ * (VisibilityTester::Tr, Enigma/Lights.cpp:718-740; Scene::intersectTr, Enigma/Scene.cpp:46-64).
+ * Same parameters as the PathIntegrator.  The BSSRDF branch (:138-162) is not built: no material in scope
+ * has one. */
+int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* integ);
 
 /* Replaces the tile loop of SamplerIntegrator::Render (Enigma/Integrator.cpp:239-320)
  * for sample numbers [sample_begin, sample_end) of every pixel; accumulates into the

@@ -170,6 +170,7 @@ struct Ray {
     Vec3 o, d;
     mutable float tMax = InfinityF32;
     float time = 0;
+    int medium = -1; // Ray::m_medium as an index into Scene::media (-1 = none); read by the VolPathIntegrator only
     Ray() {}
     Ray(Vec3 o_, Vec3 d_, float t = InfinityF32, float tm = 0) : o(o_), d(d_), tMax(t), time(tm) {}
 };
@@ -430,6 +431,8 @@ struct Material; struct AreaLightRef;
 // Interaction.h / Interaction.cpp:21-70
 struct Interaction {
     Vec3 p; float time = 0; Vec3 pError, wo, n;
+    int mInside = -1, mOutside = -1; // m_mediumInterface (VolPathIntegrator only)
+    int GetMedium(const Vec3& w) const { return Dot(w, n) > 0 ? mOutside : mInside; } // Interaction.cpp:72-75
     Ray SpawnRay(const Vec3& d) const { return Ray(OffsetRayOrigin(p, pError, n, d), d, InfinityF32, time); }
     Ray SpawnRayTo(const Interaction& it) const {
         Vec3 origin = OffsetRayOrigin(p, pError, n, it.p - p);
@@ -1448,6 +1451,7 @@ struct Scene {
     std::vector<uint32_t> triMaterial; std::vector<int32_t> triLight; std::vector<uint32_t> primId;
     std::vector<EnigmaMaterial> materials;
     std::vector<Light> lights;
+    std::vector<EnigmaMedium> media; std::vector<int32_t> triInside, triOutside; // GeometricPrimitive::m_mi per triangle
     std::unique_ptr<BVHAccel> accel;
     bool intersect(const Ray& r, SurfaceInteraction* isect, Vec3* bary = nullptr) const { return accel->intersect(r, isect, bary); }
     bool intersectP(const Ray& r) const { return accel->intersectP(r); }
@@ -1578,6 +1582,239 @@ struct PathIntegrator {
     }
 };
 
+// ---------------------------------------------------------------------------
+// VolPathIntegrator (VolPathIntegrator.cpp:45-177) with HomogeneousMedium (Medium.cpp:69-108), the
+// Henyey-Greenstein phase function (MediumInterface.cpp:159-200), EstimateDirect with handleMedia = true
+// (Integrator.cpp:94-204), VisibilityTester::Tr (Lights.cpp:718-740) and Scene::intersectTr (Scene.cpp:46-64).
+// Camera rays carry no medium: PerspectiveCamera::GenerateRayDifferential never assigns one (Camera.cpp:144-192).
+// ---------------------------------------------------------------------------
+static const float MaxF32 = std::numeric_limits<float>::max();
+static Spectrum Exp3(const Spectrum& s) { return Spectrum(std::exp(s.c[0]), std::exp(s.c[1]), std::exp(s.c[2])); }
+static Spectrum Neg3(const Spectrum& s) { return Spectrum(-s.c[0], -s.c[1], -s.c[2]); }
+static Spectrum SigmaT(const EnigmaMedium& m) { return spec3(m.sigma_s) + spec3(m.sigma_a); } // m_sigma_t(sigma_s + sigma_a)
+// HomogeneousMedium::Tr (Medium.cpp:78-81)
+static Spectrum MediumTr(const EnigmaMedium& m, const Ray& ray) { return Exp3(Neg3(SigmaT(m)) * std::min(ray.tMax * Length(ray.d), MaxF32)); }
+// PhaseHG (MediumInterface.cpp:196-200)
+static float PhaseHG(float cosTheta, float g) {
+    const float INV_FOUR_PI = 1.0f / (PI * 4.0f);
+    const float denom = 1 + g * g + 2 * g * cosTheta;
+    return INV_FOUR_PI * (1 - g * g) / (denom * std::sqrt(denom));
+}
+// HenyeyGreenstein::Sample_p (MediumInterface.cpp:159-177); the sampled direction is built around wo itself
+static float HGSample_p(float g, const Vec3& wo, Vec3* wi, const Vec2& u) {
+    float cosTheta;
+    if (std::abs(g) < 1e-3) cosTheta = 1 - 2 * u[0];
+    else {
+        float sqrTerm = (1 - g * g) / (1 + g - 2 * g * u[0]);
+        cosTheta = -(1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    float sinTheta = std::sqrt(std::max((float)0, 1 - cosTheta * cosTheta));
+    float phi = 2 * PI * u[1];
+    Vec3 v1, v2;
+    CoordinateSystem(wo, &v1, &v2);
+    *wi = (sinTheta * cosf(phi) * v1) + (sinTheta * sinf(phi) * v2) + (cosTheta * wo); // SphericalDirection, MathCommon.cpp:13-18
+    return PhaseHG(cosTheta, g);
+}
+struct MediumInteraction : Interaction { bool valid = false; float g = 0; };
+// HomogeneousMedium::Sample (Medium.cpp:83-108)
+static Spectrum MediumSample(const EnigmaMedium& m, int mediumIndex, const Ray& ray, SobolSampler& sampler, MediumInteraction* mi) {
+    Spectrum sigma_t = SigmaT(m), sigma_s = spec3(m.sigma_s);
+    int channel = std::min((int)(sampler.Get1D() * 3), 3 - 1);
+    float dist = -std::log(1 - sampler.Get1D()) / sigma_t.c[channel];
+    float t = std::min(dist / Length(ray.d), ray.tMax);
+    bool sampledMedium = t < ray.tMax;
+    if (sampledMedium) {
+        *mi = MediumInteraction();
+        mi->p = ray.o + ray.d * t; mi->wo = -ray.d; mi->time = ray.time; mi->mInside = mi->mOutside = mediumIndex;
+        mi->valid = true; mi->g = m.g;
+    }
+    Spectrum Tr = Exp3(Neg3(sigma_t) * std::min(t, MaxF32) * Length(ray.d));
+    Spectrum density = sampledMedium ? (sigma_t * Tr) : Tr;
+    float pdf = 0;
+    for (int i = 0; i < 3; ++i) pdf += density.c[i];
+    pdf *= 1 / (float)3;
+    if (pdf == 0) pdf = 1;
+    return sampledMedium ? (Tr * sigma_s / pdf) : (Tr / pdf);
+}
+// Scene::intersect + GeometricPrimitive::intersect's medium interface (Primitive.cpp:146-162)
+static bool IntersectVol(const Scene& scene, const Ray& ray, SurfaceInteraction* isect) {
+    if (!scene.intersect(ray, isect)) return false;
+    int in = scene.triInside.empty() ? -1 : scene.triInside[isect->primIndex], out = scene.triOutside.empty() ? -1 : scene.triOutside[isect->primIndex];
+    if (in != out) { isect->mInside = in; isect->mOutside = out; }
+    else isect->mInside = isect->mOutside = ray.medium;
+    return true;
+}
+static bool HasMaterial(const Scene& scene, const SurfaceInteraction& isect) { return scene.triMaterial[isect.primIndex] != ENIGMA_NO_MATERIAL; }
+static Ray SpawnRayVol(const Interaction& it, const Vec3& d) { Ray r = it.SpawnRay(d); r.medium = it.GetMedium(d); return r; }
+static Ray SpawnRayToVol(const Interaction& it, const Interaction& p1) { Ray r = it.SpawnRayTo(p1); r.medium = it.GetMedium(r.d); return r; }
+// VisibilityTester::Tr (Lights.cpp:718-740); every Scene::intersect it makes counts as a shadow ray
+static Spectrum VisibilityTr(const Scene& scene, const Interaction& p0, const Interaction& p1) {
+    Ray ray = SpawnRayToVol(p0, p1);
+    Spectrum Tr(1.f);
+    while (true) {
+        SurfaceInteraction isect;
+        if (tl_counters) { tl_counters->rays_shadow++; tl_counters->kind = 1; }
+        bool hitSurface = IntersectVol(scene, ray, &isect);
+        if (tl_counters) tl_counters->kind = 0;
+        if (hitSurface && HasMaterial(scene, isect)) return Spectrum(0.0f);
+        if (ray.medium >= 0) Tr *= MediumTr(scene.media[ray.medium], ray);
+        if (!hitSurface) break;
+        ray = SpawnRayToVol(isect, p1);
+    }
+    return Tr;
+}
+// Scene::intersectTr (Scene.cpp:46-64); every Scene::intersect it makes counts as a MIS ray
+static bool IntersectTr(const Scene& scene, Ray ray, SurfaceInteraction* isect, Spectrum* transmittance) {
+    *transmittance = Spectrum(1.f);
+    while (true) {
+        if (tl_counters) { tl_counters->rays_mis++; tl_counters->kind = 2; }
+        bool hitSurface = IntersectVol(scene, ray, isect);
+        if (tl_counters) tl_counters->kind = 0;
+        if (ray.medium >= 0) *transmittance *= MediumTr(scene.media[ray.medium], ray);
+        if (!hitSurface) return false;
+        if (HasMaterial(scene, *isect)) return true;
+        ray = SpawnRayVol(*isect, ray.d);
+    }
+}
+// EstimateDirect, handleMedia = true (Integrator.cpp:94-204): bsdf == nullptr means a medium interaction with asymmetry g
+static Spectrum EstimateDirectVol(const Interaction& it, const Vec3& shadingN, const BSDF* bsdf, float g, const Vec2& uScattering,
+                                  const Light& light, const Vec2& uLight, const Scene& scene) {
+    int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+    Spectrum Ld(0.f);
+    Vec3 wi;
+    float lightPdf = 0, scatteringPdf = 0;
+    Interaction p1;
+    Spectrum Li = light.Sample_Li(it, uLight, &wi, &lightPdf, &p1);
+    if (lightPdf > 0 && !Li.IsBlack()) {
+        Spectrum f;
+        if (bsdf) {
+            f = bsdf->f(it.wo, wi, bsdfFlags) * AbsDot(wi, shadingN);
+            scatteringPdf = bsdf->Pdf(it.wo, wi, bsdfFlags);
+        } else {
+            float p = PhaseHG(Dot(it.wo, wi), g); // HenyeyGreenstein::p
+            f = Spectrum(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack()) {
+            Li *= VisibilityTr(scene, it, p1);
+            if (!Li.IsBlack()) {
+                if (light.IsDelta()) Ld += f * Li / lightPdf;
+                else {
+                    float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                    Ld += f * Li * weight / lightPdf;
+                }
+            }
+        }
+    }
+    if (!light.IsDelta()) {
+        Spectrum f;
+        bool sampledSpecular = false;
+        if (bsdf) {
+            int sampledType = 0;
+            f = bsdf->sample_f(it.wo, &wi, uScattering, &scatteringPdf, bsdfFlags, &sampledType);
+            f *= AbsDot(wi, shadingN);
+            sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        } else {
+            float p = HGSample_p(g, it.wo, &wi, uScattering);
+            f = Spectrum(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack() && scatteringPdf > 0) {
+            float weight = 1;
+            if (!sampledSpecular) {
+                lightPdf = light.Pdf_Li(it, wi);
+                if (lightPdf == 0) return Ld;
+                weight = PowerHeuristic(1, scatteringPdf, 1, lightPdf);
+            }
+            SurfaceInteraction lightIsect;
+            Ray ray = SpawnRayVol(it, wi);
+            Spectrum Tr(1.f);
+            bool found = IntersectTr(scene, ray, &lightIsect, &Tr);
+            Spectrum Li2(0.f);
+            if (found) {
+                if (scene.triLight[lightIsect.primIndex] == light.index) Li2 = Le(scene, lightIsect, -wi);
+            } // else light.Le(ray) == 0 for every light in scope
+            if (!Li2.IsBlack()) Ld += f * Li2 * Tr * weight / scatteringPdf;
+        }
+    }
+    return Ld;
+}
+static Spectrum UniformSampleOneLightVol(const Interaction& it, const Vec3& shadingN, const BSDF* bsdf, float g, const Scene& scene,
+                                         SobolSampler& sampler, const Distribution1D* lightDistrib) {
+    int nLights = (int)scene.lights.size();
+    if (nLights == 0) return Spectrum(0.f);
+    int lightNum; float lightPdf;
+    if (lightDistrib) {
+        lightNum = lightDistrib->SampleDiscrete(sampler.Get1D(), &lightPdf);
+        if (lightPdf == 0) return Spectrum(0.f);
+    } else {
+        lightNum = std::min((int)(sampler.Get1D() * nLights), nLights - 1);
+        lightPdf = 1.0f / nLights;
+    }
+    Vec2 uLight = sampler.Get2D();
+    Vec2 uScattering = sampler.Get2D();
+    return EstimateDirectVol(it, shadingN, bsdf, g, uScattering, scene.lights[lightNum], uLight, scene) / lightPdf;
+}
+
+struct VolPathIntegrator {
+    int maxDepth = 5; float rrThreshold = 1;
+    const Distribution1D* lightDistrib = nullptr; // shared with the PathIntegrator's table
+    Spectrum Li(const Ray& _ray, const Scene& scene, SobolSampler& sampler) const {
+        Spectrum L(0.f), beta(1.f);
+        Ray ray(_ray);
+        bool specularBounce = false;
+        int bounces;
+        float etaScale = 1;
+        for (bounces = 0;; ++bounces) {
+            SurfaceInteraction isect;
+            if (tl_counters) { tl_counters->rays_closest++; tl_counters->kind = 0; }
+            bool foundIntersection = IntersectVol(scene, ray, &isect);
+            MediumInteraction mi;
+            if (ray.medium >= 0) beta *= MediumSample(scene.media[ray.medium], ray.medium, ray, sampler, &mi);
+            if (beta.IsBlack()) break;
+            if (mi.valid) {
+                if (bounces >= maxDepth) break;
+                L += beta * UniformSampleOneLightVol(mi, Vec3(0.f), nullptr, mi.g, scene, sampler, lightDistrib);
+                Vec3 wo = -ray.d, wi;
+                HGSample_p(mi.g, wo, &wi, sampler.Get2D());
+                ray = SpawnRayVol(mi, wi);
+                specularBounce = false;
+            } else {
+                if (bounces == 0 || specularBounce) {
+                    if (foundIntersection) L += beta * Le(scene, isect, -ray.d);
+                }
+                if (!foundIntersection || bounces >= maxDepth) break;
+                if (!HasMaterial(scene, isect)) { // no BSDF: a medium boundary
+                    ray = SpawnRayVol(isect, ray.d);
+                    bounces--;
+                    continue;
+                }
+                std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true));
+                L += beta * UniformSampleOneLightVol(isect, isect.shading.n, bsdf.get(), 0.f, scene, sampler, lightDistrib);
+                Vec3 wo = -ray.d, wi;
+                float pdf = 0;
+                int flags = 0;
+                Spectrum f = bsdf->sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+                if (f.IsBlack() || pdf == 0.f) break;
+                beta *= f * AbsDot(wi, isect.shading.n) / pdf;
+                specularBounce = (flags & BSDF_SPECULAR) != 0;
+                if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                    float eta = bsdf->eta;
+                    etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                }
+                ray = SpawnRayVol(isect, wi);
+            }
+            Spectrum rrBeta = beta * etaScale;
+            if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
+                float q = std::max((float).05, 1 - rrBeta.MaxComponentValue());
+                if (sampler.Get1D() < q) break;
+                beta /= 1 - q;
+            }
+        }
+        return L;
+    }
+};
+
 // Integrator.cpp:42-69
 static Spectrum UniformSampleAllLights(const SurfaceInteraction& it, const BSDF& bsdf, const Scene& scene, SobolSampler& sampler,
                                        const std::vector<int>& nLightSamples) {
@@ -1659,7 +1896,8 @@ struct Oracle {
     std::unique_ptr<Film> film;
     PathIntegrator integrator;
     DirectLightingIntegrator direct;
-    bool useDirect = false;
+    VolPathIntegrator volpath;
+    bool useDirect = false, useVolPath = false;
     std::atomic<bool> readPastArrays{false};
     EnigmaIntegratorDesc idesc;
     std::string error;
@@ -1714,7 +1952,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
                         float rayWeight = O.camera.GenerateRay(cameraSample, &ray);
                         tl_counters->samples++;
                         Spectrum L(0.f);
-                        if (rayWeight > 0) L = O.useDirect ? O.direct.Li(ray, O.scene, tileSampler, 0) : O.integrator.Li(ray, O.scene, tileSampler);
+                        if (rayWeight > 0) L = O.useDirect ? O.direct.Li(ray, O.scene, tileSampler, 0) : O.useVolPath ? O.volpath.Li(ray, O.scene, tileSampler) : O.integrator.Li(ray, O.scene, tileSampler);
                         if (L.HasNaNs()) L = Spectrum(0.f);
                         else if (L.y() < -1e-5) L = Spectrum(0.f);
                         else if (std::isinf(L.y())) L = Spectrum(0.f);
@@ -1788,6 +2026,12 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         sc.primId[i] = s->tri_prim_id ? s->tri_prim_id[i] : i + 1;
     }
     sc.materials.assign(s->materials, s->materials + s->n_materials);
+    sc.media.assign(s->media, s->media + (s->media ? s->n_media : 0));
+    sc.triInside.clear(); sc.triOutside.clear();
+    if (s->tri_medium_inside && s->tri_medium_outside) {
+        sc.triInside.assign(s->tri_medium_inside, s->tri_medium_inside + s->n_triangles);
+        sc.triOutside.assign(s->tri_medium_outside, s->tri_medium_outside + s->n_triangles);
+    }
     for (auto& m : sc.materials)
         if (m.type == ENIGMA_MAT_MATTE && m.sigma != 0) { h->o.error = "Oren-Nayar is not restated"; return -4; }
     sc.lights.resize(s->n_lights);
@@ -1840,7 +2084,7 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     Oracle& O = h->o;
     O.idesc = *d;
     O.integrator.maxDepth = d->max_depth; O.integrator.rrThreshold = d->rr_threshold;
-    O.useDirect = false;
+    O.useDirect = false; O.useVolPath = false;
     // CreateLightSampleDistribution (LightDist.cpp:20-38) + ComputeLightPowerDistribution (Integrator.cpp:30-38)
     size_t n = O.scene.lights.size();
     O.integrator.lightDistrib.reset();
@@ -1862,7 +2106,16 @@ int oracle_direct_lighting_config(OracleCtx* h, const EnigmaDirectLightingDesc* 
     O.direct.strategy = d->strategy;
     O.direct.nLightSamples.clear();
     for (const Light& l : O.scene.lights) O.direct.nLightSamples.push_back(l.nSamples);
-    O.useDirect = true;
+    O.useDirect = true; O.useVolPath = false;
+    return 0;
+}
+int oracle_volpath_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
+    int rc = oracle_integrator_config(h, d); // same parameters, same light distribution
+    if (rc) return rc;
+    Oracle& O = h->o;
+    O.volpath.maxDepth = d->max_depth; O.volpath.rrThreshold = d->rr_threshold;
+    O.volpath.lightDistrib = O.integrator.lightDistrib.get();
+    O.useVolPath = true;
     return 0;
 }
 // 1 if a render since the last call read past the sample arrays the integrator requested (undefined in the reference)
@@ -1873,6 +2126,9 @@ int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_
         BBox2i sb = h->o.film->GetSampleBounds();
         if (sb.mn.x < sb.mn.y) { h->o.error = "sample bounds with min.x < min.y: reference result undefined"; return -4; }
     }
+    if (!h->o.useVolPath)
+        for (uint32_t m : h->o.scene.triMaterial)
+            if (m == ENIGMA_NO_MATERIAL) { h->o.error = "surfaces without a material are restated for the VolPathIntegrator only"; return -4; }
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency(); // NumSystemCores, Misc.h:8-14
     Render(h->o, sample_begin, sample_end, n_threads, want_moments != 0);
     return 0;

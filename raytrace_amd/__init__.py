@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libenigma_hip.so")
 # every symbol include/enigma_hip.h declares
 SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
-    "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
+    "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
     "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint",
 ]
@@ -108,9 +108,11 @@ class Renderer:
         self.w, self.hgt = b[2] - b[0], b[3] - b[1]
 
     def set_integrator(self, integ):
-        """EnigmaIntegratorDesc -> PathIntegrator, EnigmaDirectLightingDesc -> DirectLightingIntegrator."""
+        """EnigmaIntegratorDesc -> PathIntegrator, EnigmaDirectLightingDesc -> DirectLightingIntegrator, EnigmaVolPathDesc -> VolPathIntegrator."""
         if isinstance(integ, abi.EnigmaDirectLightingDesc):
             self._chk(self.L.enigma_direct_lighting_config(self.h, C.byref(integ)))
+        elif isinstance(integ, abi.EnigmaVolPathDesc):
+            self._chk(self.L.enigma_volpath_config(self.h, C.byref(integ)))
         else:
             self._chk(self.L.enigma_integrator_config(self.h, C.byref(integ)))
 

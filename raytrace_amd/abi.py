@@ -8,6 +8,7 @@ LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT = 0, 1, 2, 3
 LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
+NO_MATERIAL = 0xFFFFFFFF
 
 
 class EnigmaMaterial(C.Structure):
@@ -23,13 +24,18 @@ class EnigmaLight(C.Structure):
                 ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float), ("world_to_light", C.c_float * 9)]
 
 
+class EnigmaMedium(C.Structure):
+    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("reserved", C.c_uint32)]
+
+
 class EnigmaSceneDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("vertices", C.c_void_p), ("indices", C.c_void_p), ("tri_material", C.c_void_p),
                 ("tri_light", C.c_void_p), ("tri_flags", C.c_void_p), ("tri_prim_id", C.c_void_p),
                 ("normals", C.c_void_p), ("uvs", C.c_void_p),
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32),
-                ("materials", C.c_void_p), ("lights", C.c_void_p)]
+                ("materials", C.c_void_p), ("lights", C.c_void_p),
+                ("n_media", C.c_uint32), ("media", C.c_void_p), ("tri_medium_inside", C.c_void_p), ("tri_medium_outside", C.c_void_p)]
 
 
 class EnigmaCameraDesc(C.Structure):
@@ -46,6 +52,10 @@ class EnigmaFilmDesc(C.Structure):
 class EnigmaIntegratorDesc(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
                 ("pixel_bounds", C.c_int32 * 4), ("samples_per_pixel", C.c_int64), ("sample_bounds", C.c_int32 * 4)]
+
+
+class EnigmaVolPathDesc(EnigmaIntegratorDesc):
+    """Same layout as EnigmaIntegratorDesc; the type selects enigma_volpath_config."""
 
 
 class EnigmaDirectLightingDesc(C.Structure):
@@ -67,7 +77,8 @@ def ptr(a):
 class SceneArrays:
     """Owns the numpy arrays an EnigmaSceneDesc points into."""
 
-    def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None):
+    def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None,
+                 media=(), tri_medium_inside=None, tri_medium_outside=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nt = self.indices.shape[0]
@@ -75,7 +86,11 @@ class SceneArrays:
         self.tri_light = np.ascontiguousarray(tri_light, dtype=np.int32).reshape(nt)
         self.tri_flags = None if tri_flags is None else np.ascontiguousarray(tri_flags, dtype=np.uint32).reshape(nt)
         self.tri_prim_id = None if tri_prim_id is None else np.ascontiguousarray(tri_prim_id, dtype=np.uint32).reshape(nt)
-        self.materials = (EnigmaMaterial * len(materials))(*materials)
+        self.media = (EnigmaMedium * max(1, len(media)))(*media)
+        self.n_media = len(media)
+        self.tri_medium_inside = None if tri_medium_inside is None else np.ascontiguousarray(tri_medium_inside, dtype=np.int32).reshape(nt)
+        self.tri_medium_outside = None if tri_medium_outside is None else np.ascontiguousarray(tri_medium_outside, dtype=np.int32).reshape(nt)
+        self.materials = (EnigmaMaterial * max(1, len(materials)))(*materials)
         self.lights = (EnigmaLight * max(1, len(lights)))(*lights)
         self.n_lights = len(lights)
         self.n_materials = len(materials)
@@ -96,6 +111,10 @@ class SceneArrays:
         d.n_lights = self.n_lights
         d.materials = C.cast(self.materials, C.c_void_p)
         d.lights = C.cast(self.lights, C.c_void_p)
+        d.n_media = self.n_media
+        d.media = C.cast(self.media, C.c_void_p) if self.n_media else None
+        d.tri_medium_inside = ptr(self.tri_medium_inside)
+        d.tri_medium_outside = ptr(self.tri_medium_outside)
         return d
 
 
@@ -138,6 +157,14 @@ def plastic(kd, ks, roughness=0.1, remap=True):
     m.uroughness = roughness
     m.vroughness = roughness
     m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def homogeneous_medium(sigma_a, sigma_s, g=0.0):
+    m = EnigmaMedium()
+    m.sigma_a[:] = sigma_a
+    m.sigma_s[:] = sigma_s
+    m.g = g
     return m
 
 

@@ -21,6 +21,7 @@ constexpr float kOneMinusEpsilon = 0.9999999403953552f;
 constexpr float kMachineEpsilon = 5.9604644775390625e-08f; // numeric_limits<float>::epsilon() * 0.5
 constexpr float kShadowEpsilon = 0.0001f;
 #define EDEV_INF __builtin_huge_valf()
+#define EDEV_MAXF 3.402823466e+38f
 
 // (n * eps) / (1 - n * eps), Enigma/MathCommon.h:133-135 -- folded at compile time in float
 DEV constexpr float gammaf(int n) { return (n * kMachineEpsilon) / (1 - n * kMachineEpsilon); }
@@ -45,6 +46,7 @@ DEV F3& operator*=(F3& a, float s) { a = a * s; return a; }
 DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV float absdot(F3 a, F3 b) { return fabsf(dot(a, b)); }
 DEV float lengthSqr(F3 a) { return dot(a, a); }
+DEV float length(F3 a) { return sqrtf(dot(a, a)); } // glm::length
 DEV F3 cross(F3 x, F3 y) { return F3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 DEV F3 normalize(F3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 DEV F3 fabs3(F3 v) { return F3(fabsf(v.x), fabsf(v.y), fabsf(v.z)); }

@@ -8,8 +8,15 @@ namespace edev {
 // upload: a smooth glass is one FresnelSpecular lobe (allowMultipleLobes is always true on the
 // PathIntegrator path, Enigma/PathIntegrator.cpp:89, Enigma/Material.cpp:190-194).
 enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4, MK_COUNT = 5,
+                          MK_NONE = 5 /* a triangle without a material: a medium boundary (VolPathIntegrator) */,
                           MK_DL_GLASS = 6 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
-constexpr int kQueueKinds = MK_COUNT + 1; // one queue per material kind + (DirectLightingIntegrator) paths that resume a pending branch
+// One queue per material kind, then queue MK_COUNT: DirectLightingIntegrator paths that resume a pending branch /
+// VolPathIntegrator paths at a material-less surface; queue MK_COUNT + 1: VolPathIntegrator medium interactions.
+constexpr int kQueueKinds = MK_COUNT + 2;
+constexpr int kQueueMedium = MK_COUNT + 1;
+
+// HomogeneousMedium (Enigma/Medium.cpp:69-108): sigma_t = sigma_s + sigma_a, Henyey-Greenstein g
+struct DevMedium { float sigmaT[3]; float g; float sigmaS[3]; float pad; };
 
 struct DevMaterial {        // 64 bytes
     uint32_t kind;          // MatKind
@@ -50,6 +57,8 @@ struct DevScene {
     const float* lightCdf;      // Distribution1D::cdf, nLights + 1
     const float* lightFunc;     // Distribution1D::func, nLights
     const uint32_t* primId;     // reference m_primitiveId by original triangle index
+    const DevMedium* media;     // VolPathIntegrator only
+    const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;
     int nLights;
     uint32_t nTris;
@@ -112,7 +121,7 @@ struct DevDirect {
 // hit record, and the pixel / sample slot of a path follow from its index (path = slot * nPixels + pixel).
 struct DevPaths {
     float4* rayO;     // o.xyz, unused
-    float4* rayD;     // d.xyz, bits(state): dim[12:22) | bounces or depth[22:30) | specularBounce[30]
+    float4* rayD;     // d.xyz, bits(state): medium + 1 [0:12) (VolPathIntegrator) | dim[12:22) | bounces or depth[22:30) | specularBounce[30]
     float4* L;        // radiance accumulated so far, unused
     float4* beta;     // throughput rgb, etaScale
     float4* hit;      // bits(triangle, device order), b0, b1, b2
@@ -126,12 +135,17 @@ struct DevPaths {
 // packed into two float4 and one float instead of three float4: a = {o.xyz, d.x}, b = {d.y, d.z, w.x, w.y},
 // wz = w.z.  Its tMax is the constant 1 - ShadowEpsilon (Enigma/Interaction.cpp:58-64).
 struct DevRayQueue {
-    float4* o;        // MIS: [slot] o.xyz, unused.                 shadow: a
+    float4* o;        // MIS: [slot] o.xyz, bits(medium + 1) under the VolPathIntegrator.  shadow: a
     float4* d;        // MIS: [slot] d.xyz, bits(light index).      shadow: b
     float4* w;        // MIS: [slot] weight of the light's Le.      shadow: unused (nullptr)
     float* wz;        // shadow only
     uint32_t* idx;    // [0, count) ray slots (= path index * perPath + ray of the path)
     uint32_t perPath; // 1 for PathIntegrator
+    // VolPathIntegrator shadow rays: the light-side end point of VisibilityTester::Tr, which respawns the ray
+    // towards it after every medium boundary (Enigma/Lights.cpp:718-740)
+    float4* tgtP;     // p1.p, bits(medium + 1 of the first segment)
+    float4* tgtE;     // p1.pError
+    float4* tgtN;     // p1.n
 };
 
 // Queue tails are bumped with device-scope atomics by every block of a launch.  Atomics on one
@@ -145,10 +159,10 @@ struct DevCounters {
     unsigned long long raysClosest, raysShadow, raysMis, samples;
 };
 
-DEV uint32_t packState(uint32_t slot, uint32_t dim, uint32_t bounces, uint32_t spec) {
-    return slot | (dim << 12) | (bounces << 22) | (spec << 30);
+DEV uint32_t packState(uint32_t medium, uint32_t dim, uint32_t bounces, uint32_t spec) {
+    return medium | ((dim & 0x3ffu) << 12) | (bounces << 22) | (spec << 30); // the reference aborts past dimension 1023; here the cursor wraps
 }
-DEV uint32_t stSlot(uint32_t s) { return s & 0xfffu; }
+DEV uint32_t stMedium(uint32_t s) { return s & 0xfffu; } // medium + 1, 0 = none
 DEV uint32_t stDim(uint32_t s) { return (s >> 12) & 0x3ffu; }
 DEV uint32_t stBounces(uint32_t s) { return (s >> 22) & 0xffu; }
 DEV uint32_t stSpec(uint32_t s) { return (s >> 30) & 1u; }

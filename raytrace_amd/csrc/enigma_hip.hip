@@ -4,7 +4,7 @@
 #include "../../include/enigma_hip.h"
 
 #include "bvh_build.h"
-#include "kernels.h"
+#include "kernels_vol.h"
 #include "sobol_host.h"
 
 #include <algorithm>
@@ -56,6 +56,9 @@ struct EnigmaCtx {
     DevBuf<DevLight> lights;
     DevBuf<float> lightCdf, lightFunc;
     DevBuf<uint32_t> primId;
+    DevBuf<DevMedium> media;
+    DevBuf<uint32_t> triMedium;
+    bool haveNoMaterial = false; // some triangle has no material (a medium boundary): VolPathIntegrator only
     std::vector<DevLight> hostLights;
     std::vector<float> lightPower; // Light::Power().y() per light
     bool kindPresent[MK_COUNT] = {false, false, false, false, false};
@@ -79,6 +82,10 @@ struct EnigmaCtx {
     DevBuf<uint32_t> tx, ty, sampleConst;
     DevSampler sampler{};
     bool lightDistDirty = true;
+    // VolPathIntegrator
+    bool useVolPath = false;
+    DevBuf<float4> shTgtP, shTgtE, shTgtN;
+    size_t volCapacity = 0;
     // DirectLightingIntegrator
     bool useDirect = false, directDirty = true;
     EnigmaDirectLightingDesc directDesc{};
@@ -140,7 +147,8 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->rayO, &h->rayD, &h->L, &h->beta, &h->hit,
                             &h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
     for (auto* b : f4) b->release();
-    h->shWz.release();
+    h->shWz.release(); h->shTgtP.release(); h->shTgtE.release(); h->shTgtN.release();
+    h->media.release(); h->triMedium.release();
     h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
     h->extQ[0].release(); h->extQ[1].release();
@@ -159,13 +167,28 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->normals || s->uvs) return h->fail(ENIGMA_E_UNSUPPORTED, "per-vertex normals / uvs are not supported");
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
     if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
-    if (s->n_materials == 0 && s->n_triangles) return h->fail(ENIGMA_E_INVALID, "no materials");
+    if (s->n_materials == 0 && s->n_triangles) {
+        bool anyMaterial = false;
+        for (uint32_t t = 0; t < s->n_triangles && s->tri_material; ++t) anyMaterial = anyMaterial || s->tri_material[t] != ENIGMA_NO_MATERIAL;
+        if (anyMaterial) return h->fail(ENIGMA_E_INVALID, "no materials");
+    }
     if (s->n_materials >= (1u << 24)) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 2^24 materials");
     for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
         if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
+    const bool haveMedia = s->tri_medium_inside && s->tri_medium_outside;
+    if ((s->tri_medium_inside != nullptr) != (s->tri_medium_outside != nullptr)) return h->fail(ENIGMA_E_INVALID, "tri_medium_inside and tri_medium_outside go together");
+    if (haveMedia && s->n_media && !s->media) return h->fail(ENIGMA_E_INVALID, "null media array");
+    if (s->n_media >= 0xfffu) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 4094 media");
+    h->haveNoMaterial = false;
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
-        if (s->tri_material[t] >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "material index out of range at triangle %u", t);
+        if (s->tri_material[t] == ENIGMA_NO_MATERIAL) {
+            h->haveNoMaterial = true;
+            if (s->tri_light[t] >= 0) return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light on a surface without a material is not supported", t);
+        } else if (s->tri_material[t] >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "material index out of range at triangle %u", t);
         if (s->tri_light[t] >= (int32_t)s->n_lights) return h->fail(ENIGMA_E_INVALID, "light index out of range at triangle %u", t);
+        if (haveMedia && (s->tri_medium_inside[t] < -1 || s->tri_medium_inside[t] >= (int32_t)s->n_media || s->tri_medium_outside[t] < -1 ||
+                          s->tri_medium_outside[t] >= (int32_t)s->n_media))
+            return h->fail(ENIGMA_E_INVALID, "medium index out of range at triangle %u", t);
     }
     // materials (Enigma/Material.cpp:76-255 parameter evaluation with constant textures)
     std::vector<DevMaterial> mats(s->n_materials);
@@ -237,7 +260,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         uint32_t t = bvh.triOrder[k];
         newPos[t] = k;
         uint32_t flip = (s->tri_flags && (s->tri_flags[t] & ENIGMA_TRI_FLIP_NORMAL)) ? 1u : 0u;
-        uint32_t w[3] = {t, s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | (flip << 31), (uint32_t)s->tri_light[t]};
+        const bool noMat = s->tri_material[t] == ENIGMA_NO_MATERIAL;
+        uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | (flip << 31) : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | (flip << 31), (uint32_t)s->tri_light[t]};
         for (int v = 0; v < 3; ++v) {
             const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
             float wf;
@@ -311,6 +335,24 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
         } else return h->fail(ENIGMA_E_UNSUPPORTED, "light type %u is not supported", l.type);
         h->hostLights[i] = d;
+    }
+    // media (Enigma/Medium.cpp:69-76) and the triangles' medium interfaces in device order
+    {
+        std::vector<DevMedium> md(haveMedia ? s->n_media : 0);
+        for (size_t i = 0; i < md.size(); ++i) {
+            const EnigmaMedium& m = s->media[i];
+            for (int c = 0; c < 3; ++c) { md[i].sigmaT[c] = m.sigma_s[c] + m.sigma_a[c]; md[i].sigmaS[c] = m.sigma_s[c]; }
+            md[i].g = m.g; md[i].pad = 0.f;
+        }
+        std::vector<uint32_t> tm(haveMedia ? s->n_triangles : 0);
+        for (uint32_t k = 0; k < (uint32_t)tm.size(); ++k) {
+            uint32_t t = bvh.triOrder[k];
+            tm[k] = (uint32_t)(s->tri_medium_inside[t] + 1) | ((uint32_t)(s->tri_medium_outside[t] + 1) << 16);
+        }
+        HIPCHK(h, h->media.upload(md));
+        HIPCHK(h, h->triMedium.upload(tm));
+        h->scene.media = h->media.p;
+        h->scene.triMedium = haveMedia ? h->triMedium.p : nullptr;
     }
     HIPCHK(h, h->nodes.upload(nodeData));
     HIPCHK(h, h->tris.upload(triData));
@@ -387,6 +429,9 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     h->nDims = nDims;
     enigma::SobolPixelTables T;
     enigma::build_pixel_tables(h->log2Res, nDims, &T);
+    // a kernel reads up to 5 dimensions past its cursor before the cursor is checked against anything: pad the tables
+    T.tx.resize(T.tx.size() + (size_t)16 * h->resolution, 0u);
+    T.ty.resize(T.ty.size() + (size_t)16 * h->resolution, 0u);
     HIPCHK(h, h->tx.upload(T.tx));
     HIPCHK(h, h->ty.upload(T.ty));
     // constant of sample number 1 << b per dimension; sample numbers stay below 2^(52 - 2 log2Res), the width of the
@@ -431,6 +476,29 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
     h->integ.raysPerPath = 1;
     h->lightDistDirty = true;
     h->useDirect = false;
+    h->useVolPath = false;
+    h->haveInteg = true;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    // every ray segment inside a medium draws two more samples and boundaries do not count as bounces, so a path's
+    // dimensions are not bounded by its depth: every dimension the 10-bit cursor can address is tabulated (the reference
+    // aborts at dimension 1024)
+    if (d->max_depth < 0 || d->max_depth > 60) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
+    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 1023u);
+    if (rc) return rc;
+    h->integDesc = *d;
+    h->integ.maxDepth = d->max_depth;
+    h->integ.rrThreshold = d->rr_threshold;
+    h->integ.raysPerPath = 1;
+    h->lightDistDirty = true;
+    h->useDirect = false;
+    h->useVolPath = true;
     h->haveInteg = true;
     return ENIGMA_OK;
 }
@@ -448,6 +516,7 @@ extern "C" int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLig
     memcpy(h->integDesc.sample_bounds, d->sample_bounds, sizeof(d->sample_bounds));
     h->integDesc.samples_per_pixel = d->samples_per_pixel;
     h->useDirect = true;
+    h->useVolPath = false;
     h->directDirty = true; // finished against the scene at render time (Preprocess needs the lights)
     h->haveInteg = true;
     // the sampler part does not depend on the scene: report its errors now
@@ -563,7 +632,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, false><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -576,6 +645,38 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->scene.nLights > 0) {
         k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+    }
+}
+
+// One iteration of VolPathIntegrator::Li's loop for every path in flight (Enigma/VolPathIntegrator.cpp:63-174):
+// trace + medium sampling, then the surface, medium and boundary branches, then the shadow and MIS rays.
+template <int LDSN, int OVF, bool LDS_SCENE>
+static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int iter, int gridTrace,
+                            int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
+    DevCounters* ctr = h->counters.p;
+    uint32_t cur = (uint32_t)iter & 1u;
+    hipStream_t s = h->stream;
+    k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, iter == 0 ? 1 : 0);
+    MatQueues mq;
+    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
+    const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
+    const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
+    (void)hipEventRecord(e0, s);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+                                                                                                              h->refillIdle, nullptr);
+    (void)hipEventRecord(e1, s);
+    uint32_t* nextQ = h->extQ[cur ^ 1u].p;
+    const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->scene.triMedium) k_shade_medium<LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
+    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
+    if (h->scene.nLights > 0) {
+        k_shadow_tr<LDSN, OVF, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
@@ -594,7 +695,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, true><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                                  h->refillIdle, D.pendCount);
     (void)hipEventRecord(e1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -624,7 +725,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
     // passes of k sample numbers over all pixels, ~32M paths in flight (capped by the 12-bit sample slot)
-    const bool direct = h->useDirect;
+    const bool direct = h->useDirect, vol = h->useVolPath && !h->useDirect;
+    if (h->haveNoMaterial && !vol) return h->fail(ENIGMA_E_UNSUPPORTED, "the scene has surfaces without a material (medium boundaries): only the VolPathIntegrator renders them");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
     size_t basePaths = (size_t)32 << 20; // ~11 GB of path state at 330 B per path; larger launches run closer to the hardware's rates
@@ -641,7 +743,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
     for (int64_t c0 = 0; c0 < nSamples; c0 += chunkMax) {
         int64_t cn = std::min(chunkMax, nSamples - c0);
-        std::vector<uint32_t> consts((size_t)cn * h->nDims);
+        std::vector<uint32_t> consts((size_t)cn * h->nDims + 16, 0u);
         for (int64_t s = 0; s < cn; ++s) enigma::sample_constants(h->log2Res, (uint64_t)(sample_begin + c0 + s), h->nDims, &consts[(size_t)s * h->nDims]);
         HIPCHK(h, h->sampleConst.upload(consts));
         h->sampler.sampleConst = h->sampleConst.p;
@@ -649,7 +751,15 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
         DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath}, misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath};
+        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath, nullptr, nullptr, nullptr};
+        DevRayQueue misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath, nullptr, nullptr, nullptr};
+        if (vol) {
+            if (passPathsMax > h->volCapacity) {
+                HIPCHK(h, h->shTgtP.alloc(passPathsMax)); HIPCHK(h, h->shTgtE.alloc(passPathsMax)); HIPCHK(h, h->shTgtN.alloc(passPathsMax));
+                h->volCapacity = passPathsMax;
+            }
+            shq.tgtP = h->shTgtP.p; shq.tgtE = h->shTgtE.p; shq.tgtN = h->shTgtN.p;
+        }
         DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
         for (int64_t s0 = 0; s0 < cn; s0 += k) {
@@ -685,7 +795,27 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                 if (alive == 0) break;
                 if (step > (1 << 20)) return h->fail(ENIGMA_E_DEVICE, "DirectLightingIntegrator walk did not terminate");
             }
-            for (int b = 0; !direct && b <= h->integ.maxDepth; ++b) {
+            // VolPathIntegrator: crossing a medium boundary is an iteration of Li's loop that is not a bounce, so the number
+            // of iterations is not known beforehand; the host reads the number of continuing paths after each one
+            for (int iter = 0; vol; ++iter) {
+                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
+                while (h->evPool.size() < need) {
+                    hipEvent_t e;
+                    HIPCHK(h, hipEventCreate(&e));
+                    h->evPool.push_back(e);
+                }
+                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
+                if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                else launchVolBounce<12, 52, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                h->stats.intersect_launches++;
+                uint32_t alive = 0;
+                HIPCHK(h, hipMemcpyAsync(&alive, &h->counters.p->extCount[(iter & 1) ^ 1].v, sizeof(alive), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (alive == 0) break;
+                if (iter > 4096) return h->fail(ENIGMA_E_DEVICE, "VolPathIntegrator: paths still alive after 4096 iterations");
+            }
+            for (int b = 0; !direct && !vol && b <= h->integ.maxDepth; ++b) {
                 size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
                 while (h->evPool.size() < need) {
                     hipEvent_t e;

@@ -234,11 +234,15 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 
 // DL: the head of DirectLightingIntegrator::Li instead (Enigma/DirectLightingIntegrator.cpp:41-55): emitted
 // radiance is added at every hit, every hit is shaded, and a path that misses resumes a pending branch.
-template <int LDSN, int OVF, bool LDS_SCENE, bool DL>
-__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, const uint32_t* queue,
+// MODE 2: the head of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:63-111): a ray that travels in a medium
+// samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
+// medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE>
+__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
-    constexpr int NK = DL ? kQueueKinds : MK_COUNT;
+    constexpr bool DL = MODE == 1, VOL = MODE == 2;
+    constexpr int NK = MODE == 0 ? MK_COUNT : (MODE == 1 ? MK_COUNT + 1 : kQueueKinds);
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];
     __shared__ uint32_t binBase[kQueueKinds];
@@ -269,7 +273,43 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
                     uint32_t kind = 0;
                     const Hit& h = w.h;
-                    if (h.tri >= 0) {
+                    bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
+                    if (VOL && stMedium(state) != 0) {
+                        const DevMedium md = sc.media[stMedium(state) - 1u];
+                        uint32_t px, py, slot;
+                        pathPixel(I, S, p, &px, &py, &slot);
+                        uint32_t dim = stDim(state);
+                        float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
+                        state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state));
+                        reinterpret_cast<float*>(P.rayD + p)[3] = __uint_as_float(state);
+                        int channel = min((int)(uc * 3), 3 - 1);
+                        float dist = -logf(1 - ud) / md.sigmaT[channel];
+                        float len = length(w.r.d);
+                        float tHit = h.tri >= 0 ? h.t : EDEV_INF;
+                        float t = smin(dist / len, tHit);
+                        bool sampledMedium = t < tHit;
+                        float tt = smin(t, EDEV_MAXF);
+                        F3 Tr(expf(-md.sigmaT[0] * tt * len), expf(-md.sigmaT[1] * tt * len), expf(-md.sigmaT[2] * tt * len));
+                        F3 sigT(md.sigmaT[0], md.sigmaT[1], md.sigmaT[2]);
+                        F3 density = sampledMedium ? sigT * Tr : Tr;
+                        float pdf = 0;
+                        pdf += density.x; pdf += density.y; pdf += density.z;
+                        pdf *= 1 / (float)3;
+                        if (pdf == 0) pdf = 1;
+                        F3 wgt = sampledMedium ? Tr * F3(md.sigmaS[0], md.sigmaS[1], md.sigmaS[2]) / pdf : Tr / pdf;
+                        float4 be = P.beta[p];
+                        F3 beta = xyz(be) * wgt;
+                        P.beta[p] = mk4(beta, be.w);
+                        if (isBlack(beta)) proceed = false;
+                        else if (sampledMedium) {
+                            proceed = false;
+                            if ((int)stBounces(state) < I.maxDepth) {
+                                kind = (uint32_t)kQueueMedium + 1u;
+                                P.hit[p] = make_float4(__int_as_float(-1), t, 0.f, 0.f);
+                            }
+                        }
+                    }
+                    if (proceed && h.tri >= 0) {
                         uint32_t st = state;
                         uint32_t bounces = stBounces(st);
                         const float4* tp = tris + (size_t)h.tri * 3;
@@ -374,14 +414,13 @@ struct DirectSample {
     bool shadow, mis;
     F3 shO, shD, Ld;
     F3 miO, miD, miF;
+    F3 tgtP, tgtE, tgtN; // the light-side end of the shadow ray as an Interaction (p, pError, n): VisibilityTester::p1
 };
-template <int MK>
-DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
-                                float ulx, float uly, float usx, float usy) {
-    const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
-    DirectSample r;
-    r.shadow = false; r.mis = false;
-    // ---- light sampling (Enigma/Integrator.cpp:104-148) ----
+// Light::Sample_Li for a reference point (Enigma/Lights.cpp:117-124,165-172,634-645,696-703): direction, radiance,
+// pdf and the sampled point as an Interaction; q0..q2 are the area light's vertices (read again by Shape::pdf).
+struct LightSample { F3 wi, Li, lp, lpErr, ln, q0, q1, q2; float pdf; };
+DEV LightSample sampleLight(const DevLight& lt, const float4* tris, F3 refP, float ulx, float uly) {
+    LightSample s;
     F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
     float lightPdf = 0.f;
     F3 q0(0.f), q1(0.f), q2(0.f);
@@ -400,27 +439,27 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
         lpErr = gammaf(6) * (fabs3(tb0 * q0) + fabs3(tb1 * q1) + fabs3((1 - tb0 - tb1) * q2));
         lightPdf = 1 / lt.area;
         // Shape::sample(ref, u) (Enigma/Shape.cpp:54-69)
-        F3 w = lp - g.p;
+        F3 w = lp - refP;
         if (lengthSqr(w) == 0) lightPdf = 0;
         else {
             w = normalize(w);
-            lightPdf *= lengthSqr(g.p - lp) / absdot(ln, -w);
+            lightPdf *= lengthSqr(refP - lp) / absdot(ln, -w);
             if (isinf(lightPdf)) lightPdf = 0.f;
         }
         // DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
-        if (lightPdf == 0 || lengthSqr(lp - g.p) == 0) lightPdf = 0;
+        if (lightPdf == 0 || lengthSqr(lp - refP) == 0) lightPdf = 0;
         else {
-            wi = normalize(lp - g.p);
+            wi = normalize(lp - refP);
             if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
         }
     } else if (lt.type == 3) { // DistantLight::Sample_Li (Enigma/Lights.cpp:696-703): wi = m_lightDir as stored
         wi = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
         lightPdf = 1.f;
-        lp = g.p + wi * (2 * lt.worldRadius);
+        lp = refP + wi * (2 * lt.worldRadius);
         Li = F3(lt.L[0], lt.L[1], lt.L[2]);
     } else { // PointLight::Sample_Li (Enigma/Lights.cpp:117-124), SpotLight::Sample_Li (:165-172)
         lp = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
-        wi = normalize(lp - g.p);
+        wi = normalize(lp - refP);
         lightPdf = 1.f;
         Li = F3(lt.L[0], lt.L[1], lt.L[2]);
         if (lt.type == 2) { // SpotLight::Falloff(-wi) (Enigma/Lights.cpp:180-190)
@@ -436,8 +475,34 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
             }
             Li = Li * fall;
         }
-        Li = Li / lengthSqr(lp - g.p);
+        Li = Li / lengthSqr(lp - refP);
     }
+    s.wi = wi; s.Li = Li; s.lp = lp; s.lpErr = lpErr; s.ln = ln; s.q0 = q0; s.q1 = q1; s.q2 = q2; s.pdf = lightPdf;
+    return s;
+}
+// Shape::pdf(ref, wi) for a light's own triangle (Enigma/Shape.cpp:80-98): the ray from o along wi against (q0, q1, q2)
+DEV float lightTrianglePdf(F3 o, F3 refP, F3 wi, F3 q0, F3 q1, F3 q2, float area) {
+    RaySetup rs = setupRay(o, wi);
+    float lt_t, lb0, lb1, lb2;
+    float pdf = 0.f;
+    if (triangleTest(rs, EDEV_INF, q0, q1, q2, &lt_t, &lb0, &lb1, &lb2)) {
+        F3 pl = lb0 * q0 + lb1 * q1 + lb2 * q2;
+        F3 nl = normalize(cross(q0 - q2, q1 - q2));
+        pdf = lengthSqr(refP - pl) / (absdot(nl, -wi) * area);
+        if (isinf(pdf)) pdf = 0.f;
+    }
+    return pdf;
+}
+template <int MK>
+DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
+                                float ulx, float uly, float usx, float usy) {
+    const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
+    DirectSample r;
+    r.shadow = false; r.mis = false;
+    // ---- light sampling (Enigma/Integrator.cpp:104-148) ----
+    LightSample ls = sampleLight(lt, tris, g.p, ulx, uly);
+    F3 wi = ls.wi, Li = ls.Li, lp = ls.lp, lpErr = ls.lpErr, ln = ls.ln, q0 = ls.q0, q1 = ls.q1, q2 = ls.q2;
+    float lightPdf = ls.pdf;
     if (lightPdf > 0 && !isBlack(Li)) {
         F3 f = bsdfF<MK>(bsdf, woN, wi, kNonSpecular) * absdot(wi, ns);
         float scatteringPdf = bsdfPdf<MK>(bsdf, woN, wi, kNonSpecular);
@@ -448,6 +513,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
             if (lt.type != 1) r.Ld = f * Li / lightPdf; // IsDeltaLight
             else r.Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
             r.shO = origin; r.shD = target - origin;
+            r.tgtP = lp; r.tgtE = lpErr; r.tgtN = ln;
             r.shadow = true;
         }
     }
@@ -460,15 +526,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
         if (!isBlack(f2) && scatPdf2 > 0) {
             // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
             F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
-            RaySetup rs = setupRay(o2, wi2);
-            float lt_t, lb0, lb1, lb2;
-            float lightPdf2 = 0.f;
-            if (triangleTest(rs, EDEV_INF, q0, q1, q2, &lt_t, &lb0, &lb1, &lb2)) {
-                F3 pl = lb0 * q0 + lb1 * q1 + lb2 * q2;
-                F3 nl = normalize(cross(q0 - q2, q1 - q2));
-                lightPdf2 = lengthSqr(g.p - pl) / (absdot(nl, -wi2) * lt.area);
-                if (isinf(lightPdf2)) lightPdf2 = 0.f;
-            }
+            float lightPdf2 = lightTrianglePdf(o2, g.p, wi2, q0, q1, q2, lt.area);
             if (lightPdf2 != 0) {
                 float weight = powerHeuristic(scatPdf2, lightPdf2);
                 r.miO = o2; r.miD = wi2;
@@ -518,7 +576,10 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
         lightFunc = ldsFunc;                                                                                             \
     }
 
-template <int MK, bool LDS_SCENE>
+// VOL: the surface branch of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:113-136): direct lighting is
+// sampled for every BSDF (no test for non-specular lobes), and every ray leaving the surface takes the medium on
+// its side of the surface (Interaction::GetMedium, Enigma/Interaction.cpp:72-75).
+template <int MK, bool LDS_SCENE, bool VOL = false>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
@@ -551,9 +612,20 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             makeBsdf<MK>(materials[g.matIdx], g.n, g.dpdu, &bsdf);
             F3 ns = g.n; // shading normal == geometric normal (no per-vertex normals)
             F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
+            // medium + 1 on either side of the surface: the triangle's MediumInterface if it is a transition, else
+            // the medium the ray arrived in (GeometricPrimitive::intersect, Enigma/Primitive.cpp:155-160)
+            uint32_t medIn = 0, medOut = 0;
+            if (VOL) {
+                medIn = medOut = stMedium(st);
+                if (sc.triMedium) {
+                    uint32_t tm = sc.triMedium[tri], a = tm & 0xffffu, b = tm >> 16;
+                    if (a != b) { medIn = a; medOut = b; }
+                }
+            }
+            auto mediumTowards = [&](F3 w) { return dot(w, g.n) > 0 ? medOut : medIn; };
 
             // ---- UniformSampleOneLight (Enigma/Integrator.cpp:71-92) ----
-            if (numComponents<MK>(bsdf, kNonSpecular) > 0 && sc.nLights > 0) {
+            if ((VOL || numComponents<MK>(bsdf, kNonSpecular) > 0) && sc.nLights > 0) {
                 float pick;
                 int lightNum = sampleDiscrete(lightCdf, lightFunc, sc.lightFuncInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
                 dim += 1;
@@ -564,10 +636,15 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     DirectSample ds = estimateDirect<MK>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
                         storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
+                        if (VOL) {
+                            shq.tgtP[p] = mk4(ds.tgtP, __uint_as_float(mediumTowards(ds.shD)));
+                            shq.tgtE[p] = mk4(ds.tgtE, 0.f);
+                            shq.tgtN[p] = mk4(ds.tgtN, 0.f);
+                        }
                         pushShadow = true;
                     }
                     if (ds.mis) {
-                        misq.o[p] = mk4(ds.miO, 0.f);
+                        misq.o[p] = mk4(ds.miO, VOL ? __uint_as_float(mediumTowards(ds.miD)) : 0.f);
                         misq.d[p] = mk4(ds.miD, __int_as_float(lightNum));
                         misq.w[p] = mk4(beta * (ds.miF / pick), 0.f);
                         pushMis = true;
@@ -600,7 +677,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                 }
                 if (alive) {
                     P.rayO[p] = mk4(no, 0.f);
-                    P.rayD[p] = mk4(wi, __uint_as_float(packState(0u, dim, bounces + 1, spec)));
+                    P.rayD[p] = mk4(wi, __uint_as_float(packState(VOL ? mediumTowards(wi) : 0u, dim, bounces + 1, spec)));
                     P.beta[p] = mk4(beta, etaScale);
                     pushNext = true;
                 }

@@ -1,0 +1,308 @@
+// VolPathIntegrator kernels (Enigma/VolPathIntegrator.cpp:45-177) beside the PathIntegrator's:
+//   k_intersect_closest<.., 2>  Scene::intersect + HomogeneousMedium::Sample (kernels.h)
+//   k_shade<kind, .., true>     the surface branch (kernels.h)
+//   k_shade_medium              the medium branch: direct lighting with the Henyey-Greenstein phase function and the
+//                               next direction (Enigma/VolPathIntegrator.cpp:74-87, Enigma/MediumInterface.cpp:159-200)
+//   k_interface                 surfaces without a material: continue through them (Enigma/VolPathIntegrator.cpp:105-111)
+//   k_shadow_tr                 VisibilityTester::Tr (Enigma/Lights.cpp:718-740)
+//   k_mis_tr                    Scene::intersectTr for the BSDF / phase sampled ray of EstimateDirect (Enigma/Scene.cpp:46-64)
+#pragma once
+#include "kernels.h"
+
+namespace edev {
+
+// PhaseHG (Enigma/MediumInterface.cpp:196-200)
+DEV float phaseHG(float cosTheta, float g) {
+    const float kInvFourPi = 1.0f / (kPi * 4.0f);
+    const float denom = 1 + g * g + 2 * g * cosTheta;
+    return kInvFourPi * (1 - g * g) / (denom * sqrtf(denom));
+}
+// HenyeyGreenstein::Sample_p (Enigma/MediumInterface.cpp:159-177): the direction is built around wo itself
+DEV float hgSample(float g, F3 wo, F3* wi, float u0, float u1) {
+    float cosTheta;
+    if (fabsf(g) < 1e-3) cosTheta = 1 - 2 * u0;
+    else {
+        float sqrTerm = (1 - g * g) / (1 + g - 2 * g * u0);
+        cosTheta = -(1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    float sinTheta = sqrtf(smax(0.f, 1 - cosTheta * cosTheta));
+    float phi = 2 * kPi * u1;
+    F3 v1, v2;
+    coordinateSystem(wo, &v1, &v2);
+    *wi = (sinTheta * cosf(phi) * v1) + (sinTheta * sinf(phi) * v2) + (cosTheta * wo); // SphericalDirection, Enigma/MathCommon.cpp:13-18
+    return phaseHG(cosTheta, g);
+}
+
+// medium + 1 on the side of triangle `tri` that w points into, for a ray that arrived in medium rayMed (+1)
+DEV uint32_t mediumBeyond(const DevScene& sc, int tri, uint32_t rayMed, F3 n, F3 w) {
+    uint32_t in = rayMed, out = rayMed;
+    if (sc.triMedium) {
+        uint32_t tm = sc.triMedium[tri], a = tm & 0xffffu, b = tm >> 16;
+        if (a != b) { in = a; out = b; }
+    }
+    return dot(w, n) > 0 ? out : in;
+}
+// HomogeneousMedium::Tr (Enigma/Medium.cpp:78-81) of a ray of direction d and parametric length tMax
+DEV F3 mediumTr(const DevMedium& m, F3 d, float tMax) {
+    float s = smin(tMax * length(d), EDEV_MAXF);
+    return F3(expf(-m.sigmaT[0] * s), expf(-m.sigmaT[1] * s), expf(-m.sigmaT[2] * s));
+}
+
+// The medium branch for the paths of the medium-interaction queue.  A medium interaction has no normal and no
+// error bounds: rays start at the point itself and stay in the interaction's medium.
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
+                                                         const uint32_t* queue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
+    __shared__ uint32_t lds[32];
+    extern __shared__ float4 sceneLds[];
+    const uint32_t count = ctr->matCount[kQueueMedium].v;
+    if (blockIdx.x * kBlock >= count) return;
+    ENIGMA_STAGE_SHADE_TABLES
+    (void)materials;
+    uint32_t parity = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock, parity ^= 16u) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        bool pushShadow = false, pushMis = false, pushNext = false;
+        uint32_t p = 0;
+        if (active) {
+            p = queue[i];
+            float4 rdv = P.rayD[p];
+            F3 d = xyz(rdv);
+            uint32_t st = __float_as_uint(rdv.w);
+            uint32_t dim = stDim(st), bounces = stBounces(st), med = stMedium(st);
+            float g = sc.media[med - 1u].g;
+            F3 pm = xyz(P.rayO[p]) + d * P.hit[p].y; // ray.scale(t)
+            F3 wo = -d;                               // MediumInteraction::m_wo, not normalised (Enigma/Interaction.cpp:33-41)
+            uint32_t px, py, slot;
+            pathPixel(I, S, p, &px, &py, &slot);
+            float4 bv = P.beta[p];
+            F3 beta = xyz(bv);
+            float etaScale = bv.w;
+            // ---- UniformSampleOneLight + EstimateDirect for a medium interaction (Enigma/Integrator.cpp:71-204) ----
+            if (sc.nLights > 0) {
+                float pick;
+                int lightNum = sampleDiscrete(lightCdf, lightFunc, sc.lightFuncInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
+                dim += 1;
+                if (pick != 0) {
+                    float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
+                    float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
+                    dim += 4;
+                    const DevLight& lt = lights[lightNum];
+                    LightSample ls = sampleLight(lt, tris, pm, ulx, uly);
+                    if (ls.pdf > 0 && !isBlack(ls.Li)) {
+                        float ph = phaseHG(dot(wo, ls.wi), g);
+                        if (ph != 0.f) {
+                            F3 f(ph, ph, ph);
+                            F3 target = offsetRayOrigin(ls.lp, ls.lpErr, ls.ln, pm - ls.lp);
+                            F3 Ld = lt.type != 1 ? f * ls.Li / ls.pdf : f * ls.Li * powerHeuristic(ls.pdf, ph) / ls.pdf;
+                            storeShadowRay(shq, p, pm, target - pm, beta * (Ld / pick));
+                            shq.tgtP[p] = mk4(ls.lp, __uint_as_float(med));
+                            shq.tgtE[p] = mk4(ls.lpErr, 0.f);
+                            shq.tgtN[p] = mk4(ls.ln, 0.f);
+                            pushShadow = true;
+                        }
+                    }
+                    if (lt.type == 1) {
+                        F3 wi2(0.f);
+                        float ph2 = hgSample(g, wo, &wi2, usx, usy);
+                        if (ph2 != 0.f && ph2 > 0) {
+                            float lightPdf2 = lightTrianglePdf(pm, pm, wi2, ls.q0, ls.q1, ls.q2, lt.area);
+                            if (lightPdf2 != 0) {
+                                float weight = powerHeuristic(ph2, lightPdf2);
+                                misq.o[p] = mk4(pm, __uint_as_float(med));
+                                misq.d[p] = mk4(wi2, __int_as_float(lightNum));
+                                misq.w[p] = mk4(beta * (F3(ph2, ph2, ph2) * weight / ph2 / pick), 0.f);
+                                pushMis = true;
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- next direction (Enigma/VolPathIntegrator.cpp:83-86) and Russian roulette (:165-173) ----
+            F3 wi(0.f);
+            float u0 = sampleDimension(S, px, py, slot, dim), u1 = sampleDimension(S, px, py, slot, dim + 1);
+            dim += 2;
+            hgSample(g, wo, &wi, u0, u1);
+            bool alive = true;
+            F3 rrBeta = beta * etaScale;
+            if (maxComponentValue(rrBeta) < I.rrThreshold && bounces > 3) {
+                float q = smax(.05f, 1 - maxComponentValue(rrBeta));
+                float ur = sampleDimension(S, px, py, slot, dim);
+                dim += 1;
+                if (ur < q) alive = false;
+                else beta = beta / (1 - q);
+            }
+            if (alive) {
+                P.rayO[p] = mk4(pm, 0.f);
+                P.rayD[p] = mk4(wi, __uint_as_float(packState(med, dim, bounces + 1, 0u)));
+                P.beta[p] = mk4(beta, etaScale);
+                pushNext = true;
+            }
+        }
+        uint32_t sSh, sMi, sNx;
+        blockReserve3(pushShadow, pushMis, pushNext, &ctr->shadowCount.v, &ctr->misCount.v, &ctr->extCount[nextIdx].v, lds + parity, &sSh, &sMi, &sNx);
+        if (pushShadow) shq.idx[sSh] = p;
+        if (pushMis) misq.idx[sMi] = p;
+        if (pushNext) nextQueue[sNx] = p;
+    }
+}
+
+// Paths at a surface without a material: the ray goes on in its direction from the far side of the surface, in
+// the medium on that side; the vertex does not count as a bounce and consumes no samples.
+__global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, const uint32_t* queue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
+    __shared__ uint32_t lds[kWavesPerBlock + 1];
+    const uint32_t count = ctr->matCount[MK_NONE].v;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        uint32_t p = 0;
+        if (active) {
+            p = queue[i];
+            float4 rdv = P.rayD[p];
+            F3 d = xyz(rdv);
+            float4 hv = P.hit[p];
+            int tri = __float_as_int(hv.x);
+            uint32_t st = __float_as_uint(rdv.w);
+            HitGeom g = hitGeometry(sc.tris, tri, hv.y, hv.z, hv.w);
+            P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, d), 0.f); // isect.SpawnRay(ray.m_dir)
+            P.rayD[p] = mk4(d, __uint_as_float(packState(mediumBeyond(sc, tri, stMedium(st), g.n, d), stDim(st), stBounces(st), stSpec(st))));
+        }
+        uint32_t s = blockReserve(active, &ctr->extCount[nextIdx].v, lds);
+        if (active) nextQueue[s] = p;
+    }
+}
+
+// VisibilityTester::Tr for the shadow rays of one bounce.  A shadow ray is a chain of segments towards the same
+// end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
+// without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
+// far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
+template <int LDSN, int OVF, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
+    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    extern __shared__ float4 sceneLds[];
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    float spillDist[OVF > 0 ? OVF : 1];
+    const uint32_t count = ctr->shadowCount.v;
+    if (blockIdx.x * kBlock >= count) return;
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    uint32_t nQueries = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
+        uint32_t p = 0, med = 0;
+        F3 o(0.f), d(0.f), contrib(0.f), Tr(1.f), lp(0.f), lpErr(0.f), ln(0.f);
+        if (active) {
+            p = shq.idx[i];
+            float4 a = shq.o[p], b = shq.d[p], tp = shq.tgtP[p];
+            o = F3(a.x, a.y, a.z); d = F3(a.w, b.x, b.y);
+            contrib = F3(b.z, b.w, shq.wz[p]);
+            lp = xyz(tp); med = __float_as_uint(tp.w);
+            lpErr = xyz(shq.tgtE[p]); ln = xyz(shq.tgtN[p]);
+            w.start(o, d, 1 - kShadowEpsilon);
+            ++nQueries;
+        }
+        while (__ballot(active) != 0) {
+            if (active && w.done()) {
+                const Hit& h = w.h;
+                bool hit = h.tri >= 0;
+                uint32_t kind = MK_NONE;
+                if (hit) kind = triKind(__float_as_uint(tris[(size_t)h.tri * 3 + 1].w));
+                if (hit && kind != MK_NONE) { Tr = F3(0.f); active = false; }
+                else {
+                    if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
+                    if (!hit) active = false;
+                    else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
+                        HitGeom g = hitGeometry(tris, h.tri, h.b0, h.b1, h.b2);
+                        o = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
+                        F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
+                        d = target - o;
+                        med = mediumBeyond(sc, h.tri, med, g.n, d);
+                        w.start(o, d, 1 - kShadowEpsilon);
+                        ++nQueries;
+                    }
+                }
+                if (!active && !isBlack(Tr)) {
+                    F3 add = contrib * Tr;
+                    float4 L = P.L[p]; // the path's only shadow ray in this launch
+                    P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+                }
+            }
+            w.step(nodes, tris);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
+    if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysShadow, (unsigned long long)nQueries);
+}
+
+// Scene::intersectTr for the MIS rays of one bounce: closest-hit queries through material-less surfaces
+// (isect.SpawnRay(ray.m_dir)), attenuated by the media on the way; the first surface with a material must be
+// the sampled light's triangle.  Every query counts as a MIS ray.
+template <int LDSN, int OVF, bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
+    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    extern __shared__ float4 sceneLds[];
+    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    float spillDist[OVF > 0 ? OVF : 1];
+    const uint32_t count = ctr->misCount.v;
+    if (blockIdx.x * kBlock >= count) return;
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    uint32_t nQueries = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < count;
+        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
+        uint32_t p = 0, med = 0;
+        int wantLight = -1;
+        F3 o(0.f), d(0.f), Tr(1.f);
+        if (active) {
+            p = misq.idx[i];
+            float4 ov = misq.o[p], dv = misq.d[p];
+            o = xyz(ov); d = xyz(dv); med = __float_as_uint(ov.w); wantLight = __float_as_int(dv.w);
+            w.start(o, d, EDEV_INF);
+            ++nQueries;
+        }
+        while (__ballot(active) != 0) {
+            if (active && w.done()) {
+                const Hit& h = w.h;
+                bool hit = h.tri >= 0;
+                if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : EDEV_INF);
+                if (!hit) active = false;
+                else {
+                    const float4* tp = tris + (size_t)h.tri * 3;
+                    float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                    uint32_t mw = __float_as_uint(v1.w);
+                    if (triKind(mw) != MK_NONE) {
+                        active = false;
+                        int lightIdx = __float_as_int(v2.w);
+                        if (lightIdx == wantLight) { // lightIsect.m_primitive->getAreaLight() == &light
+                            const DevLight& lt = sc.lights[lightIdx];
+                            F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
+                            if (lt.twoSided || dot(n, -d) > 0) { // lightIsect.Le(-wi)
+                                F3 add = xyz(misq.w[p]) * F3(lt.L[0], lt.L[1], lt.L[2]) * Tr;
+                                float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
+                                atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
+                            }
+                        }
+                    } else {
+                        HitGeom g = hitGeometry(tris, h.tri, h.b0, h.b1, h.b2);
+                        o = offsetRayOrigin(g.p, g.pError, g.n, d);
+                        med = mediumBeyond(sc, h.tri, med, g.n, d);
+                        w.start(o, d, EDEV_INF);
+                        ++nQueries;
+                    }
+                }
+            }
+            w.step(nodes, tris);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
+    if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysMis, (unsigned long long)nQueries);
+}
+
+} // namespace edev

@@ -120,6 +120,19 @@ def integrator_desc(film, spp, max_depth=5, rr_threshold=1.0, light_strategy=abi
     return d
 
 
+def volpath_desc(film, spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER, pixel_bounds=None):
+    """CreateVolPathIntegrator (Enigma/VolPathIntegrator.cpp:179-200)."""
+    d = abi.EnigmaVolPathDesc()
+    sb = sample_bounds(film)
+    d.max_depth = max_depth
+    d.rr_threshold = rr_threshold
+    d.light_strategy = light_strategy
+    d.pixel_bounds[:] = sb if pixel_bounds is None else pixel_bounds
+    d.samples_per_pixel = spp
+    d.sample_bounds[:] = sb
+    return d
+
+
 def direct_lighting_desc(film, spp, max_depth=5, strategy=abi.DL_SAMPLE_ALL, pixel_bounds=None):
     """CreateDirectLightingIntegrator (Enigma/DirectLightingIntegrator.cpp:89-114)."""
     d = abi.EnigmaDirectLightingDesc()
@@ -137,6 +150,15 @@ class MeshBuilder:
     def __init__(self):
         self.v, self.t, self.mat, self.light, self.flags = [], [], [], [], []
         self.materials, self.lights = [], []
+        self.media, self.m_in, self.m_out = [], [], []
+        self.interface = (-1, -1)   # MediumInterface (inside, outside) given to the triangles added next
+
+    def add_medium(self, m):
+        self.media.append(m)
+        return len(self.media) - 1
+
+    def medium_interface(self, inside=-1, outside=-1):
+        self.interface = (inside, outside)
 
     def add_material(self, m):
         self.materials.append(m)
@@ -160,6 +182,8 @@ class MeshBuilder:
         self.t.append((base, base + 1, base + 2))
         self.mat.append(mat)
         self.flags.append(0)
+        self.m_in.append(self.interface[0])
+        self.m_out.append(self.interface[1])
         if emit is not None:
             self.lights.append(abi.area_light(len(self.t) - 1, emit, two_sided))
             self.light.append(len(self.lights) - 1)
@@ -191,7 +215,8 @@ class MeshBuilder:
             v, t = self.weld()
         else:
             v, t = np.asarray(self.v, dtype=np.float32), np.asarray(self.t, dtype=np.uint32)
-        return abi.SceneArrays(v, t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags)
+        media = dict(media=self.media, tri_medium_inside=self.m_in, tri_medium_outside=self.m_out) if self.media else {}
+        return abi.SceneArrays(v, t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, **media)
 
 
 # ----------------------------------------------------------------------------- S1: Cornell box
@@ -257,6 +282,41 @@ def cornell_box(variant="diffuse", delta_lights=False):
         b.add_spot_light((278, 500, 100), (186, 165, 169), (4.0e5, 5.0e5, 6.0e5), coneangle=25.0, conedeltaangle=10.0)
         b.add_distant_light((0.3, 0.5, -1.1), (0, 0, 0), (1.5, 1.2, 0.9))
     return b.arrays()
+
+
+def cornell_fog(variant="diffuse", g=0.3):
+    """The Cornell box for the VolPathIntegrator: a slab of scattering fog (a box of material-less triangles whose
+    MediumInterface has the fog inside) floats in front of the blocks, and the tall block -- glass in the
+    microfacet / specular variants -- is filled with an absorbing, faintly scattering medium."""
+    base = cornell_box(variant)
+    b = MeshBuilder()
+    for i in range(base.n_materials):
+        b.add_material(base.materials[i])
+    fog = b.add_medium(abi.homogeneous_medium((0.0005, 0.0005, 0.0005), (0.006, 0.007, 0.008), g))
+    tint = b.add_medium(abi.homogeneous_medium((0.002, 0.004, 0.008), (0.001, 0.001, 0.001), 0.0))
+    tall_first = 2 * 5 + 2 * 5                      # walls, short block, then the tall block's 10 triangles
+    v = base.vertices[base.indices]
+    for t in range(base.indices.shape[0]):
+        b.medium_interface(tint, -1) if tall_first <= t < tall_first + 10 else b.medium_interface(-1, -1)
+        emit = None if base.tri_light[t] < 0 else tuple(base.lights[base.tri_light[t]].L)
+        b.add_tri(v[t, 0], v[t, 1], v[t, 2], int(base.tri_material[t]), emit=emit)
+    lo, hi = np.array([60.0, 200.0, 40.0]), np.array([500.0, 420.0, 230.0])
+    c = (lo + hi) / 2
+    b.medium_interface(fog, -1)
+    for axis in range(3):
+        for side, val in ((-1, lo[axis]), (1, hi[axis])):
+            u, w = (axis + 1) % 3, (axis + 2) % 3
+            q = []
+            for du, dw in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = np.zeros(3)
+                p[axis] = val
+                p[u] = hi[u] if du else lo[u]
+                p[w] = hi[w] if dw else lo[w]
+                q.append(tuple(p))
+            outward = c.copy()
+            outward[axis] = val + side * 100.0
+            b.add_quad(q, abi.NO_MATERIAL, toward=tuple(outward))
+    return b.arrays(weld=False)
 
 
 def cornell_camera(xres, yres, lens_radius=0.0, focal_distance=1e30):

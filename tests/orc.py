@@ -64,6 +64,8 @@ class Oracle:
     def set_integrator(self, integ):
         if isinstance(integ, abi.EnigmaDirectLightingDesc):
             self._chk(self.L.oracle_direct_lighting_config(self.h, C.byref(integ)))
+        elif isinstance(integ, abi.EnigmaVolPathDesc):
+            self._chk(self.L.oracle_volpath_config(self.h, C.byref(integ)))
         else:
             self._chk(self.L.oracle_integrator_config(self.h, C.byref(integ)))
         self.integ = integ

@@ -1,0 +1,104 @@
+"""GPU parity for the VolPathIntegrator (Enigma/VolPathIntegrator.cpp:45-177) with homogeneous media
+(Enigma/Medium.cpp:69-108) and the Henyey-Greenstein phase function, through the C ABI; the CPU oracle is the checker.
+Tolerances as for the other integrators: mean relative error < 1 % (north star), in practice ~1e-4: same samples, same
+arithmetic up to expf / logf / sinf / cosf and the order in which a contribution's factors are multiplied."""
+import numpy as np
+import pytest
+
+import common
+import orc
+import raytrace_amd as ra
+from raytrace_amd import abi, scenes
+from test_oracle_kat import _slab_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(sc, cam, film, integ):
+    return ra.Renderer(0).configure(sc, cam, film, integ), orc.Oracle(sc, cam, film, integ)
+
+
+def _compare(r, o, spp, mre=1e-3, ray_tol=2e-3):
+    r.render(0, spp)
+    o.render(0, spp, threads=8)
+    a, b = r.image(), o.image()
+    assert np.isfinite(a).all()
+    assert common.mean_relative_error(a, b) < 0.01
+    assert common.mean_relative_error(a, b) < mre
+    so, st = o.stats(), r.stats()
+    assert st["camera_samples"] == so["samples"]
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(st[k] - so[k]) <= max(3, ray_tol * so[k]), (k, st[k], so[k])
+
+
+def test_volpath_without_media_matches_the_path_integrator_on_the_gpu():
+    sc, cam, film, integ = common.cornell_setup(res=48, spp=8, variant="diffuse")
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(0, 8)
+    path_img, path_stats = r.image(), r.stats()
+    r.set_integrator(scenes.volpath_desc(film, 8))
+    r.clear()
+    r.render(0, 8)
+    assert np.allclose(r.image(), path_img, rtol=1e-6, atol=1e-7)
+    st = r.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert st[k] == 2 * path_stats[k]                    # the counters run on across renders
+    r.close()
+
+
+@pytest.mark.parametrize("variant", ["diffuse", "microfacet", "specular"])
+def test_volpath_fog_cornell(variant):
+    """Fog slab (scattering, g = 0.3) in front of the blocks, absorbing medium inside the tall block: medium sampling,
+    phase-function light sampling + MIS, transmittance along shadow and MIS rays through material-less boundaries."""
+    sc = scenes.cornell_fog(variant)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    r, o = _pair(sc, cam, film, scenes.volpath_desc(film, 16))
+    _compare(r, o, 16, mre=1e-3 if variant == "diffuse" else 5e-3)
+    # the fog changes the picture: same scene without media differs visibly
+    r2 = ra.Renderer(0).configure(scenes.cornell_box(variant), cam, film, scenes.volpath_desc(film, 16))
+    r2.render(0, 16)
+    assert common.mean_relative_error(r.image(), r2.image()) > 0.02
+    r.close(); r2.close(); o.close()
+
+
+def test_volpath_uniform_light_sampling_back_scattering_and_deep_paths():
+    sc = scenes.cornell_fog("diffuse", g=-0.5)
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    integ = scenes.volpath_desc(film, 8, max_depth=12, light_strategy=abi.LIGHTS_UNIFORM)
+    r, o = _pair(sc, cam, film, integ)
+    _compare(r, o, 8)
+    r.close(); o.close()
+
+
+def test_volpath_absorbing_slab_beer_lambert_on_the_gpu():
+    sigma, d = 0.25, 4.0
+    sc = _slab_scene((sigma, sigma, sigma), (0.0, 0.0, 0.0), thickness=d)
+    cam = scenes.camera_desc((0, 0, -20), (0, 0, 0), (0, 1, 0), 4.0, 8, 8)
+    film = scenes.film_desc(8, 8)
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.volpath_desc(film, 1024, max_depth=3))
+    r.render(0, 1024)
+    want = np.array([1.0, 2.0, 3.0]) * np.exp(-sigma * d)
+    assert np.allclose(r.image().astype(np.float64).mean(axis=(0, 1)), want, rtol=0.01)
+    # the other integrators refuse material-less surfaces
+    r.set_integrator(scenes.integrator_desc(film, 4))
+    with pytest.raises(ra.EnigmaError) as e:
+        r.render(0, 4)
+    assert e.value.code == -4
+    r.close()
+
+
+def test_volpath_delta_lights_through_fog_and_sample_ranges_add_up():
+    """Spot and distant lights seen through the fog (VisibilityTester::Tr towards a point / a far point)."""
+    base = scenes.cornell_fog("diffuse")
+    extra = [abi.spot_light((278, 500, 100), (186, 165, 169), (4.0e5, 5.0e5, 6.0e5), 25.0, 10.0), abi.distant_light((0.3, 0.5, -1.1), (0, 0, 0), (1.5, 1.2, 0.9))]
+    lights = [base.lights[i] for i in range(base.n_lights)] + extra
+    sc = abi.SceneArrays(base.vertices, base.indices, base.tri_material, base.tri_light, [base.materials[i] for i in range(base.n_materials)], lights,
+                         tri_flags=base.tri_flags, media=[base.media[i] for i in range(base.n_media)],
+                         tri_medium_inside=base.tri_medium_inside, tri_medium_outside=base.tri_medium_outside)
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    r, o = _pair(sc, cam, film, scenes.volpath_desc(film, 16))
+    _compare(r, o, 16)
+    whole = r.film()
+    r.clear(); r.render(0, 5); r.render(5, 16)
+    assert np.allclose(r.film(), whole, rtol=1e-5, atol=1e-5)
+    r.close(); o.close()

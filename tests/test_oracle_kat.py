@@ -338,3 +338,102 @@ def test_delta_light_oracle_reproduces_its_golden_fixture():
     assert np.array_equal(o.image(), g["diffuse_rgb"])
     assert [s["samples"], s["rays_closest"], s["rays_shadow"], s["rays_mis"]] == g["diffuse_rays"].tolist()
     o.close()
+
+
+# ------------------------------------------------------------------ VolPathIntegrator (oracle only, CPU)
+def _slab_scene(sigma_a, sigma_s, g=0.0, thickness=4.0):
+    """An emissive wall seen through a box of material-less triangles filled with a homogeneous medium."""
+    b = scenes.MeshBuilder()
+    white = b.add_material(abi.matte((0.0, 0.0, 0.0)))
+    b.add_quad([(-50, -50, 10), (50, -50, 10), (50, 50, 10), (-50, 50, 10)], white, toward=(0, 0, 0), emit=(1.0, 2.0, 3.0))
+    med = b.add_medium(abi.homogeneous_medium(sigma_a, sigma_s, g))
+    b.medium_interface(med, -1)
+    lo, hi = np.array([-20.0, -20.0, 2.0]), np.array([20.0, 20.0, 2.0 + thickness])
+    c = (lo + hi) / 2
+    for axis in range(3):
+        for side, val in ((-1, lo[axis]), (1, hi[axis])):
+            u, w = (axis + 1) % 3, (axis + 2) % 3
+            q = []
+            for du, dw in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = np.zeros(3)
+                p[axis] = val
+                p[u] = hi[u] if du else lo[u]
+                p[w] = hi[w] if dw else lo[w]
+                q.append(tuple(p))
+            out = c.copy()
+            out[axis] = val + side * 10.0
+            b.add_quad(q, abi.NO_MATERIAL, toward=tuple(out))
+    return b.arrays(weld=False)
+
+
+def test_volpath_without_media_is_the_path_integrator():
+    """No medium anywhere: VolPathIntegrator::Li walks the same path with the same samples (matte surfaces always
+    have a non-specular lobe, so the unconditional light sampling changes nothing)."""
+    sc, cam, film, integ = common.cornell_setup(res=32, spp=8, variant="diffuse")
+    a = orc.Oracle(sc, cam, film, integ)
+    b = orc.Oracle(sc, cam, film, scenes.volpath_desc(film, 8))
+    a.render(0, 8, threads=4); b.render(0, 8, threads=4)
+    assert np.array_equal(a.image(), b.image())
+    sa, sb = a.stats(), b.stats()
+    assert [sa[k] for k in ("rays_closest", "rays_shadow", "rays_mis")] == [sb[k] for k in ("rays_closest", "rays_shadow", "rays_mis")]
+    a.close(); b.close()
+
+
+def test_volpath_absorbing_slab_follows_beer_lambert():
+    """sigma_s = 0: the wall's radiance arrives attenuated by exp(-sigma_a * d) (HomogeneousMedium::Sample weights
+    average to the transmittance; camera rays start outside the medium and enter through the boundary)."""
+    sigma, d = 0.25, 4.0
+    sc = _slab_scene((sigma, sigma, sigma), (0.0, 0.0, 0.0), thickness=d)
+    cam = scenes.camera_desc((0, 0, -20), (0, 0, 0), (0, 1, 0), 4.0, 8, 8)      # narrow view: rays cross the slab head on
+    film = scenes.film_desc(8, 8)
+    o = orc.Oracle(sc, cam, film, scenes.volpath_desc(film, 1024, max_depth=3))
+    o.render(0, 1024, threads=8)
+    img = o.image().astype(np.float64)
+    s = o.stats()
+    o.close()
+    want = np.array([1.0, 2.0, 3.0]) * math.exp(-sigma * d)
+    assert np.allclose(img.mean(axis=(0, 1)), want, rtol=0.01)
+    assert s["rays_closest"] >= 3 * s["samples"] * 0.3            # boundary in, boundary out, wall: for the survivors
+    # a path integrator must refuse the scene: material-less surfaces are medium boundaries
+    p = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 4))
+    with pytest.raises(Exception):
+        p.render(0, 4, threads=1)
+    p.close()
+
+
+def test_volpath_scattering_slab_conserves_energy_inside_a_furnace():
+    """Albedo 1 inside a uniformly emitting closed box: whatever the scattering does, every path ends on a wall of
+    radiance 1, so the estimate is 1 up to the depth cut-off."""
+    b = scenes.MeshBuilder()
+    black = b.add_material(abi.matte((0.0, 0.0, 0.0)))
+    lo, hi = np.array([-10.0, -10.0, -30.0]), np.array([10.0, 10.0, 10.0])
+    c = (lo + hi) / 2
+
+    def box(lo, hi, mat, emit=None, inward=True):
+        for axis in range(3):
+            for side, val in ((-1, lo[axis]), (1, hi[axis])):
+                u, w = (axis + 1) % 3, (axis + 2) % 3
+                q = []
+                for du, dw in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                    p = np.zeros(3)
+                    p[axis] = val
+                    p[u] = hi[u] if du else lo[u]
+                    p[w] = hi[w] if dw else lo[w]
+                    q.append(tuple(p))
+                out = ((lo + hi) / 2).copy()
+                out[axis] = val + side * 5.0
+                b.add_quad(q, mat, toward=tuple((lo + hi) / 2) if inward else tuple(out), emit=emit, two_sided=False)
+    box(lo, hi, black, emit=(1.0, 1.0, 1.0), inward=True)
+    med = b.add_medium(abi.homogeneous_medium((0.0, 0.0, 0.0), (0.4, 0.4, 0.4), 0.6))
+    b.medium_interface(med, -1)
+    box(np.array([-4.0, -4.0, -4.0]), np.array([4.0, 4.0, 4.0]), abi.NO_MATERIAL, inward=False)
+    sc = b.arrays(weld=False)
+    cam = scenes.camera_desc((0, 0, -25), (0, 0, 0), (0, 1, 0), 10.0, 8, 8)
+    film = scenes.film_desc(8, 8)
+    o = orc.Oracle(sc, cam, film, scenes.volpath_desc(film, 256, max_depth=60, rr_threshold=0.0))
+    o.render(0, 256, threads=8)
+    img = o.image().astype(np.float64)
+    o.close()
+    # emission is only picked up at bounce 0 / after specular bounces; the rest arrives through light sampling + MIS
+    assert abs(img.mean() - 1.0) < 0.03
+    del c
