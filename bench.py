@@ -39,9 +39,10 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--variant", default="microfacet",
-                    help="workload: microfacet (Cornell, configs[1], the default) | diffuse | specular | bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3])")
-    ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one"],
-                    help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one")
+                    help="workload: microfacet (Cornell, configs[1], the default) | diffuse | specular | bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3]) | "
+                         "fog (Cornell with a fog slab and a medium-filled glass block, for --integrator volpath)")
+    ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one", "volpath"],
+                    help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=2, help="sample numbers per pixel the CPU baseline renders")
     args = ap.parse_args()
@@ -67,6 +68,8 @@ def main():
         scene, camera, cam_small, label = scenes.big_mesh(), scenes.big_mesh_camera(XRES, YRES), scenes.big_mesh_camera(480, 270), "BigMesh (terrain + spheres, conductor/dielectric microfacet)"
     elif args.variant == "manylights":
         scene, camera, cam_small, label = scenes.many_lights(), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "ManyLights (512 emissive triangles + 64 point lights)"
+    elif args.variant == "fog":
+        scene, camera, cam_small, label = scenes.cornell_fog("microfacet"), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (microfacet) with a fog slab and a medium-filled glass block"
     else:
         scene, camera, cam_small, label = scenes.cornell_box(args.variant), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (%s)" % args.variant
     film = scenes.film_desc(XRES, YRES, "box")
@@ -74,6 +77,9 @@ def main():
     if args.integrator == "path":
         integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
         integ_label = "PathIntegrator maxdepth 5, Sobol, box filter, power light sampling"
+    elif args.integrator == "volpath":
+        integ = scenes.volpath_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
+        integ_label = "VolPathIntegrator maxdepth 5, homogeneous media, Sobol, box filter, power light sampling"
     else:
         strat = abi.DL_SAMPLE_ALL if args.integrator == "direct-all" else abi.DL_SAMPLE_ONE
         integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
@@ -141,8 +147,9 @@ def main():
         }
         # --- algorithmic bytes per ray from the reference traversal (HLBVH, <=127 prims per leaf) on a small sample
         small = scenes.film_desc(480, 270, "box")
-        o_small = orc.Oracle(scene, cam_small, small, scenes.integrator_desc(small, 16) if args.integrator == "path" else
-                             scenes.direct_lighting_desc(small, 16, max_depth=5, strategy=integ.strategy), fast=True)
+        small_integ = (scenes.integrator_desc(small, 16) if args.integrator == "path" else scenes.volpath_desc(small, 16) if args.integrator == "volpath"
+                       else scenes.direct_lighting_desc(small, 16, max_depth=5, strategy=integ.strategy))
+        o_small = orc.Oracle(scene, cam_small, small, small_integ, fast=True)
         o_small.render(0, 1, threads=min(16, os.cpu_count() or 1))
         so = o_small.stats()
         n_nodes = so["nodes_closest"] / max(1, so["rays_closest"])

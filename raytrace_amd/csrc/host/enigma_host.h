@@ -233,7 +233,8 @@ struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexI
     int m_nTriangles = 0, m_nVertices = 0;
     std::vector<int> m_vertexIndices;
     std::vector<Vector3f> m_p;
-    int materialIndex = 0;          // registry index of the bound material
+    int materialIndex = 0;          // registry index of the bound material; -1 = none (MakeMaterial "" / "none": a medium boundary)
+    int mediumInside = -1, mediumOutside = -1; // GeometricPrimitive::m_mi: registry indices of the media, -1 = none
     bool reverseOrientation = false;
     bool emissive = false;          // an AreaLightSource was active when the shape was created
     Spectrum Le = 0.f;
@@ -245,6 +246,8 @@ class Scene {
 public:
     // Registry calls: the equivalent of hooking MakeShapes / MakeMaterial / MakeLight (Enigma/Api.cpp:843-932).
     int AddMaterial(const EnigmaMaterial& m) { m_materials.push_back(m); return (int)m_materials.size() - 1; }
+    // HomogeneousMedium(sigma_a, sigma_s, g) (Enigma/Medium.cpp:69-76)
+    int AddMedium(const EnigmaMedium& m) { m_media.push_back(m); return (int)m_media.size() - 1; }
     // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
     void AddTriangleMesh(const TriangleMesh& mesh) { m_meshes.push_back(mesh); }
     // Lights without a shape (point, spot, distant) keep their place among the meshes' area lights.
@@ -280,6 +283,7 @@ public:
     struct LightRec { EnigmaLight light; int order; };
     std::vector<TriangleMesh> m_meshes;
     std::vector<EnigmaMaterial> m_materials;
+    std::vector<EnigmaMedium> m_media;
     std::vector<LightRec> m_lights;
 private:
     int NextLightOrder() const { return (int)m_meshes.size(); } // point lights keep their place among the meshes' lights
@@ -324,7 +328,7 @@ public:
         struct Guard { EnigmaCtx* h; ~Guard() { enigma_ctx_destroy(h); } } guard{h};
         auto check = [&](int rc) { if (rc != ENIGMA_OK) throw std::runtime_error(std::string("enigma: ") + enigma_last_error(h)); };
         // flatten the registry
-        std::vector<float> verts; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight; std::vector<EnigmaLight> lights;
+        std::vector<float> verts; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight, triIn, triOut; std::vector<EnigmaLight> lights;
         size_t pl = 0;
         auto flushPointLights = [&](int upTo) {
             for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) lights.push_back(scene.m_lights[pl].light);
@@ -336,7 +340,8 @@ public:
             for (const Vector3f& p : m.m_p) { verts.push_back(p.x); verts.push_back(p.y); verts.push_back(p.z); }
             for (int t = 0; t < m.m_nTriangles; ++t) {
                 for (int k = 0; k < 3; ++k) idx.push_back(base + (uint32_t)m.m_vertexIndices[3 * t + k]);
-                triMat.push_back((uint32_t)m.materialIndex);
+                triMat.push_back(m.materialIndex < 0 ? ENIGMA_NO_MATERIAL : (uint32_t)m.materialIndex);
+                triIn.push_back(m.mediumInside); triOut.push_back(m.mediumOutside);
                 triFlags.push_back(m.reverseOrientation ? ENIGMA_TRI_FLIP_NORMAL : 0u);
                 if (m.emissive) {
                     EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA; l.triangle = (uint32_t)triMat.size() - 1; l.two_sided = m.twoSided; l.n_samples = (uint32_t)std::max(1, m.nSamples);
@@ -352,6 +357,7 @@ public:
         sd.vertices = verts.data(); sd.indices = idx.data(); sd.tri_material = triMat.data(); sd.tri_light = triLight.data(); sd.tri_flags = triFlags.data();
         sd.n_materials = (uint32_t)scene.m_materials.size(); sd.materials = scene.m_materials.data();
         sd.n_lights = (uint32_t)lights.size(); sd.lights = lights.data();
+        if (!scene.m_media.empty()) { sd.n_media = (uint32_t)scene.m_media.size(); sd.media = scene.m_media.data(); sd.tri_medium_inside = triIn.data(); sd.tri_medium_outside = triOut.data(); }
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());
@@ -424,6 +430,30 @@ protected:
         else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
         FillSamplerFields(id, sob);
         return enigma_integrator_config(h, &id);
+    }
+private:
+    const int m_maxDepth;
+    const float m_rrThreshold;
+    const std::string m_lightSampleStrategy;
+};
+
+// VolPathIntegrator on the GPU (constructor arguments: Enigma/VolPathIntegrator.cpp:27-35).
+class GpuVolPathIntegrator : public GpuSamplerIntegrator {
+public:
+    GpuVolPathIntegrator(int maxDepth, std::shared_ptr<Camera> camera, std::shared_ptr<Sampler> sampler, const BBox2i& pixelBounds,
+                         float rrThreshold = 1, const std::string& lightSampleStrategy = "spatial", int device = 0)
+        : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
+          m_lightSampleStrategy(lightSampleStrategy) {}
+protected:
+    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) override {
+        EnigmaIntegratorDesc id{};
+        id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
+        if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
+        else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
+        else if (nLights == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
+        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
+        FillSamplerFields(id, sob);
+        return enigma_volpath_config(h, &id);
     }
 private:
     const int m_maxDepth;

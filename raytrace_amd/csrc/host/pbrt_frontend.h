@@ -196,7 +196,8 @@ struct RenderOptions {
 };
 
 struct GraphicsState {
-    int currentMaterial = -1; // index into the scene's material registry; -1 = the default matte, made on first use
+    int currentMaterial = -1; // index into the scene's material registry; -1 = the default matte, made on first use; -2 = none
+    std::string currentInsideMedium, currentOutsideMedium;
     std::string areaLight;
     ParamSet areaLightParams;
     bool reverseOrientation = false;
@@ -279,6 +280,31 @@ public:
     }
     void pbrtReverseOrientation() { VerifyWorld("ReverseOrientation"); m_gs.reverseOrientation = !m_gs.reverseOrientation; }
     void pbrtMaterial(const std::string& name, const ParamSet& p) { VerifyWorld("Material"); m_gs.currentMaterial = MakeMaterial(name, p); }
+    // MakeMedium (Enigma/Api.cpp:282-331) into the named-media table of the render options (:644-655)
+    void pbrtMakeNamedMedium(const std::string& name, const ParamSet& p) {
+        std::string type = p.FindOneString("type", "");
+        if (type.empty()) throw std::runtime_error("No parameter string \"type\" found in MakeNamedMedium");
+        if (type == "heterogeneous") throw std::runtime_error("MakeNamedMedium \"heterogeneous\": the reference's GridDensityMedium is a stub (Tr and Sample return black); only \"homogeneous\" media are supported");
+        if (type != "homogeneous") throw std::runtime_error("Medium \"" + type + "\" unknown.");
+        if (!p.FindOneString("preset", "").empty()) throw std::runtime_error("MakeNamedMedium: \"preset\" (measured scattering tables) is not supported; give sigma_a and sigma_s");
+        float scale = p.FindOneFloat("scale", 1.f);
+        Spectrum sa = p.FindOneSpectrum("sigma_a", Spectrum(.0011f, .0024f, .014f)), ss = p.FindOneSpectrum("sigma_s", Spectrum(2.55f, 3.21f, 3.77f));
+        EnigmaMedium m{};
+        for (int c = 0; c < 3; ++c) { m.sigma_a[c] = sa[c] * scale; m.sigma_s[c] = ss[c] * scale; }
+        m.g = p.FindOneFloat("g", 0.0f);
+        m_namedMedia[name] = m_res->scene.AddMedium(m);
+        NoteUnused("MakeNamedMedium", p);
+    }
+    void pbrtMediumInterface(const std::string& insideName, const std::string& outsideName) { // Enigma/Api.cpp:657-662
+        m_gs.currentInsideMedium = insideName;
+        m_gs.currentOutsideMedium = outsideName;
+    }
+    int LookupMedium(const std::string& name) const { // GraphicsState::CreateMediumInterface, Enigma/Api.cpp:1017-1036
+        if (name.empty()) return -1;
+        auto it = m_namedMedia.find(name);
+        if (it == m_namedMedia.end()) throw std::runtime_error("Named medium \"" + name + "\" undefined.");
+        return it->second;
+    }
     void pbrtMakeNamedMaterial(const std::string& name, const ParamSet& p) {
         VerifyWorld("MakeNamedMaterial");
         std::string type = p.FindOneString("type", "");
@@ -368,8 +394,9 @@ public:
             m_ctm.Point(&P[3 * (size_t)i], w);
             m.m_p.push_back(Vector3f((float)w[0], (float)w[1], (float)w[2]));
         }
-        if (m_gs.currentMaterial < 0 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet()); // GraphicsState ctor, Enigma/Api.cpp:992-999
-        m.materialIndex = m_gs.currentMaterial < 0 ? m_defaultMaterial : m_gs.currentMaterial;
+        if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet()); // GraphicsState ctor, Enigma/Api.cpp:992-999
+        m.materialIndex = m_gs.currentMaterial == -1 ? m_defaultMaterial : (m_gs.currentMaterial == -2 ? -1 : m_gs.currentMaterial);
+        m.mediumInside = LookupMedium(m_gs.currentInsideMedium); m.mediumOutside = LookupMedium(m_gs.currentOutsideMedium);
         m.reverseOrientation = m_gs.reverseOrientation ^ m_ctm.SwapsHandedness(); // Enigma/TriangleMesh.cpp:287-289
         if (!m_gs.areaLight.empty()) {
             if (m_gs.areaLight != "diffuse" && m_gs.areaLight != "area") throw std::runtime_error("AreaLightSource \"" + m_gs.areaLight + "\" is not supported (diffuse)");
@@ -384,7 +411,6 @@ public:
         NoteUnused("Shape", p);
     }
     void pbrtObjectBegin(const std::string&) { throw std::runtime_error("ObjectBegin: object instancing is not supported"); }
-    void pbrtMakeNamedMedium(const std::string&, const ParamSet&) { throw std::runtime_error("MakeNamedMedium: participating media are not supported"); }
 
     // WorldEnd: MakeIntegrator (camera, film, filter, sampler) + MakeScene + Render (Enigma/Api.cpp:1170-1254, 1103-1135)
     void pbrtWorldEnd() {
@@ -467,7 +493,11 @@ public:
             R.integrator.reset(new GpuDirectLightingIntegrator(st == "one" ? GpuDirectLightingIntegrator::eLightStrategy::UniformSampleOne
                                                                            : GpuDirectLightingIntegrator::eLightStrategy::UniformSampleAll,
                                                                R.maxDepth, R.camera, R.sampler, pixelBounds, m_device));
-        } else throw std::runtime_error("Integrator \"" + m_opt.IntegratorName + "\" is not supported (path, directlighting)");
+        } else if (m_opt.IntegratorName == "volpath") { // CreateVolPathIntegrator, Enigma/VolPathIntegrator.cpp:179-200
+            R.rrThreshold = ip.FindOneFloat("rrthreshold", 1.f);
+            R.lightStrategy = ip.FindOneString("lightsamplestrategy", "spatial");
+            R.integrator.reset(new GpuVolPathIntegrator(R.maxDepth, R.camera, R.sampler, pixelBounds, R.rrThreshold, R.lightStrategy, m_device));
+        } else throw std::runtime_error("Integrator \"" + m_opt.IntegratorName + "\" is not supported (path, directlighting, volpath)");
         for (const char* what : {"Film", "Camera", "Sampler", "Integrator", "PixelFilter"}) {
             const ParamSet& ps = std::string(what) == "Film" ? flp : std::string(what) == "Camera" ? cp : std::string(what) == "Sampler" ? m_opt.SamplerParams
                                  : std::string(what) == "Integrator" ? ip : fp;
@@ -506,7 +536,8 @@ private:
         if (p.Has("bumpmap")) throw std::runtime_error("bump mapping is not supported");
         auto put = [](float* dst, const Spectrum& s) { dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; };
         m.remap_roughness = p.FindOneBool("remaproughness", true) ? 1u : 0u;
-        if (name == "matte" || name == "") {
+        if (name == "" || name == "none") return -2; // MakeMaterial returns no material (Enigma/Api.cpp:135): a medium boundary
+        if (name == "matte") {
             m.type = ENIGMA_MAT_MATTE;
             put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.5f)));
             m.sigma = p.FindOneFloat("sigma", 0.f);
@@ -669,7 +700,11 @@ private:
             else if (d == "ObjectBegin") pbrtObjectBegin(c.str("ObjectBegin"));
             else if (d == "ObjectEnd" || d == "ObjectInstance") throw std::runtime_error(d + ": object instancing is not supported");
             else if (d == "MakeNamedMedium") { std::string n = c.str("MakeNamedMedium"); pbrtMakeNamedMedium(n, ParseParams(c)); }
-            else if (d == "MediumInterface") throw std::runtime_error("MediumInterface: participating media are not supported");
+            else if (d == "MediumInterface") { // one name = both sides (Enigma/Parser.cpp:980-999)
+                std::string in = c.str("MediumInterface"), out = in;
+                if (!c.done() && c.peek().quoted) out = c.str("MediumInterface");
+                pbrtMediumInterface(in, out);
+            }
             else if (d == "ActiveTransform" || d == "TransformTimes") throw std::runtime_error(d + ": animated transforms are not supported");
             else throw std::runtime_error("unknown directive \"" + d + "\"");
         }
@@ -686,6 +721,7 @@ private:
     std::vector<Mat4d> m_pushedTransforms;
     std::string m_imageFile;
     int m_defaultMaterial = -1;
+    std::map<std::string, int> m_namedMedia; // RenderOptions::namedMedia: name -> index in the scene's medium registry
     std::unique_ptr<FrontEndResult> m_res{new FrontEndResult()};
 };
 

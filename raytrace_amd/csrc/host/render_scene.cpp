@@ -55,12 +55,17 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o << "],\n\"meshes\":[";
     for (size_t i = 0; i < R.scene.m_meshes.size(); ++i) {
         const TriangleMesh& m = R.scene.m_meshes[i];
-        o << (i ? ",\n" : "") << "{\"material\":" << m.materialIndex << ",\"reverse\":" << (m.reverseOrientation ? 1 : 0) << ",\"emissive\":" << (m.emissive ? 1 : 0)
+        o << (i ? ",\n" : "") << "{\"material\":" << m.materialIndex << ",\"medium_inside\":" << m.mediumInside << ",\"medium_outside\":" << m.mediumOutside << ",\"reverse\":" << (m.reverseOrientation ? 1 : 0) << ",\"emissive\":" << (m.emissive ? 1 : 0)
           << ",\"twosided\":" << (m.twoSided ? 1 : 0) << ",\"nsamples\":" << m.nSamples << ",\"Le\":[" << m.Le[0] << "," << m.Le[1] << "," << m.Le[2] << "],\"indices\":[";
         for (size_t k = 0; k < m.m_vertexIndices.size(); ++k) o << (k ? "," : "") << m.m_vertexIndices[k];
         o << "],\"P\":[";
         for (size_t k = 0; k < m.m_p.size(); ++k) o << (k ? "," : "") << m.m_p[k].x << "," << m.m_p[k].y << "," << m.m_p[k].z;
         o << "]}";
+    }
+    o << "],\n\"media\":[";
+    for (size_t i = 0; i < R.scene.m_media.size(); ++i) {
+        const EnigmaMedium& m = R.scene.m_media[i];
+        o << (i ? "," : "") << "{\"sigma_a\":"; arr(m.sigma_a, 3); o << ",\"sigma_s\":"; arr(m.sigma_s, 3); o << ",\"g\":"; arr(&m.g, 1); o << "}";
     }
     o << "],\n\"lights\":[";
     for (size_t i = 0; i < R.scene.m_lights.size(); ++i) {

@@ -39,6 +39,11 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         out.append(world_prefix)
     for i in range(sc.n_materials):
         out.append(material_text(i, sc.materials[i]))
+    n_media = getattr(sc, "n_media", 0)
+    for i in range(n_media):
+        m = sc.media[i]
+        out.append('MakeNamedMedium "med%d" "string type" "homogeneous" %s %s "float g" %.9g' % (i, _rgb("sigma_a", m.sigma_a), _rgb("sigma_s", m.sigma_s), m.g))
+    med = lambda k: (int(sc.tri_medium_inside[k]), int(sc.tri_medium_outside[k])) if n_media else (-1, -1)
     nT = sc.indices.shape[0]
     # point lights keep their position among the area lights: emit each before the first triangle whose light index is larger
     point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type != abi.LIGHT_DIFFUSE_AREA]
@@ -65,7 +70,7 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         li = int(sc.tri_light[t])
         key = lambda k: (int(sc.tri_material[k]), int(sc.tri_light[k]) >= 0,
                          tuple(sc.lights[sc.tri_light[k]].L) + (sc.lights[sc.tri_light[k]].two_sided, sc.lights[sc.tri_light[k]].n_samples) if sc.tri_light[k] >= 0 else None,
-                         int(sc.tri_flags[k]) if sc.tri_flags is not None else 0)
+                         int(sc.tri_flags[k]) if sc.tri_flags is not None else 0, med(k))
         while e < nT and key(e) == key(t) and (li < 0 or int(sc.tri_light[e]) == li + (e - t)):
             e += 1
         if li >= 0:
@@ -73,7 +78,12 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         verts = sc.vertices[sc.indices[t:e].reshape(-1)]
         idx = np.arange(verts.shape[0])
         out.append("AttributeBegin")
-        out.append('  NamedMaterial "m%d"' % int(sc.tri_material[t]))
+        if int(sc.tri_material[t]) == abi.NO_MATERIAL:
+            out.append('  Material "none"')
+        else:
+            out.append('  NamedMaterial "m%d"' % int(sc.tri_material[t]))
+        if med(t) != (-1, -1):
+            out.append('  MediumInterface "%s" "%s"' % tuple("" if i < 0 else "med%d" % i for i in med(t)))
         if sc.tri_flags is not None and int(sc.tri_flags[t]) & 1:
             out.append("  ReverseOrientation")
         if li >= 0:

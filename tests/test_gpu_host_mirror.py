@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -88,10 +88,11 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     import pbrt_writer
     assert os.path.exists(EXE), "raytrace_amd/enigma_render is not built (make -C raytrace_amd/csrc)"
     xres, yres, spp = 72, 48, 8
-    sc = scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
+    sc = scenes.cornell_fog(variant.split(":")[1]) if variant.startswith("fog:") else scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
-    itext = ('Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"' if integrator == "path"
-             else 'Integrator "directlighting" "integer maxdepth" 5 "string strategy" "all"')
+    itext = {"path": 'Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
+             "volpath": 'Integrator "volpath" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
+             "directlighting": 'Integrator "directlighting" "integer maxdepth" 5 "string strategy" "all"'}[integrator]
     text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp, integrator=itext)
     scene_file, out_file = str(tmp_path / "cornell.pbrt"), str(tmp_path / "out.pfm")
     with open(scene_file, "w") as f:
@@ -100,11 +101,11 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     assert p.returncode == 0, p.stderr
     img = _read_pfm(out_file)
     cam, film = scenes.cornell_camera(xres, yres), scenes.film_desc(xres, yres)
-    integ = scenes.integrator_desc(film, spp) if integrator == "path" else scenes.direct_lighting_desc(film, spp)
+    integ = {"path": scenes.integrator_desc, "volpath": scenes.volpath_desc, "directlighting": scenes.direct_lighting_desc}[integrator](film, spp)
     o = orc.Oracle(sc, cam, film, integ)
     o.render(0, spp, threads=4)
     # the front end evaluates the camera matrices in double and rounds once; the Python builder does the same
-    assert common.mean_relative_error(img, o.image()) < 1e-3
+    assert common.mean_relative_error(img, o.image()) < (5e-3 if integrator == "volpath" else 1e-3)
     o.close()
 
 

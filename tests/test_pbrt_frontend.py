@@ -247,3 +247,33 @@ WorldEnd
     assert np.allclose(spot2["from"], [0, 0, 0]) and np.allclose(spot2["I"], [1, 1, 1])
     assert np.isclose(spot2["cos_total_width"], np.cos(np.radians(30.0)), atol=1e-6) and np.isclose(spot2["cos_falloff_start"], np.cos(np.radians(25.0)), atol=1e-6)
     assert np.allclose(np.array(spot2["world_to_light"]).reshape(3, 3) @ np.array([0.6, 0.0, 0.8]), [0, 0, 1], atol=1e-6)
+
+
+def test_media_medium_interfaces_and_the_volpath_integrator(tmp_path):
+    """MakeNamedMedium / MediumInterface / Material "none" / Integrator "volpath" (Enigma/Api.cpp:135,282-331,644-662,
+    1017-1036; Enigma/VolPathIntegrator.cpp:179-200) against the Python-built fog scene."""
+    sc = scenes.cornell_fog("microfacet")
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4,
+                                  integrator='Integrator "volpath" "integer maxdepth" 7 "float rrthreshold" 0.5 "string lightsamplestrategy" "uniform"')
+    d = dump(tmp_path, text)
+    assert d["integrator"]["name"] == "volpath" and d["integrator"]["maxdepth"] == 7 and d["integrator"]["rrthreshold"] == 0.5
+    assert d["integrator"]["lightsamplestrategy"] == "uniform"
+    assert len(d["media"]) == 2
+    for got, ref in zip(d["media"], [sc.media[0], sc.media[1]]):
+        assert np.array_equal(np.float32(got["sigma_a"]), np.float32(list(ref.sigma_a))) and np.array_equal(np.float32(got["sigma_s"]), np.float32(list(ref.sigma_s)))
+        assert np.float32(got["g"][0]) == np.float32(ref.g)
+    tri_mat, tri_in, tri_out = [], [], []
+    for m in d["meshes"]:
+        n = len(m["indices"]) // 3
+        tri_mat += [m["material"]] * n; tri_in += [m["medium_inside"]] * n; tri_out += [m["medium_outside"]] * n
+    assert tri_in == list(sc.tri_medium_inside) and tri_out == list(sc.tri_medium_outside)
+    assert [(-1 if int(x) == abi.NO_MATERIAL else int(x)) for x in sc.tri_material] == tri_mat
+    # a medium named before it is made, a heterogeneous medium, a preset: reported, not guessed
+    head = 'Camera "perspective"\nFilm "image" "integer xresolution" 4 "integer yresolution" 4\nSampler "sobol"\nWorldBegin\n'
+    for body, msg in (('MediumInterface "fog" ""\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "undefined"),
+                      ('MakeNamedMedium "a" "string type" "heterogeneous" "float density" [1]\nWorldEnd\n', "stub"),
+                      ('MakeNamedMedium "a" "string type" "homogeneous" "string preset" "Skin1"\nWorldEnd\n', "preset")):
+        f = tmp_path / "bad.pbrt"
+        f.write_text(head + body)
+        p = subprocess.run([EXE, "--dump", str(f), str(tmp_path / "bad.json")], capture_output=True, text=True)
+        assert p.returncode != 0 and msg in p.stderr
