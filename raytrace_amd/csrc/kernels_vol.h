@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
                     P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
                 }
             }
-            w.step(nodes, tris);
+            w.template advance<LDS_SCENE>(nodes, tris);
         }
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                     }
                 }
             }
-            w.step(nodes, tris);
+            w.template advance<LDS_SCENE>(nodes, tris);
         }
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
