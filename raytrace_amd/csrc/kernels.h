@@ -216,8 +216,12 @@ struct MatQueues { uint32_t* q[kQueueKinds]; };
 // not sit out the slowest ray of their wave.  The pool cursor is an LDS atomic; nothing global is
 // bumped per wave.  After the chunk the block bins the surviving paths by material kind with ONE
 // tail bump per kind and block (per-wave ballots -> LDS -> block totals).
-constexpr uint32_t kTraceChunk = 512;
+// 2048 rays = eight per lane: a chunk ends with a tail in which lanes run dry one after the other, and the longer
+// the chunk the smaller the tail's share (BigMesh: 145 ms per step at 512, 129 at 1024, 122 at 2048); at 4096 the
+// per-chunk table no longer leaves room for six blocks per CU and the gain is lost again.
+constexpr uint32_t kTraceChunk = 2048;
 constexpr int kTraceItems = kTraceChunk / kBlock;
+static_assert(kTraceItems >= 1 && kTraceItems <= 16, "the chunk's material kinds are packed four bits per item into 64 bits");
 
 constexpr uint32_t kNoRay = 0xffffffffu;
 
@@ -351,17 +355,17 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         }
         __syncthreads();
         // ---- bin the chunk: order inside a material queue is wave, item, lane
-        uint32_t kinds = 0; // 4 bits per item
+        unsigned long long kinds = 0; // 4 bits per item
 #pragma unroll
         for (int it = 0; it < kTraceItems; ++it) {
             uint32_t j = it * kBlock + threadIdx.x;
-            kinds |= (j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
+            kinds |= (unsigned long long)(j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             uint32_t c = 0;
 #pragma unroll
-            for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot(((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
+            for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot((uint32_t)((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
             if (lane == 0) binCnt[k * kWavesPerBlock + wid] = c;
         }
         __syncthreads();
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
             for (uint32_t w2 = 0; w2 < wid; ++w2) off += binCnt[k * kWavesPerBlock + w2];
 #pragma unroll
             for (int it = 0; it < kTraceItems; ++it) {
-                bool mine = ((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u;
+                bool mine = (uint32_t)((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u;
                 unsigned long long mask = __ballot(mine);
                 if (mine) {
                     uint32_t i = chunk + it * kBlock + threadIdx.x;
