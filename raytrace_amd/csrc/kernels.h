@@ -52,11 +52,33 @@ DEV float sampleDimensionOf(const DevSampler& S, uint32_t relx, uint32_t rely, u
     return smin((float)v * 0x1p-32f, kOneMinusEpsilon); // dims >= 2 only
 }
 
+// Pixels of the render region are numbered tile by tile: 8 x 8 tiles in row-major order (64 consecutive numbers =
+// one wave = one compact bundle of camera rays), then the pixels right of the last full tile column and below the
+// last full tile row in scanline order.  Which number a pixel gets changes nothing in the image; it decides which
+// rays travel through the kernels side by side.
+DEV void pixelOfIndex(const DevIntegrator& I, uint32_t pix, uint32_t* xo, uint32_t* yo) {
+    const uint32_t rw = (uint32_t)I.rw, rh = (uint32_t)I.rh;
+    const uint32_t tX = rw >> 3, tY = rh >> 3, tiled = tX * tY * 64u;
+    if (pix < tiled) {
+        uint32_t tile = pix >> 6, in = pix & 63u;
+        uint32_t ty = tile / tX, tx = tile - ty * tX;
+        *xo = tx * 8u + (in & 7u); *yo = ty * 8u + (in >> 3);
+        return;
+    }
+    uint32_t r = pix - tiled;
+    const uint32_t stripW = rw - tX * 8u, stripH = tY * 8u; // right strip: stripW x stripH
+    if (r < stripW * stripH) { uint32_t y = r / stripW; *xo = tX * 8u + (r - y * stripW); *yo = y; return; }
+    r -= stripW * stripH;                                    // bottom strip: rw x (rh - stripH)
+    uint32_t y = r / rw;
+    *xo = r - y * rw; *yo = stripH + y;
+}
+
 // Pixel (relative to the sample-bounds origin) and sample slot of a path: paths of a pass are numbered
-// slot-major over the pixels of the render region.
+// slot-major over the pixel numbers of the render region.
 DEV void pathPixel(const DevIntegrator& I, const DevSampler& S, uint32_t p, uint32_t* relx, uint32_t* rely, uint32_t* slot) {
     uint32_t s = p / I.nPixels, pix = p - s * I.nPixels;
-    uint32_t y = pix / (uint32_t)I.rw, x = pix - y * (uint32_t)I.rw;
+    uint32_t x, y;
+    pixelOfIndex(I, pix, &x, &y);
     *relx = (uint32_t)(I.rx0 - S.sbx0) + x;
     *rely = (uint32_t)(I.ry0 - S.sby0) + y;
     *slot = I.slotBase + s;
@@ -189,7 +211,9 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nPaths) return;
     uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
-    int px = I.rx0 + (int)(pix % (uint32_t)I.rw), py = I.ry0 + (int)(pix / (uint32_t)I.rw);
+    uint32_t tx, ty;
+    pixelOfIndex(I, pix, &tx, &ty);
+    int px = I.rx0 + (int)tx, py = I.ry0 + (int)ty;
     uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
     // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
     float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
@@ -1003,7 +1027,9 @@ DEV void filmFootprint(const DevFilm& F, float fx, float fy, SINK sink) {
 __global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, DevIntegrator I, uint32_t nPixels, uint32_t nSlots) {
     uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
     if (pix >= nPixels) return;
-    const int ownX = I.rx0 + (int)(pix % (uint32_t)I.rw), ownY = I.ry0 + (int)(pix / (uint32_t)I.rw);
+    uint32_t tx, ty;
+    pixelOfIndex(I, pix, &tx, &ty);
+    const int ownX = I.rx0 + (int)tx, ownY = I.ry0 + (int)ty;
     const int width = F.x1 - F.x0;
     F3 acc(0.f);
     float accW = 0.f;
