@@ -56,7 +56,8 @@ typedef struct EnigmaMaterial {
 
 /* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651), SpotLight (:133-190),
  * DistantLight (:656-708).  One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
-enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT = 2, ENIGMA_LIGHT_DISTANT = 3 };
+enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT = 2, ENIGMA_LIGHT_DISTANT = 3,
+       ENIGMA_LIGHT_INFINITE = 4 /* InfiniteAreaLight, Enigma/Lights.cpp:395-546 */ };
 
 typedef struct EnigmaLight {
     uint32_t type;      /* ENIGMA_LIGHT_* */
@@ -70,7 +71,13 @@ typedef struct EnigmaLight {
                            normalise it (Enigma/Lights.cpp:656-663) and neither does this library */
     float cos_total_width;    /* spot: cosf(radians(coneangle)) (Enigma/Lights.cpp:138) */
     float cos_falloff_start;  /* spot: cosf(radians(coneangle - conedeltaangle)) (Enigma/Lights.cpp:139) */
-    float world_to_light[9];  /* spot: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
+    float world_to_light[9];  /* spot, infinite: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
+    float light_to_world[9];  /* infinite: upper-left 3x3 of m_lightToWorld */
+    /* infinite: the latitude-longitude radiance map the constructor reads (ReadImage -> RGB texels, row 0 = theta 0),
+     * multiplied by L; NULL = the 1 x 1 map of colour L (no "mapname").  Width and height must be powers of two: the
+     * reference resamples other sizes with a Lanczos filter first, which is left to the caller. */
+    uint32_t map_width, map_height;
+    const float* map_rgb;     /* [map_height * map_width * 3] */
 } EnigmaLight;
 
 #define ENIGMA_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness */

@@ -1392,10 +1392,162 @@ struct Distribution1D { // MonteCarlo.h:15-84
         if (pdf) *pdf = func[offset] / (funcInt * count);
         return offset;
     }
+    float SampleContinuous(float u, float* pdf, int* off = nullptr) const { // MonteCarlo.h:42-59
+        auto iter = std::upper_bound(cdf.begin(), cdf.begin() + count + 1, u);
+        int offset = std::max(0, int((iter - cdf.begin()) - 1));
+        if (off) *off = offset;
+        float du = (u - cdf[offset]) / (cdf[offset + 1] - cdf[offset]);
+        if (pdf) *pdf = func[offset] / funcInt;
+        return (offset + du) / count;
+    }
+};
+
+
+// ---------------------------------------------------------------------------
+// InfiniteAreaLight (Lights.cpp:395-546): MipMap<RGBSpectrum> (MipMap.h:111-152, 256-399), Distribution2D
+// (MonteCarlo.h:86-107, MonteCarlo.cpp:236-271)
+// ---------------------------------------------------------------------------
+struct MipMapRGB {
+    std::vector<std::vector<Spectrum>> level; std::vector<int> lw, lh;
+    float weightLut[128];
+    int levels() const { return (int)level.size(); }
+    void build(int w, int h, const std::vector<Spectrum>& img) { // power-of-two sizes only (the resize step is not restated)
+        for (int i = 0; i < 128; ++i) { float alpha = 2; float r2 = float(i) / float(128 - 1); weightLut[i] = expf(-alpha * r2) - expf(-alpha); }
+        int n = 1 + Log2Int(float(std::max(w, h)));
+        level.assign(n, {}); lw.assign(n, 0); lh.assign(n, 0);
+        level[0] = img; lw[0] = w; lh[0] = h;
+        for (int i = 1; i < n; ++i) {
+            int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
+            lw[i] = sRes; lh[i] = tRes; level[i].resize((size_t)sRes * tRes);
+            for (int t = 0; t < tRes; ++t)
+                for (int s = 0; s < sRes; ++s)
+                    level[i][(size_t)t * sRes + s] = .25f * (texel(i - 1, 2 * s, 2 * t) + texel(i - 1, 2 * s + 1, 2 * t) + texel(i - 1, 2 * s, 2 * t + 1) + texel(i - 1, 2 * s + 1, 2 * t + 1));
+        }
+    }
+    const Spectrum& texel(int l, int s, int t) const { // TEXTURE_WRAP_REPEAT: int % unsigned (MipMap.h:337-339)
+        uint32_t us = (uint32_t)s % (uint32_t)lw[l], ut = (uint32_t)t % (uint32_t)lh[l];
+        return level[l][(size_t)ut * lw[l] + us];
+    }
+    Spectrum triangle(int l, const Vec2& st) const {
+        l = std::clamp(l, 0, levels() - 1);
+        float s = st[0] * lw[l] - 0.5f, t = st[1] * lh[l] - 0.5f;
+        int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+        float ds = s - s0, dt = t - t0;
+        return (1 - ds) * (1 - dt) * texel(l, s0, t0) + (1 - ds) * dt * texel(l, s0, t0 + 1) + ds * (1 - dt) * texel(l, s0 + 1, t0) + ds * dt * texel(l, s0 + 1, t0 + 1);
+    }
+    Spectrum lookup(const Vec2& st, float width = 0.f) const {
+        float lv = levels() - 1.0f + Log2(std::max(width, 1e-8f));
+        if (lv < 0) return triangle(0, st);
+        else if (lv >= levels() - 1) return texel(levels() - 1, 0, 0);
+        int iLevel = Floor2Int(lv);
+        float delta = lv - iLevel;
+        return (1.f - delta) * triangle(iLevel, st) + delta * triangle(iLevel + 1, st);
+    }
+    Spectrum EWA(int l, Vec2 st, Vec2 dst0, Vec2 dst1) const {
+        if (l >= levels()) return texel(levels() - 1, 0, 0);
+        st.x = st.x * lw[l] - 0.5f; st.y = st.y * lh[l] - 0.5f;
+        dst0.x *= lw[l]; dst0.y *= lh[l]; dst1.x *= lw[l]; dst1.y *= lh[l];
+        float A = dst0.y * dst0.y + dst1.y * dst1.y + 1;
+        float B = -2 * (dst0.x * dst0.y + dst1.x * dst1.y);
+        float C = dst0.x * dst0.x + dst1.x * dst1.x + 1;
+        float invF = 1 / (A * C - B * B * 0.25f);
+        A *= invF; B *= invF; C *= invF;
+        float det = -B * B + 4 * A * C;
+        float invDet = 1 / det;
+        float uSqrt = std::sqrt(det * C), vSqrt = std::sqrt(A * det);
+        int s0 = (int)std::ceil(st.x - 2 * invDet * uSqrt), s1 = (int)std::floor(st.x + 2 * invDet * uSqrt);
+        int t0 = (int)std::ceil(st.y - 2 * invDet * vSqrt), t1 = (int)std::floor(st.y + 2 * invDet * vSqrt);
+        Spectrum sum(0.f);
+        float sumWts = 0;
+        for (int it = t0; it <= t1; ++it) {
+            float tt = it - st.y;
+            for (int is = s0; is <= s1; ++is) {
+                float ss = is - st.x;
+                float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+                if (r2 < 1) {
+                    int index = std::min((int)(r2 * 128), 128 - 1);
+                    float weight = weightLut[index];
+                    sum += texel(l, is, it) * weight;
+                    sumWts += weight;
+                }
+            }
+        }
+        return sum / sumWts;
+    }
+    Spectrum lookup(const Vec2& st, Vec2 dst0, Vec2 dst1) const { // m_doTrilinear = false, m_maxAnisotropy = 8 (MipMap.h:60-61)
+        if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) std::swap(dst0, dst1);
+        float majorLength = std::sqrt(dst0.x * dst0.x + dst0.y * dst0.y), minorLength = std::sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+        if (minorLength * 8.0f < majorLength && minorLength > 0) {
+            float scale = majorLength / (minorLength * 8.0f);
+            dst1.x *= scale; dst1.y *= scale;
+            minorLength *= scale;
+        }
+        if (minorLength == 0) return triangle(0, st);
+        float lod = std::max((float)0, levels() - (float)1 + Log2(minorLength));
+        int ilod = (int)std::floor(lod);
+        Spectrum a = EWA(ilod, st, dst0, dst1), b = EWA(ilod + 1, st, dst0, dst1);
+        float t = lod - ilod; // Lerp(start, end, t), MathCommon.h:31-39
+        if (t < 0.f) return a;
+        if (t > 1.f) return b;
+        return a + (b - a) * t;
+    }
+};
+struct Distribution2D {
+    std::vector<Distribution1D> cond; std::unique_ptr<Distribution1D> marg;
+    Distribution2D(const float* data, int nu, int nv) {
+        for (int v = 0; v < nv; ++v) cond.emplace_back(&data[v * nu], nu);
+        std::vector<float> mf;
+        for (int v = 0; v < nv; ++v) mf.push_back(cond[v].funcInt);
+        marg.reset(new Distribution1D(mf.data(), nv));
+    }
+    Vec2 SampleContinuous(const Vec2& u, float* pdf) const {
+        float pdfs[2]; int v;
+        float d1 = marg->SampleContinuous(u[1], &pdfs[1], &v);
+        float d0 = cond[v].SampleContinuous(u[0], &pdfs[0]);
+        *pdf = pdfs[0] * pdfs[1];
+        return Vec2(d0, d1);
+    }
+    float Pdf(float u, float v) const {
+        int iu = std::clamp((int)(u * cond[0].count), 0, cond[0].count - 1);
+        int iv = std::clamp((int)(v * marg->count), 0, marg->count - 1);
+        if (cond[iv].funcInt * marg->funcInt == 0.f) return 0.f;
+        return (cond[iv].func[iu] * marg->func[iv]) / (cond[iv].funcInt * marg->funcInt);
+    }
+};
+static float SphericalTheta(const Vec3& n) { return std::acos(std::clamp(n.z, -1.0f, 1.0f)); }            // MathCommon.cpp:25-28
+static float SphericalPhi(const Vec3& n) { const float p = atan2f(n.y, n.x); return (p < 0.0f) ? p + PI * 2.0f : p; } // MathCommon.cpp:30-35
+struct InfiniteData {
+    float l2w[9], w2l[9];
+    MipMapRGB map;
+    std::unique_ptr<Distribution2D> dist;
+    static Vec3 mul(const float* m, const Vec3& v) { return Vec3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
+    void build(const EnigmaLight& l) { // InfiniteAreaLight ctor, Lights.cpp:395-442 + Task :368-392
+        memcpy(l2w, l.light_to_world, sizeof(l2w)); memcpy(w2l, l.world_to_light, sizeof(w2l));
+        int width = l.map_rgb ? (int)l.map_width : 1, height = l.map_rgb ? (int)l.map_height : 1;
+        std::vector<Spectrum> texels((size_t)width * height);
+        Spectrum L(l.L[0], l.L[1], l.L[2]);
+        for (size_t i = 0; i < texels.size(); ++i) texels[i] = l.map_rgb ? Spectrum(l.map_rgb[3 * i], l.map_rgb[3 * i + 1], l.map_rgb[3 * i + 2]) * L : L;
+        map.build(width, height, texels);
+        width = map.lw[0] * 2; height = map.lh[0] * 2;
+        std::vector<float> img((size_t)width * height);
+        for (int v = 0; v < height; ++v) {
+            float filter = 0.5f / std::min(width, height);
+            float vp = (v + 0.5f) / (float)height;
+            float sinTheta = sinf(PI * float(v + .5f) / float(height));
+            for (int u = 0; u < width; ++u) {
+                float up = float(u + .5f) / (float)width;
+                size_t idx = u + (size_t)v * width;
+                img[idx] = map.lookup(Vec2(up, vp), filter).y();
+                img[idx] *= sinTheta;
+            }
+        }
+        dist.reset(new Distribution2D(img.data(), width, height));
+    }
 };
 
 struct Light {
     int nSamples = 1; // Light::m_nSamples
+    std::shared_ptr<InfiniteData> inf; // InfiniteAreaLight (flags & 8)
     int flags; // 1 = delta position, 2 = delta direction, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
     bool spot = false; float cosTotalWidth = 0, cosFalloffStart = 0; float w2l[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // SpotLight
@@ -1413,7 +1565,15 @@ struct Light {
     }
     // DiffuseAreaLight::L (Lights.cpp:575-578)
     Spectrum L(const Interaction& intr, const Vec3& w) const { return (twoSided || Dot(intr.n, w) > 0) ? I_or_L : Spectrum(0.f); }
+    // InfiniteAreaLight::Le (Lights.cpp:452-457); every other light returns black (Light::Le, Lights.cpp:80-83)
+    Spectrum LeRay(const Ray& r) const {
+        if (!(flags & 8)) return Spectrum(0.f);
+        Vec3 w = Normalize(InfiniteData::mul(inf->w2l, r.d));
+        Vec2 st(SphericalPhi(w) * (1.0f / (PI * 2.0f)), SphericalTheta(w) * INV_PI);
+        return inf->map.lookup(st);
+    }
     Spectrum Power() const {
+        if (flags & 8) return PI * worldRadius * worldRadius * inf->map.lookup(Vec2(0.5f, 0.5f), Vec2(0.5f, 0.5f), Vec2(0.5f, 0.5f)); // Lights.cpp:541-546
         if (flags & 4) { float scale = twoSided ? 2.0f : 1.0f; return I_or_L * (area * PI * scale); } // Lights.cpp:647-651
         if (flags & 2) return I_or_L * PI * worldRadius * worldRadius;                                   // Lights.cpp:705-708
         if (spot) return I_or_L * 2.f * PI * (1.f - .5f * (cosFalloffStart + cosTotalWidth));            // Lights.cpp:174-178
@@ -1427,6 +1587,20 @@ struct Light {
             *wi = Normalize(pShape.p - ref.p);
             *p1 = pShape;
             return L(pShape, -*wi);
+        }
+        if (flags & 8) { // InfiniteAreaLight::Sample_Li (Lights.cpp:516-539)
+            float mapPdf;
+            Vec2 uv = inf->dist->SampleContinuous(u, &mapPdf);
+            if (mapPdf == 0) { *pdf = 0; return Spectrum(0.f); } // the reference leaves *pdf as the caller set it: 0
+            float theta = uv[1] * PI, phi = uv[0] * 2 * PI;
+            float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
+            float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+            *wi = InfiniteData::mul(inf->l2w, Vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+            *pdf = mapPdf / (2 * PI * PI * sinTheta);
+            if (sinTheta == 0) *pdf = 0;
+            Interaction po; po.p = ref.p + *wi * (2 * worldRadius); po.time = ref.time;
+            *p1 = po;
+            return inf->map.lookup(uv);
         }
         if (flags & 2) { // DistantLight::Sample_Li (Lights.cpp:696-703)
             *wi = lightDir;
@@ -1442,7 +1616,17 @@ struct Light {
         if (spot) return I_or_L * Falloff(-*wi) / DistanceSqr(pos, ref.p); // SpotLight::Sample_Li (Lights.cpp:165-172)
         return I_or_L / DistanceSqr(pos, ref.p);
     }
-    float Pdf_Li(const Interaction& ref, const Vec3& wi) const { return (flags & 4) ? shape->pdf(ref, wi) : 0; }
+    float Pdf_Li(const Interaction& ref, const Vec3& w) const {
+        if (flags & 8) { // InfiniteAreaLight::Pdf_Li (Lights.cpp:464-472); theta is scaled by 1 / (2 pi) there, not 1 / pi
+            Vec3 wi = InfiniteData::mul(inf->w2l, w);
+            float theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+            float sinTheta = std::sin(theta);
+            if (sinTheta == 0) return 0;
+            const float INV_TWO_PI = 1.0f / (PI * 2.0f);
+            return inf->dist->Pdf(phi * INV_TWO_PI, theta * INV_TWO_PI) / (2 * PI * PI * sinTheta);
+        }
+        return (flags & 4) ? shape->pdf(ref, w) : 0;
+    }
 };
 
 struct Scene {
@@ -1508,7 +1692,7 @@ static Spectrum EstimateDirect(const SurfaceInteraction& it, const BSDF& bsdf, c
             Spectrum Li2(0.f);
             if (found) {
                 if (scene.triLight[lightIsect.primIndex] == light.index) Li2 = Le(scene, lightIsect, -wi);
-            } // else light.Le(ray) == 0 for every light in scope
+            } else Li2 = light.LeRay(ray);
             if (!Li2.IsBlack()) Ld += f * Li2 * Spectrum(1.f) * weight / scatteringPdf;
         }
     }
@@ -1550,6 +1734,7 @@ struct PathIntegrator {
             bool foundIntersection = scene.intersect(ray, &isect);
             if (bounces == 0 || specularBounce) {
                 if (foundIntersection) L += beta * Le(scene, isect, -ray.d);
+                else for (const Light& light : scene.lights) if (light.flags & 8) L += beta * light.LeRay(ray); // scene.m_infiniteLights
             }
             if (!foundIntersection || bounces >= maxDepth) break;
             std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true));
@@ -1733,7 +1918,7 @@ static Spectrum EstimateDirectVol(const Interaction& it, const Vec3& shadingN, c
             Spectrum Li2(0.f);
             if (found) {
                 if (scene.triLight[lightIsect.primIndex] == light.index) Li2 = Le(scene, lightIsect, -wi);
-            } // else light.Le(ray) == 0 for every light in scope
+            } else Li2 = light.LeRay(ray);
             if (!Li2.IsBlack()) Ld += f * Li2 * Tr * weight / scatteringPdf;
         }
     }
@@ -1782,6 +1967,7 @@ struct VolPathIntegrator {
             } else {
                 if (bounces == 0 || specularBounce) {
                     if (foundIntersection) L += beta * Le(scene, isect, -ray.d);
+                    else for (const Light& light : scene.lights) if (light.flags & 8) L += beta * light.LeRay(ray);
                 }
                 if (!foundIntersection || bounces >= maxDepth) break;
                 if (!HasMaterial(scene, isect)) { // no BSDF: a medium boundary
@@ -1858,7 +2044,10 @@ struct DirectLightingIntegrator {
         Spectrum L(0.f);
         SurfaceInteraction isect;
         if (tl_counters) { tl_counters->rays_closest++; tl_counters->kind = 0; }
-        if (!scene.intersect(ray, &isect)) return L; // light->Le(ray) is zero for point and area lights
+        if (!scene.intersect(ray, &isect)) { // DirectLightingIntegrator.cpp:43-47
+            for (const Light& light : scene.lights) L += light.LeRay(ray);
+            return L;
+        }
         // allowMultipleLobes defaults to false here (Interaction.h:68): smooth glass = two specular lobes
         std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false));
         Vec3 wo = isect.wo;
@@ -2051,6 +2240,11 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
             }
         } else if (l.type == ENIGMA_LIGHT_DISTANT) {
             L.flags = 2; L.lightDir = Vec3(l.dir[0], l.dir[1], l.dir[2]);
+        } else if (l.type == ENIGMA_LIGHT_INFINITE) {
+            if (l.map_rgb && ((l.map_width & (l.map_width - 1)) || (l.map_height & (l.map_height - 1)) || !l.map_width || !l.map_height)) {
+                h->o.error = "radiance maps must have power-of-two sizes (MipMap::resizeImage is not restated)"; return -4;
+            }
+            L.flags = 8; L.inf.reset(new InfiniteData()); L.inf->build(l);
         } else { h->o.error = "light type is not restated"; return -4; }
     }
     sc.accel.reset(new BVHAccel(&sc.tris, max_node_prims, split_method == 1 ? SplitMethod::HLBVH : SplitMethod::SAH));

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
-LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT = 0, 1, 2, 3
+LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3, 4
 LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
@@ -21,7 +21,8 @@ class EnigmaMaterial(C.Structure):
 class EnigmaLight(C.Structure):
     _fields_ = [("type", C.c_uint32), ("triangle", C.c_uint32), ("two_sided", C.c_uint32), ("n_samples", C.c_uint32),
                 ("L", C.c_float * 3), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
-                ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float), ("world_to_light", C.c_float * 9)]
+                ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float), ("world_to_light", C.c_float * 9),
+                ("light_to_world", C.c_float * 9), ("map_width", C.c_uint32), ("map_height", C.c_uint32), ("map_rgb", C.c_void_p)]
 
 
 class EnigmaMedium(C.Structure):
@@ -92,6 +93,7 @@ class SceneArrays:
         self.tri_medium_outside = None if tri_medium_outside is None else np.ascontiguousarray(tri_medium_outside, dtype=np.int32).reshape(nt)
         self.materials = (EnigmaMaterial * max(1, len(materials)))(*materials)
         self.lights = (EnigmaLight * max(1, len(lights)))(*lights)
+        self._light_maps = [getattr(l, "_map", None) for l in lights]   # the arrays map_rgb points into
         self.n_lights = len(lights)
         self.n_materials = len(materials)
 
@@ -216,6 +218,25 @@ def spot_light(pos, to, I, coneangle=30.0, conedeltaangle=5.0, n_samples=1):
     l.cos_total_width = float(np.cos(f(np.radians(f(coneangle)))))
     l.cos_falloff_start = float(np.cos(f(np.radians(f(coneangle - conedeltaangle)))))
     l.world_to_light[:] = [float(x) for x in np.concatenate([du, dv, d])]
+    return l
+
+
+def infinite_light(L, radiance_map=None, light_to_world=None, n_samples=1):
+    """InfiniteAreaLight (Enigma/Lights.cpp:395-442): radiance_map is a (height, width, 3) float32 latitude-longitude
+    image (power-of-two sizes) or None for the constant environment L; light_to_world a 3x3 rotation (default identity)."""
+    l = EnigmaLight()
+    l.type = LIGHT_INFINITE
+    l.n_samples = n_samples
+    l.L[:] = L
+    m = np.eye(3, dtype=np.float64) if light_to_world is None else np.asarray(light_to_world, dtype=np.float64).reshape(3, 3)
+    l.light_to_world[:] = [float(np.float32(x)) for x in m.reshape(-1)]
+    l.world_to_light[:] = [float(np.float32(x)) for x in np.linalg.inv(m).reshape(-1)]
+    if radiance_map is not None:
+        a = np.ascontiguousarray(radiance_map, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[2] == 3
+        l.map_height, l.map_width = a.shape[0], a.shape[1]
+        l.map_rgb = a.ctypes.data_as(C.c_void_p)
+        l._map = a
     return l
 
 

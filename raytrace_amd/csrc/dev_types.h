@@ -29,8 +29,8 @@ struct DevMaterial {        // 64 bytes
 
 static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
 
-struct DevLight {           // 96 bytes
-    uint32_t type;          // 0 point, 1 diffuse area, 2 spot, 3 distant
+struct DevLight {           // 144 bytes
+    uint32_t type;          // 0 point, 1 diffuse area, 2 spot, 3 distant, 4 infinite area
     uint32_t tri;           // area: triangle position in the device (BVH) order
     uint32_t twoSided;
     float area;             // Triangle::area() (Enigma/TriangleMesh.cpp:438-446)
@@ -40,10 +40,26 @@ struct DevLight {           // 96 bytes
     float w2l0[3]; float cosFalloffStart; // spot: rows of the upper 3x3 of m_worldToLight
     float w2l1[3]; float worldRadius;     // distant: radius of the scene's bounding sphere (Light::Preprocess)
     float w2l2[3]; float pad;
+    float l2w0[3]; float pad2;             // infinite: rows of the upper 3x3 of m_lightToWorld (its m_worldToLight sits in w2l0..2,
+    float l2w1[3]; float pad3;             // its radiance map and sampling distribution in DevScene::envMaps[tri])
+    float l2w2[3]; float pad4;
 };
-constexpr uint32_t kLightVec4 = 6;
+constexpr uint32_t kLightVec4 = 9;
 
 static_assert(sizeof(DevLight) == kLightVec4 * 16, "k_shade copies lights as float4");
+
+// InfiniteAreaLight data (Enigma/Lights.cpp:395-442): level 0 of the radiance MipMap (texels already times L) and the
+// Distribution2D over the 2w x 2h luminance image (Enigma/MonteCarlo.cpp:236-271), flattened row by row.
+struct DevEnvMap {
+    const float4* texels;   // [h][w]
+    const float* condFunc;  // [nv][nu]
+    const float* condCdf;   // [nv][nu + 1]
+    const float* condInt;   // [nv] funcInt of each row
+    const float* margFunc;  // [nv]
+    const float* margCdf;   // [nv + 1]
+    float margInt;
+    int w, h, nu, nv;
+};
 
 // One triangle, 48 bytes, three float4 loads:
 //   v0 = {p0.xyz, bits(original triangle index)}
@@ -57,6 +73,9 @@ struct DevScene {
     const float* lightCdf;      // Distribution1D::cdf, nLights + 1
     const float* lightFunc;     // Distribution1D::func, nLights
     const uint32_t* primId;     // reference m_primitiveId by original triangle index
+    const DevEnvMap* envMaps;   // one per infinite area light (DevLight::tri indexes it)
+    const uint32_t* infiniteLights; // Scene::m_infiniteLights: indices of the infinite area lights
+    int nInfinite;
     const DevMedium* media;     // VolPathIntegrator only
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;

@@ -5,6 +5,8 @@
 
 #include "bvh_build.h"
 #include "kernels_vol.h"
+#include "envmap_host.h"
+#include <memory>
 #include "sobol_host.h"
 
 #include <algorithm>
@@ -57,6 +59,11 @@ struct EnigmaCtx {
     DevBuf<float> lightCdf, lightFunc;
     DevBuf<uint32_t> primId;
     DevBuf<DevMedium> media;
+    // infinite area lights: per light the radiance map and its sampling distribution
+    std::vector<std::unique_ptr<DevBuf<float4>>> envTexels;
+    std::vector<std::unique_ptr<DevBuf<float>>> envFloats;
+    DevBuf<DevEnvMap> envMaps;
+    DevBuf<uint32_t> infiniteLights;
     DevBuf<uint32_t> triMedium;
     bool haveNoMaterial = false; // some triangle has no material (a medium boundary): VolPathIntegrator only
     std::vector<DevLight> hostLights;
@@ -149,6 +156,9 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shTgtP.release(); h->shTgtE.release(); h->shTgtN.release();
     h->media.release(); h->triMedium.release();
+    for (auto& b : h->envTexels) b->release();
+    for (auto& b : h->envFloats) b->release();
+    h->envMaps.release(); h->infiniteLights.release();
     h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
     h->extQ[0].release(); h->extQ[1].release();
@@ -293,6 +303,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         for (int c = 0; c < 3; ++c) d2 += (ctr[c] - hi[c]) * (ctr[c] - hi[c]);
         worldRadius = inside ? std::sqrt(d2) : 0.f;
     }
+    for (auto& b : h->envTexels) b->release();
+    for (auto& b : h->envFloats) b->release();
+    h->envTexels.clear(); h->envFloats.clear();
+    std::vector<DevEnvMap> envTable;
+    std::vector<uint32_t> infinite;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const EnigmaLight& l = s->lights[i];
         DevLight d;
@@ -333,6 +348,40 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             float P[3]; // DistantLight::Power, Enigma/Lights.cpp:705-708: m_L * PI * r * r, evaluated left to right
             for (int c = 0; c < 3; ++c) P[c] = d.L[c] * PI * worldRadius * worldRadius;
             h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
+        } else if (l.type == ENIGMA_LIGHT_INFINITE) {
+            if (l.map_rgb && (!l.map_width || !l.map_height || (l.map_width & (l.map_width - 1)) || (l.map_height & (l.map_height - 1))))
+                return h->fail(ENIGMA_E_UNSUPPORTED, "light %u: a radiance map of %u x %u texels is not a power of two on both sides", i, l.map_width, l.map_height);
+            if (l.map_rgb && (uint64_t)l.map_width * l.map_height > (1u << 26)) return h->fail(ENIGMA_E_UNSUPPORTED, "light %u: radiance map too large", i);
+            enigma::HostEnvMap em;
+            em.build(l.map_rgb, (int)l.map_width, (int)l.map_height, l.L);
+            d.type = 4; d.tri = (uint32_t)envTable.size();
+            d.worldRadius = worldRadius;
+            for (int c = 0; c < 3; ++c) {
+                d.w2l0[c] = l.world_to_light[c]; d.w2l1[c] = l.world_to_light[3 + c]; d.w2l2[c] = l.world_to_light[6 + c];
+                d.l2w0[c] = l.light_to_world[c]; d.l2w1[c] = l.light_to_world[3 + c]; d.l2w2[c] = l.light_to_world[6 + c];
+            }
+            h->haveAreaLights = true; // not a delta light: EstimateDirect traces its BSDF-sampled ray
+            DevEnvMap t{};
+            t.w = em.w; t.h = em.h; t.nu = em.nu; t.nv = em.nv; t.margInt = em.margInt;
+            {
+                std::vector<float4> tex((size_t)em.w * em.h);
+                memcpy(tex.data(), em.texels.data(), tex.size() * sizeof(float4));
+                h->envTexels.emplace_back(new DevBuf<float4>());
+                HIPCHK(h, h->envTexels.back()->upload(tex));
+                t.texels = h->envTexels.back()->p;
+            }
+            const std::vector<float>* arrays[] = {&em.condFunc, &em.condCdf, &em.condInt, &em.margFunc, &em.margCdf};
+            const float** slots[] = {&t.condFunc, &t.condCdf, &t.condInt, &t.margFunc, &t.margCdf};
+            for (int a = 0; a < 5; ++a) {
+                h->envFloats.emplace_back(new DevBuf<float>());
+                HIPCHK(h, h->envFloats.back()->upload(*arrays[a]));
+                *slots[a] = h->envFloats.back()->p;
+            }
+            envTable.push_back(t);
+            infinite.push_back(i);
+            // InfiniteAreaLight::Power, Enigma/Lights.cpp:541-546: PI * r * r * lookup(half, half, half), left to right
+            float k = PI * worldRadius * worldRadius;
+            h->lightPower[i] = YW[0] * (k * em.powerLookup.r) + YW[1] * (k * em.powerLookup.g) + YW[2] * (k * em.powerLookup.b);
         } else return h->fail(ENIGMA_E_UNSUPPORTED, "light type %u is not supported", l.type);
         h->hostLights[i] = d;
     }
@@ -354,6 +403,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->scene.media = h->media.p;
         h->scene.triMedium = haveMedia ? h->triMedium.p : nullptr;
     }
+    HIPCHK(h, h->envMaps.upload(envTable));
+    HIPCHK(h, h->infiniteLights.upload(infinite));
+    h->scene.envMaps = h->envMaps.p;
+    h->scene.infiniteLights = h->infiniteLights.p;
+    h->scene.nInfinite = (int)infinite.size();
     HIPCHK(h, h->nodes.upload(nodeData));
     HIPCHK(h, h->tris.upload(triData));
     HIPCHK(h, h->materials.upload(mats));

@@ -1,0 +1,157 @@
+// Host-side preparation of an InfiniteAreaLight (Enigma/Lights.cpp:395-442): the radiance MipMap
+// (Enigma/MipMap.h:111-152: box-filtered pyramid, repeat wrap), the 2w x 2h luminance image its constructor
+// tabulates through trilinear lookups (Task, Enigma/Lights.cpp:368-392), the Distribution2D over that image
+// (Enigma/MonteCarlo.cpp:236-249) and the EWA lookup Power() makes (Enigma/Lights.cpp:541-546, Enigma/MipMap.h:256-399).
+// The device reads level 0 and the flattened distribution only.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace enigma {
+
+struct Rgb { float r, g, b; };
+inline Rgb operator+(Rgb a, Rgb b) { return {a.r + b.r, a.g + b.g, a.b + b.b}; }
+inline Rgb operator-(Rgb a, Rgb b) { return {a.r - b.r, a.g - b.g, a.b - b.b}; }
+inline Rgb operator*(Rgb a, float s) { return {a.r * s, a.g * s, a.b * s}; }
+inline Rgb operator*(float s, Rgb a) { return {a.r * s, a.g * s, a.b * s}; }
+inline Rgb operator/(Rgb a, float s) { return {a.r / s, a.g / s, a.b / s}; }
+inline float luminanceY(Rgb c) { return 0.212671f * c.r + 0.715160f * c.g + 0.072169f * c.b; } // Enigma/Spectrum.cpp:1483-1487
+
+struct EnvPyramid {
+    std::vector<std::vector<Rgb>> level;
+    std::vector<int> lw, lh;
+    float weightLut[128];
+    int levels() const { return (int)level.size(); }
+    static float log2f_(float x) { static const float invLog2 = 1.f / logf(2.f); return logf(x) * invLog2; } // Enigma/MathCommon.h:117-120
+    void build(int w, int h, std::vector<Rgb> img) {
+        for (int i = 0; i < 128; ++i) { float alpha = 2; float r2 = float(i) / float(128 - 1); weightLut[i] = expf(-alpha * r2) - expf(-alpha); }
+        int n = 1 + (int)floorf(log2f_(float(std::max(w, h))));
+        level.assign(n, {}); lw.assign(n, 0); lh.assign(n, 0);
+        level[0] = std::move(img); lw[0] = w; lh[0] = h;
+        for (int i = 1; i < n; ++i) {
+            int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
+            lw[i] = sRes; lh[i] = tRes; level[i].resize((size_t)sRes * tRes);
+            for (int t = 0; t < tRes; ++t)
+                for (int s = 0; s < sRes; ++s)
+                    level[i][(size_t)t * sRes + s] = .25f * (texel(i - 1, 2 * s, 2 * t) + texel(i - 1, 2 * s + 1, 2 * t) + texel(i - 1, 2 * s, 2 * t + 1) + texel(i - 1, 2 * s + 1, 2 * t + 1));
+        }
+    }
+    const Rgb& texel(int l, int s, int t) const { // repeat wrap: int % unsigned, exact for the pyramid's power-of-two sizes
+        uint32_t us = (uint32_t)s % (uint32_t)lw[l], ut = (uint32_t)t % (uint32_t)lh[l];
+        return level[l][(size_t)ut * lw[l] + us];
+    }
+    Rgb triangle(int l, float s0f, float t0f) const {
+        l = std::min(std::max(l, 0), levels() - 1);
+        float s = s0f * lw[l] - 0.5f, t = t0f * lh[l] - 0.5f;
+        int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+        float ds = s - s0, dt = t - t0;
+        return (1 - ds) * (1 - dt) * texel(l, s0, t0) + (1 - ds) * dt * texel(l, s0, t0 + 1) + ds * (1 - dt) * texel(l, s0 + 1, t0) + ds * dt * texel(l, s0 + 1, t0 + 1);
+    }
+    Rgb lookup(float s, float t, float width) const { // Enigma/MipMap.h:355-367
+        float lv = levels() - 1.0f + log2f_(std::max(width, 1e-8f));
+        if (lv < 0) return triangle(0, s, t);
+        else if (lv >= levels() - 1) return texel(levels() - 1, 0, 0);
+        int iLevel = (int)floorf(lv);
+        float delta = lv - iLevel;
+        return (1.f - delta) * triangle(iLevel, s, t) + delta * triangle(iLevel + 1, s, t);
+    }
+    Rgb ewa(int l, float s, float t, float d0x, float d0y, float d1x, float d1y) const { // Enigma/MipMap.h:258-306
+        if (l >= levels()) return texel(levels() - 1, 0, 0);
+        s = s * lw[l] - 0.5f; t = t * lh[l] - 0.5f;
+        d0x *= lw[l]; d0y *= lh[l]; d1x *= lw[l]; d1y *= lh[l];
+        float A = d0y * d0y + d1y * d1y + 1;
+        float B = -2 * (d0x * d0y + d1x * d1y);
+        float C = d0x * d0x + d1x * d1x + 1;
+        float invF = 1 / (A * C - B * B * 0.25f);
+        A *= invF; B *= invF; C *= invF;
+        float det = -B * B + 4 * A * C;
+        float invDet = 1 / det;
+        float uSqrt = std::sqrt(det * C), vSqrt = std::sqrt(A * det);
+        int s0 = (int)std::ceil(s - 2 * invDet * uSqrt), s1 = (int)std::floor(s + 2 * invDet * uSqrt);
+        int t0 = (int)std::ceil(t - 2 * invDet * vSqrt), t1 = (int)std::floor(t + 2 * invDet * vSqrt);
+        Rgb sum{0.f, 0.f, 0.f};
+        float sumWts = 0;
+        for (int it = t0; it <= t1; ++it) {
+            float tt = it - t;
+            for (int is = s0; is <= s1; ++is) {
+                float ss = is - s;
+                float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+                if (r2 < 1) {
+                    float weight = weightLut[std::min((int)(r2 * 128), 128 - 1)];
+                    sum = sum + texel(l, is, it) * weight;
+                    sumWts += weight;
+                }
+            }
+        }
+        return sum / sumWts;
+    }
+    // lookup(st, dst0, dst1) with both differentials (0.5, 0.5), EWA filtering, maximum anisotropy 8: what Power() asks for
+    Rgb lookupHalf() const {
+        float d0x = .5f, d0y = .5f, d1x = .5f, d1y = .5f;
+        float majorLength = std::sqrt(d0x * d0x + d0y * d0y), minorLength = std::sqrt(d1x * d1x + d1y * d1y);
+        if (minorLength * 8.0f < majorLength && minorLength > 0) { float sc = majorLength / (minorLength * 8.0f); d1x *= sc; d1y *= sc; minorLength *= sc; }
+        if (minorLength == 0) return triangle(0, .5f, .5f);
+        float lod = std::max((float)0, levels() - (float)1 + log2f_(minorLength));
+        int ilod = (int)std::floor(lod);
+        Rgb a = ewa(ilod, .5f, .5f, d0x, d0y, d1x, d1y), b = ewa(ilod + 1, .5f, .5f, d0x, d0y, d1x, d1y);
+        float tl = lod - ilod; // Lerp(start, end, t), Enigma/MathCommon.h:31-39
+        if (tl < 0.f) return a;
+        if (tl > 1.f) return b;
+        return a + (b - a) * tl;
+    }
+};
+
+// Distribution1D (Enigma/MonteCarlo.h:17-38) of one row appended to flat arrays
+inline float appendDistribution1D(const float* f, int n, std::vector<float>* func, std::vector<float>* cdf) {
+    size_t c0 = cdf->size();
+    func->insert(func->end(), f, f + n);
+    cdf->resize(c0 + n + 1);
+    float* c = cdf->data() + c0;
+    c[0] = 0.;
+    for (int i = 1; i < n + 1; ++i) c[i] = c[i - 1] + f[i - 1] / n;
+    float funcInt = c[n];
+    if (funcInt == 0.f) for (int i = 1; i < n + 1; ++i) c[i] = float(i) / float(n);
+    else for (int i = 1; i < n + 1; ++i) c[i] /= funcInt;
+    return funcInt;
+}
+
+struct HostEnvMap {
+    int w = 0, h = 0, nu = 0, nv = 0;
+    std::vector<float> texels;                       // level 0, float4 per texel
+    std::vector<float> condFunc, condCdf, condInt, margFunc, margCdf;
+    float margInt = 0.f;
+    Rgb powerLookup{0.f, 0.f, 0.f};                  // m_radianceMap->lookup(half, half, half)
+    // map: h x w RGB (or nullptr: one texel), L: the light's scale colour
+    void build(const float* map, int width, int height, const float L[3]) {
+        if (!map) { width = 1; height = 1; }
+        std::vector<Rgb> tex((size_t)width * height);
+        for (size_t i = 0; i < tex.size(); ++i) tex[i] = map ? Rgb{map[3 * i] * L[0], map[3 * i + 1] * L[1], map[3 * i + 2] * L[2]} : Rgb{L[0], L[1], L[2]};
+        EnvPyramid pyr;
+        pyr.build(width, height, tex);
+        w = width; h = height;
+        texels.resize(tex.size() * 4);
+        for (size_t i = 0; i < tex.size(); ++i) { texels[4 * i] = tex[i].r; texels[4 * i + 1] = tex[i].g; texels[4 * i + 2] = tex[i].b; texels[4 * i + 3] = 0.f; }
+        nu = 2 * width; nv = 2 * height;
+        std::vector<float> img((size_t)nu * nv);
+        for (int v = 0; v < nv; ++v) {
+            float filter = 0.5f / std::min(nu, nv);
+            float vp = (v + 0.5f) / (float)nv;
+            float sinTheta = sinf(3.1415926535897932384f * float(v + .5f) / float(nv));
+            for (int u = 0; u < nu; ++u) {
+                float up = float(u + .5f) / (float)nu;
+                size_t idx = u + (size_t)v * nu;
+                img[idx] = luminanceY(pyr.lookup(up, vp, filter));
+                img[idx] *= sinTheta;
+            }
+        }
+        condFunc.clear(); condCdf.clear(); condInt.clear(); margFunc.clear(); margCdf.clear();
+        for (int v = 0; v < nv; ++v) condInt.push_back(appendDistribution1D(&img[(size_t)v * nu], nu, &condFunc, &condCdf));
+        std::vector<float> mf(condInt);
+        margInt = appendDistribution1D(mf.data(), nv, &margFunc, &margCdf);
+        powerLookup = pyr.lookupHalf();
+    }
+};
+
+} // namespace enigma

@@ -275,6 +275,14 @@ public:
         for (int c = 0; c < 3; ++c) l.L[c] = L[c];
         AddLight(l);
     }
+    // InfiniteAreaLight(light2world, L, nSamples, texmap) without a map file (Enigma/Lights.cpp:395-442): a constant
+    // environment.  A radiance map can be attached afterwards through m_lights.back().light.map_* (RGB texels, power-of-two sides).
+    void AddInfiniteLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& L, int nSamples = 1) {
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_INFINITE; l.n_samples = (uint32_t)std::max(1, nSamples);
+        for (int c = 0; c < 3; ++c) l.L[c] = L[c];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { l.light_to_world[3 * r + c] = lightToWorld.m_mat[r][c]; l.world_to_light[3 * r + c] = worldToLight.m_mat[r][c]; }
+        AddLight(l);
+    }
     int getNumLights() const {
         int n = (int)m_lights.size();
         for (auto& m : m_meshes) if (m.emissive) n += m.m_nTriangles;

@@ -324,7 +324,15 @@ public:
         VerifyWorld("LightSource");
         if (name == "spot") { MakeSpotLight(p); NoteUnused("LightSource", p); return; }
         if (name == "distant") { MakeDistantLight(p); NoteUnused("LightSource", p); return; }
-        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, and diffuse area lights)");
+        if (name == "infinite" || name == "exinfinite") { // CreateInfiniteLight, Enigma/Lights.cpp:801-810
+            if (!p.FindOneString("mapname", "").empty()) throw std::runtime_error("LightSource \"infinite\": \"mapname\" needs an image reader, which this front end does not have; the library takes the texels through EnigmaLight::map_rgb");
+            Spectrum L = p.FindOneSpectrum("L", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+            int nSamples = p.FindOneInt("samples", p.FindOneInt("nsamples", 1));
+            m_res->scene.AddInfiniteLight(m_ctm.ToFloat(), m_ctm.Inverse().ToFloat(), Spectrum(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]), nSamples);
+            NoteUnused("LightSource", p);
+            return;
+        }
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, infinite without a map, and diffuse area lights)");
         Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
         Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
         // l2w = Translate(P) * lightToWorld, position = l2w(0,0,0) (Enigma/Lights.cpp:742-750,89-95)

@@ -357,7 +357,15 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                             kind = triKind(mw) + 1u;
                             P.hit[p] = make_float4(__int_as_float(h.tri), h.b0, h.b1, h.b2);
                         }
-                    } else if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
+                    } else {
+                        if (proceed && sc.nInfinite > 0 && (DL || stBounces(state) == 0 || stSpec(state))) { // L += beta * light->Le(ray) over the infinite lights
+                            float4 L = P.L[p];
+                            F3 be = xyz(P.beta[p]), acc = xyz(L);
+                            for (int k = 0; k < sc.nInfinite; ++k) acc += be * infiniteLe(sc, sc.lights[sc.infiniteLights[k]], w.r.d);
+                            P.L[p] = mk4(acc, 0.f);
+                        }
+                        if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
+                    }
                     kindOf[pos] = (uint8_t)kind;
                     pos = kNoRay;
                 }
@@ -438,6 +446,58 @@ DEV float powerHeuristic(float fPdf, float gPdf) { float f = 1 * fPdf, g = 1 * g
 // up to the two rays it traces: the shadow ray of the light sample (Ld = its contribution if unoccluded)
 // and the BSDF-sampled ray (miF = f * weight / scatteringPdf, multiplies the light's Le if the closest hit
 // is the light's own triangle).  The caller scales both by throughput / light-choice pdf and queues them.
+// ---------------------------------------------------------------- InfiniteAreaLight (Enigma/Lights.cpp:395-546)
+DEV bool isDeltaLight(uint32_t type) { return type == 0u || type == 2u || type == 3u; } // point, spot, distant (Enigma/Lights.h:15-18)
+DEV F3 mul3(const float* r0, const float* r1, const float* r2, F3 v) {
+    return F3(r0[0] * v.x + r0[1] * v.y + r0[2] * v.z, r1[0] * v.x + r1[1] * v.y + r1[2] * v.z, r2[0] * v.x + r2[1] * v.y + r2[2] * v.z);
+}
+// MipMap::lookup(st) with width 0 = triangle(0, st), repeat wrap (Enigma/MipMap.h:310-322,328-339,355-359)
+DEV F3 envLookup(const DevEnvMap& m, float s0f, float t0f) {
+    float s = s0f * m.w - 0.5f, t = t0f * m.h - 0.5f;
+    int s0 = (int)floorf(s), t0 = (int)floorf(t);
+    float ds = s - s0, dt = t - t0;
+    auto texel = [&](int a, int b) { return xyz(m.texels[(size_t)((uint32_t)b % (uint32_t)m.h) * m.w + ((uint32_t)a % (uint32_t)m.w)]); };
+    return (1 - ds) * (1 - dt) * texel(s0, t0) + (1 - ds) * dt * texel(s0, t0 + 1) + ds * (1 - dt) * texel(s0 + 1, t0) + ds * dt * texel(s0 + 1, t0 + 1);
+}
+DEV float sphericalTheta(F3 n) { return acosf(clampf(n.z, -1.0f, 1.0f)); }
+DEV float sphericalPhi(F3 n) { const float p = atan2f(n.y, n.x); return (p < 0.0f) ? p + kPi * 2.0f : p; }
+// InfiniteAreaLight::Le(ray) (Enigma/Lights.cpp:452-457)
+DEV F3 infiniteLe(const DevScene& sc, const DevLight& lt, F3 d) {
+    F3 w = normalize(mul3(lt.w2l0, lt.w2l1, lt.w2l2, d));
+    return envLookup(sc.envMaps[lt.tri], sphericalPhi(w) * (1.0f / (kPi * 2.0f)), sphericalTheta(w) * kInvPi);
+}
+// Distribution1D::SampleContinuous (Enigma/MonteCarlo.h:42-59) on a cdf of n + 1 entries
+DEV float sampleContinuous1D(const float* func, const float* cdf, float funcInt, int n, float u, float* pdf, int* off) {
+    int lo = 0, len = n + 1; // std::upper_bound
+    while (len > 0) {
+        int half = len >> 1;
+        if (!(u < cdf[lo + half])) { lo += half + 1; len -= half + 1; }
+        else len = half;
+    }
+    int offset = max(0, lo - 1);
+    offset = min(offset, n - 1); // unreachable for u < 1; keeps the reads in bounds
+    *off = offset;
+    float du = (u - cdf[offset]) / (cdf[offset + 1] - cdf[offset]);
+    *pdf = func[offset] / funcInt;
+    return (offset + du) / n;
+}
+// Distribution2D::Pdf (Enigma/MonteCarlo.h:94-102)
+DEV float envPdf(const DevEnvMap& m, float u, float v) {
+    int iu = min(max((int)(u * m.nu), 0), m.nu - 1);
+    int iv = min(max((int)(v * m.nv), 0), m.nv - 1);
+    if (m.condInt[iv] * m.margInt == 0.f) return 0.f;
+    return (m.condFunc[(size_t)iv * m.nu + iu] * m.margFunc[iv]) / (m.condInt[iv] * m.margInt);
+}
+// InfiniteAreaLight::Pdf_Li (Enigma/Lights.cpp:464-472); theta is scaled by 1 / (2 pi) there, as in the reference
+DEV float infinitePdfLi(const DevScene& sc, const DevLight& lt, F3 w) {
+    F3 wi = mul3(lt.w2l0, lt.w2l1, lt.w2l2, w);
+    float theta = sphericalTheta(wi), phi = sphericalPhi(wi);
+    float sinTheta = sinf(theta);
+    if (sinTheta == 0) return 0;
+    const float kInvTwoPi = 1.0f / (kPi * 2.0f);
+    return envPdf(sc.envMaps[lt.tri], phi * kInvTwoPi, theta * kInvTwoPi) / (2 * kPi * kPi * sinTheta);
+}
+
 struct DirectSample {
     bool shadow, mis;
     F3 shO, shD, Ld;
@@ -447,7 +507,7 @@ struct DirectSample {
 // Light::Sample_Li for a reference point (Enigma/Lights.cpp:117-124,165-172,634-645,696-703): direction, radiance,
 // pdf and the sampled point as an Interaction; q0..q2 are the area light's vertices (read again by Shape::pdf).
 struct LightSample { F3 wi, Li, lp, lpErr, ln, q0, q1, q2; float pdf; };
-DEV LightSample sampleLight(const DevLight& lt, const float4* tris, F3 refP, float ulx, float uly) {
+DEV LightSample sampleLight(const DevScene& sc, const DevLight& lt, const float4* tris, F3 refP, float ulx, float uly) {
     LightSample s;
     F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
     float lightPdf = 0.f;
@@ -479,6 +539,23 @@ DEV LightSample sampleLight(const DevLight& lt, const float4* tris, F3 refP, flo
         else {
             wi = normalize(lp - refP);
             if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+        }
+    } else if (lt.type == 4) { // InfiniteAreaLight::Sample_Li (Enigma/Lights.cpp:516-539)
+        const DevEnvMap& em = sc.envMaps[lt.tri];
+        float pv, pu;
+        int v, uo;
+        float d1 = sampleContinuous1D(em.margFunc, em.margCdf, em.margInt, em.nv, uly, &pv, &v);
+        float d0 = sampleContinuous1D(em.condFunc + (size_t)v * em.nu, em.condCdf + (size_t)v * (em.nu + 1), em.condInt[v], em.nu, ulx, &pu, &uo);
+        float mapPdf = pu * pv;
+        if (mapPdf != 0) {
+            float theta = d1 * kPi, phi = d0 * 2 * kPi;
+            float cosTheta = cosf(theta), sinTheta = sinf(theta);
+            float sinPhi = sinf(phi), cosPhi = cosf(phi);
+            wi = mul3(lt.l2w0, lt.l2w1, lt.l2w2, F3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+            lightPdf = mapPdf / (2 * kPi * kPi * sinTheta);
+            if (sinTheta == 0) lightPdf = 0;
+            lp = refP + wi * (2 * lt.worldRadius);
+            Li = envLookup(em, d0, d1);
         }
     } else if (lt.type == 3) { // DistantLight::Sample_Li (Enigma/Lights.cpp:696-703): wi = m_lightDir as stored
         wi = F3(lt.pos[0], lt.pos[1], lt.pos[2]);
@@ -522,13 +599,13 @@ DEV float lightTrianglePdf(F3 o, F3 refP, F3 wi, F3 q0, F3 q1, F3 q2, float area
     return pdf;
 }
 template <int MK>
-DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
+DEV DirectSample estimateDirect(const DevScene& sc, const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
                                 float ulx, float uly, float usx, float usy) {
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     DirectSample r;
     r.shadow = false; r.mis = false;
     // ---- light sampling (Enigma/Integrator.cpp:104-148) ----
-    LightSample ls = sampleLight(lt, tris, g.p, ulx, uly);
+    LightSample ls = sampleLight(sc, lt, tris, g.p, ulx, uly);
     F3 wi = ls.wi, Li = ls.Li, lp = ls.lp, lpErr = ls.lpErr, ln = ls.ln, q0 = ls.q0, q1 = ls.q1, q2 = ls.q2;
     float lightPdf = ls.pdf;
     if (lightPdf > 0 && !isBlack(Li)) {
@@ -538,7 +615,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
             // VisibilityTester(ref, pShape) -> ref.SpawnRayTo(pShape) (Enigma/Interaction.cpp:58-64)
             F3 origin = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
             F3 target = offsetRayOrigin(lp, lpErr, ln, origin - lp);
-            if (lt.type != 1) r.Ld = f * Li / lightPdf; // IsDeltaLight
+            if (isDeltaLight(lt.type)) r.Ld = f * Li / lightPdf;
             else r.Ld = f * Li * powerHeuristic(lightPdf, scatteringPdf) / lightPdf;
             r.shO = origin; r.shD = target - origin;
             r.tgtP = lp; r.tgtE = lpErr; r.tgtN = ln;
@@ -546,7 +623,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
         }
     }
     // ---- BSDF sampling (Enigma/Integrator.cpp:150-199) ----
-    if (lt.type == 1) {
+    if (!isDeltaLight(lt.type)) {
         F3 wi2(0.f);
         float scatPdf2; int sampledType;
         F3 f2 = bsdfSample<MK>(bsdf, woN, &wi2, usx, usy, &scatPdf2, kNonSpecular, &sampledType);
@@ -554,7 +631,7 @@ DEV DirectSample estimateDirect(const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 n
         if (!isBlack(f2) && scatPdf2 > 0) {
             // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
             F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
-            float lightPdf2 = lightTrianglePdf(o2, g.p, wi2, q0, q1, q2, lt.area);
+            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2) : lightTrianglePdf(o2, g.p, wi2, q0, q1, q2, lt.area);
             if (lightPdf2 != 0) {
                 float weight = powerHeuristic(scatPdf2, lightPdf2);
                 r.miO = o2; r.miD = wi2;
@@ -661,7 +738,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
-                    DirectSample ds = estimateDirect<MK>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    DirectSample ds = estimateDirect<MK>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
                         storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
                         if (VOL) {
@@ -832,7 +909,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                             unsigned long long sn = sampleNum * n + k; // entry of the array that belongs to this sample
                             float ulx = sampleDimensionOf(S, px, py, sn, dimL), uly = sampleDimensionOf(S, px, py, sn, dimL + 1);
                             float usx = sampleDimensionOf(S, px, py, sn, dimS), usy = sampleDimensionOf(S, px, py, sn, dimS + 1);
-                            DirectSample ds = estimateDirect<MKD>(bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
+                            DirectSample ds = estimateDirect<MKD>(sc, bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
                             emit(ds, (float)n, l);
                         }
                     }
@@ -844,7 +921,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                     float ulx = sampleDimension(S, px, py, slot, dim + 1), uly = sampleDimension(S, px, py, slot, dim + 2);
                     float usx = sampleDimension(S, px, py, slot, dim + 3), usy = sampleDimension(S, px, py, slot, dim + 4);
                     dim += 5;
-                    DirectSample ds = estimateDirect<MKD>(bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    DirectSample ds = estimateDirect<MKD>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     emit(ds, lightPdf, lightNum);
                 }
             }
@@ -984,7 +1061,15 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
         Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
-        if (h.tri < 0) continue;
+        if (h.tri < 0) { // Li = light.Le(ray): only an infinite area light returns anything (Enigma/Integrator.cpp:194-195)
+            const DevLight& lt = sc.lights[__float_as_int(d.w)];
+            if (lt.type == 4) {
+                F3 add = xyz(misq.w[p]) * infiniteLe(sc, lt, xyz(d));
+                float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
+                atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
+            }
+            continue;
+        }
         const float4* tp = tris + (size_t)h.tri * 3;
         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
         int lightIdx = __float_as_int(v2.w);

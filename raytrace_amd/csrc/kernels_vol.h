@@ -89,13 +89,13 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
                     const DevLight& lt = lights[lightNum];
-                    LightSample ls = sampleLight(lt, tris, pm, ulx, uly);
+                    LightSample ls = sampleLight(sc, lt, tris, pm, ulx, uly);
                     if (ls.pdf > 0 && !isBlack(ls.Li)) {
                         float ph = phaseHG(dot(wo, ls.wi), g);
                         if (ph != 0.f) {
                             F3 f(ph, ph, ph);
                             F3 target = offsetRayOrigin(ls.lp, ls.lpErr, ls.ln, pm - ls.lp);
-                            F3 Ld = lt.type != 1 ? f * ls.Li / ls.pdf : f * ls.Li * powerHeuristic(ls.pdf, ph) / ls.pdf;
+                            F3 Ld = isDeltaLight(lt.type) ? f * ls.Li / ls.pdf : f * ls.Li * powerHeuristic(ls.pdf, ph) / ls.pdf;
                             storeShadowRay(shq, p, pm, target - pm, beta * (Ld / pick));
                             shq.tgtP[p] = mk4(ls.lp, __uint_as_float(med));
                             shq.tgtE[p] = mk4(ls.lpErr, 0.f);
@@ -103,11 +103,11 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
                             pushShadow = true;
                         }
                     }
-                    if (lt.type == 1) {
+                    if (!isDeltaLight(lt.type)) {
                         F3 wi2(0.f);
                         float ph2 = hgSample(g, wo, &wi2, usx, usy);
                         if (ph2 != 0.f && ph2 > 0) {
-                            float lightPdf2 = lightTrianglePdf(pm, pm, wi2, ls.q0, ls.q1, ls.q2, lt.area);
+                            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2) : lightTrianglePdf(pm, pm, wi2, ls.q0, ls.q1, ls.q2, lt.area);
                             if (lightPdf2 != 0) {
                                 float weight = powerHeuristic(ph2, lightPdf2);
                                 misq.o[p] = mk4(pm, __uint_as_float(med));
@@ -272,8 +272,15 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                 const Hit& h = w.h;
                 bool hit = h.tri >= 0;
                 if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : EDEV_INF);
-                if (!hit) active = false;
-                else {
+                if (!hit) {
+                    active = false;
+                    const DevLight& lt = sc.lights[wantLight];
+                    if (lt.type == 4) { // Li = light.Le(ray)
+                        F3 add = xyz(misq.w[p]) * infiniteLe(sc, lt, d) * Tr;
+                        float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
+                        atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
+                    }
+                } else {
                     const float4* tp = tris + (size_t)h.tri * 3;
                     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                     uint32_t mw = __float_as_uint(v1.w);

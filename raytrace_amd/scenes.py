@@ -319,6 +319,26 @@ def cornell_fog(variant="diffuse", g=0.3):
     return b.arrays(weld=False)
 
 
+def sky_map(height=16, width=32):
+    """A small latitude-longitude radiance map: a vertical gradient with a bright patch (a sun)."""
+    a = np.zeros((height, width, 3), np.float32)
+    th = (np.arange(height) + 0.5) / height
+    a[:] = (np.stack([0.3 + 0.7 * (1 - th), 0.5 + 0.5 * (1 - th), 1.0 + 0 * th], -1)[:, None, :] * 0.5).astype(np.float32)
+    a[height // 8:height // 4, width // 6:width // 4] = (30.0, 25.0, 15.0)
+    return a
+
+
+def cornell_sky(variant="microfacet", radiance_map=True):
+    """The Cornell box (open towards the camera) with an InfiniteAreaLight added: a constant environment or the
+    sky_map, rotated so that the map's pole points up (+y)."""
+    base = cornell_box(variant)
+    light = (abi.infinite_light((1.0, 1.0, 1.0), sky_map(), light_to_world=[[1, 0, 0], [0, 0, 1], [0, -1, 0]]) if radiance_map
+             else abi.infinite_light((0.8, 0.9, 1.0)))
+    lights = [base.lights[i] for i in range(base.n_lights)] + [light]
+    return abi.SceneArrays(base.vertices, base.indices, base.tri_material, base.tri_light, [base.materials[i] for i in range(base.n_materials)], lights,
+                           tri_flags=base.tri_flags)
+
+
 def cornell_camera(xres, yres, lens_radius=0.0, focal_distance=1e30):
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))  # 39.3 degrees: the narrower image side
     return camera_desc((278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, lens_radius, focal_distance)

@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -88,7 +88,12 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     import pbrt_writer
     assert os.path.exists(EXE), "raytrace_amd/enigma_render is not built (make -C raytrace_amd/csrc)"
     xres, yres, spp = 72, 48, 8
-    sc = scenes.cornell_fog(variant.split(":")[1]) if variant.startswith("fog:") else scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
+    if variant.startswith("fog:"):
+        sc = scenes.cornell_fog(variant.split(":")[1])
+    elif variant.startswith("sky:"):
+        sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment: scene files carry no texels
+    else:
+        sc = scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
     itext = {"path": 'Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
              "volpath": 'Integrator "volpath" "integer maxdepth" 5 "string lightsamplestrategy" "power"',

@@ -293,6 +293,34 @@ def test_image_parity_spot_and_distant_lights(variant, strategy):
     r.close(); r2.close(); o.close()
 
 
+@pytest.mark.parametrize("radiance_map", [False, True])
+def test_image_parity_infinite_area_light(radiance_map):
+    """InfiniteAreaLight (Enigma/Lights.cpp:395-546): constant environment and a latitude-longitude map, under the three
+    integrators; escaped camera / specular rays read the map, light samples come from its Distribution2D, BSDF samples
+    that escape are weighted with the reference's Pdf_Li."""
+    sc = scenes.cornell_sky("microfacet", radiance_map)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    for integ in (scenes.integrator_desc(film, 16), scenes.integrator_desc(film, 16, light_strategy=abi.LIGHTS_UNIFORM),
+                  scenes.direct_lighting_desc(film, 16, max_depth=3, strategy=abi.DL_SAMPLE_ONE), scenes.volpath_desc(film, 16)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
+        r.close(); o.close()
+    # a map whose sides are not powers of two is refused (the reference resamples it first)
+    bad = abi.infinite_light((1, 1, 1), np.ones((6, 12, 3), np.float32))
+    base = scenes.cornell_box("diffuse")
+    sc2 = abi.SceneArrays(base.vertices, base.indices, base.tri_material, base.tri_light, [base.materials[i] for i in range(base.n_materials)],
+                          [base.lights[0], base.lights[1], bad], tri_flags=base.tri_flags)
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(sc2, cam, film, scenes.integrator_desc(film, 4))
+    assert e.value.code == -4
+
+
 def test_image_parity_mesh_scene():
     sc = scenes.big_mesh(grid=128, sphere_level=4, n_spheres=6)
     film = scenes.film_desc(96, 54)

@@ -437,3 +437,57 @@ def test_volpath_scattering_slab_conserves_energy_inside_a_furnace():
     # emission is only picked up at bounce 0 / after specular bounces; the rest arrives through light sampling + MIS
     assert abs(img.mean() - 1.0) < 0.03
     del c
+
+
+# ------------------------------------------------------------------ InfiniteAreaLight (oracle only, CPU)
+def test_infinite_light_constant_environment_closed_forms():
+    """A matte floor (albedo 0.5) under a constant environment of radiance 1 reflects 0.5; rays that miss everything
+    see the environment itself; the DirectLightingIntegrator agrees (InfiniteAreaLight, Enigma/Lights.cpp:395-546)."""
+    b = scenes.MeshBuilder()
+    grey = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([(-1, 0, -1), (-1, 0, 1), (1, 0, 1), (1, 0, -1)], grey, toward=(0, 1, 0))
+    b.lights.append(abi.infinite_light((1.0, 2.0, 3.0)))
+    sc = b.arrays()
+    film = scenes.film_desc(8, 8)
+    down = scenes.camera_desc((0, 3, 0.001), (0, 0, 0), (0, 0, 1), 20.0, 8, 8)
+    up = scenes.camera_desc((0, 3, 0), (0, 6, 0.001), (0, 0, 1), 20.0, 8, 8)
+    for integ in (scenes.integrator_desc(film, 256, max_depth=1, light_strategy=abi.LIGHTS_UNIFORM),
+                  scenes.direct_lighting_desc(film, 256, max_depth=1, strategy=abi.DL_SAMPLE_ONE), scenes.volpath_desc(film, 256, max_depth=1)):
+        o = orc.Oracle(sc, down, film, integ)
+        o.render(0, 256, threads=8)
+        assert np.allclose(o.image().mean(axis=(0, 1)), [0.5, 1.0, 1.5], rtol=0.01)
+        o.close()
+        o = orc.Oracle(sc, up, film, integ)
+        o.render(0, 4, threads=2)
+        assert np.allclose(o.image(), np.float32([1.0, 2.0, 3.0])[None, None, :], rtol=1e-5)   # Le(ray) of the 1 x 1 map
+        o.close()
+
+
+def test_infinite_light_map_is_seen_where_it_points_and_integrates_like_its_mean():
+    """With a radiance map: camera rays that escape read the map bilinearly at (phi / 2pi, theta / pi) of the direction in
+    light space; a matte floor under it reflects albedo / pi * integral of L cos over the upper hemisphere, estimated by
+    importance sampling the map (Distribution2D) and by BSDF sampling with the MIS weights of the reference."""
+    m = np.zeros((8, 16, 3), np.float32)
+    m[0:4] = 1.0                                       # upper hemisphere white (theta < pi / 2 in light space), lower black
+    light = abi.infinite_light((2.0, 2.0, 2.0), m, light_to_world=[[1, 0, 0], [0, 0, 1], [0, -1, 0]])   # map pole = world +y
+    b = scenes.MeshBuilder()
+    grey = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([(-1, 0, -1), (-1, 0, 1), (1, 0, 1), (1, 0, -1)], grey, toward=(0, 1, 0))
+    b.lights.append(light)
+    sc = b.arrays()
+    film = scenes.film_desc(8, 8)
+    up = scenes.camera_desc((0, 3, 0), (3, 6, 0), (0, 0, 1), 10.0, 8, 8)    # 45 degrees above the horizon: rows 1..2 of the map
+    o = orc.Oracle(sc, up, film, scenes.integrator_desc(film, 4, max_depth=1))
+    o.render(0, 4, threads=2)
+    assert np.allclose(o.image(), 2.0, rtol=1e-5)       # inside the white half, times L (at the pole itself the
+    o.close()                                           # repeat wrap of the reference blends in the opposite pole's row)
+    down = scenes.camera_desc((0, 3, 0.001), (0, 0, 0), (0, 0, 1), 20.0, 8, 8)
+    o = orc.Oracle(sc, down, film, scenes.integrator_desc(film, 1024, max_depth=1, light_strategy=abi.LIGHTS_UNIFORM))
+    o.render(0, 1024, threads=8)
+    got = o.image().mean()
+    o.close()
+    # An unbiased estimator gives albedo * L = 1 (minus the horizon blur of the bilinear map).  The reference's
+    # Pdf_Li scales theta by 1 / (2 pi) instead of 1 / pi (Enigma/Lights.cpp:471), so the BSDF-sampled half of the MIS
+    # pair looks its pdf up in the wrong rows and is over-weighted: the restated result is ~18 % high.  A "fix" of that
+    # line would land near 0.98 and fail here.
+    assert 1.10 < got < 1.25

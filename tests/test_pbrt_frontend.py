@@ -230,11 +230,18 @@ TransformBegin
   LightSource "distant" "rgb L" [1 2 3] "rgb scale" [2 2 2] "point from" [0 3 0] "point to" [0 0 4]
 TransformEnd
 LightSource "spot" "point to" [3 0 4]
+AttributeBegin
+  Rotate 90 1 0 0
+  LightSource "infinite" "rgb L" [1 2 3] "rgb scale" [0.5 0.5 0.5] "integer samples" 4
+AttributeEnd
 Shape "trianglemesh" "point P" [0 0 0  1 0 0  0 1 0]
 WorldEnd
 '''
     d = dump(tmp_path, text)
-    spot, dist, spot2 = d["lights"]
+    spot, dist, spot2, inf = d["lights"]
+    assert inf["type"] == abi.LIGHT_INFINITE and np.allclose(inf["I"], [0.5, 1.0, 1.5]) and inf["nsamples"] == 4
+    l2w, w2l = np.array(inf["light_to_world"]).reshape(3, 3), np.array(inf["world_to_light"]).reshape(3, 3)
+    assert np.allclose(l2w @ [0, 0, 1], [0, -1, 0], atol=1e-6) and np.allclose(l2w @ w2l, np.eye(3), atol=1e-6)   # Rotate 90 about x
     assert spot["type"] == abi.LIGHT_SPOT and dist["type"] == abi.LIGHT_DISTANT
     assert np.allclose(spot["from"], [1, 12, 3]) and np.allclose(spot["I"], [2, 3, 4])
     assert np.isclose(spot["cos_total_width"], np.cos(np.radians(40.0)), atol=1e-6) and np.isclose(spot["cos_falloff_start"], np.cos(np.radians(25.0)), atol=1e-6)
