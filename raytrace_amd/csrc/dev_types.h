@@ -160,6 +160,8 @@ struct DevRayQueue {
     float* wz;        // shadow only
     uint32_t* idx;    // [0, count) ray slots (= path index * perPath + ray of the path)
     uint32_t perPath; // 1 for PathIntegrator
+    uint32_t dense;   // shadow rays: 1 = the ray of queue position i is stored at i (PathIntegrator: the shadow kernel then
+                      // streams o/d/wz instead of gathering 16-byte pieces at path slots), 0 = at the slot idx[i] names
     // VolPathIntegrator shadow rays: the light-side end point of VisibilityTester::Tr, which respawns the ray
     // towards it after every medium boundary (Enigma/Lights.cpp:718-740)
     float4* tgtP;     // p1.p, bits(medium + 1 of the first segment)

@@ -805,8 +805,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
         DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath, nullptr, nullptr, nullptr};
-        DevRayQueue misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath, nullptr, nullptr, nullptr};
+        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath, (!direct && !vol) ? 1u : 0u, nullptr, nullptr, nullptr};
+        DevRayQueue misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath, 0u, nullptr, nullptr, nullptr};
         if (vol) {
             if (passPathsMax > h->volCapacity) {
                 HIPCHK(h, h->shTgtP.alloc(passPathsMax)); HIPCHK(h, h->shTgtE.alloc(passPathsMax)); HIPCHK(h, h->shTgtN.alloc(passPathsMax));

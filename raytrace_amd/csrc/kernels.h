@@ -699,6 +699,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
         bool active = i < count;
         bool pushShadow = false, pushMis = false, pushNext = false;
         uint32_t p = 0;
+        F3 shRayO(0.f), shRayD(0.f), shRayW(0.f);
         if (active) {
             p = matQueue[i];
             float4 rdv = P.rayD[p];
@@ -740,7 +741,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     dim += 4;
                     DirectSample ds = estimateDirect<MK>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
-                        storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
+                        if (VOL) storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
+                        else { shRayO = ds.shO; shRayD = ds.shD; shRayW = beta * (ds.Ld / pick); } // stored at its queue position below
                         if (VOL) {
                             shq.tgtP[p] = mk4(ds.tgtP, __uint_as_float(mediumTowards(ds.shD)));
                             shq.tgtE[p] = mk4(ds.tgtE, 0.f);
@@ -790,7 +792,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
         }
         uint32_t sSh, sMi, sNx;
         blockReserve3(pushShadow, pushMis, pushNext, &ctr->shadowCount.v, &ctr->misCount.v, &ctr->extCount[nextIdx].v, lds + parity, &sSh, &sMi, &sNx);
-        if (pushShadow) shq.idx[sSh] = p;
+        if (pushShadow) {
+            shq.idx[sSh] = p;
+            if (!VOL) storeShadowRay(shq, sSh, shRayO, shRayD, shRayW);
+        }
         if (pushMis) misq.idx[sMi] = p;
         if (pushNext) nextQueue[sNx] = p;
     }
@@ -1031,8 +1036,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
                     uint32_t mine = poolTake(&poolNext, idleMask, &base);
                     if (idle && mine < chunkCount) {
                         p = shq.idx[chunk + mine];
-                        float4 a = shq.o[p], b = shq.d[p];
-                        contrib = F3(b.z, b.w, shq.wz[p]);
+                        const size_t at = shq.dense ? (size_t)(chunk + mine) : (size_t)p;
+                        float4 a = shq.o[at], b = shq.d[at];
+                        contrib = F3(b.z, b.w, shq.wz[at]);
                         w.start(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), 1 - kShadowEpsilon);
                     }
                     exhausted = base + nIdle >= chunkCount;
