@@ -138,12 +138,19 @@ struct DevDirect {
 // Per-path state, structure of arrays of float4 so that a kernel touches one 16-byte slot per field group:
 // the sampler cursor travels in the spare word of the ray direction, the hit triangle in the spare word of the
 // hit record, and the pixel / sample slot of a path follow from its index (path = slot * nPixels + pixel).
+// rayO, rayD, beta and hit of a path are the four float4 of one 64-byte record: a kernel that visits paths in queue
+// order touches one 64-byte piece of memory per path instead of one in each of four arrays.  L and pfilm have other
+// readers (shadow / MIS kernels, film splat) and stay arrays of their own.
+struct PathField { // field k of the records: element i is at base[4 * i]
+    float4* base;
+    DEV float4& operator[](size_t i) const { return base[i * 4]; }
+};
 struct DevPaths {
-    float4* rayO;     // o.xyz, unused
-    float4* rayD;     // d.xyz, bits(state): medium + 1 [0:12) (VolPathIntegrator) | dim[12:22) | bounces or depth[22:30) | specularBounce[30]
+    PathField rayO;   // o.xyz, unused
+    PathField rayD;   // d.xyz, bits(state): medium + 1 [0:12) (VolPathIntegrator) | dim[12:22) | bounces or depth[22:30) | specularBounce[30]
     float4* L;        // radiance accumulated so far, unused
-    float4* beta;     // throughput rgb, etaScale
-    float4* hit;      // bits(triangle, device order), b0, b1, b2
+    PathField beta;   // throughput rgb, etaScale
+    PathField hit;    // bits(triangle, device order), b0, b1, b2
     float2* pfilm;    // CameraSample::m_image
 };
 

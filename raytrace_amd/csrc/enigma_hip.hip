@@ -103,7 +103,7 @@ struct EnigmaCtx {
 
     // wavefront state
     size_t capacity = 0;
-    DevBuf<float4> rayO, rayD, L, beta, hit, shO, shD, miO, miD, miW;
+    DevBuf<float4> pathRec, L, shO, shD, miO, miD, miW; // pathRec: four float4 per path (rayO, rayD, beta, hit)
     DevBuf<float> shWz;
     DevBuf<uint32_t> shIdx, miIdx;
     DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
@@ -151,8 +151,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
-    DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->rayO, &h->rayD, &h->L, &h->beta, &h->hit,
-                            &h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
+    DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shTgtP.release(); h->shTgtE.release(); h->shTgtN.release();
     h->media.release(); h->triMedium.release();
@@ -653,8 +652,8 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
         h->pendCapacity = n * pendingLevels;
     }
     if (n <= h->capacity) return ENIGMA_OK;
-    DevBuf<float4>* f4[] = {&h->rayO, &h->rayD, &h->L, &h->beta, &h->hit};
-    for (auto* b : f4) HIPCHK(h, b->alloc(n));
+    HIPCHK(h, h->pathRec.alloc(n * 4));
+    HIPCHK(h, h->L.alloc(n));
     HIPCHK(h, h->arrayOff.alloc(n));
     HIPCHK(h, h->pendCount.alloc(n));
     HIPCHK(h, h->pfilm.alloc(n));
@@ -804,7 +803,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         h->sampler.sampleBase = (unsigned long long)(sample_begin + c0);
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
-        DevPaths P{h->rayO.p, h->rayD.p, h->L.p, h->beta.p, h->hit.p, h->pfilm.p};
+        DevPaths P{{h->pathRec.p}, {h->pathRec.p + 1}, h->L.p, {h->pathRec.p + 2}, {h->pathRec.p + 3}, h->pfilm.p};
         DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath, (!direct && !vol) ? 1u : 0u, nullptr, nullptr, nullptr};
         DevRayQueue misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath, 0u, nullptr, nullptr, nullptr};
         if (vol) {

@@ -208,27 +208,42 @@ DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b
 // ---------------------------------------------------------------- kernels
 __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, DevCamera C, DevIntegrator I, uint32_t nPaths, uint32_t nPixels,
                                                      uint32_t slotBase, DevCounters* ctr, uint32_t firstDim, DevDirect D) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nPaths) return;
-    uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
-    uint32_t tx, ty;
-    pixelOfIndex(I, pix, &tx, &ty);
-    int px = I.rx0 + (int)tx, py = I.ry0 + (int)ty;
-    uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
-    // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
-    float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
-    float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
-    float lu = 0.f, lv = 0.f;
-    if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
-    F3 o, d;
-    cameraRay(C, fx, fy, lu, lv, &o, &d);
-    P.rayO[i] = mk4(o, 0.f);
-    P.rayD[i] = mk4(d, __uint_as_float(packState(0u, firstDim, 0u, 0u))); // 5 after GetCameraSample; DirectLightingIntegrator skips its sample arrays
-    P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    P.beta[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-    P.pfilm[i] = make_float2(fx, fy);
-    if (D.arrayOff) { D.arrayOff[i] = 0; D.pendCount[i] = 0; }
-    if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
+    __shared__ float4 recs[kBlock * 4];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < nPaths;
+    F3 o(0.f), d(0.f);
+    if (active) {
+        uint32_t slot = slotBase + i / nPixels, pix = i % nPixels;
+        uint32_t tx, ty;
+        pixelOfIndex(I, pix, &tx, &ty);
+        int px = I.rx0 + (int)tx, py = I.ry0 + (int)ty;
+        uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
+        // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
+        float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
+        float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
+        float lu = 0.f, lv = 0.f;
+        if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
+        cameraRay(C, fx, fy, lu, lv, &o, &d);
+        P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        P.pfilm[i] = make_float2(fx, fy);
+        if (D.arrayOff) { D.arrayOff[i] = 0; D.pendCount[i] = 0; }
+        if (i == 0) atomicAdd(&ctr->samples, (unsigned long long)nPaths);
+    }
+    // the 64-byte records of the block's paths go out through LDS, so that every store instruction of a wave
+    // covers 1 KB of consecutive bytes (a lane writing its own record would touch 64 separate lines four times)
+    float4* mine = recs + threadIdx.x * 4;
+    mine[0] = mk4(o, 0.f);
+    mine[1] = mk4(d, __uint_as_float(packState(0u, firstDim, 0u, 0u))); // 5 after GetCameraSample; DirectLightingIntegrator skips its sample arrays
+    mine[2] = make_float4(1.f, 1.f, 1.f, 1.f);
+    mine[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const size_t blockBase = (size_t)blockIdx.x * kBlock * 4;
+    const size_t limit = (size_t)nPaths * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        size_t e = blockBase + (size_t)k * kBlock + threadIdx.x;
+        if (e < limit) P.rayO.base[e] = recs[k * kBlock + threadIdx.x];
+    }
 }
 
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
@@ -309,7 +324,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                         uint32_t dim = stDim(state);
                         float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
                         state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state));
-                        reinterpret_cast<float*>(P.rayD + p)[3] = __uint_as_float(state);
+                        reinterpret_cast<float*>(&P.rayD[p])[3] = __uint_as_float(state);
                         int channel = min((int)(uc * 3), 3 - 1);
                         float dist = -logf(1 - ud) / md.sigmaT[channel];
                         float len = length(w.r.d);
