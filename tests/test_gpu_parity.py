@@ -321,6 +321,23 @@ def test_image_parity_infinite_area_light(radiance_map):
     assert e.value.code == -4
 
 
+@pytest.mark.parametrize("xres,yres", [(37, 23), (8, 61), (67, 8), (5, 3)])
+def test_image_parity_sizes_that_are_not_multiples_of_the_pixel_tiles(xres, yres):
+    """Pixels are numbered in 8 x 8 tiles with scanline strips right of and below the last full tile: every pixel of
+    an odd-sized image must still be rendered exactly once per sample."""
+    sc = scenes.cornell_box("diffuse")
+    cam, film = scenes.cornell_camera(xres, yres), scenes.film_desc(xres, yres)
+    integ = scenes.integrator_desc(film, 4)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(0, 4)
+    o.render(0, 4, threads=4)
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+    assert np.allclose(r.film()[..., 3], o.film_xyzw()[..., 3])          # filter weight sums: one deposit per pixel and sample
+    assert r.stats()["camera_samples"] == xres * yres * 4
+    r.close(); o.close()
+
+
 def test_image_parity_mesh_scene():
     sc = scenes.big_mesh(grid=128, sphere_level=4, n_spheres=6)
     film = scenes.film_desc(96, 54)
