@@ -160,20 +160,25 @@ struct DevPaths {
 // A shadow ray (origin, direction to just short of the light sample, contribution) is nine floats; they are
 // packed into two float4 and one float instead of three float4: a = {o.xyz, d.x}, b = {d.y, d.z, w.x, w.y},
 // wz = w.z.  Its tMax is the constant 1 - ShadowEpsilon (Enigma/Interaction.cpp:58-64).
+// A field of the ray slots: element i at base[i * stride].  Stride 1 = an array of its own; the VolPathIntegrator's
+// shadow rays keep all their fields in one 96-byte record per slot (stride 6 float4), two 64-byte pieces of memory
+// instead of six.
+struct RayField { float4* base; uint32_t stride; DEV float4& operator[](size_t i) const { return base[i * stride]; } };
+struct RayFieldF { float* base; uint32_t stride; DEV float& operator[](size_t i) const { return base[i * stride]; } };
 struct DevRayQueue {
-    float4* o;        // MIS: [slot] o.xyz, bits(medium + 1) under the VolPathIntegrator.  shadow: a
-    float4* d;        // MIS: [slot] d.xyz, bits(light index).      shadow: b
-    float4* w;        // MIS: [slot] weight of the light's Le.      shadow: unused (nullptr)
-    float* wz;        // shadow only
+    RayField o;       // MIS: [slot] o.xyz, bits(medium + 1) under the VolPathIntegrator.  shadow: a
+    RayField d;       // MIS: [slot] d.xyz, bits(light index).      shadow: b
+    RayField w;       // MIS: [slot] weight of the light's Le.      shadow: unused
+    RayFieldF wz;     // shadow only
     uint32_t* idx;    // [0, count) ray slots (= path index * perPath + ray of the path)
     uint32_t perPath; // 1 for PathIntegrator
     uint32_t dense;   // shadow rays: 1 = the ray of queue position i is stored at i (PathIntegrator: the shadow kernel then
                       // streams o/d/wz instead of gathering 16-byte pieces at path slots), 0 = at the slot idx[i] names
     // VolPathIntegrator shadow rays: the light-side end point of VisibilityTester::Tr, which respawns the ray
     // towards it after every medium boundary (Enigma/Lights.cpp:718-740)
-    float4* tgtP;     // p1.p, bits(medium + 1 of the first segment)
-    float4* tgtE;     // p1.pError
-    float4* tgtN;     // p1.n
+    RayField tgtP;    // p1.p, bits(medium + 1 of the first segment)
+    RayField tgtE;    // p1.pError
+    RayField tgtN;    // p1.n
 };
 
 // Queue tails are bumped with device-scope atomics by every block of a launch.  Atomics on one

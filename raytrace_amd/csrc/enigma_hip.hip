@@ -91,7 +91,7 @@ struct EnigmaCtx {
     bool lightDistDirty = true;
     // VolPathIntegrator
     bool useVolPath = false;
-    DevBuf<float4> shTgtP, shTgtE, shTgtN;
+    DevBuf<float4> shRec;
     size_t volCapacity = 0;
     // DirectLightingIntegrator
     bool useDirect = false, directDirty = true;
@@ -103,7 +103,7 @@ struct EnigmaCtx {
 
     // wavefront state
     size_t capacity = 0;
-    DevBuf<float4> pathRec, L, shO, shD, miO, miD, miW; // pathRec: four float4 per path (rayO, rayD, beta, hit)
+    DevBuf<float4> pathRec, L, shO, shD, miRec; // pathRec: four float4 per path (rayO, rayD, beta, hit)
     DevBuf<float> shWz;
     DevBuf<uint32_t> shIdx, miIdx;
     DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
@@ -151,9 +151,9 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
-    DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
+    DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
-    h->shWz.release(); h->shTgtP.release(); h->shTgtE.release(); h->shTgtN.release();
+    h->shWz.release(); h->shRec.release();
     h->media.release(); h->triMedium.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
@@ -638,8 +638,9 @@ static int buildLightDistribution(EnigmaCtx* h) {
 // n paths, each with raysPerPath shadow/MIS ray slots and (DirectLightingIntegrator) pendingLevels stack entries
 static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pendingLevels) {
     if (n * raysPerPath > h->rayCapacity) {
-        DevBuf<float4>* r4[] = {&h->shO, &h->shD, &h->miO, &h->miD, &h->miW};
+        DevBuf<float4>* r4[] = {&h->shO, &h->shD};
         for (auto* b : r4) HIPCHK(h, b->alloc(n * raysPerPath));
+        HIPCHK(h, h->miRec.alloc(n * raysPerPath * 3));
         HIPCHK(h, h->shWz.alloc(n * raysPerPath));
         HIPCHK(h, h->shIdx.alloc(n * raysPerPath));
         HIPCHK(h, h->miIdx.alloc(n * raysPerPath));
@@ -804,14 +805,18 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
         DevPaths P{{h->pathRec.p}, {h->pathRec.p + 1}, h->L.p, {h->pathRec.p + 2}, {h->pathRec.p + 3}, h->pfilm.p};
-        DevRayQueue shq{h->shO.p, h->shD.p, nullptr, h->shWz.p, h->shIdx.p, (uint32_t)raysPerPath, (!direct && !vol) ? 1u : 0u, nullptr, nullptr, nullptr};
-        DevRayQueue misq{h->miO.p, h->miD.p, h->miW.p, nullptr, h->miIdx.p, (uint32_t)raysPerPath, 0u, nullptr, nullptr, nullptr};
-        if (vol) {
+        const RayField none{nullptr, 1u};
+        DevRayQueue shq{{h->shO.p, 1u}, {h->shD.p, 1u}, none, {h->shWz.p, 1u}, h->shIdx.p, (uint32_t)raysPerPath, (!direct && !vol) ? 1u : 0u, none, none, none};
+        // a MIS ray is one 48-byte record per slot (origin, direction + light, weight)
+        DevRayQueue misq{{h->miRec.p, 3u}, {h->miRec.p + 1, 3u}, {h->miRec.p + 2, 3u}, {nullptr, 1u}, h->miIdx.p, (uint32_t)raysPerPath, 0u, none, none, none};
+        if (vol) { // one 96-byte record per shadow-ray slot: a, b, {wz}, p1.p, p1.pError, p1.n
             if (passPathsMax > h->volCapacity) {
-                HIPCHK(h, h->shTgtP.alloc(passPathsMax)); HIPCHK(h, h->shTgtE.alloc(passPathsMax)); HIPCHK(h, h->shTgtN.alloc(passPathsMax));
+                HIPCHK(h, h->shRec.alloc(passPathsMax * 6));
                 h->volCapacity = passPathsMax;
             }
-            shq.tgtP = h->shTgtP.p; shq.tgtE = h->shTgtE.p; shq.tgtN = h->shTgtN.p;
+            float4* rec = h->shRec.p;
+            shq.o = {rec, 6u}; shq.d = {rec + 1, 6u}; shq.wz = {reinterpret_cast<float*>(rec + 2), 24u};
+            shq.tgtP = {rec + 3, 6u}; shq.tgtE = {rec + 4, 6u}; shq.tgtN = {rec + 5, 6u};
         }
         DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
