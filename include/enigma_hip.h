@@ -81,6 +81,12 @@ typedef struct EnigmaLight {
 } EnigmaLight;
 
 #define ENIGMA_TRI_FLIP_NORMAL 1u /* reverseOrientation ^ transformSwapsHandedness */
+/* The triangle's mesh has per-vertex normals (TriangleMesh::m_n) / uvs (m_uv): Triangle::intersect then builds the
+ * shading geometry from them (Enigma/TriangleMesh.cpp:238-262,290-371).  Meshes without them use the default uvs
+ * (0,0), (1,0), (1,1) and shade with the geometric normal. */
+#define ENIGMA_TRI_HAS_NORMALS 2u
+#define ENIGMA_TRI_HAS_UVS 4u
+#define ENIGMA_TRI_REVERSE_ORIENTATION 8u /* m_reverseOrientation alone: flips the shading bitangent (:369) */
 
 /* HomogeneousMedium (Enigma/Medium.cpp:69-108) with its HenyeyGreenstein phase function
  * (Enigma/MediumInterface.cpp:159-200).  Read by the VolPathIntegrator only. */
@@ -105,8 +111,11 @@ typedef struct EnigmaSceneDesc {
     const uint32_t* tri_flags;    /* [n_triangles] ENIGMA_TRI_* (NULL = all 0) */
     const uint32_t* tri_prim_id;  /* [n_triangles] reference m_primitiveId
                                      (Enigma/Primitive.cpp:19-26); NULL = i+1 */
-    const float* normals;         /* optional per-vertex normals; must be NULL */
-    const float* uvs;             /* optional per-vertex uvs; must be NULL */
+    const float* normals;         /* [n_vertices*3] world-space per-vertex normals (as the TriangleMesh constructor leaves
+                                     them), read for triangles flagged ENIGMA_TRI_HAS_NORMALS; may be NULL otherwise.
+                                     Per-vertex tangents (m_s) are not supported.  An emissive triangle must not carry
+                                     normals (its DiffuseAreaLight would need them in Triangle::sample too). */
+    const float* uvs;             /* [n_vertices*2] per-vertex uvs for triangles flagged ENIGMA_TRI_HAS_UVS */
     uint32_t n_materials;
     uint32_t n_lights;
     const EnigmaMaterial* materials;

@@ -452,6 +452,8 @@ struct Scene; // fwd
 struct TriangleMesh { // world-space vertex store (TriangleMesh.cpp:23-58)
     std::vector<Vec3> p;
     std::vector<uint32_t> idx;
+    std::vector<Vec3> n;   // per-vertex normals (m_n), empty = none anywhere
+    std::vector<Vec2> uv;  // per-vertex uvs (m_uv)
 };
 
 struct Counters {
@@ -464,6 +466,7 @@ static thread_local Counters* tl_counters = nullptr;
 // TriangleMesh.cpp:180-632
 struct Triangle {
     const TriangleMesh* mesh; const uint32_t* v; bool flip; // flip = reverseOrientation ^ transformSwapsHandedness
+    bool hasN = false, hasUV = false, reverse = false; // the mesh has m_n / m_uv; m_reverseOrientation
     void verts(Vec3& p0, Vec3& p1, Vec3& p2) const { p0 = mesh->p[v[0]]; p1 = mesh->p[v[1]]; p2 = mesh->p[v[2]]; }
     BBox3 worldBound() const { Vec3 a, b, c; verts(a, b, c); BBox3 r; r.addPoint(a); r.addPoint(b); r.addPoint(c); return r; }
     // TriangleMesh.cpp:491-602
@@ -522,7 +525,8 @@ struct Triangle {
         Vec3 p0, p1, p2; verts(p0, p1, p2);
         float b0 = b[0], b1 = b[1], b2 = b[2];
         Vec3 dpdu, dpdv;
-        Vec2 uv[3] = {Vec2(0, 0), Vec2(1, 0), Vec2(1, 1)}; // getUVs default, :456-460
+        Vec2 uv[3] = {Vec2(0, 0), Vec2(1, 0), Vec2(1, 1)}; // getUVs, :448-461
+        if (hasUV) { uv[0] = mesh->uv[v[0]]; uv[1] = mesh->uv[v[1]]; uv[2] = mesh->uv[v[2]]; }
         Vec2 duv02 = uv[0] - uv[2], duv12 = uv[1] - uv[2];
         Vec3 dp02 = p0 - p2, dp12 = p1 - p2;
         float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
@@ -551,6 +555,20 @@ struct Triangle {
         isect->shading.dpdu = dpdu; isect->shading.dpdv = dpdv;
         isect->n = isect->shading.n = Normalize(Cross(dp02, dp12));
         if (flip) isect->n = isect->shading.n = -isect->n;
+        if (hasN) { // shading geometry, :290-371 (no per-vertex tangents; dndu / dndv feed ray differentials only)
+            Vec3 ns = (b0 * mesh->n[v[0]] + b1 * mesh->n[v[1]] + b2 * mesh->n[v[2]]);
+            if (LengthSqr(ns) > 0) ns = Normalize(ns);
+            else ns = isect->n;
+            Vec3 ss = Normalize(isect->dpdu);
+            Vec3 ts = Cross(ss, ns);
+            if (LengthSqr(ts) > 0.f) { ts = Normalize(ts); ss = Cross(ts, ns); }
+            else CoordinateSystem(ns, &ss, &ts);
+            if (reverse) ts = -ts;
+            // SetShadingGeometry(ss, ts, ..., orientationIsAuthoritative = true), Interaction.cpp:132-150
+            isect->shading.n = Normalize(Cross(ss, ts));
+            isect->n = Dot(isect->n, isect->shading.n) < 0 ? -isect->n : isect->n; // FaceForward
+            isect->shading.dpdu = ss; isect->shading.dpdv = ts;
+        }
         *tHit = t;
         if (baryOut) *baryOut = b;
         return true;
@@ -2202,7 +2220,9 @@ const char* oracle_last_error(OracleCtx* h) { return h->o.error.c_str(); }
 // split_method: 0 = "sah", 1 = "hlbvh" (reference default, BVH.cpp:726); max_node_prims default 128 (BVH.cpp:742)
 int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method, int max_node_prims) {
     Scene& sc = h->o.scene;
-    if (s->normals || s->uvs) { h->o.error = "per-vertex normals/uvs are not restated"; return -4; }
+    sc.mesh.n.clear(); sc.mesh.uv.clear();
+    if (s->normals) { sc.mesh.n.resize(s->n_vertices); for (uint32_t i = 0; i < s->n_vertices; ++i) sc.mesh.n[i] = Vec3(s->normals[3 * i], s->normals[3 * i + 1], s->normals[3 * i + 2]); }
+    if (s->uvs) { sc.mesh.uv.resize(s->n_vertices); for (uint32_t i = 0; i < s->n_vertices; ++i) sc.mesh.uv[i] = Vec2(s->uvs[2 * i], s->uvs[2 * i + 1]); }
     sc.mesh.p.resize(s->n_vertices);
     for (uint32_t i = 0; i < s->n_vertices; ++i) sc.mesh.p[i] = Vec3(s->vertices[3 * i], s->vertices[3 * i + 1], s->vertices[3 * i + 2]);
     sc.mesh.idx.assign(s->indices, s->indices + 3 * (size_t)s->n_triangles);
@@ -2211,7 +2231,11 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     sc.triLight.assign(s->tri_light, s->tri_light + s->n_triangles);
     sc.primId.resize(s->n_triangles);
     for (uint32_t i = 0; i < s->n_triangles; ++i) {
-        sc.tris[i] = Triangle{&sc.mesh, &sc.mesh.idx[3 * (size_t)i], s->tri_flags ? (s->tri_flags[i] & ENIGMA_TRI_FLIP_NORMAL) != 0 : false};
+        const uint32_t fl = s->tri_flags ? s->tri_flags[i] : 0u;
+        sc.tris[i] = Triangle{&sc.mesh, &sc.mesh.idx[3 * (size_t)i], (fl & ENIGMA_TRI_FLIP_NORMAL) != 0};
+        sc.tris[i].hasN = (fl & ENIGMA_TRI_HAS_NORMALS) && s->normals; sc.tris[i].hasUV = (fl & ENIGMA_TRI_HAS_UVS) && s->uvs;
+        sc.tris[i].reverse = (fl & ENIGMA_TRI_REVERSE_ORIENTATION) != 0;
+        if (sc.tris[i].hasN && s->tri_light[i] >= 0) { h->o.error = "an emissive triangle with per-vertex normals is not restated"; return -4; }
         sc.primId[i] = s->tri_prim_id ? s->tri_prim_id[i] : i + 1;
     }
     sc.materials.assign(s->materials, s->materials + s->n_materials);

@@ -8,6 +8,9 @@ LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 
 LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
+TRI_HAS_NORMALS = 2
+TRI_HAS_UVS = 4
+TRI_REVERSE_ORIENTATION = 8
 NO_MATERIAL = 0xFFFFFFFF
 
 
@@ -79,7 +82,7 @@ class SceneArrays:
     """Owns the numpy arrays an EnigmaSceneDesc points into."""
 
     def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None,
-                 media=(), tri_medium_inside=None, tri_medium_outside=None):
+                 media=(), tri_medium_inside=None, tri_medium_outside=None, normals=None, uvs=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nt = self.indices.shape[0]
@@ -87,6 +90,9 @@ class SceneArrays:
         self.tri_light = np.ascontiguousarray(tri_light, dtype=np.int32).reshape(nt)
         self.tri_flags = None if tri_flags is None else np.ascontiguousarray(tri_flags, dtype=np.uint32).reshape(nt)
         self.tri_prim_id = None if tri_prim_id is None else np.ascontiguousarray(tri_prim_id, dtype=np.uint32).reshape(nt)
+        nv = self.vertices.shape[0]
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(nv, 3)
+        self.uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32).reshape(nv, 2)
         self.media = (EnigmaMedium * max(1, len(media)))(*media)
         self.n_media = len(media)
         self.tri_medium_inside = None if tri_medium_inside is None else np.ascontiguousarray(tri_medium_inside, dtype=np.int32).reshape(nt)
@@ -107,8 +113,8 @@ class SceneArrays:
         d.tri_light = ptr(self.tri_light)
         d.tri_flags = ptr(self.tri_flags)
         d.tri_prim_id = ptr(self.tri_prim_id)
-        d.normals = None
-        d.uvs = None
+        d.normals = ptr(self.normals)
+        d.uvs = ptr(self.uvs)
         d.n_materials = self.n_materials
         d.n_lights = self.n_lights
         d.materials = C.cast(self.materials, C.c_void_p)

@@ -180,7 +180,8 @@ struct Bsdf {
     float ax, ay;          // shared microfacet distribution of the material
     float eta;             // BSDF::m_eta (glass index, else 1)
     float dEtaI, dEtaT;    // dielectric Fresnel / transmission interface
-    F3 ng, ss, ts;         // frame: ss, ts, geometric normal (ns == ng without shading normals)
+    F3 ng, ss, ts;         // the reference's local frame (Enigma/BxDF.cpp:872-882): shading tangent, shading bitangent ns x ss, and the
+                           // GEOMETRIC normal as its third axis (not the shading normal; not orthonormal when they differ)
 };
 
 DEV F3 toLocal(const Bsdf& b, F3 v) { return F3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ng)); }
@@ -190,10 +191,10 @@ DEV F3 toWorld(const Bsdf& b, F3 v) {
 
 // Material::computeScatteringFunctions for the four materials (Enigma/Material.cpp:76-93,115-136,176-220,232-255).
 template <int MK>
-DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 dpdu, Bsdf* b) {
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b) {
     b->ng = ng;
     b->ss = normalize(dpdu);
-    b->ts = cross(ng, b->ss);
+    b->ts = cross(ns, b->ss);
     b->eta = 1.f;
     b->ax = m.alphax; b->ay = m.alphay;
     b->col0 = F3(m.c0[0], m.c0[1], m.c0[2]); b->col1 = F3(m.c1[0], m.c1[1], m.c1[2]);

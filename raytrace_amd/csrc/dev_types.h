@@ -77,6 +77,8 @@ struct DevScene {
     const uint32_t* infiniteLights; // Scene::m_infiniteLights: indices of the infinite area lights
     int nInfinite;
     const DevMedium* media;     // VolPathIntegrator only
+    const float4* triShade;     // 4 float4 per triangle (device order): (n0, u0) (n1, u1) (n2, u2) (v0, v1, v2, -), read for triangles whose
+                                // second word flags per-vertex normals or uvs; nullptr = no mesh has either
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;
     int nLights;

@@ -65,6 +65,7 @@ struct EnigmaCtx {
     DevBuf<DevEnvMap> envMaps;
     DevBuf<uint32_t> infiniteLights;
     DevBuf<uint32_t> triMedium;
+    DevBuf<float4> triShade;
     bool haveNoMaterial = false; // some triangle has no material (a medium boundary): VolPathIntegrator only
     std::vector<DevLight> hostLights;
     std::vector<float> lightPower; // Light::Power().y() per light
@@ -154,7 +155,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shRec.release();
-    h->media.release(); h->triMedium.release();
+    h->media.release(); h->triMedium.release(); h->triShade.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
@@ -173,7 +174,6 @@ extern "C" const char* enigma_last_error(const EnigmaCtx* h) { return h ? h->err
 extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (!h || !s) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    if (s->normals || s->uvs) return h->fail(ENIGMA_E_UNSUPPORTED, "per-vertex normals / uvs are not supported");
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
     if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
     if (s->n_materials == 0 && s->n_triangles) {
@@ -195,6 +195,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             if (s->tri_light[t] >= 0) return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light on a surface without a material is not supported", t);
         } else if (s->tri_material[t] >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "material index out of range at triangle %u", t);
         if (s->tri_light[t] >= (int32_t)s->n_lights) return h->fail(ENIGMA_E_INVALID, "light index out of range at triangle %u", t);
+        const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
+        if ((fl & ENIGMA_TRI_HAS_NORMALS) && !s->normals) return h->fail(ENIGMA_E_INVALID, "triangle %u is flagged to have normals but the normals array is null", t);
+        if ((fl & ENIGMA_TRI_HAS_UVS) && !s->uvs) return h->fail(ENIGMA_E_INVALID, "triangle %u is flagged to have uvs but the uvs array is null", t);
+        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0)
+            return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light on a mesh with per-vertex normals is not supported", t);
         if (haveMedia && (s->tri_medium_inside[t] < -1 || s->tri_medium_inside[t] >= (int32_t)s->n_media || s->tri_medium_outside[t] < -1 ||
                           s->tri_medium_outside[t] >= (int32_t)s->n_media))
             return h->fail(ENIGMA_E_INVALID, "medium index out of range at triangle %u", t);
@@ -265,12 +270,27 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->bvhNodes = (uint32_t)bvh.nodes.size();
     std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> newPos(s->n_triangles);
+    std::vector<float4> shadeData; // filled when some triangle has per-vertex normals or uvs
     for (uint32_t k = 0; k < s->n_triangles; ++k) {
         uint32_t t = bvh.triOrder[k];
         newPos[t] = k;
-        uint32_t flip = (s->tri_flags && (s->tri_flags[t] & ENIGMA_TRI_FLIP_NORMAL)) ? 1u : 0u;
+        const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
+        const uint32_t bits = ((fl & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u) | ((fl & ENIGMA_TRI_HAS_NORMALS) ? 1u << 27 : 0u) |
+                              ((fl & ENIGMA_TRI_HAS_UVS) ? 1u << 28 : 0u) | ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
         const bool noMat = s->tri_material[t] == ENIGMA_NO_MATERIAL;
-        uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | (flip << 31) : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | (flip << 31), (uint32_t)s->tri_light[t]};
+        uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | bits : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | bits, (uint32_t)s->tri_light[t]};
+        if (fl & (ENIGMA_TRI_HAS_NORMALS | ENIGMA_TRI_HAS_UVS)) {
+            if (shadeData.empty()) shadeData.assign((size_t)s->n_triangles * 4, make_float4(0, 0, 0, 0));
+            float4* sd = &shadeData[(size_t)k * 4];
+            float uvw[6] = {0, 0, 0, 0, 0, 0};
+            for (int v = 0; v < 3; ++v) {
+                const size_t vi = s->indices[3 * (size_t)t + v];
+                if (fl & ENIGMA_TRI_HAS_UVS) { uvw[v] = s->uvs[2 * vi]; uvw[3 + v] = s->uvs[2 * vi + 1]; }
+                const float* n = (fl & ENIGMA_TRI_HAS_NORMALS) ? &s->normals[3 * vi] : nullptr;
+                sd[v] = make_float4(n ? n[0] : 0.f, n ? n[1] : 0.f, n ? n[2] : 0.f, uvw[v]);
+            }
+            sd[3] = make_float4(uvw[3], uvw[4], uvw[5], 0.f);
+        }
         for (int v = 0; v < 3; ++v) {
             const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
             float wf;
@@ -402,6 +422,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->scene.media = h->media.p;
         h->scene.triMedium = haveMedia ? h->triMedium.p : nullptr;
     }
+    HIPCHK(h, h->triShade.upload(shadeData));
+    h->scene.triShade = shadeData.empty() ? nullptr : h->triShade.p;
     HIPCHK(h, h->envMaps.upload(envTable));
     HIPCHK(h, h->infiniteLights.upload(infinite));
     h->scene.envMaps = h->envMaps.p;

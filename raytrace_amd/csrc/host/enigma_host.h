@@ -229,13 +229,16 @@ public:
 using SamplerPtr = std::shared_ptr<Sampler>;
 
 // ---- scene registry ----
-struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexIndices
+struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexIndices, optional m_n (world space) and m_uv
     int m_nTriangles = 0, m_nVertices = 0;
     std::vector<int> m_vertexIndices;
     std::vector<Vector3f> m_p;
+    std::vector<Vector3f> m_n;      // empty or m_nVertices normals, already through ObjectToWorld.transformNormal
+    std::vector<Vector2f> m_uv;     // empty or m_nVertices uvs
     int materialIndex = 0;          // registry index of the bound material; -1 = none (MakeMaterial "" / "none": a medium boundary)
     int mediumInside = -1, mediumOutside = -1; // GeometricPrimitive::m_mi: registry indices of the media, -1 = none
-    bool reverseOrientation = false;
+    bool reverseOrientation = false;        // Shape::m_reverseOrientation
+    bool transformSwapsHandedness = false;  // Shape::m_transformSwapsHandedness
     bool emissive = false;          // an AreaLightSource was active when the shape was created
     Spectrum Le = 0.f;
     bool twoSided = false;
@@ -336,7 +339,7 @@ public:
         struct Guard { EnigmaCtx* h; ~Guard() { enigma_ctx_destroy(h); } } guard{h};
         auto check = [&](int rc) { if (rc != ENIGMA_OK) throw std::runtime_error(std::string("enigma: ") + enigma_last_error(h)); };
         // flatten the registry
-        std::vector<float> verts; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight, triIn, triOut; std::vector<EnigmaLight> lights;
+        std::vector<float> verts, normals, uvs; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight, triIn, triOut; std::vector<EnigmaLight> lights;
         size_t pl = 0;
         auto flushPointLights = [&](int upTo) {
             for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) lights.push_back(scene.m_lights[pl].light);
@@ -346,11 +349,15 @@ public:
             const TriangleMesh& m = scene.m_meshes[mi];
             uint32_t base = (uint32_t)(verts.size() / 3);
             for (const Vector3f& p : m.m_p) { verts.push_back(p.x); verts.push_back(p.y); verts.push_back(p.z); }
+            const bool hasN = (int)m.m_n.size() == m.m_nVertices && m.m_nVertices > 0, hasUV = (int)m.m_uv.size() == m.m_nVertices && m.m_nVertices > 0;
+            if (hasN) { normals.resize(3 * (size_t)base, 0.f); for (const Vector3f& n : m.m_n) { normals.push_back(n.x); normals.push_back(n.y); normals.push_back(n.z); } }
+            if (hasUV) { uvs.resize(2 * (size_t)base, 0.f); for (const Vector2f& t : m.m_uv) { uvs.push_back(t.x); uvs.push_back(t.y); } }
             for (int t = 0; t < m.m_nTriangles; ++t) {
                 for (int k = 0; k < 3; ++k) idx.push_back(base + (uint32_t)m.m_vertexIndices[3 * t + k]);
                 triMat.push_back(m.materialIndex < 0 ? ENIGMA_NO_MATERIAL : (uint32_t)m.materialIndex);
                 triIn.push_back(m.mediumInside); triOut.push_back(m.mediumOutside);
-                triFlags.push_back(m.reverseOrientation ? ENIGMA_TRI_FLIP_NORMAL : 0u);
+                triFlags.push_back(((m.reverseOrientation ^ m.transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u) | (hasN ? ENIGMA_TRI_HAS_NORMALS : 0u) |
+                                   (hasUV ? ENIGMA_TRI_HAS_UVS : 0u) | (m.reverseOrientation ? ENIGMA_TRI_REVERSE_ORIENTATION : 0u));
                 if (m.emissive) {
                     EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA; l.triangle = (uint32_t)triMat.size() - 1; l.two_sided = m.twoSided; l.n_samples = (uint32_t)std::max(1, m.nSamples);
                     l.L[0] = m.Le[0]; l.L[1] = m.Le[1]; l.L[2] = m.Le[2];
@@ -363,6 +370,8 @@ public:
         EnigmaSceneDesc sd{};
         sd.n_vertices = (uint32_t)(verts.size() / 3); sd.n_triangles = (uint32_t)triMat.size();
         sd.vertices = verts.data(); sd.indices = idx.data(); sd.tri_material = triMat.data(); sd.tri_light = triLight.data(); sd.tri_flags = triFlags.data();
+        if (!normals.empty()) { normals.resize(verts.size(), 0.f); sd.normals = normals.data(); }
+        if (!uvs.empty()) { uvs.resize(verts.size() / 3 * 2, 0.f); sd.uvs = uvs.data(); }
         sd.n_materials = (uint32_t)scene.m_materials.size(); sd.materials = scene.m_materials.data();
         sd.n_lights = (uint32_t)lights.size(); sd.lights = lights.data();
         if (!scene.m_media.empty()) { sd.n_media = (uint32_t)scene.m_media.size(); sd.media = scene.m_media.data(); sd.tri_medium_inside = triIn.data(); sd.tri_medium_outside = triOut.data(); }

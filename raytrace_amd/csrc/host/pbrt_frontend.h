@@ -67,6 +67,9 @@ public:
         return out;
     }
     std::vector<double> FindPoint3(const std::string& n) const { auto* i = find(n, "point", 0); return i ? i->nums : std::vector<double>(); }
+    std::vector<double> FindNormal3(const std::string& n) const { auto* i = find(n, "normal", 0); return i ? i->nums : std::vector<double>(); }
+    std::vector<double> FindVector3(const std::string& n) const { auto* i = find(n, "vector", 0); return i ? i->nums : std::vector<double>(); }
+    std::vector<double> FindPoint2(const std::string& n) const { auto* i = find(n, "point2", 0); return i ? i->nums : std::vector<double>(); }
     std::string FindTexture(const std::string& n) const { auto* i = find(n, "texture", 1, false); return i ? i->strs[0] : ""; }
     std::vector<std::string> Unused() const { // ReportUnused
         std::vector<std::string> out;
@@ -389,10 +392,16 @@ public:
         if (vi.size() % 3) throw std::runtime_error("trianglemesh: number of indices is not a multiple of 3");
         for (int v : vi) if (v < 0 || v >= nVerts) throw std::runtime_error("trianglemesh has out-of-bounds vertex index");
         for (const auto& it : p.Items()) {
-            if (it.name == "N" || it.name == "S") throw std::runtime_error("trianglemesh: shading normals / tangents (\"" + it.name + "\") are not supported");
+            if (it.name == "S") throw std::runtime_error("trianglemesh: shading tangents (\"S\") are not supported");
             if (it.name == "alpha" || it.name == "shadowalpha") throw std::runtime_error("trianglemesh: alpha textures are not supported");
-            if (it.name == "uv" || it.name == "st") it.lookedUp = true; // parametrisation feeds textures only; materials here are constant
         }
+        // uv / st as point2 or float pairs (Enigma/TriangleMesh.cpp:693-722); normal N (:737-741)
+        std::vector<double> uv = p.FindPoint2("uv");
+        if (uv.empty()) uv = p.FindPoint2("st");
+        if (uv.empty()) { std::vector<float> f = p.FindFloat("uv"); if (f.empty()) f = p.FindFloat("st"); uv.assign(f.begin(), f.end()); }
+        if (!uv.empty() && (int)uv.size() / 2 < nVerts) { Warn("Not enough of \"uv\"s for triangle mesh.  Discarding."); uv.clear(); }
+        std::vector<double> N = p.FindNormal3("N");
+        if (!N.empty() && (int)N.size() / 3 != nVerts) { Warn("Number of \"N\"s for triangle mesh must match \"P\"s"); N.clear(); }
         TriangleMesh m;
         m.m_nTriangles = (int)vi.size() / 3; m.m_nVertices = nVerts;
         m.m_vertexIndices = vi;
@@ -405,7 +414,17 @@ public:
         if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet()); // GraphicsState ctor, Enigma/Api.cpp:992-999
         m.materialIndex = m_gs.currentMaterial == -1 ? m_defaultMaterial : (m_gs.currentMaterial == -2 ? -1 : m_gs.currentMaterial);
         m.mediumInside = LookupMedium(m_gs.currentInsideMedium); m.mediumOutside = LookupMedium(m_gs.currentOutsideMedium);
-        m.reverseOrientation = m_gs.reverseOrientation ^ m_ctm.SwapsHandedness(); // Enigma/TriangleMesh.cpp:287-289
+        m.reverseOrientation = m_gs.reverseOrientation; // Enigma/TriangleMesh.cpp:287-289,369 use both flags
+        m.transformSwapsHandedness = m_ctm.SwapsHandedness();
+        if (!N.empty()) { // ObjectToWorld.transformNormal: the inverse transpose (Enigma/Transform.h:54-59, Enigma/TriangleMesh.cpp:44-48)
+            Mat4d inv = m_ctm.Inverse();
+            for (int i = 0; i < nVerts; ++i) {
+                const double* n = &N[3 * (size_t)i];
+                m.m_n.push_back(Vector3f((float)(inv.m[0][0] * n[0] + inv.m[1][0] * n[1] + inv.m[2][0] * n[2]), (float)(inv.m[0][1] * n[0] + inv.m[1][1] * n[1] + inv.m[2][1] * n[2]),
+                                         (float)(inv.m[0][2] * n[0] + inv.m[1][2] * n[1] + inv.m[2][2] * n[2])));
+            }
+        }
+        for (int i = 0; i < nVerts && !uv.empty(); ++i) m.m_uv.push_back(Vector2f((float)uv[2 * (size_t)i], (float)uv[2 * (size_t)i + 1]));
         if (!m_gs.areaLight.empty()) {
             if (m_gs.areaLight != "diffuse" && m_gs.areaLight != "area") throw std::runtime_error("AreaLightSource \"" + m_gs.areaLight + "\" is not supported (diffuse)");
             const ParamSet& ap = m_gs.areaLightParams; // CreateDiffuseAreaLight, Enigma/Lights.cpp:812-822

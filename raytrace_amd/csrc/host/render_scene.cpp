@@ -55,11 +55,16 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o << "],\n\"meshes\":[";
     for (size_t i = 0; i < R.scene.m_meshes.size(); ++i) {
         const TriangleMesh& m = R.scene.m_meshes[i];
-        o << (i ? ",\n" : "") << "{\"material\":" << m.materialIndex << ",\"medium_inside\":" << m.mediumInside << ",\"medium_outside\":" << m.mediumOutside << ",\"reverse\":" << (m.reverseOrientation ? 1 : 0) << ",\"emissive\":" << (m.emissive ? 1 : 0)
+        o << (i ? ",\n" : "") << "{\"material\":" << m.materialIndex << ",\"medium_inside\":" << m.mediumInside << ",\"medium_outside\":" << m.mediumOutside << ",\"reverse\":" << ((m.reverseOrientation ^ m.transformSwapsHandedness) ? 1 : 0)
+          << ",\"reverse_orientation\":" << (m.reverseOrientation ? 1 : 0) << ",\"emissive\":" << (m.emissive ? 1 : 0)
           << ",\"twosided\":" << (m.twoSided ? 1 : 0) << ",\"nsamples\":" << m.nSamples << ",\"Le\":[" << m.Le[0] << "," << m.Le[1] << "," << m.Le[2] << "],\"indices\":[";
         for (size_t k = 0; k < m.m_vertexIndices.size(); ++k) o << (k ? "," : "") << m.m_vertexIndices[k];
         o << "],\"P\":[";
         for (size_t k = 0; k < m.m_p.size(); ++k) o << (k ? "," : "") << m.m_p[k].x << "," << m.m_p[k].y << "," << m.m_p[k].z;
+        o << "],\"N\":[";
+        for (size_t k = 0; k < m.m_n.size(); ++k) o << (k ? "," : "") << m.m_n[k].x << "," << m.m_n[k].y << "," << m.m_n[k].z;
+        o << "],\"uv\":[";
+        for (size_t k = 0; k < m.m_uv.size(); ++k) o << (k ? "," : "") << m.m_uv[k].x << "," << m.m_uv[k].y;
         o << "]}";
     }
     o << "],\n\"media\":[";

@@ -168,19 +168,25 @@ DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
 }
 
 // ---------------------------------------------------------------- geometry at a hit
-// second triangle word: material index [0:24) | material kind [24:27) | flip-normal [31]
+// second triangle word: material index [0:24) | material kind [24:27) | per-vertex normals [27] | per-vertex uvs [28] |
+// reverseOrientation [29] | flip-normal [31]
 DEV uint32_t triMaterial(uint32_t mw) { return mw & 0xffffffu; }
 DEV uint32_t triKind(uint32_t mw) { return (mw >> 24) & 7u; }
 DEV bool triFlip(uint32_t mw) { return (mw >> 31) != 0; }
 
-struct HitGeom { F3 p, pError, n, dpdu; int matIdx, lightIdx; };
+DEV bool triHasNormals(uint32_t mw) { return (mw >> 27) & 1u; }
+DEV bool triHasUvs(uint32_t mw) { return (mw >> 28) & 1u; }
+DEV bool triReverse(uint32_t mw) { return (mw >> 29) & 1u; }
+
+// n: geometric normal (turned towards the shading normal when the mesh has normals); ns, dpdu: shading normal and shading dpdu
+struct HitGeom { F3 p, pError, n, ns, dpdu; int matIdx, lightIdx; };
 
 DEV F3 triNormal(F3 p0, F3 p1, F3 p2, bool flip) { // Enigma/TriangleMesh.cpp:287-289
     F3 n = normalize(cross(p0 - p2, p1 - p2));
     return flip ? -n : n;
 }
-// Triangle::intersect after the hit test, Enigma/TriangleMesh.cpp:226-289 (default uvs, no normals)
-DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b2) {
+// Triangle::intersect after the hit test, Enigma/TriangleMesh.cpp:226-371 (no alpha mask, no per-vertex tangents)
+DEV HitGeom hitGeometry(const DevScene& sc, const float4* tris, int tri, float b0, float b1, float b2) {
     const float4* tp = tris + (size_t)tri * 3;
     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
     F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
@@ -189,9 +195,27 @@ DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b
     g.matIdx = (int)triMaterial(mw);
     g.lightIdx = __float_as_int(v2.w);
     F3 dp02 = p0 - p2, dp12 = p1 - p2;
-    F3 dpdu = dp12 - dp02;
+    F3 dpdu = dp12 - dp02; // the default uvs (0,0), (1,0), (1,1): determinant 1
     F3 dpdv = -dp12;
-    if (lengthSqr(cross(dpdu, dpdv)) == 0) {
+    bool degenerateUV = false;
+    const bool shaded = sc.triShade && (triHasNormals(mw) || triHasUvs(mw));
+    float4 s0, s1, s2;
+    if (shaded) {
+        const float4* sp = sc.triShade + (size_t)tri * 4;
+        s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
+        if (triHasUvs(mw)) {
+            float4 vv = sp[3];
+            float du02 = s0.w - s2.w, dv02 = vv.x - vv.z, du12 = s1.w - s2.w, dv12 = vv.y - vv.z;
+            float determinant = du02 * dv12 - dv02 * du12;
+            degenerateUV = fabsf(determinant) < 1e-8;
+            if (!degenerateUV) {
+                float invdet = 1 / determinant;
+                dpdu = (dv12 * dp02 - dv02 * dp12) * invdet;
+                dpdv = (-du12 * dp02 + du02 * dp12) * invdet;
+            }
+        }
+    }
+    if (degenerateUV || lengthSqr(cross(dpdu, dpdv)) == 0) {
         F3 ng = cross(p2 - p0, p1 - p0);
         coordinateSystem(normalize(ng), &dpdu, &dpdv);
     }
@@ -202,6 +226,19 @@ DEV HitGeom hitGeometry(const float4* tris, int tri, float b0, float b1, float b
     g.pError = gammaf(7) * F3(xAbsSum, yAbsSum, zAbsSum);
     g.p = b0 * p0 + b1 * p1 + b2 * p2;
     g.n = triNormal(p0, p1, p2, triFlip(mw));
+    g.ns = g.n;
+    if (shaded && triHasNormals(mw)) { // shading geometry, Enigma/TriangleMesh.cpp:291-370 and SetShadingGeometry, Enigma/Interaction.cpp:132-150
+        F3 ns = b0 * xyz(s0) + b1 * xyz(s1) + b2 * xyz(s2);
+        ns = lengthSqr(ns) > 0 ? normalize(ns) : g.n;
+        F3 ss = normalize(dpdu);
+        F3 ts = cross(ss, ns);
+        if (lengthSqr(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinateSystem(ns, &ss, &ts);
+        if (triReverse(mw)) ts = -ts;
+        g.ns = normalize(cross(ss, ts));
+        if (dot(g.n, g.ns) < 0.f) g.n = -g.n;
+        g.dpdu = ss;
+    }
     return g;
 }
 
@@ -728,10 +765,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             float4 bv = P.beta[p];
             F3 beta = xyz(bv);
             float etaScale = bv.w;
-            HitGeom g = hitGeometry(tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
-            makeBsdf<MK>(materials[g.matIdx], g.n, g.dpdu, &bsdf);
-            F3 ns = g.n; // shading normal == geometric normal (no per-vertex normals)
+            makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf);
+            F3 ns = g.ns;
             F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
             // medium + 1 on either side of the surface: the triangle's MediumInterface if it is a transition, else
             // the medium the ray arrived in (GeometricPrimitive::intersect, Enigma/Primitive.cpp:155-160)
@@ -899,10 +936,10 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             uint32_t px, py, slot;
             pathPixel(I, S, p, &px, &py, &slot);
             F3 beta = xyz(P.beta[p]);
-            HitGeom g = hitGeometry(tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
-            makeBsdf<MKD>(materials[g.matIdx], g.n, g.dpdu, &bsdf);
-            F3 ns = g.n;
+            makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf);
+            F3 ns = g.ns;
             F3 woN = normalize(-d); // isect.m_wo
             const size_t raySlot0 = (size_t)p * I.raysPerPath;
             auto emit = [&](const DirectSample& ds, float div, int lightNum) { // div: sample count (all) or light-choice pdf (one)

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
             float4 hv = P.hit[p];
             int tri = __float_as_int(hv.x);
             uint32_t st = __float_as_uint(rdv.w);
-            HitGeom g = hitGeometry(sc.tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, sc.tris, tri, hv.y, hv.z, hv.w);
             P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, d), 0.f); // isect.SpawnRay(ray.m_dir)
             P.rayD[p] = mk4(d, __uint_as_float(packState(mediumBeyond(sc, tri, stMedium(st), g.n, d), stDim(st), stBounces(st), stSpec(st))));
         }
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
                     if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
                     if (!hit) active = false;
                     else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
-                        HitGeom g = hitGeometry(tris, h.tri, h.b0, h.b1, h.b2);
+                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2);
                         o = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
                         F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
                         d = target - o;
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                             }
                         }
                     } else {
-                        HitGeom g = hitGeometry(tris, h.tri, h.b0, h.b1, h.b2);
+                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2);
                         o = offsetRayOrigin(g.p, g.pError, g.n, d);
                         med = mediumBeyond(sc, h.tri, med, g.n, d);
                         w.start(o, d, EDEV_INF);

@@ -152,6 +152,7 @@ class MeshBuilder:
         self.materials, self.lights = [], []
         self.media, self.m_in, self.m_out = [], [], []
         self.interface = (-1, -1)   # MediumInterface (inside, outside) given to the triangles added next
+        self.vn, self.vuv = [], []  # per-vertex normal / uv (zeros where the triangle has none)
 
     def add_medium(self, m):
         self.media.append(m)
@@ -170,18 +171,27 @@ class MeshBuilder:
         # (Enigma/TriangleMesh.cpp:287)
         return np.cross(np.asarray(p0, float) - p2, np.asarray(p1, float) - p2)
 
-    def add_tri(self, p0, p1, p2, mat, toward=None, emit=None, two_sided=False):
-        """toward: a point the reference geometric normal must face (winding is swapped if not)."""
+    def add_tri(self, p0, p1, p2, mat, toward=None, emit=None, two_sided=False, normals=None, uvs=None, reverse_orientation=False):
+        """toward: a point the reference geometric normal must face (winding is swapped if not).
+        normals / uvs: the three per-vertex normals / uvs of a mesh that has them (TriangleMesh::m_n, m_uv);
+        reverse_orientation: the shape's ReverseOrientation flag (no handedness-swapping transform assumed)."""
         p0, p1, p2 = (np.asarray(p, dtype=np.float64) for p in (p0, p1, p2))
         if toward is not None:
             n = self._ref_normal(p0, p1, p2)
             if np.dot(n, np.asarray(toward, float) - p0) < 0:
                 p1, p2 = p2, p1
+                if normals is not None:
+                    normals = (normals[0], normals[2], normals[1])
+                if uvs is not None:
+                    uvs = (uvs[0], uvs[2], uvs[1])
         base = len(self.v)
         self.v += [p0, p1, p2]
+        self.vn += [np.zeros(3)] * 3 if normals is None else [np.asarray(n, dtype=np.float64) for n in normals]
+        self.vuv += [np.zeros(2)] * 3 if uvs is None else [np.asarray(u, dtype=np.float64) for u in uvs]
         self.t.append((base, base + 1, base + 2))
         self.mat.append(mat)
-        self.flags.append(0)
+        self.flags.append((abi.TRI_HAS_NORMALS if normals is not None else 0) | (abi.TRI_HAS_UVS if uvs is not None else 0) |
+                          ((abi.TRI_REVERSE_ORIENTATION | abi.TRI_FLIP_NORMAL) if reverse_orientation else 0))
         self.m_in.append(self.interface[0])
         self.m_out.append(self.interface[1])
         if emit is not None:
@@ -204,8 +214,8 @@ class MeshBuilder:
         self.lights.append(abi.distant_light(frm, to, L))
 
     def weld(self):
-        """Share identical vertices (keeps triangle order and winding)."""
-        v = np.asarray(self.v, dtype=np.float32)
+        """Share identical vertices: same position, normal and uv (keeps triangle order and winding)."""
+        v = np.concatenate([np.asarray(self.v, dtype=np.float32), np.asarray(self.vn, dtype=np.float32), np.asarray(self.vuv, dtype=np.float32)], axis=1)
         uniq, inv = np.unique(v, axis=0, return_inverse=True)
         t = inv.reshape(-1)[np.asarray(self.t, dtype=np.int64)]
         return uniq, t.astype(np.uint32)
@@ -214,9 +224,15 @@ class MeshBuilder:
         if weld:
             v, t = self.weld()
         else:
-            v, t = np.asarray(self.v, dtype=np.float32), np.asarray(self.t, dtype=np.uint32)
+            v = np.concatenate([np.asarray(self.v, dtype=np.float32), np.asarray(self.vn, dtype=np.float32), np.asarray(self.vuv, dtype=np.float32)], axis=1)
+            t = np.asarray(self.t, dtype=np.uint32)
         media = dict(media=self.media, tri_medium_inside=self.m_in, tri_medium_outside=self.m_out) if self.media else {}
-        return abi.SceneArrays(v, t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, **media)
+        shading = {}
+        if any(f & abi.TRI_HAS_NORMALS for f in self.flags):
+            shading["normals"] = v[:, 3:6]
+        if any(f & abi.TRI_HAS_UVS for f in self.flags):
+            shading["uvs"] = v[:, 6:8]
+        return abi.SceneArrays(v[:, :3], t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, **media, **shading)
 
 
 # ----------------------------------------------------------------------------- S1: Cornell box
@@ -281,6 +297,36 @@ def cornell_box(variant="diffuse", delta_lights=False):
     if delta_lights:
         b.add_spot_light((278, 500, 100), (186, 165, 169), (4.0e5, 5.0e5, 6.0e5), coneangle=25.0, conedeltaangle=10.0)
         b.add_distant_light((0.3, 0.5, -1.1), (0, 0, 0), (1.5, 1.2, 0.9))
+    return b.arrays()
+
+
+def cornell_smooth(level=2):
+    """The Cornell box with its blocks replaced by four coarse icospheres that exercise the shading geometry of
+    Triangle::intersect (Enigma/TriangleMesh.cpp:238-262,290-371): an anisotropic metal sphere with per-vertex
+    normals and spherical uvs (its tangent frame follows the uvs, seam included), a rough-glass sphere with normals
+    only, a plastic sphere with uvs only, and a smooth-glass sphere with normals and ReverseOrientation."""
+    b = MeshBuilder()
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    c = CORNELL_CENTER
+    for name, m in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        b.add_quad(_CORNELL[name], m, toward=c)
+    b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
+    sv, sf = _icosphere(level)
+    uv = np.stack([np.arctan2(sv[:, 2], sv[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(sv[:, 1], -1, 1)) / math.pi], axis=1)
+    spheres = (
+        ((185.0, 90.0, 170.0), 90.0, b.add_material(abi.metal(COPPER_ETA, COPPER_K, remap=False, uroughness=0.04, vroughness=0.35)), True, True, False),
+        ((390.0, 110.0, 340.0), 110.0, b.add_material(abi.glass(1.5, 0.05, 0.05)), True, False, False),
+        ((400.0, 330.0, 330.0), 70.0, b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05)), False, True, False),
+        ((150.0, 300.0, 300.0), 75.0, b.add_material(abi.glass(1.5, 0.0, 0.0)), True, False, True),
+    )
+    for centre, radius, mat, with_n, with_uv, reverse in spheres:
+        centre = np.asarray(centre)
+        for f in sf:
+            p = sv[f] * radius + centre
+            b.add_tri(p[0], p[1], p[2], mat, toward=p[0] + sv[f[0]], normals=tuple(sv[f]) if with_n else None,
+                      uvs=tuple(uv[f]) if with_uv else None, reverse_orientation=reverse)
     return b.arrays()
 
 

@@ -93,8 +93,14 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         if li >= 0:
             l = sc.lights[li]
             out.append('  AreaLightSource "diffuse" %s "bool twosided" "%s" "integer samples" %d' % (_rgb("L", l.L), "true" if l.two_sided else "false", max(1, l.n_samples)))
-        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]' %
-                   (" ".join(str(int(v)) for v in idx), " ".join("%.9g" % float(v) for v in verts.reshape(-1))))
+        fl = int(sc.tri_flags[t]) if sc.tri_flags is not None else 0
+        extra = ""
+        if fl & abi.TRI_HAS_NORMALS:
+            extra += ' "normal N" [%s]' % " ".join("%.9g" % float(v) for v in sc.normals[sc.indices[t:e].reshape(-1)].reshape(-1))
+        if fl & abi.TRI_HAS_UVS:
+            extra += ' "float uv" [%s]' % " ".join("%.9g" % float(v) for v in sc.uvs[sc.indices[t:e].reshape(-1)].reshape(-1))
+        out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]%s' %
+                   (" ".join(str(int(v)) for v in idx), " ".join("%.9g" % float(v) for v in verts.reshape(-1)), extra))
         out.append("AttributeEnd")
         t = e
     flush_points(1 << 30)

@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -92,6 +92,8 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
         sc = scenes.cornell_fog(variant.split(":")[1])
     elif variant.startswith("sky:"):
         sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment: scene files carry no texels
+    elif variant == "smooth":
+        sc = scenes.cornell_smooth()       # per-vertex normals, uvs and ReverseOrientation through "normal N" / "float uv"
     else:
         sc = scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"))
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))

@@ -321,6 +321,73 @@ def test_image_parity_infinite_area_light(radiance_map):
     assert e.value.code == -4
 
 
+def test_image_parity_shading_normals_and_uvs():
+    """Per-vertex normals and uvs (Enigma/TriangleMesh.cpp:238-262,290-371; BSDF frame Enigma/BxDF.cpp:843-852): four
+    coarse spheres -- anisotropic metal with normals + uvs, rough glass with normals, plastic with uvs only, smooth
+    glass with normals and ReverseOrientation -- under the three integrators; primary hits stay bit-exact."""
+    sc = scenes.cornell_smooth()
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    for integ in (scenes.integrator_desc(film, 16), scenes.direct_lighting_desc(film, 16, max_depth=4, strategy=abi.DL_SAMPLE_ONE),
+                  scenes.volpath_desc(film, 16)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert np.isfinite(r.image()).all()
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
+        r.close(); o.close()
+    # the shading data changes the picture: the same spheres without normals / uvs look faceted
+    flat = abi.SceneArrays(sc.vertices, sc.indices, sc.tri_material, sc.tri_light, [sc.materials[i] for i in range(sc.n_materials)],
+                           [sc.lights[i] for i in range(sc.n_lights)], tri_flags=sc.tri_flags & abi.TRI_FLIP_NORMAL)
+    integ = scenes.integrator_desc(film, 16)
+    a, b = ra.Renderer(0).configure(sc, cam, film, integ), ra.Renderer(0).configure(flat, cam, film, integ)
+    a.render(0, 16); b.render(0, 16)
+    assert common.mean_relative_error(a.image(), b.image()) > 0.02
+    a.close(); b.close()
+    # flags without their arrays, and an emissive triangle with normals, are refused
+    bad = abi.SceneArrays(sc.vertices, sc.indices, sc.tri_material, sc.tri_light, [sc.materials[i] for i in range(sc.n_materials)],
+                          [sc.lights[i] for i in range(sc.n_lights)], tri_flags=sc.tri_flags)
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(bad, cam, film, integ)
+    assert e.value.code == -1
+    fl = sc.tri_flags.copy()
+    fl[sc.tri_light >= 0] |= abi.TRI_HAS_NORMALS
+    bad = abi.SceneArrays(sc.vertices, sc.indices, sc.tri_material, sc.tri_light, [sc.materials[i] for i in range(sc.n_materials)],
+                          [sc.lights[i] for i in range(sc.n_lights)], tri_flags=fl, normals=sc.normals, uvs=sc.uvs)
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(bad, cam, film, integ)
+    assert e.value.code == -4
+
+
+def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
+    """The uv axes orient the anisotropic tangent frame: a quarter turn of the uvs equals swapping u / v roughness
+    (deterministic with a point light and depth 1)."""
+    def floor(ur, vr, axes):
+        b = scenes.MeshBuilder()
+        m = b.add_material(abi.metal(scenes.COPPER_ETA, scenes.COPPER_K, remap=False, uroughness=ur, vroughness=vr))
+        q = [np.array(p, float) for p in ((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50))]
+        for tri in ((0, 1, 2), (0, 2, 3)):
+            p = [q[i] for i in tri]
+            b.add_tri(p[0], p[1], p[2], m, toward=(0, 1, 0), uvs=tuple((np.dot(axes[0], x) / 100 + .5, np.dot(axes[1], x) / 100 + .5) for x in p))
+        b.add_point_light((15, 30, 5), (4000.0, 3000.0, 2000.0))
+        return b.arrays()
+    ex, ez = np.array([1.0, 0, 0]), np.array([0, 0, 1.0])
+    cam, film = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, 32, 32), scenes.film_desc(32, 32)
+    integ = scenes.direct_lighting_desc(film, 4, max_depth=1, strategy=abi.DL_SAMPLE_ALL)
+    imgs = []
+    for ur, vr, axes in ((0.1, 0.5, (ex, ez)), (0.5, 0.1, (ez, -ex)), (0.5, 0.1, (ex, ez))):
+        r = ra.Renderer(0).configure(floor(ur, vr, axes), cam, film, integ)
+        r.render(0, 4)
+        imgs.append(r.image().astype(np.float64))
+        r.close()
+    assert imgs[0].max() > 0
+    assert np.allclose(imgs[0], imgs[1], rtol=2e-4, atol=1e-7)
+    assert not np.allclose(imgs[0], imgs[2], rtol=0.05)
+
+
 @pytest.mark.parametrize("xres,yres", [(37, 23), (8, 61), (67, 8), (5, 3)])
 def test_image_parity_sizes_that_are_not_multiples_of_the_pixel_tiles(xres, yres):
     """Pixels are numbered in 8 x 8 tiles with scanline strips right of and below the last full tile: every pixel of

@@ -491,3 +491,84 @@ def test_infinite_light_map_is_seen_where_it_points_and_integrates_like_its_mean
     # pair looks its pdf up in the wrong rows and is over-weighted: the restated result is ~18 % high.  A "fix" of that
     # line would land near 0.98 and fail here.
     assert 1.10 < got < 1.25
+
+
+# ------------------------------------------------------------------ per-vertex normals and uvs (oracle only, CPU)
+def _shaded_floor(material, normal=None, uv_axes=None, reverse=False):
+    """A 100 x 100 floor at y = 0.  normal: the same per-vertex normal at every vertex; uv_axes: (a, b) with
+    u = a . p / 100 + .5 and v = b . p / 100 + .5."""
+    b = scenes.MeshBuilder()
+    m = b.add_material(material)
+    q = [np.array(p, float) for p in ((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50))]
+    for tri in ((0, 1, 2), (0, 2, 3)):
+        p = [q[i] for i in tri]
+        b.add_tri(p[0], p[1], p[2], m, toward=(0, 1, 0), normals=None if normal is None else (normal,) * 3,
+                  uvs=None if uv_axes is None else tuple((np.dot(uv_axes[0], x) / 100 + .5, np.dot(uv_axes[1], x) / 100 + .5) for x in p),
+                  reverse_orientation=reverse)
+    return b
+
+
+def _render_floor(b, light_dir=None, point=None, spp=4, res=9):
+    if light_dir is not None:
+        b.add_distant_light(light_dir, (0, 0, 0), (2.0, 1.0, 0.5))
+    if point is not None:
+        b.add_point_light(point, (4000.0, 3000.0, 2000.0))
+    cam = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, res, res)
+    film = scenes.film_desc(res, res)
+    o = orc.Oracle(b.arrays(), cam, film, scenes.direct_lighting_desc(film, spp, max_depth=1, strategy=abi.DL_SAMPLE_ALL))
+    o.render(0, spp, threads=2)
+    img = o.image().astype(np.float64)
+    o.close()
+    return img
+
+
+def test_shading_normals_replace_the_geometric_normal_in_the_cosine():
+    """Triangle::intersect interpolates the mesh's normals into shading.n (Enigma/TriangleMesh.cpp:291-304,370) and
+    the integrators weight by |wi . shading.n| (Enigma/Integrator.cpp:208): a matte floor whose vertices all carry
+    the tilted normal m reflects Kd/pi * L * |w . m| under a distant light from w."""
+    L = np.array([2.0, 1.0, 0.5])
+    w = np.array([0.3, 0.8, 0.1])
+    w /= np.linalg.norm(w)
+    w = w.astype(np.float32).astype(np.float64)
+    for m in ((0.0, 1.0, 0.0), (0.5, 0.7, -0.2), (-0.5, -0.7, 0.2)):      # the last points below the floor: FaceForward
+        mn = np.asarray(m) / np.linalg.norm(m)
+        img = _render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5)), normal=tuple(mn)), light_dir=tuple(w))
+        want = (0.5 / math.pi) * L * abs(np.dot(w, mn)) * np.linalg.norm(w)
+        assert np.allclose(img, want[None, None, :], rtol=2e-5), (m, img[4, 4], want)
+    flat = _render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5))), light_dir=tuple(w))
+    assert np.allclose(flat, ((0.5 / math.pi) * L * w[1] * np.linalg.norm(w))[None, None, :], rtol=2e-5)
+
+
+def test_uvs_orient_the_anisotropic_tangent_frame():
+    """dpdu follows the mesh's uvs (Enigma/TriangleMesh.cpp:238-262) and the BSDF frame is (dpdu, n x dpdu, n)
+    (Enigma/BxDF.cpp:843-852): turning the uv axes by a quarter turn equals swapping the metal's u / v roughness.
+    A point light and depth 1 make the estimate deterministic."""
+    ex, ez = np.array([1.0, 0, 0]), np.array([0, 0, 1.0])
+    metal = lambda ur, vr: abi.metal(scenes.COPPER_ETA, scenes.COPPER_K, remap=False, uroughness=ur, vroughness=vr)
+    a = _render_floor(_shaded_floor(metal(0.1, 0.5), uv_axes=(ex, ez)), point=(15, 30, 5), res=17)
+    b = _render_floor(_shaded_floor(metal(0.5, 0.1), uv_axes=(ez, -ex)), point=(15, 30, 5), res=17)
+    c = _render_floor(_shaded_floor(metal(0.5, 0.1), uv_axes=(ex, ez)), point=(15, 30, 5), res=17)
+    assert a.max() > 0
+    assert np.allclose(a, b, rtol=2e-4, atol=1e-7)
+    assert not np.allclose(a, c, rtol=0.05)
+    # the default uvs (0,0), (1,0), (1,1) give each triangle its own frame: (p1 - p0) is dpdu
+    d = _render_floor(_shaded_floor(metal(0.1, 0.5)), point=(15, 30, 5), res=17)
+    assert not np.allclose(a, d, rtol=0.05)
+    # degenerate uvs fall back to CoordinateSystem(ng), Enigma/TriangleMesh.cpp:257-262
+    e = _render_floor(_shaded_floor(metal(0.1, 0.5), uv_axes=(ex, ex)), point=(15, 30, 5), res=17)
+    assert np.isfinite(e).all() and e.max() > 0
+
+
+def test_reverse_orientation_turns_the_shading_normal_and_so_the_glass_interface():
+    """ReverseOrientation flips the geometric normal and the shading bitangent (Enigma/TriangleMesh.cpp:288-289,369):
+    with per-vertex normals the shading normal ends up opposite to them, so a glass pane seen from the side its
+    normals point to refracts as if the viewer were inside the glass (eta inverted): the radiance a point light
+    below a rough-glass pane sends through it changes accordingly, exactly as it does for a mesh without normals."""
+    up = (0.0, 1.0, 0.0)
+    glass = abi.glass(1.5, 0.3, 0.3)
+    img = {}
+    for key, normal, rev in (("n", up, False), ("n_rev", up, True), ("flat", None, False), ("flat_rev", None, True)):
+        img[key] = _render_floor(_shaded_floor(glass, normal=normal, reverse=rev), point=(5, -30, 2), res=9)
+    assert np.allclose(img["n"], img["flat"], rtol=1e-4)
+    assert np.allclose(img["n_rev"], img["flat_rev"], rtol=1e-4)
+    assert not np.allclose(img["n"], img["n_rev"], rtol=0.05)

@@ -173,7 +173,7 @@ WorldEnd
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "textures"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
     ('WorldBegin\nMaterial "metal"\nWorldEnd\n', "eta"),
-    ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "normal N" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "normals"),
+    ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),
     ('Sampler "halton"\nWorldBegin\nWorldEnd\n', "sobol"),
     ('Integrator "bdpt"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', "bdpt"),
     ('WorldBegin\nCamera "perspective"\nWorldEnd\n', "world block"),
@@ -284,3 +284,52 @@ def test_media_medium_interfaces_and_the_volpath_integrator(tmp_path):
         f.write_text(head + body)
         p = subprocess.run([EXE, "--dump", str(f), str(tmp_path / "bad.json")], capture_output=True, text=True)
         assert p.returncode != 0 and msg in p.stderr
+
+
+def test_shading_normals_and_uvs_reach_the_mesh(tmp_path):
+    """"normal N" goes through the inverse transpose of the CTM (Enigma/TriangleMesh.cpp:44-48, Enigma/Transform.h:54-59),
+    uvs are taken from "point2 uv" / "float uv" / "st" (Enigma/TriangleMesh.cpp:693-708) and dropped when too few,
+    ReverseOrientation and a mirroring CTM are kept apart (Enigma/TriangleMesh.cpp:288,369)."""
+    sc = scenes.cornell_smooth()
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4)
+    d = dump(tmp_path, text)
+    N, UV, rev = [], [], []
+    for m in d["meshes"]:
+        idx = np.array(m["indices"]).reshape(-1, 3)
+        n = np.array(m["N"], dtype=np.float32).reshape(-1, 3) if m["N"] else None
+        uv = np.array(m["uv"], dtype=np.float32).reshape(-1, 2) if m["uv"] else None
+        for tri in idx:
+            N.append(None if n is None else n[tri])
+            UV.append(None if uv is None else uv[tri])
+            rev.append((m["reverse"], m["reverse_orientation"]))
+    for t in range(sc.indices.shape[0]):
+        fl = int(sc.tri_flags[t])
+        assert (N[t] is not None) == bool(fl & abi.TRI_HAS_NORMALS) and (UV[t] is not None) == bool(fl & abi.TRI_HAS_UVS)
+        if N[t] is not None:
+            assert np.allclose(N[t], sc.normals[sc.indices[t]], rtol=1e-6, atol=1e-7)
+        if UV[t] is not None:
+            assert np.array_equal(UV[t], sc.uvs[sc.indices[t]])
+        assert rev[t] == (fl & 1, 1 if fl & abi.TRI_REVERSE_ORIENTATION else 0)
+    head = '''
+LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" 60
+Film "image" "integer xresolution" 8 "integer yresolution" 8
+Sampler "sobol" "integer pixelsamples" 1
+Integrator "path"
+WorldBegin
+'''
+    d = dump(tmp_path, head + '''
+AttributeBegin
+  Scale 2 4 -1
+  Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 0 0  0 1 0  0 0 1] "normal N" [1 0 0  0 1 0  1 1 1] "point2 st" [0 0  1 0  0 1]
+AttributeEnd
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 0 0  0 1 0  0 0 1] "float uv" [0 0 1 0]
+WorldEnd
+''')
+    m0, m1 = d["meshes"]
+    assert np.allclose(np.array(m0["N"]).reshape(3, 3), [[0.5, 0, 0], [0, 0.25, 0], [0.5, 0.25, -1]])   # n * M^-1
+    assert np.allclose(np.array(m0["uv"]).reshape(3, 2), [[0, 0], [1, 0], [0, 1]])
+    assert m0["reverse"] == 1 and m0["reverse_orientation"] == 0                                          # the mirror flips ng only
+    assert m1["uv"] == [] and m1["N"] == []                                                                # too few uvs: discarded
+    err = dump(tmp_path, head + 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 0 0  0 1 0  0 0 1] "vector S" [1 0 0 1 0 0 1 0 0]\nWorldEnd\n', expect_fail=True)
+    assert "tangents" in err
