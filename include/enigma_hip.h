@@ -52,7 +52,31 @@ typedef struct EnigmaMaterial {
     float uroughness;         /* metal / glass: u roughness; plastic: roughness */
     float vroughness;         /* metal / glass: v roughness; plastic: roughness */
     float index;              /* glass: index of refraction */
+    /* Image textures bound to the spectrum parameters: index + 1 into EnigmaSceneDesc.textures, 0 = the constant
+     * above (a ConstantTexture, Enigma/Texture.h:119-131).  The float parameters stay constants. */
+    uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_eta, tex_k;
 } EnigmaMaterial;
+
+/* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (Enigma/Texture.h:313-415, Enigma/Texture.cpp:22-29,412-453).
+ * Two properties of the reference are kept because they decide the picture:
+ *  - without "trilinear" the EWA path takes the component count of its differential vectors for their length
+ *    (Enigma/MipMap.h:380-381), which puts every lookup on the coarsest MIP level: the texture evaluates to the
+ *    image's average colour wherever it is looked up;
+ *  - "gamma" reaches TexInfo::m_gamma as a bool turned float and is used as the EXPONENT of the conversion
+ *    pow(texel * scale, m_gamma) (Enigma/Texture.h:375-380, Enigma/Texture.cpp:449-451): 1 keeps the texels, 0 makes
+ *    every texel 1.
+ * With "trilinear", camera rays are filtered with their ray differentials (Enigma/Interaction.cpp:161-209,
+ * Enigma/MipMap.h:354-376) and every later ray reads level 0 bilinearly (SpawnRay drops the differentials). */
+enum { ENIGMA_WRAP_REPEAT = 0, ENIGMA_WRAP_BLACK = 1, ENIGMA_WRAP_CLAMP = 2 };
+typedef struct EnigmaTexture {
+    uint32_t width, height; /* power-of-two sides (the reference resamples other sizes first, MipMap.h:121-127) */
+    const float* rgb;       /* [height*width*3] as ReadImage returns them: top row first, before scale and gamma */
+    float scale;            /* TexInfo::m_scale */
+    float gamma;            /* TexInfo::m_gamma, the exponent (see above) */
+    uint32_t trilinear;     /* TexInfo::m_doTrilinear */
+    uint32_t wrap;          /* ENIGMA_WRAP_* */
+    float su, sv, du, dv;   /* UVMapping2D: st = (su * u + du, sv * v + dv) */
+} EnigmaTexture;
 
 /* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651), SpotLight (:133-190),
  * DistantLight (:656-708).  One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
@@ -127,6 +151,8 @@ typedef struct EnigmaSceneDesc {
     const EnigmaMedium* media;
     const int32_t* tri_medium_inside;
     const int32_t* tri_medium_outside;
+    uint32_t n_textures;            /* image textures the materials' tex_* fields index */
+    const EnigmaTexture* textures;
 } EnigmaSceneDesc;
 
 /* PerspectiveCamera state read by GenerateRayDifferential (Enigma/Camera.cpp:144-192):

@@ -171,6 +171,13 @@ struct Ray {
     mutable float tMax = InfinityF32;
     float time = 0;
     int medium = -1; // Ray::m_medium as an index into Scene::media (-1 = none); read by the VolPathIntegrator only
+    // RayDifferential (Ray.h:44-60): set by the camera, dropped by every SpawnRay (Ray.cpp:44-47)
+    bool hasDifferentials = false;
+    Vec3 rxOrigin, ryOrigin, rxDirection, ryDirection;
+    void scaleDifferentials(float s) { // Ray.cpp:60-66
+        rxOrigin = o + (rxOrigin - o) * s; ryOrigin = o + (ryOrigin - o) * s;
+        rxDirection = d + (rxDirection - d) * s; ryDirection = d + (ryDirection - d) * s;
+    }
     Ray() {}
     Ray(Vec3 o_, Vec3 d_, float t = InfinityF32, float tm = 0) : o(o_), d(d_), tMax(t), time(tm) {}
 };
@@ -226,12 +233,15 @@ static float PowerHeuristic(int nf, float fPdf, int ng, float gPdf) {
     return (f * f) / (f * f + g * g);
 }
 
-// Camera.cpp:144-192 -- main ray only.  The rx/ry differentials feed texture
-// filtering and bump mapping only (Interaction.cpp:161-209); with constant
-// textures they never reach the radiance, so they are not computed.
+// Camera.cpp:102-109,144-192.  The rx/ry differentials feed texture filtering (Interaction.cpp:161-209).
 struct PerspectiveCamera {
     Mat4 rasterToCamera, cameraToWorld;
     float lensRadius = 0, focalDistance = 0;
+    Vec3 dxCamera, dyCamera;
+    void init() {
+        dxCamera = rasterToCamera.transformPoint(Vec3(1, 0, 0)) - rasterToCamera.transformPoint(Vec3(0, 0, 0));
+        dyCamera = rasterToCamera.transformPoint(Vec3(0, 1, 0)) - rasterToCamera.transformPoint(Vec3(0, 0, 0));
+    }
     float GenerateRay(const CameraSample& sample, Ray* ray) const {
         Vec3 Pras(sample.image.x, sample.image.y, 0);
         Vec3 Pcamera = rasterToCamera.transformPoint(Pras);
@@ -243,6 +253,23 @@ struct PerspectiveCamera {
             ray->o = Vec3(lens.x, lens.y, 0.f);
             ray->d = Normalize(Pfocus - ray->o);
         }
+        if (lensRadius > 0.) { // Camera.cpp:164-181
+            Vec2 lens = ConcentricSampleDisk(sample.lens) * lensRadius;
+            Vec3 dx = Normalize(Pcamera + dxCamera);
+            float ft = focalDistance / dx.z;
+            Vec3 pFocus = Vec3(0, 0, 0) + (ft * dx);
+            ray->rxOrigin = Vec3(lens.x, lens.y, 0.f);
+            ray->rxDirection = Normalize(pFocus - ray->rxOrigin);
+            Vec3 dy = Normalize(Pcamera + dyCamera);
+            ft = focalDistance / dy.z;
+            pFocus = Vec3(0, 0, 0) + (ft * dy);
+            ray->ryOrigin = Vec3(lens.x, lens.y, 0.f);
+            ray->ryDirection = Normalize(pFocus - ray->ryOrigin);
+        } else {
+            ray->rxOrigin = ray->ryOrigin = ray->o;
+            ray->rxDirection = Normalize(Pcamera + dxCamera);
+            ray->ryDirection = Normalize(Pcamera + dyCamera);
+        }
         ray->time = sample.time;
         // AnimatedTransform::interpolateRayDifferential, not animated (Transform.cpp:417-420)
         // -> Transform::transformRayDifferential (Transform.h:68-80)
@@ -250,6 +277,9 @@ struct PerspectiveCamera {
         Vec3 o = cameraToWorld.transformPoint(ray->o);
         ray->d = d;
         ray->o = o;
+        ray->rxOrigin = cameraToWorld.transformPoint(ray->rxOrigin); ray->ryOrigin = cameraToWorld.transformPoint(ray->ryOrigin);
+        ray->rxDirection = cameraToWorld.transformVector(ray->rxDirection); ray->ryDirection = cameraToWorld.transformVector(ray->ryDirection);
+        ray->hasDifferentials = true;
         return 1.f;
     }
 };
@@ -445,6 +475,36 @@ struct SurfaceInteraction : Interaction {
     Vec2 uv; Vec3 dpdu, dpdv;
     struct { Vec3 n, dpdu, dpdv; } shading;
     int primIndex = -1; // GeometricPrimitive (creation order index)
+    mutable float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    // Interaction.cpp:161-209 (dpdx / dpdy feed bump mapping and specular ray differentials only)
+    void ComputeDifferentials(const Ray& ray) const {
+        dudx = dvdx = dudy = dvdy = 0;
+        if (!ray.hasDifferentials) return;
+        float d = Dot(n, p);
+        float tx = -(Dot(n, ray.rxOrigin) - d) / Dot(n, ray.rxDirection);
+        if (std::isinf(tx) || std::isnan(tx)) return;
+        Vec3 px = ray.rxOrigin + tx * ray.rxDirection;
+        float ty = -(Dot(n, ray.ryOrigin) - d) / Dot(n, ray.ryDirection);
+        if (std::isinf(ty) || std::isnan(ty)) return;
+        Vec3 py = ray.ryOrigin + ty * ray.ryDirection;
+        int dim[2];
+        if (std::abs(n.x) > std::abs(n.y) && std::abs(n.x) > std::abs(n.z)) { dim[0] = 1; dim[1] = 2; }
+        else if (std::abs(n.y) > std::abs(n.z)) { dim[0] = 0; dim[1] = 2; }
+        else { dim[0] = 0; dim[1] = 1; }
+        float A[2][2] = {{dpdu[dim[0]], dpdv[dim[0]]}, {dpdu[dim[1]], dpdv[dim[1]]}};
+        float Bx[2] = {px[dim[0]] - p[dim[0]], px[dim[1]] - p[dim[1]]};
+        float By[2] = {py[dim[0]] - p[dim[0]], py[dim[1]] - p[dim[1]]};
+        auto solve = [](const float A[2][2], const float B[2], float* x0, float* x1) { // SolveLinearSystem2x2, Transform.cpp:190-200
+            float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+            if (std::fabs(det) < 1e-10f) return false;
+            *x0 = (A[1][1] * B[0] - A[0][1] * B[1]) / det;
+            *x1 = (A[0][0] * B[1] - A[1][0] * B[0]) / det;
+            if (std::isnan(*x0) || std::isnan(*x1)) return false;
+            return true;
+        };
+        if (!solve(A, Bx, &dudx, &dvdx)) dudx = dvdx = 0;
+        if (!solve(A, By, &dudy, &dvdy)) dudy = dvdy = 0;
+    }
 };
 
 struct Scene; // fwd
@@ -1323,11 +1383,21 @@ struct BSDF {
 
 // Material.cpp:76-93,115-136,176-220,232-255 with ConstantTexture parameters
 static Spectrum spec3(const float v[3]) { return Spectrum(v[0], v[1], v[2]); }
-static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes) {
+// A spectrum parameter is a ConstantTexture (Texture.h:119-131) or, when the material binds one, an ImageTexture.
+struct TextureSet;
+static Spectrum EvaluateImageTexture(const TextureSet& ts, uint32_t index, const SurfaceInteraction& si);
+struct ParamEval {
+    const TextureSet* ts; const SurfaceInteraction& si;
+    Spectrum operator()(const float v[3], uint32_t tex) const { return tex && ts ? EvaluateImageTexture(*ts, tex - 1, si) : Spectrum(v[0], v[1], v[2]); }
+};
+// SurfaceInteraction::ComputeScatteringFunctions (Interaction.cpp:152-159): differentials first, then the material
+static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes, const Ray& ray, const TextureSet* ts) {
+    si.ComputeDifferentials(ray);
+    ParamEval spec3{ts, si};
     switch (m.type) {
     case ENIGMA_MAT_MATTE: {
         BSDF* bsdf = new BSDF(si);
-        Spectrum r = spec3(m.kd).Clamp();
+        Spectrum r = spec3(m.kd, m.tex_kd).Clamp();
         float sig = clampf(m.sigma, 0.f, 90.f);
         if (!r.IsBlack()) {
             if (sig == 0) bsdf->addBxDF(new LambertianReflection(r));
@@ -1342,14 +1412,14 @@ static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceIn
             uRough = TrowbridgeReitzDistribution::RoughnessToAlpha(uRough);
             vRough = TrowbridgeReitzDistribution::RoughnessToAlpha(vRough);
         }
-        Fresnel* frMf = new FresnelConductor(1., spec3(m.eta), spec3(m.k));
+        Fresnel* frMf = new FresnelConductor(1., spec3(m.eta, m.tex_eta), spec3(m.k, m.tex_k));
         bsdf->distrib.reset(new TrowbridgeReitzDistribution(uRough, vRough));
         bsdf->addBxDF(new MicrofacetReflection(1., bsdf->distrib.get(), frMf));
         return bsdf;
     }
     case ENIGMA_MAT_GLASS: {
         float eta = m.index, urough = m.uroughness, vrough = m.vroughness;
-        Spectrum R = spec3(m.kr).Clamp(), T = spec3(m.kt).Clamp();
+        Spectrum R = spec3(m.kr, m.tex_kr).Clamp(), T = spec3(m.kt, m.tex_kt).Clamp();
         BSDF* bsdf = new BSDF(si, eta);
         if (R.IsBlack() && T.IsBlack()) return bsdf;
         bool isSpecular = urough == 0 && vrough == 0;
@@ -1375,9 +1445,9 @@ static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceIn
     }
     case ENIGMA_MAT_PLASTIC: {
         BSDF* bsdf = new BSDF(si);
-        Spectrum kd = spec3(m.kd).Clamp();
+        Spectrum kd = spec3(m.kd, m.tex_kd).Clamp();
         if (!kd.IsBlack()) bsdf->addBxDF(new LambertianReflection(kd));
-        Spectrum ks = spec3(m.ks).Clamp();
+        Spectrum ks = spec3(m.ks, m.tex_ks).Clamp();
         if (!ks.IsBlack()) {
             Fresnel* fresnel = new FresnelDielectric(1.5f, 1.f);
             float rough = m.uroughness;
@@ -1428,6 +1498,8 @@ struct Distribution1D { // MonteCarlo.h:15-84
 struct MipMapRGB {
     std::vector<std::vector<Spectrum>> level; std::vector<int> lw, lh;
     float weightLut[128];
+    int wrap = 0;             // eImageWrapMode: 0 repeat, 1 black, 2 clamp
+    bool doTrilinear = false; // m_doTrilinear
     int levels() const { return (int)level.size(); }
     void build(int w, int h, const std::vector<Spectrum>& img) { // power-of-two sizes only (the resize step is not restated)
         for (int i = 0; i < 128; ++i) { float alpha = 2; float r2 = float(i) / float(128 - 1); weightLut[i] = expf(-alpha * r2) - expf(-alpha); }
@@ -1442,7 +1514,10 @@ struct MipMapRGB {
                     level[i][(size_t)t * sRes + s] = .25f * (texel(i - 1, 2 * s, 2 * t) + texel(i - 1, 2 * s + 1, 2 * t) + texel(i - 1, 2 * s, 2 * t + 1) + texel(i - 1, 2 * s + 1, 2 * t + 1));
         }
     }
-    const Spectrum& texel(int l, int s, int t) const { // TEXTURE_WRAP_REPEAT: int % unsigned (MipMap.h:337-339)
+    const Spectrum& texel(int l, int s, int t) const { // MipMap.h:327-352; TEXTURE_WRAP_REPEAT is int % unsigned
+        static const Spectrum black(0.f);
+        if (wrap == 2) { s = std::clamp(s, 0, lw[l] - 1); t = std::clamp(t, 0, lh[l] - 1); }
+        else if (wrap == 1) { if (s < 0 || s >= lw[l] || t < 0 || t >= lh[l]) return black; }
         uint32_t us = (uint32_t)s % (uint32_t)lw[l], ut = (uint32_t)t % (uint32_t)lh[l];
         return level[l][(size_t)ut * lw[l] + us];
     }
@@ -1492,9 +1567,16 @@ struct MipMapRGB {
         }
         return sum / sumWts;
     }
-    Spectrum lookup(const Vec2& st, Vec2 dst0, Vec2 dst1) const { // m_doTrilinear = false, m_maxAnisotropy = 8 (MipMap.h:60-61)
+    Spectrum lookup(const Vec2& st, Vec2 dst0, Vec2 dst1) const { // MipMap.h:369-396, m_maxAnisotropy = 8
+        if (doTrilinear) {
+            float width = std::max(std::max(std::abs(dst0[0]), std::abs(dst0[1])), std::max(std::abs(dst1[0]), std::abs(dst1[1])));
+            return lookup(st, width);
+        }
         if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) std::swap(dst0, dst1);
-        float majorLength = std::sqrt(dst0.x * dst0.x + dst0.y * dst0.y), minorLength = std::sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+        // sic: MipMap.h:380-381 call dst0.length() / dst1.length(); on the reference's glm vectors (Defines.h:72) that member is
+        // the COMPONENT COUNT, 2, not the Euclidean length -- so the level of detail is always levels() and both EWA calls
+        // below return the coarsest texel
+        float majorLength = 2.f, minorLength = 2.f;
         if (minorLength * 8.0f < majorLength && minorLength > 0) {
             float scale = majorLength / (minorLength * 8.0f);
             dst1.x *= scale; dst1.y *= scale;
@@ -1647,7 +1729,18 @@ struct Light {
     }
 };
 
+// ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (Texture.h:313-415, Texture.cpp:22-29,412-453)
+struct ImageTex { MipMapRGB mip; float su = 1, sv = 1, du = 0, dv = 0; };
+struct TextureSet { std::vector<ImageTex> tex; };
+static Spectrum EvaluateImageTexture(const TextureSet& ts, uint32_t index, const SurfaceInteraction& si) {
+    const ImageTex& t = ts.tex[index];
+    Vec2 dstdx(t.su * si.dudx, t.sv * si.dvdx), dstdy(t.su * si.dudy, t.sv * si.dvdy);
+    Vec2 st(t.su * si.uv[0] + t.du, t.sv * si.uv[1] + t.dv);
+    return t.mip.lookup(st, dstdx, dstdy);
+}
+
 struct Scene {
+    TextureSet textures;
     TriangleMesh mesh;
     std::vector<Triangle> tris;
     std::vector<uint32_t> triMaterial; std::vector<int32_t> triLight; std::vector<uint32_t> primId;
@@ -1755,7 +1848,7 @@ struct PathIntegrator {
                 else for (const Light& light : scene.lights) if (light.flags & 8) L += beta * light.LeRay(ray); // scene.m_infiniteLights
             }
             if (!foundIntersection || bounces >= maxDepth) break;
-            std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true));
+            std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
             const Distribution1D* distrib = lightDistrib.get();
             if (bsdf->numComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                 Spectrum Ld = beta * UniformSampleOneLight(isect, *bsdf, scene, sampler, distrib);
@@ -1993,7 +2086,7 @@ struct VolPathIntegrator {
                     bounces--;
                     continue;
                 }
-                std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true));
+                std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
                 L += beta * UniformSampleOneLightVol(isect, isect.shading.n, bsdf.get(), 0.f, scene, sampler, lightDistrib);
                 Vec3 wo = -ray.d, wi;
                 float pdf = 0;
@@ -2067,7 +2160,7 @@ struct DirectLightingIntegrator {
             return L;
         }
         // allowMultipleLobes defaults to false here (Interaction.h:68): smooth glass = two specular lobes
-        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false));
+        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false, ray, &scene.textures));
         Vec3 wo = isect.wo;
         L += Le(scene, isect, wo);
         if (scene.lights.size() > 0) {
@@ -2157,6 +2250,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
                         CameraSample cameraSample = tileSampler.GetCameraSample(pixel);
                         Ray ray;
                         float rayWeight = O.camera.GenerateRay(cameraSample, &ray);
+                        ray.scaleDifferentials(1 / std::sqrt((float)tileSampler.samplesPerPixel)); // Integrator.cpp:276
                         tl_counters->samples++;
                         Spectrum L(0.f);
                         if (rayWeight > 0) L = O.useDirect ? O.direct.Li(ray, O.scene, tileSampler, 0) : O.useVolPath ? O.volpath.Li(ray, O.scene, tileSampler) : O.integrator.Li(ray, O.scene, tileSampler);
@@ -2245,8 +2339,27 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         sc.triInside.assign(s->tri_medium_inside, s->tri_medium_inside + s->n_triangles);
         sc.triOutside.assign(s->tri_medium_outside, s->tri_medium_outside + s->n_triangles);
     }
-    for (auto& m : sc.materials)
+    for (auto& m : sc.materials) {
         if (m.type == ENIGMA_MAT_MATTE && m.sigma != 0) { h->o.error = "Oren-Nayar is not restated"; return -4; }
+        for (uint32_t t : {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_eta, m.tex_k})
+            if (t > s->n_textures) { h->o.error = "texture index out of range"; return -1; }
+    }
+    // ImageTexture::getTexture (Texture.h:331-372): flip in y, ConvertIn = pow(texel * scale, gamma), MipMap
+    sc.textures.tex.clear(); sc.textures.tex.resize(s->n_textures);
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const EnigmaTexture& t = s->textures[i];
+        const int w = (int)t.width, hgt = (int)t.height;
+        if (w <= 0 || hgt <= 0 || (w & (w - 1)) || (hgt & (hgt - 1))) { h->o.error = "textures must have power-of-two sizes (MipMap::resizeImage is not restated)"; return -4; }
+        std::vector<Spectrum> px((size_t)w * hgt);
+        for (size_t k = 0; k < px.size(); ++k) px[k] = Spectrum(t.rgb[3 * k], t.rgb[3 * k + 1], t.rgb[3 * k + 2]);
+        for (int y = 0; y < hgt / 2; ++y)
+            for (int x = 0; x < w; ++x) std::swap(px[(size_t)y * w + x], px[(size_t)(hgt - 1 - y) * w + x]);
+        for (Spectrum& c : px) { Spectrum v = c * t.scale; c = Spectrum(std::pow(v.c[0], t.gamma), std::pow(v.c[1], t.gamma), std::pow(v.c[2], t.gamma)); }
+        ImageTex& T = sc.textures.tex[i];
+        T.mip.wrap = (int)t.wrap; T.mip.doTrilinear = t.trilinear != 0;
+        T.mip.build(w, hgt, px);
+        T.su = t.su; T.sv = t.sv; T.du = t.du; T.dv = t.dv;
+    }
     sc.lights.resize(s->n_lights);
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const EnigmaLight& l = s->lights[i];
@@ -2290,6 +2403,7 @@ int oracle_camera_set(OracleCtx* h, const EnigmaCameraDesc* c) {
     memcpy(h->o.camera.rasterToCamera.m, c->raster_to_camera, 64);
     memcpy(h->o.camera.cameraToWorld.m, c->camera_to_world, 64);
     h->o.camera.lensRadius = c->lens_radius; h->o.camera.focalDistance = c->focal_distance;
+    h->o.camera.init();
     return 0;
 }
 int oracle_film_config(OracleCtx* h, const EnigmaFilmDesc* f) { h->o.film.reset(new Film(*f)); return 0; }
@@ -2347,6 +2461,12 @@ int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_
     if (!h->o.useVolPath)
         for (uint32_t m : h->o.scene.triMaterial)
             if (m == ENIGMA_NO_MATERIAL) { h->o.error = "surfaces without a material are restated for the VolPathIntegrator only"; return -4; }
+    if (h->o.useDirect) { // SpecularReflect / SpecularTransmit carry ray differentials on (Integrator.cpp:329-444): not restated
+        bool trilinear = false, smoothGlass = false;
+        for (const ImageTex& t : h->o.scene.textures.tex) trilinear = trilinear || t.mip.doTrilinear;
+        for (const EnigmaMaterial& m : h->o.scene.materials) smoothGlass = smoothGlass || (m.type == ENIGMA_MAT_GLASS && m.uroughness == 0 && m.vroughness == 0);
+        if (trilinear && smoothGlass) { h->o.error = "trilinear textures with specular recursion of the DirectLightingIntegrator are not restated"; return -4; }
+    }
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency(); // NumSystemCores, Misc.h:8-14
     Render(h->o, sample_begin, sample_end, n_threads, want_moments != 0);
     return 0;
@@ -2470,7 +2590,7 @@ int oracle_debug_bsdf(const EnigmaMaterial* m, uint32_t n, const float* wo3, con
     SurfaceInteraction si;
     si.n = si.shading.n = Vec3(0, 0, 1); si.dpdu = si.shading.dpdu = Vec3(1, 0, 0); si.dpdv = si.shading.dpdv = Vec3(0, 1, 0);
     for (uint32_t i = 0; i < n; ++i) {
-        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(*m, si, true));
+        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(*m, si, true, Ray(), nullptr));
         Vec3 wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
         float* o = &out12[12 * (size_t)i];
         Spectrum f = bsdf->f(wo, wi, BSDF_ALL);

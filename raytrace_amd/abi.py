@@ -18,7 +18,17 @@ class EnigmaMaterial(C.Structure):
     _fields_ = [("type", C.c_uint32), ("remap_roughness", C.c_uint32),
                 ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("kr", C.c_float * 3), ("kt", C.c_float * 3),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3),
-                ("sigma", C.c_float), ("uroughness", C.c_float), ("vroughness", C.c_float), ("index", C.c_float)]
+                ("sigma", C.c_float), ("uroughness", C.c_float), ("vroughness", C.c_float), ("index", C.c_float),
+                ("tex_kd", C.c_uint32), ("tex_ks", C.c_uint32), ("tex_kr", C.c_uint32), ("tex_kt", C.c_uint32),
+                ("tex_eta", C.c_uint32), ("tex_k", C.c_uint32)]
+
+
+WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
+
+
+class EnigmaTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.c_void_p), ("scale", C.c_float), ("gamma", C.c_float),
+                ("trilinear", C.c_uint32), ("wrap", C.c_uint32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float)]
 
 
 class EnigmaLight(C.Structure):
@@ -39,7 +49,8 @@ class EnigmaSceneDesc(C.Structure):
                 ("normals", C.c_void_p), ("uvs", C.c_void_p),
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32),
                 ("materials", C.c_void_p), ("lights", C.c_void_p),
-                ("n_media", C.c_uint32), ("media", C.c_void_p), ("tri_medium_inside", C.c_void_p), ("tri_medium_outside", C.c_void_p)]
+                ("n_media", C.c_uint32), ("media", C.c_void_p), ("tri_medium_inside", C.c_void_p), ("tri_medium_outside", C.c_void_p),
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p)]
 
 
 class EnigmaCameraDesc(C.Structure):
@@ -82,7 +93,7 @@ class SceneArrays:
     """Owns the numpy arrays an EnigmaSceneDesc points into."""
 
     def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None,
-                 media=(), tri_medium_inside=None, tri_medium_outside=None, normals=None, uvs=None):
+                 media=(), tri_medium_inside=None, tri_medium_outside=None, normals=None, uvs=None, textures=()):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nt = self.indices.shape[0]
@@ -98,6 +109,9 @@ class SceneArrays:
         self.tri_medium_inside = None if tri_medium_inside is None else np.ascontiguousarray(tri_medium_inside, dtype=np.int32).reshape(nt)
         self.tri_medium_outside = None if tri_medium_outside is None else np.ascontiguousarray(tri_medium_outside, dtype=np.int32).reshape(nt)
         self.materials = (EnigmaMaterial * max(1, len(materials)))(*materials)
+        self.textures = (EnigmaTexture * max(1, len(textures)))(*textures)
+        self._texture_maps = [getattr(t, "_map", None) for t in textures]   # the arrays rgb points into
+        self.n_textures = len(textures)
         self.lights = (EnigmaLight * max(1, len(lights)))(*lights)
         self._light_maps = [getattr(l, "_map", None) for l in lights]   # the arrays map_rgb points into
         self.n_lights = len(lights)
@@ -123,7 +137,24 @@ class SceneArrays:
         d.media = C.cast(self.media, C.c_void_p) if self.n_media else None
         d.tri_medium_inside = ptr(self.tri_medium_inside)
         d.tri_medium_outside = ptr(self.tri_medium_outside)
+        d.n_textures = self.n_textures
+        d.textures = C.cast(self.textures, C.c_void_p) if self.n_textures else None
         return d
+
+
+def image_texture(rgb, trilinear=False, gamma=True, scale=1.0, wrap=WRAP_REPEAT, su=1.0, sv=1.0, du=0.0, dv=0.0):
+    """CreateImageSpectrumTexture (Enigma/Texture.cpp:412-453) for texels already read: rgb is [height, width, 3],
+    top row first.  gamma is the reference's bool (it ends up as the exponent 1 or 0 of the conversion)."""
+    t = EnigmaTexture()
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    assert a.ndim == 3 and a.shape[2] == 3
+    t._map = a
+    t.height, t.width = a.shape[0], a.shape[1]
+    t.rgb = a.ctypes.data_as(C.c_void_p)
+    t.scale, t.gamma = scale, 1.0 if gamma else 0.0
+    t.trilinear, t.wrap = int(bool(trilinear)), wrap
+    t.su, t.sv, t.du, t.dv = su, sv, du, dv
+    return t
 
 
 def matte(kd, sigma=0.0):

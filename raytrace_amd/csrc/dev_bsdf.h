@@ -191,7 +191,7 @@ DEV F3 toWorld(const Bsdf& b, F3 v) {
 
 // Material::computeScatteringFunctions for the four materials (Enigma/Material.cpp:76-93,115-136,176-220,232-255).
 template <int MK>
-DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b) {
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b, const float4* texColors = nullptr) {
     b->ng = ng;
     b->ss = normalize(dpdu);
     b->ts = cross(ns, b->ss);
@@ -201,6 +201,10 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b) {
     b->cEta = F3(0.f); b->cK = F3(0.f);
     b->dEtaI = 1.f; b->dEtaT = 1.f;
     bool nb0 = m.flags & 1u, nb1 = m.flags & 2u;
+    if (texColors && (m.tex0 | m.tex1)) { // the texture's value at this hit replaces the constant; Spectrum::Clamp() for all but the metal's eta / k
+        if (m.tex0) { float4 c = texColors[0]; b->col0 = MK == MK_METAL ? F3(c.x, c.y, c.z) : F3(smax(c.x, 0.f), smax(c.y, 0.f), smax(c.z, 0.f)); nb0 = b->col0.x != 0.f || b->col0.y != 0.f || b->col0.z != 0.f; }
+        if (m.tex1) { float4 c = texColors[1]; b->col1 = MK == MK_METAL ? F3(c.x, c.y, c.z) : F3(smax(c.x, 0.f), smax(c.y, 0.f), smax(c.z, 0.f)); nb1 = b->col1.x != 0.f || b->col1.y != 0.f || b->col1.z != 0.f; }
+    }
     b->has0 = nb0; b->has1 = false;
     if (MK == MK_METAL) {
         b->cEta = b->col0; b->cK = b->col1; b->col0 = F3(1.f); b->has0 = true;

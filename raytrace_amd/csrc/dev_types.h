@@ -24,7 +24,8 @@ struct DevMaterial {        // 64 bytes
     float alphax, alphay;   // TrowbridgeReitz alphas after remap + clamp (Enigma/MicrofacetDist.cpp:256-263,323-328)
     float c0[3]; float eta; // matte/plastic: Kd.  metal: eta rgb.  glass: Kr; eta = index
     float c1[3]; float pad; // plastic: Ks.  metal: k rgb.  glass: Kt
-    float pad2[4];
+    uint32_t tex0, tex1;    // device texture index + 1 bound to c0 / c1 (trilinear image textures), 0 = the constant
+    float pad2[2];
 };
 
 static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
@@ -65,6 +66,13 @@ struct DevEnvMap {
 //   v0 = {p0.xyz, bits(original triangle index)}
 //   v1 = {p1.xyz, bits(material index [0:24) | material kind [24:27) | flip << 31)}
 //   v2 = {p2.xyz, bits(light index or -1)}
+struct DevTexture {         // a trilinear ImageTexture: the MipMap pyramid (level 0 first) and its UVMapping2D
+    const float4* texels;
+    uint32_t w, h, nLevels, wrap; // wrap: 0 repeat, 1 black, 2 clamp
+    float su, sv, du, dv;
+    uint32_t levelOff[16];  // first texel of each level
+};
+
 struct DevScene {
     const float4* nodes;        // 4-wide BVH nodes, 8 float4 each
     const float4* tris;         // triangles in BVH order, 3 float4 each
@@ -79,6 +87,8 @@ struct DevScene {
     const DevMedium* media;     // VolPathIntegrator only
     const float4* triShade;     // 4 float4 per triangle (device order): (n0, u0) (n1, u1) (n2, u2) (v0, v1, v2, -), read for triangles whose
                                 // second word flags per-vertex normals or uvs; nullptr = no mesh has either
+    const DevTexture* textures; // trilinear image textures; nullptr = none
+    float4* texColors;          // two float4 per path: the textured colours k_texture evaluated at the path's hit
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;
     int nLights;
@@ -201,5 +211,9 @@ DEV uint32_t stMedium(uint32_t s) { return s & 0xfffu; } // medium + 1, 0 = none
 DEV uint32_t stDim(uint32_t s) { return (s >> 12) & 0x3ffu; }
 DEV uint32_t stBounces(uint32_t s) { return (s >> 22) & 0xffu; }
 DEV uint32_t stSpec(uint32_t s) { return (s >> 30) & 1u; }
+// bit 31: the ray is no longer the camera's own ray although no bounce has been counted (a VolPath ray continued
+// through a material-less surface): it carries no ray differentials (Enigma/VolPathIntegrator.cpp:108, Enigma/Ray.cpp:44-47)
+constexpr uint32_t kStNoDifferentials = 1u << 31;
+DEV bool stNoDifferentials(uint32_t s) { return (s >> 31) != 0; }
 
 } // namespace edev

@@ -5,6 +5,7 @@
 
 #include "bvh_build.h"
 #include "kernels_vol.h"
+#include "kernels_tex.h"
 #include "envmap_host.h"
 #include <memory>
 #include "sobol_host.h"
@@ -66,6 +67,10 @@ struct EnigmaCtx {
     DevBuf<uint32_t> infiniteLights;
     DevBuf<uint32_t> triMedium;
     DevBuf<float4> triShade;
+    DevBuf<float4> texTexels, texColors;
+    DevBuf<DevTexture> textures;
+    bool kindTextured[MK_COUNT] = {false, false, false, false, false};
+    bool haveTrilinear = false, smoothGlass = false;
     bool haveNoMaterial = false; // some triangle has no material (a medium boundary): VolPathIntegrator only
     std::vector<DevLight> hostLights;
     std::vector<float> lightPower; // Light::Power().y() per light
@@ -155,7 +160,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shRec.release();
-    h->media.release(); h->triMedium.release(); h->triShade.release();
+    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
@@ -204,9 +209,47 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
                           s->tri_medium_outside[t] >= (int32_t)s->n_media))
             return h->fail(ENIGMA_E_INVALID, "medium index out of range at triangle %u", t);
     }
-    // materials (Enigma/Material.cpp:76-255 parameter evaluation with constant textures)
+    // image textures (ImageTexture::getTexture, Enigma/Texture.h:331-372): flip in y, pow(texel * scale, gamma), MipMap.
+    // A texture without "trilinear" evaluates to its coarsest texel everywhere (Enigma/MipMap.h:380-395: the EWA path
+    // takes the component count of its differential vectors for their length), so it becomes a constant here.
+    if (s->n_textures && !s->textures) return h->fail(ENIGMA_E_INVALID, "null texture array");
+    std::vector<enigma::Rgb> texConstant(s->n_textures);
+    std::vector<uint32_t> texDevice(s->n_textures, 0u); // device index + 1 of the trilinear ones
+    std::vector<DevTexture> devTex;
+    std::vector<float4> texels;
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const EnigmaTexture& t = s->textures[i];
+        if (!t.rgb || !t.width || !t.height) return h->fail(ENIGMA_E_INVALID, "texture %u has no texels", i);
+        if ((t.width & (t.width - 1)) || (t.height & (t.height - 1)) || t.width > 32768u || t.height > 32768u)
+            return h->fail(ENIGMA_E_UNSUPPORTED, "texture %u is %u x %u: sides must be powers of two up to 32768 (the reference resamples other sizes)", i, t.width, t.height);
+        if (t.wrap > 2u) return h->fail(ENIGMA_E_INVALID, "texture %u: unknown wrap mode %u", i, t.wrap);
+        const int w = (int)t.width, hh = (int)t.height;
+        std::vector<enigma::Rgb> px((size_t)w * hh);
+        for (int y = 0; y < hh; ++y)
+            for (int x = 0; x < w; ++x) {
+                const float* c = &t.rgb[3 * ((size_t)(hh - 1 - y) * w + x)];
+                px[(size_t)y * w + x] = enigma::Rgb{std::pow(c[0] * t.scale, t.gamma), std::pow(c[1] * t.scale, t.gamma), std::pow(c[2] * t.scale, t.gamma)};
+            }
+        enigma::EnvPyramid pyr;
+        pyr.wrap = (int)t.wrap;
+        pyr.build(w, hh, std::move(px));
+        texConstant[i] = pyr.texel(pyr.levels() - 1, 0, 0);
+        if (!t.trilinear) continue;
+        DevTexture d{};
+        d.w = t.width; d.h = t.height; d.nLevels = (uint32_t)pyr.levels(); d.wrap = t.wrap;
+        d.su = t.su; d.sv = t.sv; d.du = t.du; d.dv = t.dv;
+        for (int l = 0; l < pyr.levels(); ++l) {
+            d.levelOff[l] = (uint32_t)texels.size();
+            for (const enigma::Rgb& c : pyr.level[l]) texels.push_back(make_float4(c.r, c.g, c.b, 0.f));
+        }
+        devTex.push_back(d);
+        texDevice[i] = (uint32_t)devTex.size();
+    }
+    h->haveTrilinear = !devTex.empty();
+    // materials (Enigma/Material.cpp:76-255 parameter evaluation)
     std::vector<DevMaterial> mats(s->n_materials);
-    for (int k = 0; k < MK_COUNT; ++k) h->kindPresent[k] = false;
+    for (int k = 0; k < MK_COUNT; ++k) { h->kindPresent[k] = false; h->kindTextured[k] = false; }
+    h->smoothGlass = false;
     h->glassBranches = h->glassSpecular = false;
     auto clamp01inf = [](float v) { return v < 0.f ? 0.f : v; }; // Spectrum::Clamp(0, inf)
     auto remap = [](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
@@ -215,9 +258,21 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
     };
     for (uint32_t i = 0; i < s->n_materials; ++i) {
-        const EnigmaMaterial& m = s->materials[i];
+        EnigmaMaterial m = s->materials[i];
         DevMaterial d;
         memset(&d, 0, sizeof(d));
+        // bound textures: constants for the EWA ones, a device texture for the trilinear ones (first / second colour of the kind)
+        struct Bind { uint32_t tex; float* value; int slot; };
+        const Bind binds[6] = {{m.tex_kd, m.kd, 0}, {m.tex_ks, m.ks, 1}, {m.tex_kr, m.kr, 0}, {m.tex_kt, m.kt, 1}, {m.tex_eta, m.eta, 0}, {m.tex_k, m.k, 1}};
+        const bool used[6] = {m.type == ENIGMA_MAT_MATTE || m.type == ENIGMA_MAT_PLASTIC, m.type == ENIGMA_MAT_PLASTIC, m.type == ENIGMA_MAT_GLASS,
+                              m.type == ENIGMA_MAT_GLASS, m.type == ENIGMA_MAT_METAL, m.type == ENIGMA_MAT_METAL};
+        for (int b = 0; b < 6; ++b) {
+            if (!binds[b].tex || !used[b]) continue;
+            if (binds[b].tex > s->n_textures) return h->fail(ENIGMA_E_INVALID, "material %u: texture index out of range", i);
+            const enigma::Rgb c = texConstant[binds[b].tex - 1];
+            binds[b].value[0] = c.r; binds[b].value[1] = c.g; binds[b].value[2] = c.b;
+            (binds[b].slot ? d.tex1 : d.tex0) = texDevice[binds[b].tex - 1];
+        }
         float ur = m.uroughness, vr = m.vroughness;
         bool specularGlass = false;
         switch (m.type) {
@@ -251,9 +306,13 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         d.alphay = std::max(float(0.001), vr);
         bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f;
         bool nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
+        if (d.tex0) nb0 = true; // decided per hit
+        if (d.tex1) nb1 = true;
         d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
         if (d.kind == MK_GLASS_SMOOTH && (nb0 || nb1)) h->glassSpecular = true;
         if (d.kind == MK_GLASS_SMOOTH && nb0 && nb1) h->glassBranches = true;
+        if (d.kind == MK_GLASS_SMOOTH) h->smoothGlass = true;
+        if (d.tex0 | d.tex1) h->kindTextured[d.kind] = true;
         h->kindPresent[d.kind] = true;
         mats[i] = d;
     }
@@ -422,6 +481,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->scene.media = h->media.p;
         h->scene.triMedium = haveMedia ? h->triMedium.p : nullptr;
     }
+    HIPCHK(h, h->texTexels.upload(texels));
+    for (DevTexture& d : devTex) d.texels = h->texTexels.p;
+    HIPCHK(h, h->textures.upload(devTex));
+    h->scene.textures = devTex.empty() ? nullptr : h->textures.p;
+    h->scene.texColors = nullptr; // allocated with the path state
     HIPCHK(h, h->triShade.upload(shadeData));
     h->scene.triShade = shadeData.empty() ? nullptr : h->triShade.p;
     HIPCHK(h, h->envMaps.upload(envTable));
@@ -674,6 +738,8 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
         HIPCHK(h, h->pendB.alloc(n * pendingLevels));
         h->pendCapacity = n * pendingLevels;
     }
+    if (h->haveTrilinear && h->texColors.n < n * 2) HIPCHK(h, h->texColors.alloc(n * 2));
+    h->scene.texColors = h->haveTrilinear ? h->texColors.p : nullptr;
     if (n <= h->capacity) return ENIGMA_OK;
     HIPCHK(h, h->pathRec.alloc(n * 4));
     HIPCHK(h, h->L.alloc(n));
@@ -696,6 +762,15 @@ static size_t shadeLdsBytes(const EnigmaCtx* h) {
     return ((size_t)h->scene.nTris * 3 + (size_t)h->scene.nMaterials * 4 + (size_t)h->scene.nLights * kLightVec4) * sizeof(float4) + (2 * (size_t)h->scene.nLights + 1) * sizeof(float);
 }
 
+// Evaluates the trilinear image textures at this bounce's hits (the material queues of the kinds that have a textured
+// material), between the closest-hit kernel and the shade kernels.
+static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
+    if (!h->haveTrilinear) return;
+    const float diffScale = 1 / std::sqrt((float)h->spp); // RayDifferential::scaleDifferentials, Enigma/Integrator.cpp:276
+    for (int k = 0; k < MK_COUNT; ++k)
+        if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
+}
+
 template <int LDSN, int OVF, bool LDS_SCENE>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
@@ -712,6 +787,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
+    launchTextures(h, P, gridShade);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -743,6 +819,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     (void)hipEventRecord(e1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    launchTextures(h, P, gridShade);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -776,6 +853,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     (void)hipEventRecord(e1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    launchTextures(h, P, gridShade);
     if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -802,6 +880,9 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
     // passes of k sample numbers over all pixels, ~32M paths in flight (capped by the 12-bit sample slot)
     const bool direct = h->useDirect, vol = h->useVolPath && !h->useDirect;
+    if (direct && h->haveTrilinear && h->smoothGlass)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "trilinear textures with a smooth glass under the DirectLightingIntegrator: its specular rays carry ray differentials on "
+                                             "(Enigma/Integrator.cpp:329-444), which is not supported");
     if (h->haveNoMaterial && !vol) return h->fail(ENIGMA_E_UNSUPPORTED, "the scene has surfaces without a material (medium boundaries): only the VolPathIntegrator renders them");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)

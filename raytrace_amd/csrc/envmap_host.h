@@ -38,7 +38,11 @@ struct EnvPyramid {
                     level[i][(size_t)t * sRes + s] = .25f * (texel(i - 1, 2 * s, 2 * t) + texel(i - 1, 2 * s + 1, 2 * t) + texel(i - 1, 2 * s, 2 * t + 1) + texel(i - 1, 2 * s + 1, 2 * t + 1));
         }
     }
+    int wrap = 0; // eImageWrapMode: 0 repeat, 1 black, 2 clamp (Enigma/MipMap.h:327-352)
     const Rgb& texel(int l, int s, int t) const { // repeat wrap: int % unsigned, exact for the pyramid's power-of-two sizes
+        static const Rgb black{0.f, 0.f, 0.f};
+        if (wrap == 2) { s = std::min(std::max(s, 0), lw[l] - 1); t = std::min(std::max(t, 0), lh[l] - 1); }
+        else if (wrap == 1) { if (s < 0 || s >= lw[l] || t < 0 || t >= lh[l]) return black; }
         uint32_t us = (uint32_t)s % (uint32_t)lw[l], ut = (uint32_t)t % (uint32_t)lh[l];
         return level[l][(size_t)ut * lw[l] + us];
     }
@@ -90,7 +94,9 @@ struct EnvPyramid {
     // lookup(st, dst0, dst1) with both differentials (0.5, 0.5), EWA filtering, maximum anisotropy 8: what Power() asks for
     Rgb lookupHalf() const {
         float d0x = .5f, d0y = .5f, d1x = .5f, d1y = .5f;
-        float majorLength = std::sqrt(d0x * d0x + d0y * d0y), minorLength = std::sqrt(d1x * d1x + d1y * d1y);
+        // Enigma/MipMap.h:380-381 take dst0.length() / dst1.length(): on the reference's glm vectors (Enigma/Defines.h:72) that
+        // is the component count, 2, not the Euclidean length, so the level of detail below comes out as levels()
+        float majorLength = 2.f, minorLength = 2.f;
         if (minorLength * 8.0f < majorLength && minorLength > 0) { float sc = majorLength / (minorLength * 8.0f); d1x *= sc; d1y *= sc; minorLength *= sc; }
         if (minorLength == 0) return triangle(0, .5f, .5f);
         float lod = std::max((float)0, levels() - (float)1 + log2f_(minorLength));

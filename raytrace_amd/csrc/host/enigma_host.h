@@ -249,6 +249,19 @@ class Scene {
 public:
     // Registry calls: the equivalent of hooking MakeShapes / MakeMaterial / MakeLight (Enigma/Api.cpp:843-932).
     int AddMaterial(const EnigmaMaterial& m) { m_materials.push_back(m); return (int)m_materials.size() - 1; }
+    // ImageTexture<RGBSpectrum, Spectrum>(UVMapping2D(su, sv, du, dv), TexInfo(...)) (Enigma/Texture.h:313-324,
+    // Enigma/Texture.cpp:412-453) for texels already read: rgb is height x width x 3 as ReadImage returns it (top row
+    // first); gamma is TexInfo::m_gamma, the exponent the reference applies (its bool "gamma" turned float).  Returns the
+    // value for a material's tex_* field.
+    uint32_t AddImageTexture(int width, int height, std::vector<float> rgb, bool trilinear, float gamma, float scale, uint32_t wrap,
+                             float su = 1.f, float sv = 1.f, float du = 0.f, float dv = 0.f) {
+        EnigmaTexture t{};
+        t.width = (uint32_t)width; t.height = (uint32_t)height; t.scale = scale; t.gamma = gamma; t.trilinear = trilinear ? 1u : 0u; t.wrap = wrap;
+        t.su = su; t.sv = sv; t.du = du; t.dv = dv;
+        m_textureTexels.push_back(std::move(rgb));
+        m_textures.push_back(t);
+        return (uint32_t)m_textures.size();
+    }
     // HomogeneousMedium(sigma_a, sigma_s, g) (Enigma/Medium.cpp:69-76)
     int AddMedium(const EnigmaMedium& m) { m_media.push_back(m); return (int)m_media.size() - 1; }
     // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
@@ -296,6 +309,8 @@ public:
     std::vector<EnigmaMaterial> m_materials;
     std::vector<EnigmaMedium> m_media;
     std::vector<LightRec> m_lights;
+    std::vector<EnigmaTexture> m_textures;              // rgb pointers are filled in at Render time
+    std::vector<std::vector<float>> m_textureTexels;
 private:
     int NextLightOrder() const { return (int)m_meshes.size(); } // point lights keep their place among the meshes' lights
 };
@@ -375,6 +390,9 @@ public:
         sd.n_materials = (uint32_t)scene.m_materials.size(); sd.materials = scene.m_materials.data();
         sd.n_lights = (uint32_t)lights.size(); sd.lights = lights.data();
         if (!scene.m_media.empty()) { sd.n_media = (uint32_t)scene.m_media.size(); sd.media = scene.m_media.data(); sd.tri_medium_inside = triIn.data(); sd.tri_medium_outside = triOut.data(); }
+        std::vector<EnigmaTexture> textures(scene.m_textures);
+        for (size_t i = 0; i < textures.size(); ++i) textures[i].rgb = scene.m_textureTexels[i].data();
+        sd.n_textures = (uint32_t)textures.size(); sd.textures = textures.empty() ? nullptr : textures.data();
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());

@@ -21,6 +21,7 @@
 
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -320,8 +321,52 @@ public:
         if (it == m_gs.namedMaterials.end()) throw std::runtime_error("NamedMaterial \"" + name + "\" unknown.");
         m_gs.currentMaterial = it->second;
     }
-    void pbrtTexture(const std::string& name, const std::string&, const std::string&, const ParamSet&) {
-        throw std::runtime_error("Texture \"" + name + "\": textures are outside the GPU path (constant material parameters only)");
+    // pbrtTexture (Enigma/Api.cpp:742-790) for spectrum textures of class "constant" and "imagemap"
+    // (CreateImageSpectrumTexture, Enigma/Texture.cpp:412-453; uv mapping; PFM files only)
+    void pbrtTexture(const std::string& name, const std::string& type, const std::string& texname, const ParamSet& p, const std::string& dir) {
+        VerifyWorld("Texture");
+        if (type == "float") throw std::runtime_error("Texture \"" + name + "\": float textures are not supported (the float material parameters are constants)");
+        if (type != "spectrum" && type != "color") throw std::runtime_error("Texture type \"" + type + "\" unknown.");
+        if (m_spectrumTextures.count(name)) Warn("Texture \"" + name + "\" being redefined");
+        NamedTexture nt;
+        if (texname == "constant") {
+            nt.value = p.FindOneSpectrum("value", Spectrum(1.f));
+        } else if (texname == "imagemap") {
+            if (p.FindOneString("mapping", "uv") != "uv") throw std::runtime_error("Texture \"" + name + "\": only the uv mapping is supported");
+            const float su = p.FindOneFloat("uscale", 1.f), sv = p.FindOneFloat("vscale", 1.f), du = p.FindOneFloat("udelta", 0.f), dv = p.FindOneFloat("vdelta", 0.f);
+            p.FindOneFloat("maxanisotropy", 8.f); // no effect: the EWA path never looks below the coarsest level
+            const bool trilerp = p.FindOneBool("trilinear", false);
+            const std::string wrap = p.FindOneString("wrap", "repeat");
+            const uint32_t wrapMode = wrap == "black" ? ENIGMA_WRAP_BLACK : (wrap == "clamp" ? ENIGMA_WRAP_CLAMP : ENIGMA_WRAP_REPEAT);
+            const float scale = p.FindOneFloat("scale", 1.f);
+            std::string filename = p.FindOneString("filename", "");
+            auto hasExt = [&](const char* e) { size_t n = strlen(e); return filename.size() >= n && filename.compare(filename.size() - n, n, e) == 0; };
+            const bool gamma = p.FindOneBool("gamma", hasExt(".tga") || hasExt(".png")); // ends up as the exponent 1 or 0
+            if (!hasExt(".pfm")) throw std::runtime_error("Texture \"" + name + "\": only PFM image files are read (\"" + filename + "\")");
+            if (!filename.empty() && filename[0] != '/') filename = dir + filename;
+            int w = 0, hgt = 0;
+            std::vector<float> rgb = ReadPfm(filename, &w, &hgt);
+            nt.index = m_res->scene.AddImageTexture(w, hgt, std::move(rgb), trilerp, gamma ? 1.f : 0.f, scale, wrapMode, su, sv, du, dv);
+        } else throw std::runtime_error("Texture \"" + name + "\": class \"" + texname + "\" is not supported (constant, imagemap)");
+        m_spectrumTextures[name] = nt;
+        NoteUnused("Texture", p);
+    }
+    // PFM: "PF", width height, scale (negative = little endian), rows bottom to top; returned top row first like ReadImage
+    static std::vector<float> ReadPfm(const std::string& path, int* w, int* h) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("unable to read image \"" + path + "\"");
+        std::string magic; float scale = 0.f;
+        f >> magic >> *w >> *h >> scale;
+        if (magic != "PF" || *w <= 0 || *h <= 0 || scale == 0.f) throw std::runtime_error("\"" + path + "\" is not a colour PFM file");
+        f.get();
+        std::vector<float> rows((size_t)*w * *h * 3);
+        f.read(reinterpret_cast<char*>(rows.data()), (std::streamsize)(rows.size() * sizeof(float)));
+        if (!f) throw std::runtime_error("\"" + path + "\" is truncated");
+        if (scale > 0) for (float& v : rows) { unsigned char* b = reinterpret_cast<unsigned char*>(&v); std::swap(b[0], b[3]); std::swap(b[1], b[2]); }
+        std::vector<float> out(rows.size());
+        const size_t rowLen = (size_t)*w * 3;
+        for (int y = 0; y < *h; ++y) std::copy(rows.begin() + (size_t)(*h - 1 - y) * rowLen, rows.begin() + (size_t)(*h - y) * rowLen, out.begin() + (size_t)y * rowLen);
+        return out;
     }
     void pbrtLightSource(const std::string& name, const ParamSet& p) {
         VerifyWorld("LightSource");
@@ -559,35 +604,45 @@ private:
     }
     int MakeMaterial(const std::string& name, const ParamSet& p) {
         EnigmaMaterial m{};
-        for (const char* n : {"Kd", "Ks", "Kr", "Kt", "eta", "k", "sigma", "roughness", "uroughness", "vroughness", "index", "bumpmap"}) texGuard(p, n);
+        for (const char* n : {"sigma", "roughness", "uroughness", "vroughness", "index", "bumpmap"}) texGuard(p, n);
         if (p.Has("bumpmap")) throw std::runtime_error("bump mapping is not supported");
         auto put = [](float* dst, const Spectrum& s) { dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2]; };
+        // TextureParams::GetSpectrumTexture (Enigma/ParameterSet.cpp:686-743): a named texture if "texture <n>" is given, else a constant
+        auto bind = [&](const char* n, float* dst, uint32_t* tex) {
+            const std::string t = p.FindTexture(n);
+            if (t.empty()) return;
+            for (const auto& it : p.Items()) if (it.name == n && it.type == "texture") it.lookedUp = true;
+            auto f = m_spectrumTextures.find(t);
+            if (f == m_spectrumTextures.end()) throw std::runtime_error(std::string("Couldn't find spectrum texture named \"") + t + "\" for parameter \"" + n + "\"");
+            if (f->second.index) *tex = f->second.index;
+            else put(dst, f->second.value);
+        };
         m.remap_roughness = p.FindOneBool("remaproughness", true) ? 1u : 0u;
         if (name == "" || name == "none") return -2; // MakeMaterial returns no material (Enigma/Api.cpp:135): a medium boundary
         if (name == "matte") {
             m.type = ENIGMA_MAT_MATTE;
-            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.5f)));
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.5f))); bind("Kd", m.kd, &m.tex_kd);
             m.sigma = p.FindOneFloat("sigma", 0.f);
         } else if (name == "metal") {
             m.type = ENIGMA_MAT_METAL;
             // the reference's defaults are the sampled copper spectra (Material.cpp:604-605); their RGB needs the CIE tables
-            if (!p.HasSpectrum("eta") || !p.HasSpectrum("k")) throw std::runtime_error("metal: give \"rgb eta\" and \"rgb k\" explicitly (sampled-spectrum defaults are not supported)");
-            put(m.eta, p.FindOneSpectrum("eta", Spectrum(1.f)));
-            put(m.k, p.FindOneSpectrum("k", Spectrum(1.f)));
+            if ((!p.HasSpectrum("eta") && p.FindTexture("eta").empty()) || (!p.HasSpectrum("k") && p.FindTexture("k").empty())) throw std::runtime_error("metal: give \"rgb eta\" and \"rgb k\" explicitly (sampled-spectrum defaults are not supported)");
+            put(m.eta, p.FindOneSpectrum("eta", Spectrum(1.f))); bind("eta", m.eta, &m.tex_eta);
+            put(m.k, p.FindOneSpectrum("k", Spectrum(1.f))); bind("k", m.k, &m.tex_k);
             float rough = p.FindOneFloat("roughness", .5f);
             m.uroughness = p.FindOneFloat("uroughness", rough); // MetalMaterial: u/v fall back to roughness (Material.cpp:121-126)
             m.vroughness = p.FindOneFloat("vroughness", rough);
         } else if (name == "glass") {
             m.type = ENIGMA_MAT_GLASS;
-            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(1.f)));
-            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(1.f)));
+            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(1.f))); bind("Kr", m.kr, &m.tex_kr);
+            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(1.f))); bind("Kt", m.kt, &m.tex_kt);
             m.index = p.Has("eta") ? p.FindOneFloat("eta", 1.5f) : p.FindOneFloat("index", 1.5f);
             m.uroughness = p.FindOneFloat("uroughness", 0.f);
             m.vroughness = p.FindOneFloat("vroughness", 0.f);
         } else if (name == "plastic") {
             m.type = ENIGMA_MAT_PLASTIC;
-            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
-            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f))); bind("Kd", m.kd, &m.tex_kd);
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f))); bind("Ks", m.ks, &m.tex_ks);
             m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
         } else throw std::runtime_error("Material \"" + name + "\" is not supported (matte, metal, glass, plastic)");
         p.FindOneString("type", ""); // consumed by MakeNamedMaterial
@@ -719,7 +774,7 @@ private:
             else if (d == "LightSource") { std::string n = c.str("LightSource"); pbrtLightSource(n, ParseParams(c)); }
             else if (d == "AreaLightSource") { std::string n = c.str("AreaLightSource"); pbrtAreaLightSource(n, ParseParams(c)); }
             else if (d == "Shape") { std::string n = c.str("Shape"); pbrtShape(n, ParseParams(c)); }
-            else if (d == "Texture") { std::string n = c.str("Texture"), ty = c.str("Texture"), cl = c.str("Texture"); pbrtTexture(n, ty, cl, ParseParams(c)); }
+            else if (d == "Texture") { std::string n = c.str("Texture"), ty = c.str("Texture"), cl = c.str("Texture"); pbrtTexture(n, ty, cl, ParseParams(c), dir); }
             else if (d == "Include") {
                 std::string inc = c.str("Include");
                 pbrtParseFile((!inc.empty() && inc[0] == '/') ? inc : dir + inc);
@@ -748,6 +803,8 @@ private:
     std::vector<Mat4d> m_pushedTransforms;
     std::string m_imageFile;
     int m_defaultMaterial = -1;
+    struct NamedTexture { Spectrum value = Spectrum(1.f); uint32_t index = 0; }; // index: tex_* value of an image texture, 0 = the constant
+    std::map<std::string, NamedTexture> m_spectrumTextures;
     std::map<std::string, int> m_namedMedia; // RenderOptions::namedMedia: name -> index in the scene's medium registry
     std::unique_ptr<FrontEndResult> m_res{new FrontEndResult()};
 };

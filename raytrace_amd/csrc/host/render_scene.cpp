@@ -50,7 +50,8 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         const EnigmaMaterial& m = R.scene.m_materials[i];
         o << (i ? "," : "") << "{\"type\":" << m.type << ",\"remap\":" << m.remap_roughness << ",\"kd\":"; arr(m.kd, 3);
         o << ",\"ks\":"; arr(m.ks, 3); o << ",\"kr\":"; arr(m.kr, 3); o << ",\"kt\":"; arr(m.kt, 3); o << ",\"eta\":"; arr(m.eta, 3); o << ",\"k\":"; arr(m.k, 3);
-        o << ",\"sigma\":" << m.sigma << ",\"uroughness\":" << m.uroughness << ",\"vroughness\":" << m.vroughness << ",\"index\":" << m.index << "}";
+        o << ",\"sigma\":" << m.sigma << ",\"uroughness\":" << m.uroughness << ",\"vroughness\":" << m.vroughness << ",\"index\":" << m.index
+          << ",\"tex\":[" << m.tex_kd << "," << m.tex_ks << "," << m.tex_kr << "," << m.tex_kt << "," << m.tex_eta << "," << m.tex_k << "]}";
     }
     o << "],\n\"meshes\":[";
     for (size_t i = 0; i < R.scene.m_meshes.size(); ++i) {
@@ -66,6 +67,16 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         o << "],\"uv\":[";
         for (size_t k = 0; k < m.m_uv.size(); ++k) o << (k ? "," : "") << m.m_uv[k].x << "," << m.m_uv[k].y;
         o << "]}";
+    }
+    o << "],\n\"textures\":[";
+    for (size_t i = 0; i < R.scene.m_textures.size(); ++i) {
+        const EnigmaTexture& t = R.scene.m_textures[i];
+        const std::vector<float>& px = R.scene.m_textureTexels[i];
+        double sum = 0;
+        for (float v : px) sum += v;
+        o << (i ? "," : "") << "{\"width\":" << t.width << ",\"height\":" << t.height << ",\"trilinear\":" << t.trilinear << ",\"gamma\":" << t.gamma << ",\"scale\":" << t.scale
+          << ",\"wrap\":" << t.wrap << ",\"mapping\":[" << t.su << "," << t.sv << "," << t.du << "," << t.dv << "],\"first_texel\":[" << px[0] << "," << px[1] << "," << px[2]
+          << "],\"sum\":" << sum << "}";
     }
     o << "],\n\"media\":[";
     for (size_t i = 0; i < R.scene.m_media.size(); ++i) {

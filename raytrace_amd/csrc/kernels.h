@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                         pathPixel(I, S, p, &px, &py, &slot);
                         uint32_t dim = stDim(state);
                         float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
-                        state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state));
+                        state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state)) | (state & kStNoDifferentials);
                         reinterpret_cast<float*>(&P.rayD[p])[3] = __uint_as_float(state);
                         int channel = min((int)(uc * 3), 3 - 1);
                         float dist = -logf(1 - ud) / md.sigmaT[channel];
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             float etaScale = bv.w;
             HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
-            makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf);
+            makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
             F3 ns = g.ns;
             F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
             // medium + 1 on either side of the surface: the triangle's MediumInterface if it is a transition, else
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             F3 beta = xyz(P.beta[p]);
             HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
             Bsdf bsdf;
-            makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf);
+            makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
             F3 ns = g.ns;
             F3 woN = normalize(-d); // isect.m_wo
             const size_t raySlot0 = (size_t)p * I.raysPerPath;

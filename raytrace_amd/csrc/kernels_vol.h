@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
             uint32_t st = __float_as_uint(rdv.w);
             HitGeom g = hitGeometry(sc, sc.tris, tri, hv.y, hv.z, hv.w);
             P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, d), 0.f); // isect.SpawnRay(ray.m_dir)
-            P.rayD[p] = mk4(d, __uint_as_float(packState(mediumBeyond(sc, tri, stMedium(st), g.n, d), stDim(st), stBounces(st), stSpec(st))));
+            P.rayD[p] = mk4(d, __uint_as_float(packState(mediumBeyond(sc, tri, stMedium(st), g.n, d), stDim(st), stBounces(st), stSpec(st)) | kStNoDifferentials));
         }
         uint32_t s = blockReserve(active, &ctr->extCount[nextIdx].v, lds);
         if (active) nextQueue[s] = p;

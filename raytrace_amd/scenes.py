@@ -153,6 +153,12 @@ class MeshBuilder:
         self.media, self.m_in, self.m_out = [], [], []
         self.interface = (-1, -1)   # MediumInterface (inside, outside) given to the triangles added next
         self.vn, self.vuv = [], []  # per-vertex normal / uv (zeros where the triangle has none)
+        self.textures = []
+
+    def add_texture(self, t):
+        """Returns the value for a material's tex_* field (index + 1)."""
+        self.textures.append(t)
+        return len(self.textures)
 
     def add_medium(self, m):
         self.media.append(m)
@@ -200,9 +206,10 @@ class MeshBuilder:
         else:
             self.light.append(-1)
 
-    def add_quad(self, q, mat, toward=None, emit=None, two_sided=False):
-        self.add_tri(q[0], q[1], q[2], mat, toward, emit, two_sided)
-        self.add_tri(q[0], q[2], q[3], mat, toward, emit, two_sided)
+    def add_quad(self, q, mat, toward=None, emit=None, two_sided=False, uvs=None):
+        """uvs: one uv per corner (omitted: the reference's default per-triangle uvs)."""
+        self.add_tri(q[0], q[1], q[2], mat, toward, emit, two_sided, uvs=None if uvs is None else (uvs[0], uvs[1], uvs[2]))
+        self.add_tri(q[0], q[2], q[3], mat, toward, emit, two_sided, uvs=None if uvs is None else (uvs[0], uvs[2], uvs[3]))
 
     def add_point_light(self, pos, I):
         self.lights.append(abi.point_light(pos, I))
@@ -232,7 +239,7 @@ class MeshBuilder:
             shading["normals"] = v[:, 3:6]
         if any(f & abi.TRI_HAS_UVS for f in self.flags):
             shading["uvs"] = v[:, 6:8]
-        return abi.SceneArrays(v[:, :3], t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, **media, **shading)
+        return abi.SceneArrays(v[:, :3], t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, textures=self.textures, **media, **shading)
 
 
 # ----------------------------------------------------------------------------- S1: Cornell box
@@ -327,6 +334,58 @@ def cornell_smooth(level=2):
             p = sv[f] * radius + centre
             b.add_tri(p[0], p[1], p[2], mat, toward=p[0] + sv[f[0]], normals=tuple(sv[f]) if with_n else None,
                       uvs=tuple(uv[f]) if with_uv else None, reverse_orientation=reverse)
+    return b.arrays()
+
+
+def test_pattern(height=32, width=64, seed=0x7E87):
+    """A small RGB image with every spatial frequency a MIP pyramid has to average: checker, gradient and noise."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    checker = ((x // 4 + y // 4) % 2).astype(np.float32)
+    img = np.stack([0.15 + 0.7 * checker, 0.1 + 0.8 * x / (width - 1.0), 0.2 + 0.6 * y / (height - 1.0)], -1).astype(np.float32)
+    return (img * (0.75 + 0.25 * rng.rand(height, width, 1))).astype(np.float32)
+
+
+def cornell_textured(trilinear=True, wrap=abi.WRAP_REPEAT):
+    """The Cornell box with image textures on the material colours: the floor and the back wall matte with a tiled Kd
+    (the back wall's uvs run past [0, 1] so the wrap mode shows), the short block plastic with textured Kd and Ks,
+    the tall block rough glass with a textured Kt, the left wall a metal whose eta comes from a texture.  One of the
+    textures is always made without "trilinear" (the reference then evaluates it to its average colour) and one with
+    gamma false (every texel 1)."""
+    b = MeshBuilder()
+    img = test_pattern()
+    tiled = b.add_texture(abi.image_texture(img, trilinear=trilinear, su=3.0, sv=2.0, du=0.25, wrap=wrap))
+    plain = b.add_texture(abi.image_texture(img, trilinear=trilinear, wrap=wrap))
+    average = b.add_texture(abi.image_texture(img * 0.6, trilinear=False))
+    ones = b.add_texture(abi.image_texture(img, trilinear=trilinear, gamma=False, scale=0.9))
+    eta_map = b.add_texture(abi.image_texture(0.2 + 1.5 * test_pattern(16, 16, seed=3), trilinear=trilinear))
+
+    def mat(m, **tex):
+        for k, v in tex.items():
+            setattr(m, k, v)
+        return b.add_material(m)
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    floor_m = mat(abi.matte((0.0, 0.0, 0.0)), tex_kd=tiled)
+    back_m = mat(abi.matte((0.5, 0.5, 0.5)), tex_kd=plain)
+    left_m = mat(abi.metal(COPPER_ETA, COPPER_K, roughness=0.2, remap=True), tex_eta=eta_map)
+    short_m = mat(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05), tex_kd=plain, tex_ks=average)
+    tall_m = mat(abi.glass(1.5, 0.05, 0.05), tex_kt=ones)
+    c = CORNELL_CENTER
+    unit = [(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)]
+    wide = [(-0.5, -0.25), (1.5, -0.25), (1.5, 1.25), (-0.5, 1.25)]
+    b.add_quad(_CORNELL["floor"], floor_m, toward=c, uvs=unit)
+    b.add_quad(_CORNELL["ceiling"], white, toward=c)
+    b.add_quad(_CORNELL["back"], back_m, toward=c, uvs=wide)
+    b.add_quad(_CORNELL["right"], green, toward=c)
+    b.add_quad(_CORNELL["left"], left_m, toward=c, uvs=unit)
+    for name, m in (("short", short_m), ("tall", tall_m)):
+        faces = _CORNELL[name]
+        centre = np.mean([p for f in faces for p in f], axis=0)
+        centre[1] = centre[1] * 0.5
+        for f in faces:
+            b.add_quad(f, m, toward=np.mean(f, axis=0) * 2 - centre, uvs=unit if name == "short" else None)
+    b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
     return b.arrays()
 
 

@@ -1,7 +1,9 @@
 """Writes a pbrt-format scene description for a SceneArrays scene (test helper for the scene-description
 front end).  One trianglemesh Shape per run of triangles that share material and emission; materials as
 MakeNamedMaterial.  Light order in the file = light order in SceneArrays (lights are created in file order)."""
+import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -12,9 +14,30 @@ def _rgb(name, v):
     return '"rgb %s" [%.9g %.9g %.9g]' % (name, v[0], v[1], v[2])
 
 
+def write_pfm(path, rgb):
+    """rgb: [height, width, 3], top row first.  PFM stores rows bottom to top; a negative scale marks little endian."""
+    a = np.ascontiguousarray(rgb, dtype="<f4")
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (a.shape[1], a.shape[0]))
+        f.write(a[::-1].tobytes())
+
+
+def texture_text(i, t, directory):
+    """One Texture directive per image texture; the texels go into <directory>/tex<i>.pfm."""
+    rgb = np.ctypeslib.as_array(C.cast(t.rgb, C.POINTER(C.c_float)), shape=(t.height, t.width, 3))
+    write_pfm(os.path.join(directory, "tex%d.pfm" % i), rgb)
+    wrap = {abi.WRAP_REPEAT: "repeat", abi.WRAP_BLACK: "black", abi.WRAP_CLAMP: "clamp"}[t.wrap]
+    return ('Texture "t%d" "spectrum" "imagemap" "string filename" "tex%d.pfm" "bool trilinear" "%s" "bool gamma" "%s" "float scale" %.9g '
+            '"string wrap" "%s" "float uscale" %.9g "float vscale" %.9g "float udelta" %.9g "float vdelta" %.9g' %
+            (i, i, "true" if t.trilinear else "false", "true" if t.gamma != 0 else "false", t.scale, wrap, t.su, t.sv, t.du, t.dv))
+
+
 def material_text(i, m):
     t = {abi.MAT_MATTE: "matte", abi.MAT_METAL: "metal", abi.MAT_GLASS: "glass", abi.MAT_PLASTIC: "plastic"}[m.type]
     parts = ['MakeNamedMaterial "m%d" "string type" "%s"' % (i, t)]
+    for name, tex in (("Kd", m.tex_kd), ("Ks", m.tex_ks), ("Kr", m.tex_kr), ("Kt", m.tex_kt), ("eta", m.tex_eta), ("k", m.tex_k)):
+        if tex:
+            parts.append('"texture %s" "t%d"' % (name, tex - 1))
     remap = '"bool remaproughness" "%s"' % ("true" if m.remap_roughness else "false")
     if t == "matte":
         parts += [_rgb("Kd", m.kd), '"float sigma" %.9g' % m.sigma]
@@ -29,7 +52,7 @@ def material_text(i, m):
 
 
 def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
-               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens=""):
+               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens="", texture_dir=None):
     out = ["# written by tests/pbrt_writer.py",
            "LookAt %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g" % (tuple(eye) + tuple(look) + tuple(up)),
            'Camera "perspective" "float fov" %.9g %s' % (fov, lens),
@@ -37,6 +60,8 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
            'Sampler "sobol" "integer pixelsamples" %d' % spp, pixel_filter, integrator, "WorldBegin"]
     if world_prefix:
         out.append(world_prefix)
+    for i in range(getattr(sc, "n_textures", 0)):
+        out.append(texture_text(i, sc.textures[i], texture_dir))
     for i in range(sc.n_materials):
         out.append(material_text(i, sc.materials[i]))
     n_media = getattr(sc, "n_media", 0)

@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -92,6 +92,8 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
         sc = scenes.cornell_fog(variant.split(":")[1])
     elif variant.startswith("sky:"):
         sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment: scene files carry no texels
+    elif variant == "textured":
+        sc = scenes.cornell_textured(True)  # Texture "imagemap" directives over PFM files, "texture Kd" bindings, uvs
     elif variant == "smooth":
         sc = scenes.cornell_smooth()       # per-vertex normals, uvs and ReverseOrientation through "normal N" / "float uv"
     else:
@@ -100,7 +102,7 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     itext = {"path": 'Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
              "volpath": 'Integrator "volpath" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
              "directlighting": 'Integrator "directlighting" "integer maxdepth" 5 "string strategy" "all"'}[integrator]
-    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp, integrator=itext)
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp, integrator=itext, texture_dir=str(tmp_path))
     scene_file, out_file = str(tmp_path / "cornell.pbrt"), str(tmp_path / "out.pfm")
     with open(scene_file, "w") as f:
         f.write(text)

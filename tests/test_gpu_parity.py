@@ -362,6 +362,68 @@ def test_image_parity_shading_normals_and_uvs():
     assert e.value.code == -4
 
 
+@pytest.mark.parametrize("trilinear,wrap", [(True, abi.WRAP_REPEAT), (True, abi.WRAP_CLAMP), (True, abi.WRAP_BLACK), (False, abi.WRAP_REPEAT)])
+def test_image_parity_image_textures(trilinear, wrap):
+    """Image textures on Kd / Ks / Kt / eta (Enigma/Texture.h:313-415, Enigma/MipMap.h:309-376, Enigma/Interaction.cpp:161-209):
+    camera rays filtered through their ray differentials, later rays at level 0; textures without "trilinear" as their
+    average colour, gamma false as ones; under the three integrators, with and without a lens."""
+    sc = scenes.cornell_textured(trilinear, wrap)
+    film = scenes.film_desc(64, 64)
+    cases = [(scenes.cornell_camera(64, 64), scenes.integrator_desc(film, 16)),
+             (scenes.cornell_camera(64, 64, lens_radius=12.0, focal_distance=900.0), scenes.integrator_desc(film, 16)),
+             (scenes.cornell_camera(64, 64), scenes.direct_lighting_desc(film, 16, max_depth=3, strategy=abi.DL_SAMPLE_ALL)),
+             (scenes.cornell_camera(64, 64), scenes.volpath_desc(film, 16))]
+    for cam, integ in cases if wrap == abi.WRAP_REPEAT else cases[:1]:
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert np.isfinite(r.image()).all()
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
+        r.close(); o.close()
+
+
+def test_textures_change_the_picture_and_bad_ones_are_refused():
+    film, cam = scenes.film_desc(48, 48), scenes.cornell_camera(48, 48)
+    integ = scenes.integrator_desc(film, 8)
+    imgs = []
+    for sc in (scenes.cornell_textured(True), scenes.cornell_textured(False)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        r.render(0, 8)
+        imgs.append(r.image())
+        r.close()
+    assert common.mean_relative_error(imgs[0], imgs[1]) > 0.02          # trilinear shows the pattern, the default shows its average
+    sc = scenes.cornell_textured(True)
+    base = dict(vertices=sc.vertices, indices=sc.indices, tri_material=sc.tri_material, tri_light=sc.tri_light,
+                materials=[sc.materials[i] for i in range(sc.n_materials)], lights=[sc.lights[i] for i in range(sc.n_lights)],
+                tri_flags=sc.tri_flags, uvs=sc.uvs)
+    odd = abi.SceneArrays(**base, textures=[abi.image_texture(np.ones((6, 8, 3), np.float32))] * sc.n_textures)
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(odd, cam, film, integ)
+    assert e.value.code == -4
+    missing = abi.SceneArrays(**base, textures=[sc.textures[0]])       # the materials index five textures
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(missing, cam, film, integ)
+    assert e.value.code == -1
+    # trilinear textures + smooth glass under the DirectLightingIntegrator: its specular rays would carry differentials
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0, 0, 0)))
+    b.materials[m].tex_kd = b.add_texture(abi.image_texture(scenes.test_pattern(), trilinear=True))
+    g = b.add_material(abi.glass(1.5, 0.0, 0.0))
+    b.add_quad([(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)], m, toward=(0, 1, 0), uvs=[(0, 0), (1, 0), (1, 1), (0, 1)])
+    b.add_quad([(-5, 5, -5), (-5, 5, 5), (5, 5, 5), (5, 5, -5)], g, toward=(0, 10, 0))
+    b.add_point_light((0, 30, 0), (100.0, 100.0, 100.0))
+    cam2 = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, 16, 16)
+    film2 = scenes.film_desc(16, 16)
+    with pytest.raises(ra.EnigmaError) as e:
+        r = ra.Renderer(0).configure(b.arrays(), cam2, film2, scenes.direct_lighting_desc(film2, 4, max_depth=3, strategy=abi.DL_SAMPLE_ONE))
+        r.render(0, 4)
+    assert e.value.code == -4
+
+
 def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
     """The uv axes orient the anisotropic tangent frame: a quarter turn of the uvs equals swapping u / v roughness
     (deterministic with a point light and depth 1)."""

@@ -572,3 +572,71 @@ def test_reverse_orientation_turns_the_shading_normal_and_so_the_glass_interface
     assert np.allclose(img["n"], img["flat"], rtol=1e-4)
     assert np.allclose(img["n_rev"], img["flat_rev"], rtol=1e-4)
     assert not np.allclose(img["n"], img["n_rev"], rtol=0.05)
+
+
+# ------------------------------------------------------------------ image textures (oracle only, CPU)
+def _textured_floor(tex, spp=4, res=9):
+    """The 100 x 100 floor with u = x / 100 + .5, v = z / 100 + .5, matte with Kd from the texture, under a distant
+    light from straight above: pixel = Kd(u, v) / pi * L."""
+    b = _shaded_floor(abi.matte((0.0, 0.0, 0.0)), uv_axes=(np.array([1.0, 0, 0]), np.array([0, 0, 1.0])))
+    b.materials[0].tex_kd = b.add_texture(tex)
+    return _render_floor(b, light_dir=(0.0, 1.0, 0.0), spp=spp, res=res)
+
+
+def test_image_texture_without_trilinear_is_its_average_colour():
+    """MipMap::lookup's EWA branch measures its differential vectors with glm's length(), the component count
+    (Enigma/MipMap.h:380-381, Enigma/Defines.h:72): the level of detail is always the coarsest one, so the texture
+    evaluates to the box-filtered average of the image wherever it is looked up."""
+    img = scenes.test_pattern()
+    L = np.array([2.0, 1.0, 0.5])
+    got = _textured_floor(abi.image_texture(img, trilinear=False))
+    want = img.reshape(-1, 3).mean(axis=0) / math.pi * L
+    assert np.allclose(got, want[None, None, :], rtol=1e-4)
+    # "gamma" is the exponent of the conversion (Enigma/Texture.h:375-380): false turns every texel into 1
+    got = _textured_floor(abi.image_texture(img, trilinear=False, gamma=False, scale=0.37))
+    assert np.allclose(got, (1.0 / math.pi * L)[None, None, :], rtol=1e-5)
+    got = _textured_floor(abi.image_texture(img, trilinear=False, scale=0.5))
+    assert np.allclose(got, 0.5 * want[None, None, :], rtol=1e-4)
+
+
+def test_trilinear_texture_follows_the_uvs_and_filters_with_the_camera_footprint():
+    """With "trilinear" the lookup is MipMap::lookup(st, width) (Enigma/MipMap.h:354-376).  A linear ramp survives
+    bilinear interpolation and box filtering, so the floor shows Kd = u across the image (orientation, uv mapping and
+    the y flip of ImageTexture::getTexture); a one-texel checker seen through a footprint wider than two texels is the
+    grey of MIP level >= 1, and the same checker magnified shows both of its colours."""
+    L = np.array([2.0, 1.0, 0.5])
+    n = 64
+    x = (np.arange(n) + 0.5) / n
+    ramp_u = np.broadcast_to(x[None, :, None], (n, n, 3)).astype(np.float32)
+    got = _textured_floor(abi.image_texture(ramp_u, trilinear=True), res=9, spp=16)
+    half = 40 * math.tan(math.radians(10.0))
+    u = ((np.arange(9) + 0.5) / 9 * 2 * half - half) / 100 + 0.5            # u at the pixel centres
+    # raster x runs against world x for this camera (up = +z): find the orientation from the oracle's own camera
+    want_a = u[None, :, None] / math.pi * L[None, None, :]
+    want_b = u[::-1][None, :, None] / math.pi * L[None, None, :]
+    assert np.allclose(got, want_a, rtol=1e-2) or np.allclose(got, want_b, rtol=1e-2)     # 16 samples average to about the pixel centre
+    ramp_v = np.broadcast_to(x[::-1][:, None, None], (n, n, 3)).astype(np.float32)   # top row first: v = 1 at row 0
+    got = _textured_floor(abi.image_texture(ramp_v, trilinear=True), res=9, spp=16)
+    want_a = u[:, None, None] / math.pi * L[None, None, :]
+    want_b = u[::-1][:, None, None] / math.pi * L[None, None, :]
+    assert np.allclose(got, want_a * np.ones((1, 9, 1)), rtol=1e-2) or np.allclose(got, want_b * np.ones((1, 9, 1)), rtol=1e-2)
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = np.broadcast_to(((xx + yy) % 2)[..., None], (n, n, 3)).astype(np.float32)
+    far = _textured_floor(abi.image_texture(checker, trilinear=True, su=8.0, sv=8.0), res=9)        # footprint of several texels
+    assert np.allclose(far, (0.5 / math.pi * L)[None, None, :], rtol=1e-3)
+    near = _textured_floor(abi.image_texture(checker, trilinear=True, su=0.5, sv=0.5), res=9)                          # 4.5 texels across the image
+    lum = near[..., 0] * math.pi / L[0]
+    assert lum.min() < 0.35 and lum.max() > 0.65                                                      # magnified: the texels show
+
+
+def test_texture_wrap_modes():
+    """uvs outside [0, 1]: repeat tiles the image, clamp smears its border texels, black returns 0
+    (MipMap::texel, Enigma/MipMap.h:327-352)."""
+    L = np.array([2.0, 1.0, 0.5])
+    img = np.full((8, 8, 3), 0.6, np.float32)
+    out = {}
+    for name, wrap in (("repeat", abi.WRAP_REPEAT), ("clamp", abi.WRAP_CLAMP), ("black", abi.WRAP_BLACK)):
+        out[name] = _textured_floor(abi.image_texture(img, trilinear=True, wrap=wrap, du=3.0, dv=3.0), res=5)   # every lookup outside [0, 1]
+    want = 0.6 / math.pi * L
+    assert np.allclose(out["repeat"], want[None, None, :], rtol=1e-4) and np.allclose(out["clamp"], want[None, None, :], rtol=1e-4)
+    assert np.all(out["black"] == 0)

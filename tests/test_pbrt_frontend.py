@@ -170,7 +170,7 @@ WorldEnd
 
 @pytest.mark.parametrize("text,needle", [
     ('WorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n', "sphere"),
-    ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "textures"),
+    ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
     ('WorldBegin\nMaterial "metal"\nWorldEnd\n', "eta"),
     ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),
@@ -333,3 +333,50 @@ WorldEnd
     assert m1["uv"] == [] and m1["N"] == []                                                                # too few uvs: discarded
     err = dump(tmp_path, head + 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 0 0  0 1 0  0 0 1] "vector S" [1 0 0 1 0 0 1 0 0]\nWorldEnd\n', expect_fail=True)
     assert "tangents" in err
+
+
+def test_image_textures_reach_the_scene(tmp_path):
+    """Texture "<name>" "spectrum" "imagemap" (CreateImageSpectrumTexture, Enigma/Texture.cpp:412-453) read from PFM files and
+    bound through "texture Kd" (TextureParams::GetSpectrumTexture, Enigma/ParameterSet.cpp:686-743); "constant" textures
+    become the constant; gamma defaults to false for a PFM file (it is true for .png / .tga only)."""
+    sc = scenes.cornell_textured(True)
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4, texture_dir=str(tmp_path))
+    d = dump(tmp_path, text)
+    assert len(d["textures"]) == sc.n_textures
+    for got, ref in zip(d["textures"], sc.textures[: sc.n_textures]):
+        rgb = np.ctypeslib.as_array(__import__("ctypes").cast(ref.rgb, __import__("ctypes").POINTER(__import__("ctypes").c_float)), shape=(ref.height, ref.width, 3))
+        assert (got["width"], got["height"], got["trilinear"], got["wrap"]) == (ref.width, ref.height, ref.trilinear, ref.wrap)
+        assert got["gamma"] == ref.gamma and np.float32(got["scale"]) == np.float32(ref.scale)
+        assert np.allclose(got["mapping"], [ref.su, ref.sv, ref.du, ref.dv])
+        assert np.allclose(got["first_texel"], rgb[0, 0], rtol=1e-6) and np.isclose(got["sum"], float(rgb.astype(np.float64).sum()), rtol=1e-5)
+    for got, ref in zip(d["materials"], sc.materials[: sc.n_materials]):
+        assert got["tex"] == [ref.tex_kd, ref.tex_ks, ref.tex_kr, ref.tex_kt, ref.tex_eta, ref.tex_k]
+    P, mat, lights = flatten(d)
+    assert np.array_equal(P, sc.vertices[sc.indices])
+    pbrt_writer.write_pfm(str(tmp_path / "one.pfm"), np.full((2, 2, 3), 0.25, np.float32))
+    head = '''
+LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" 60
+Film "image" "integer xresolution" 8 "integer yresolution" 8
+Sampler "sobol" "integer pixelsamples" 1
+Integrator "path"
+WorldBegin
+'''
+    d = dump(tmp_path, head + '''
+Texture "c" "color" "constant" "rgb value" [0.1 0.2 0.3]
+Texture "img" "spectrum" "imagemap" "string filename" "one.pfm"
+Material "plastic" "texture Kd" "c" "texture Ks" "img"
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [1 0 0  0 1 0  0 0 1]
+WorldEnd
+''')
+    m = d["materials"][-1]
+    assert np.allclose(m["kd"], [0.1, 0.2, 0.3]) and m["tex"] == [0, 1, 0, 0, 0, 0]
+    t = d["textures"][0]
+    assert (t["trilinear"], t["gamma"], t["wrap"]) == (0, 0, 0)
+    for body, needle in (('Texture "f" "float" "constant" "float value" 1', "float textures"),
+                         ('Texture "x" "spectrum" "checkerboard"', "not supported"),
+                         ('Texture "x" "spectrum" "imagemap" "string filename" "one.png"', "PFM"),
+                         ('Texture "x" "spectrum" "imagemap" "string filename" "missing.pfm"', "unable to read"),
+                         ('Material "matte" "texture Kd" "nope"', "Couldn\'t find")):
+        err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
+        assert needle in err, err
