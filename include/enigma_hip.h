@@ -125,6 +125,21 @@ typedef struct EnigmaMedium {
  * a medium boundary the VolPathIntegrator passes through (Enigma/VolPathIntegrator.cpp:105-111). */
 #define ENIGMA_NO_MATERIAL 0xffffffffu
 
+/* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or
+ * partial (z range, phi sweep), any object-to-world transform.  Spheres are tested one by one beside the triangles'
+ * BVH (at most ENIGMA_MAX_SPHERES of them); they cannot be area lights, carry no medium interface and their material
+ * must not bind a trilinear texture. */
+#define ENIGMA_MAX_SPHERES 256u
+typedef struct EnigmaSphere {
+    float object_to_world[16]; /* Shape::m_objectToWorld->m_mat, row-major m[r][c] */
+    float world_to_object[16]; /* Shape::m_worldToObject->m_mat */
+    float radius, z_min, z_max, phi_max; /* the constructor's arguments (phi_max in degrees) */
+    uint32_t material;         /* index into materials */
+    uint32_t flags;            /* ENIGMA_TRI_FLIP_NORMAL: m_reverseOrientation ^ m_transformSwapsHandedness */
+    uint32_t prim_id;          /* Primitive::m_primitiveId; 0 = n_triangles + index + 1 */
+    uint32_t reserved;
+} EnigmaSphere;
+
 typedef struct EnigmaSceneDesc {
     uint32_t n_vertices;
     uint32_t n_triangles;
@@ -153,6 +168,8 @@ typedef struct EnigmaSceneDesc {
     const int32_t* tri_medium_outside;
     uint32_t n_textures;            /* image textures the materials' tex_* fields index */
     const EnigmaTexture* textures;
+    uint32_t n_spheres;
+    const EnigmaSphere* spheres;
 } EnigmaSceneDesc;
 
 /* PerspectiveCamera state read by GenerateRayDifferential (Enigma/Camera.cpp:144-192):

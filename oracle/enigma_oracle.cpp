@@ -1729,6 +1729,179 @@ struct Light {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Sphere (ShapeImp.cpp:13-203) with its running-error arithmetic (eFloat.h) and the error-carrying transforms
+// (Transform.h:212-330).  Release build of EFloat: no vPrecise.
+// ---------------------------------------------------------------------------
+struct EFloat {
+    float v = 0, low = 0, high = 0;
+    EFloat() {}
+    EFloat(float v_, float err = 0.f) : v(v_) {
+        if (err == 0.) low = high = v_;
+        else { low = NextFloatDown(v_ - err); high = NextFloatUp(v_ + err); }
+    }
+    float UpperBound() const { return high; }
+    float LowerBound() const { return low; }
+    explicit operator float() const { return v; }
+    EFloat operator+(EFloat ef) const { EFloat r; r.v = v + ef.v; r.low = NextFloatDown(low + ef.low); r.high = NextFloatUp(high + ef.high); return r; }
+    EFloat operator-(EFloat ef) const { EFloat r; r.v = v - ef.v; r.low = NextFloatDown(low - ef.high); r.high = NextFloatUp(high - ef.low); return r; }
+    EFloat operator*(EFloat ef) const {
+        EFloat r; r.v = v * ef.v;
+        float prod[4] = {low * ef.low, high * ef.low, low * ef.high, high * ef.high};
+        r.low = NextFloatDown(std::min(std::min(prod[0], prod[1]), std::min(prod[2], prod[3])));
+        r.high = NextFloatUp(std::max(std::max(prod[0], prod[1]), std::max(prod[2], prod[3])));
+        return r;
+    }
+    EFloat operator/(EFloat ef) const {
+        EFloat r; r.v = v / ef.v;
+        if (ef.low < 0 && ef.high > 0) { r.low = -InfinityF32; r.high = InfinityF32; }
+        else {
+            float div[4] = {low / ef.low, high / ef.low, low / ef.high, high / ef.high};
+            r.low = NextFloatDown(std::min(std::min(div[0], div[1]), std::min(div[2], div[3])));
+            r.high = NextFloatUp(std::max(std::max(div[0], div[1]), std::max(div[2], div[3])));
+        }
+        return r;
+    }
+    bool operator==(EFloat fe) const { return v == fe.v; }
+};
+static inline EFloat operator*(float f, EFloat fe) { return EFloat(f) * fe; }
+// eFloat.h:225-243
+static bool Quadratic(EFloat A, EFloat B, EFloat C, EFloat* t0, EFloat* t1) {
+    double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
+    if (discrim < 0.) return false;
+    double rootDiscrim = std::sqrt(discrim);
+    EFloat floatRootDiscrim((float)rootDiscrim, (float)(MachineEpsilon * rootDiscrim));
+    EFloat q;
+    if ((float)B < 0) q = -.5f * (B - floatRootDiscrim);
+    else q = -.5f * (B + floatRootDiscrim);
+    *t0 = q / A;
+    *t1 = C / q;
+    if ((float)*t0 > (float)*t1) std::swap(*t0, *t1);
+    return true;
+}
+// Transform.h:212-235: note the pairwise grouping of the sums
+static Vec3 TransformPointErr(const Mat4& M, const Vec3& p, Vec3* pError) {
+    const float (*m)[4] = M.m;
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    float wp = (m[3][0] * x + m[3][1] * y) + (m[3][2] * z + m[3][3]);
+    float xAbsSum = (std::abs(m[0][0] * x) + std::abs(m[0][1] * y) + std::abs(m[0][2] * z) + std::abs(m[0][3]));
+    float yAbsSum = (std::abs(m[1][0] * x) + std::abs(m[1][1] * y) + std::abs(m[1][2] * z) + std::abs(m[1][3]));
+    float zAbsSum = (std::abs(m[2][0] * x) + std::abs(m[2][1] * y) + std::abs(m[2][2] * z) + std::abs(m[2][3]));
+    *pError = gamma(3) * Vec3(xAbsSum, yAbsSum, zAbsSum);
+    if (wp == 1) return Vec3(xp, yp, zp);
+    else return Vec3(xp, yp, zp) / wp;
+}
+// Transform.h:237-269
+static Vec3 TransformPointErr(const Mat4& M, const Vec3& pt, const Vec3& ptError, Vec3* absError) {
+    const float (*m)[4] = M.m;
+    float x = pt.x, y = pt.y, z = pt.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    float wp = (m[3][0] * x + m[3][1] * y) + (m[3][2] * z + m[3][3]);
+    for (int r = 0; r < 3; ++r)
+        (*absError)[r] = (gamma(3) + 1.f) * (std::abs(m[r][0]) * ptError.x + std::abs(m[r][1]) * ptError.y + std::abs(m[r][2]) * ptError.z) +
+                         gamma(3) * (std::abs(m[r][0] * x) + std::abs(m[r][1] * y) + std::abs(m[r][2] * z) + std::abs(m[r][3]));
+    if (wp == 1.) return Vec3(xp, yp, zp);
+    else return Vec3(xp, yp, zp) / wp;
+}
+// Transform.h:271-287
+static Vec3 TransformVectorErr(const Mat4& M, const Vec3& v, Vec3* absError) {
+    const float (*m)[4] = M.m;
+    for (int r = 0; r < 3; ++r) (*absError)[r] = gamma(3) * (std::abs(m[r][0] * v.x) + std::abs(m[r][1] * v.y) + std::abs(m[r][2] * v.z));
+    return Vec3(m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z, m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z);
+}
+struct Sphere {
+    Mat4 o2w, w2o;
+    float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
+    bool flip = false; // m_reverseOrientation ^ m_transformSwapsHandedness
+    void init(float r, float z0, float z1, float phiDeg) { // ShapeImp.cpp:13-27
+        radius = r;
+        zMin = clampf(std::min(z0, z1), -radius, radius);
+        zMax = clampf(std::max(z0, z1), -radius, radius);
+        thetaMin = std::acos(clampf(zMin / radius, -1.f, 1.f));
+        thetaMax = std::acos(clampf(zMax / radius, -1.f, 1.f));
+        phiMax = (PI / 180.f) * clampf(phiDeg, 0.0f, 360.0f);
+    }
+    // the part intersect and intersectP share, ShapeImp.cpp:38-92 / 147-201
+    bool hitPoint(const Ray& worldRay, Ray* rayOut, Vec3* pHitOut, float* phiOut, float* tOut) const {
+        Vec3 oErr, dErr;
+        Vec3 o = TransformPointErr(w2o, worldRay.o, &oErr); // Transform::transformRay(r, &oErr, &dErr), Transform.h:317-330
+        Vec3 d = TransformVectorErr(w2o, worldRay.d, &dErr);
+        float lengthSquared = LengthSqr(d);
+        if (lengthSquared > 0) { float dt = Dot(Abs(d), oErr) / lengthSquared; o += d * dt; }
+        Ray ray(o, d, worldRay.tMax, worldRay.time);
+        EFloat ox(ray.o.x, oErr.x), oy(ray.o.y, oErr.y), oz(ray.o.z, oErr.z);
+        EFloat dx(ray.d.x, dErr.x), dy(ray.d.y, dErr.y), dz(ray.d.z, dErr.z);
+        EFloat a = dx * dx + dy * dy + dz * dz;
+        EFloat b = 2 * (dx * ox + dy * oy + dz * oz);
+        EFloat c = ox * ox + oy * oy + oz * oz - EFloat(radius) * EFloat(radius);
+        EFloat t0, t1;
+        if (!Quadratic(a, b, c, &t0, &t1)) return false;
+        if (t0.UpperBound() > ray.tMax || t1.LowerBound() <= 0) return false;
+        EFloat tShapeHit = t0;
+        if (tShapeHit.LowerBound() <= 0) {
+            tShapeHit = t1;
+            if (tShapeHit.UpperBound() > ray.tMax) return false;
+        }
+        auto place = [&](Vec3* pHit, float* phi) {
+            *pHit = ray.o + ray.d * (float)tShapeHit;
+            *pHit *= radius / Distance(*pHit, Vec3(0, 0, 0));
+            if (pHit->x == 0 && pHit->y == 0) pHit->x = 1e-5f * radius;
+            *phi = std::atan2(pHit->y, pHit->x);
+            if (*phi < 0) *phi += 2 * PI;
+        };
+        Vec3 pHit; float phi;
+        place(&pHit, &phi);
+        if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) {
+            if (tShapeHit == t1) return false;
+            if (t1.UpperBound() > ray.tMax) return false;
+            tShapeHit = t1;
+            place(&pHit, &phi);
+            if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) return false;
+        }
+        *rayOut = ray; *pHitOut = pHit; *phiOut = phi; *tOut = (float)tShapeHit;
+        return true;
+    }
+    bool intersectP(const Ray& r) const { Ray ray; Vec3 pHit; float phi, t; return hitPoint(r, &ray, &pHit, &phi, &t); }
+    bool intersect(const Ray& r, float* tHit, SurfaceInteraction* isect) const {
+        Ray ray; Vec3 pHit; float phi, t;
+        if (!hitPoint(r, &ray, &pHit, &phi, &t)) return false;
+        float u = phi / phiMax;
+        float theta = std::acos(clampf(pHit.z / radius, -1.0f, 1.0f));
+        float v = (theta - thetaMin) / (thetaMax - thetaMin);
+        float zRadius = std::sqrt(pHit.x * pHit.x + pHit.y * pHit.y);
+        float invZRadius = 1 / zRadius;
+        float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+        Vec3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+        Vec3 dpdv = (thetaMax - thetaMin) * Vec3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * std::sin(theta));
+        Vec3 pError = gamma(5) * Abs(pHit);
+        // SurfaceInteraction ctor (Interaction.cpp:101-130) in object space, then Transform::transformSurfInteraction
+        // (Transform.cpp:322-356) with m_objectToWorld: wo is NOT renormalised after the transform
+        Vec3 nObj = Normalize(Cross(dpdu, dpdv));
+        if (flip) nObj = -nObj;
+        Vec3 woObj = Normalize(-ray.d);
+        isect->p = TransformPointErr(o2w, pHit, pError, &isect->pError);
+        auto xfNormal = [&](const Vec3& n) { // transformNormal: the inverse's transpose (Transform.h:54-59)
+            const float (*m)[4] = w2o.m;
+            return Vec3(m[0][0] * n.x + m[1][0] * n.y + m[2][0] * n.z, m[0][1] * n.x + m[1][1] * n.y + m[2][1] * n.z, m[0][2] * n.x + m[1][2] * n.y + m[2][2] * n.z);
+        };
+        isect->n = Normalize(xfNormal(nObj));
+        isect->wo = o2w.transformVector(woObj);
+        isect->time = ray.time;
+        isect->uv = Vec2(u, v);
+        isect->dpdu = o2w.transformVector(dpdu); isect->dpdv = o2w.transformVector(dpdv);
+        isect->shading.n = Normalize(xfNormal(nObj));
+        isect->shading.dpdu = isect->dpdu; isect->shading.dpdv = isect->dpdv;
+        if (Dot(isect->shading.n, isect->n) < 0) isect->shading.n = -isect->shading.n; // FaceForward, Transform.cpp:353
+        *tHit = t;
+        return true;
+    }
+};
+
 // ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (Texture.h:313-415, Texture.cpp:22-29,412-453)
 struct ImageTex { MipMapRGB mip; float su = 1, sv = 1, du = 0, dv = 0; };
 struct TextureSet { std::vector<ImageTex> tex; };
@@ -1748,8 +1921,23 @@ struct Scene {
     std::vector<Light> lights;
     std::vector<EnigmaMedium> media; std::vector<int32_t> triInside, triOutside; // GeometricPrimitive::m_mi per triangle
     std::unique_ptr<BVHAccel> accel;
-    bool intersect(const Ray& r, SurfaceInteraction* isect, Vec3* bary = nullptr) const { return accel->intersect(r, isect, bary); }
-    bool intersectP(const Ray& r) const { return accel->intersectP(r); }
+    // Spheres are not in the restated BVH: they are tested one by one after it.  The closest hit is the same whichever
+    // structure finds it (the traversal counters then cover the triangles only); primitive index = nTris + sphere index.
+    std::vector<Sphere> spheres;
+    bool intersect(const Ray& r, SurfaceInteraction* isect, Vec3* bary = nullptr) const {
+        bool hit = accel->intersect(r, isect, bary);
+        for (size_t s = 0; s < spheres.size(); ++s) {
+            float tHit;
+            SurfaceInteraction si;
+            if (spheres[s].intersect(r, &tHit, &si)) { r.tMax = tHit; *isect = si; isect->primIndex = (int)(tris.size() + s); hit = true; }
+        }
+        return hit;
+    }
+    bool intersectP(const Ray& r) const {
+        if (accel->intersectP(r)) return true;
+        for (const Sphere& s : spheres) if (s.intersectP(r)) return true;
+        return false;
+    }
 };
 
 // Interaction.cpp:211-214
@@ -2384,13 +2572,40 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
             L.flags = 8; L.inf.reset(new InfiniteData()); L.inf->build(l);
         } else { h->o.error = "light type is not restated"; return -4; }
     }
+    // spheres: primitive index n_triangles + s in the per-primitive arrays
+    sc.spheres.clear();
+    BBox3 sphereBounds;
+    if (s->n_spheres > ENIGMA_MAX_SPHERES) { h->o.error = "too many spheres"; return -4; }
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const EnigmaSphere& e = s->spheres[i];
+        if (e.material >= s->n_materials) { h->o.error = "sphere material index out of range"; return -1; }
+        if (!(e.radius > 0)) { h->o.error = "sphere radius must be positive"; return -1; }
+        const EnigmaMaterial& m = s->materials[e.material];
+        for (uint32_t t : {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_eta, m.tex_k})
+            if (t && s->textures[t - 1].trilinear) { h->o.error = "trilinear textures on spheres are not restated"; return -4; }
+        Sphere sp;
+        memcpy(sp.o2w.m, e.object_to_world, 64); memcpy(sp.w2o.m, e.world_to_object, 64);
+        sp.init(e.radius, e.z_min, e.z_max, e.phi_max);
+        sp.flip = (e.flags & ENIGMA_TRI_FLIP_NORMAL) != 0;
+        sc.spheres.push_back(sp);
+        sc.triMaterial.push_back(e.material); sc.triLight.push_back(-1);
+        sc.primId.push_back(e.prim_id ? e.prim_id : s->n_triangles + i + 1);
+        if (!sc.triInside.empty()) { sc.triInside.push_back(-1); sc.triOutside.push_back(-1); }
+        // Shape::worldBound = m_objectToWorld->transformBounds(objectBound()) (Transform.h:82-94, ShapeImp.cpp:29-34)
+        const float lo[3] = {-sp.radius, -sp.radius, sp.zMin}, hi[3] = {sp.radius, sp.radius, sp.zMax};
+        for (int c = 0; c < 8; ++c) {
+            Vec3 q = sp.o2w.transformPoint(Vec3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+            sphereBounds.addPoint(q);
+        }
+    }
     sc.accel.reset(new BVHAccel(&sc.tris, max_node_prims, split_method == 1 ? SplitMethod::HLBVH : SplitMethod::SAH));
     {   // Scene::Scene (Scene.cpp:19-30): every light's Preprocess sees the aggregate's world bound;
         // BBox3::getBoundingSphere (BBox.h:322-326), getCenter (BBox.h:263-265)
         BBox3 wb;
         for (const Triangle& t : sc.tris) { BBox3 b = t.worldBound(); wb.addPoint(b.mn); wb.addPoint(b.mx); }
+        if (!sc.spheres.empty()) { wb.addPoint(sphereBounds.mn); wb.addPoint(sphereBounds.mx); }
         float radius = 0.f;
-        if (!sc.tris.empty()) {
+        if (!sc.tris.empty() || !sc.spheres.empty()) {
             Vec3 center = (wb.mn * .5f) + (wb.mx * .5f);
             bool inside = center.x >= wb.mn.x && center.x <= wb.mx.x && center.y >= wb.mn.y && center.y <= wb.mx.y && center.z >= wb.mn.z && center.z <= wb.mx.z;
             radius = inside ? Length(center - wb.mx) : 0.0f;

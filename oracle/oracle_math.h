@@ -71,6 +71,7 @@ inline float LengthSqr(Vec3 v) { return Dot(v, v); }          // MathCommon.h:20
 inline float LengthSqr(Vec2 v) { return Dot(v, v); }
 inline float Length(Vec3 v) { return std::sqrt(Dot(v, v)); }  // glm::length
 inline float DistanceSqr(Vec3 a, Vec3 b) { return LengthSqr(a - b); }
+inline float Distance(Vec3 a, Vec3 b) { return Length(a - b); } // glm::distance = length(p0 - p1)
 inline float AbsDot(Vec3 a, Vec3 b) { return std::abs(Dot(a, b)); }
 // glm::cross
 inline Vec3 Cross(Vec3 x, Vec3 y) {

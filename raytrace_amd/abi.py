@@ -42,6 +42,15 @@ class EnigmaMedium(C.Structure):
     _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("reserved", C.c_uint32)]
 
 
+MAX_SPHERES = 256
+
+
+class EnigmaSphere(C.Structure):
+    _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
+                ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("phi_max", C.c_float),
+                ("material", C.c_uint32), ("flags", C.c_uint32), ("prim_id", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class EnigmaSceneDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("vertices", C.c_void_p), ("indices", C.c_void_p), ("tri_material", C.c_void_p),
@@ -50,7 +59,7 @@ class EnigmaSceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32),
                 ("materials", C.c_void_p), ("lights", C.c_void_p),
                 ("n_media", C.c_uint32), ("media", C.c_void_p), ("tri_medium_inside", C.c_void_p), ("tri_medium_outside", C.c_void_p),
-                ("n_textures", C.c_uint32), ("textures", C.c_void_p)]
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_spheres", C.c_uint32), ("spheres", C.c_void_p)]
 
 
 class EnigmaCameraDesc(C.Structure):
@@ -93,7 +102,7 @@ class SceneArrays:
     """Owns the numpy arrays an EnigmaSceneDesc points into."""
 
     def __init__(self, vertices, indices, tri_material, tri_light, materials, lights, tri_flags=None, tri_prim_id=None,
-                 media=(), tri_medium_inside=None, tri_medium_outside=None, normals=None, uvs=None, textures=()):
+                 media=(), tri_medium_inside=None, tri_medium_outside=None, normals=None, uvs=None, textures=(), spheres=()):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         nt = self.indices.shape[0]
@@ -112,6 +121,8 @@ class SceneArrays:
         self.textures = (EnigmaTexture * max(1, len(textures)))(*textures)
         self._texture_maps = [getattr(t, "_map", None) for t in textures]   # the arrays rgb points into
         self.n_textures = len(textures)
+        self.spheres = (EnigmaSphere * max(1, len(spheres)))(*spheres)
+        self.n_spheres = len(spheres)
         self.lights = (EnigmaLight * max(1, len(lights)))(*lights)
         self._light_maps = [getattr(l, "_map", None) for l in lights]   # the arrays map_rgb points into
         self.n_lights = len(lights)
@@ -139,7 +150,26 @@ class SceneArrays:
         d.tri_medium_outside = ptr(self.tri_medium_outside)
         d.n_textures = self.n_textures
         d.textures = C.cast(self.textures, C.c_void_p) if self.n_textures else None
+        d.n_spheres = self.n_spheres
+        d.spheres = C.cast(self.spheres, C.c_void_p) if self.n_spheres else None
         return d
+
+
+def sphere(material, radius=1.0, object_to_world=None, z_min=None, z_max=None, phi_max=360.0, reverse_orientation=False):
+    """CreateSphereShape (Enigma/ShapeImp.cpp) under a given object-to-world matrix (4 x 4, row-major; identity if omitted).
+    The inverse is taken in double and rounded once, as the scene-description front end does."""
+    s = EnigmaSphere()
+    m = np.eye(4) if object_to_world is None else np.asarray(object_to_world, dtype=np.float64).reshape(4, 4)
+    s.object_to_world[:] = m.astype(np.float32).reshape(-1).tolist()
+    s.world_to_object[:] = np.linalg.inv(m).astype(np.float32).reshape(-1).tolist()
+    s.radius = radius
+    s.z_min = -radius if z_min is None else z_min
+    s.z_max = radius if z_max is None else z_max
+    s.phi_max = phi_max
+    s.material = material
+    swaps = np.linalg.det(m[:3, :3]) < 0
+    s.flags = TRI_FLIP_NORMAL if (bool(reverse_orientation) != bool(swaps)) else 0
+    return s
 
 
 def image_texture(rgb, trilinear=False, gamma=True, scale=1.0, wrap=WRAP_REPEAT, su=1.0, sv=1.0, du=0.0, dv=0.0):

@@ -73,6 +73,13 @@ struct DevTexture {         // a trilinear ImageTexture: the MipMap pyramid (lev
     uint32_t levelOff[16];  // first texel of each level
 };
 
+struct DevSphere {          // 128 bytes: a Sphere shape and its primitive
+    float o2w[12], w2o[12]; // rows 0..2 of Shape::m_objectToWorld / m_worldToObject (affine)
+    float radius, zMin, zMax, thetaMin, thetaMax, phiMax; // Sphere's members (Enigma/ShapeImp.cpp:13-27)
+    uint32_t mw;            // the second triangle word's layout: material | kind << 24 | flip-normal << 31
+    uint32_t pad;
+};
+
 struct DevScene {
     const float4* nodes;        // 4-wide BVH nodes, 8 float4 each
     const float4* tris;         // triangles in BVH order, 3 float4 each
@@ -87,6 +94,10 @@ struct DevScene {
     const DevMedium* media;     // VolPathIntegrator only
     const float4* triShade;     // 4 float4 per triangle (device order): (n0, u0) (n1, u1) (n2, u2) (v0, v1, v2, -), read for triangles whose
                                 // second word flags per-vertex normals or uvs; nullptr = no mesh has either
+    const DevSphere* spheres;   // primitive index nTris + i in hit records
+    uint32_t nSpheres;
+    float4* sphereGeom;         // four float4 per path: the surface interaction k_sphere_surface worked out for a sphere hit
+                                // (p | pError.x) (n | pError.y) (dpdu | pError.z) (wo | material index)
     const DevTexture* textures; // trilinear image textures; nullptr = none
     float4* texColors;          // two float4 per path: the textured colours k_texture evaluated at the path's hit
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media

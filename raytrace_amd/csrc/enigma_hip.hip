@@ -67,6 +67,8 @@ struct EnigmaCtx {
     DevBuf<uint32_t> infiniteLights;
     DevBuf<uint32_t> triMedium;
     DevBuf<float4> triShade;
+    DevBuf<DevSphere> spheres;
+    DevBuf<float4> sphereGeom;
     DevBuf<float4> texTexels, texColors;
     DevBuf<DevTexture> textures;
     bool kindTextured[MK_COUNT] = {false, false, false, false, false};
@@ -160,7 +162,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shRec.release();
-    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release();
+    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release(); h->spheres.release(); h->sphereGeom.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
@@ -361,6 +363,31 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh4Node));
     std::vector<uint32_t> prim(std::max(1u, s->n_triangles));
     for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
+    // spheres (Enigma/ShapeImp.cpp:13-27): tested one by one beside the BVH, primitive index n_triangles + i
+    std::vector<DevSphere> sphereTable;
+    if (s->n_spheres > ENIGMA_MAX_SPHERES) return h->fail(ENIGMA_E_UNSUPPORTED, "%u spheres (limit %u: spheres are not in the BVH)", s->n_spheres, ENIGMA_MAX_SPHERES);
+    if (s->n_spheres && !s->spheres) return h->fail(ENIGMA_E_INVALID, "null sphere array");
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const EnigmaSphere& e = s->spheres[i];
+        if (e.material >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "sphere %u: material index out of range", i);
+        if (!(e.radius > 0.f)) return h->fail(ENIGMA_E_INVALID, "sphere %u: radius must be positive", i);
+        if (mats[e.material].tex0 | mats[e.material].tex1) return h->fail(ENIGMA_E_UNSUPPORTED, "sphere %u: trilinear textures on spheres are not supported", i);
+        for (int c = 0; c < 4; ++c)
+            if (e.object_to_world[12 + c] != (c == 3 ? 1.f : 0.f) || e.world_to_object[12 + c] != (c == 3 ? 1.f : 0.f))
+                return h->fail(ENIGMA_E_UNSUPPORTED, "sphere %u: projective transforms are not supported", i);
+        DevSphere d;
+        memcpy(d.o2w, e.object_to_world, 48); memcpy(d.w2o, e.world_to_object, 48);
+        auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        d.radius = e.radius;
+        d.zMin = clampf(std::min(e.z_min, e.z_max), -e.radius, e.radius);
+        d.zMax = clampf(std::max(e.z_min, e.z_max), -e.radius, e.radius);
+        d.thetaMin = std::acos(clampf(d.zMin / d.radius, -1.f, 1.f));
+        d.thetaMax = std::acos(clampf(d.zMax / d.radius, -1.f, 1.f));
+        d.phiMax = (3.14159265358979323846f / 180.f) * clampf(e.phi_max, 0.0f, 360.0f);
+        d.mw = e.material | (mats[e.material].kind << 24) | ((e.flags & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u);
+        d.pad = 0;
+        sphereTable.push_back(d);
+    }
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
     h->hostLights.assign(s->n_lights, DevLight());
     h->haveAreaLights = false;
@@ -369,11 +396,22 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     const float PI = 3.1415926535897932384f;
     // Scene::worldBound() = the union of the primitives' bounds; BBox3::getBoundingSphere (Enigma/BBox.h:322-326)
     float worldRadius = 0.f;
-    if (s->n_triangles) {
+    if (s->n_triangles || s->n_spheres) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t k = 0; k < (size_t)s->n_triangles * 3; ++k) {
             const float* p = &s->vertices[3 * (size_t)s->indices[k]];
             for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], p[c]); hi[c] = std::max(hi[c], p[c]); }
+        }
+        for (const DevSphere& sp : sphereTable) { // Shape::worldBound: the eight corners of objectBound() through m_objectToWorld (Enigma/Transform.h:82-94)
+            const float olo[3] = {-sp.radius, -sp.radius, sp.zMin}, ohi[3] = {sp.radius, sp.radius, sp.zMax};
+            for (int k = 0; k < 8; ++k) {
+                const float x = (k & 1) ? ohi[0] : olo[0], y = (k & 2) ? ohi[1] : olo[1], z = (k & 4) ? ohi[2] : olo[2];
+                for (int c = 0; c < 3; ++c) { // Transform::transformPoint, Enigma/Transform.h:36-45
+                    const float* m = &sp.o2w[4 * c];
+                    const float q = m[0] * x + m[1] * y + m[2] * z + m[3];
+                    lo[c] = std::min(lo[c], q); hi[c] = std::max(hi[c], q);
+                }
+            }
         }
         float ctr[3], d2 = 0.f;
         bool inside = true;
@@ -471,8 +509,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             for (int c = 0; c < 3; ++c) { md[i].sigmaT[c] = m.sigma_s[c] + m.sigma_a[c]; md[i].sigmaS[c] = m.sigma_s[c]; }
             md[i].g = m.g; md[i].pad = 0.f;
         }
-        std::vector<uint32_t> tm(haveMedia ? s->n_triangles : 0);
-        for (uint32_t k = 0; k < (uint32_t)tm.size(); ++k) {
+        std::vector<uint32_t> tm(haveMedia ? std::max(1u, s->n_triangles) + s->n_spheres : 0, 0u); // spheres: no medium interface
+        for (uint32_t k = 0; k < (haveMedia ? s->n_triangles : 0u); ++k) {
             uint32_t t = bvh.triOrder[k];
             tm[k] = (uint32_t)(s->tri_medium_inside[t] + 1) | ((uint32_t)(s->tri_medium_outside[t] + 1) << 16);
         }
@@ -481,6 +519,10 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->scene.media = h->media.p;
         h->scene.triMedium = haveMedia ? h->triMedium.p : nullptr;
     }
+    HIPCHK(h, h->spheres.upload(sphereTable));
+    h->scene.spheres = sphereTable.empty() ? nullptr : h->spheres.p;
+    h->scene.nSpheres = (uint32_t)sphereTable.size();
+    h->scene.sphereGeom = nullptr; // allocated with the path state
     HIPCHK(h, h->texTexels.upload(texels));
     for (DevTexture& d : devTex) d.texels = h->texTexels.p;
     HIPCHK(h, h->textures.upload(devTex));
@@ -738,6 +780,8 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
         HIPCHK(h, h->pendB.alloc(n * pendingLevels));
         h->pendCapacity = n * pendingLevels;
     }
+    if (h->scene.nSpheres && h->sphereGeom.n < n * 4) HIPCHK(h, h->sphereGeom.alloc(n * 4));
+    h->scene.sphereGeom = h->scene.nSpheres ? h->sphereGeom.p : nullptr;
     if (h->haveTrilinear && h->texColors.n < n * 2) HIPCHK(h, h->texColors.alloc(n * 2));
     h->scene.texColors = h->haveTrilinear ? h->texColors.p : nullptr;
     if (n <= h->capacity) return ENIGMA_OK;
@@ -765,13 +809,16 @@ static size_t shadeLdsBytes(const EnigmaCtx* h) {
 // Evaluates the trilinear image textures at this bounce's hits (the material queues of the kinds that have a textured
 // material), between the closest-hit kernel and the shade kernels.
 static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
+    if (h->scene.nSpheres) // the surface interactions of this bounce's sphere hits
+        for (int k = 0; k < MK_COUNT; ++k)
+            if (h->kindPresent[k]) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[k].p, k, h->counters.p);
     if (!h->haveTrilinear) return;
     const float diffScale = 1 / std::sqrt((float)h->spp); // RayDifferential::scaleDifferentials, Enigma/Integrator.cpp:276
     for (int k = 0; k < MK_COUNT; ++k)
         if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
 }
 
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -783,7 +830,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(e1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -795,14 +842,14 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One iteration of VolPathIntegrator::Li's loop for every path in flight (Enigma/VolPathIntegrator.cpp:63-174):
 // trace + medium sampling, then the surface, medium and boundary branches, then the shadow and MIS rays.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int iter, int gridTrace,
                             int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -814,7 +861,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                               h->refillIdle, nullptr);
     (void)hipEventRecord(e1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -828,15 +875,15 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
-        k_shadow_tr<LDSN, OVF, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
-        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One step of the depth-first walk of DirectLightingIntegrator::Li's recursion for every path in flight:
 // trace the current rays, shade the hits (direct lighting + the specular children), resume pending branches
 // of the paths that missed, then the shadow and MIS rays of this step.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths,
                              int step, int gridTrace, int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
     DevCounters* ctr = h->counters.p;
@@ -848,7 +895,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(e0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                                  h->refillIdle, D.pendCount);
     (void)hipEventRecord(e1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -862,8 +909,8 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
-        k_shadow<LDSN, OVF, LDS_SCENE><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
@@ -894,7 +941,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
-    const bool ldsScene = h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    const bool ldsScene = h->scene.nSpheres == 0 && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -946,7 +993,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                if (h->scene.nSpheres) launchDirectStep<12, 52, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
                 else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
                 else launchDirectStep<12, 52, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
@@ -966,7 +1014,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                if (h->scene.nSpheres) launchVolBounce<12, 52, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
                 else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
                 else launchVolBounce<12, 52, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
@@ -984,7 +1033,8 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                     h->evPool.push_back(e);
                 }
                 hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                if (h->scene.nSpheres) launchBounce<12, 52, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 else launchBounce<12, 52, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
                 h->stats.intersect_launches++;
@@ -1130,6 +1180,7 @@ extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t*
 
 static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyHit, int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
     if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
+    if (h->scene.nSpheres) return h->fail(ENIGMA_E_UNSUPPORTED, "the intersection taps cover triangles only; the scene has spheres");
     if (n == 0) return ENIGMA_OK;
     DevBuf<float> dRays, dT, dB; DevBuf<int32_t> dTri; DevBuf<uint32_t> dPrim;
     std::vector<float> r(rays7, rays7 + 7 * (size_t)n);

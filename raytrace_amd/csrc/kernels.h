@@ -20,6 +20,7 @@
 #pragma once
 #include "dev_bsdf.h"
 #include "dev_trace.h"
+#include "dev_sphere.h"
 
 namespace edev {
 
@@ -179,14 +180,26 @@ DEV bool triHasUvs(uint32_t mw) { return (mw >> 28) & 1u; }
 DEV bool triReverse(uint32_t mw) { return (mw >> 29) & 1u; }
 
 // n: geometric normal (turned towards the shading normal when the mesh has normals); ns, dpdu: shading normal and shading dpdu
-struct HitGeom { F3 p, pError, n, ns, dpdu; int matIdx, lightIdx; };
+// wo: Interaction::m_wo.  normalize(-d) for a triangle; a sphere's comes back from object space un-normalised.
+struct HitGeom { F3 p, pError, n, ns, dpdu, wo; int matIdx, lightIdx; };
 
 DEV F3 triNormal(F3 p0, F3 p1, F3 p2, bool flip) { // Enigma/TriangleMesh.cpp:287-289
     F3 n = normalize(cross(p0 - p2, p1 - p2));
     return flip ? -n : n;
 }
 // Triangle::intersect after the hit test, Enigma/TriangleMesh.cpp:226-371 (no alpha mask, no per-vertex tangents)
-DEV HitGeom hitGeometry(const DevScene& sc, const float4* tris, int tri, float b0, float b1, float b2) {
+DEV HitGeom hitGeometry(const DevScene& sc, const float4* tris, int tri, float b0, float b1, float b2, F3 rayDir, uint32_t path) {
+    if (sc.sphereGeom && tri >= (int)sc.nTris) { // a sphere hit: k_sphere_surface has left the interaction in the path's slot
+        const float4* sg = sc.sphereGeom + (size_t)path * 4;
+        float4 a = sg[0], b = sg[1], c = sg[2], d = sg[3];
+        HitGeom g;
+        g.p = xyz(a); g.n = xyz(b); g.dpdu = xyz(c); g.wo = xyz(d);
+        g.pError = F3(a.w, b.w, c.w);
+        g.ns = g.n;
+        g.matIdx = __float_as_int(d.w);
+        g.lightIdx = -1;
+        return g;
+    }
     const float4* tp = tris + (size_t)tri * 3;
     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
     F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
@@ -227,6 +240,7 @@ DEV HitGeom hitGeometry(const DevScene& sc, const float4* tris, int tri, float b
     g.p = b0 * p0 + b1 * p1 + b2 * p2;
     g.n = triNormal(p0, p1, p2, triFlip(mw));
     g.ns = g.n;
+    g.wo = normalize(-rayDir); // Interaction.cpp:26
     if (shaded && triHasNormals(mw)) { // shading geometry, Enigma/TriangleMesh.cpp:291-370 and SetShadingGeometry, Enigma/Interaction.cpp:132-150
         F3 ns = b0 * xyz(s0) + b1 * xyz(s1) + b2 * xyz(s2);
         ns = lengthSqr(ns) > 0 ? normalize(ns) : g.n;
@@ -240,6 +254,38 @@ DEV HitGeom hitGeometry(const DevScene& sc, const float4* tris, int tri, float b
         g.dpdu = ss;
     }
     return g;
+}
+
+// The surface interactions of this bounce's sphere hits, worked out before the shade kernels run so that those only
+// load them: with the sphere code inlined the shade kernels of every scene would carry its registers.
+__global__ void __launch_bounds__(kBlock) k_sphere_surface(DevScene sc, DevPaths P, const uint32_t* matQueue, int kind, DevCounters* ctr) {
+    const uint32_t count = ctr->matCount[kind].v;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        const uint32_t p = matQueue[i];
+        const float4 hv = P.hit[p];
+        const int tri = __float_as_int(hv.x);
+        if (tri < (int)sc.nTris) continue;
+        const DevSphere& sp = sc.spheres[tri - (int)sc.nTris];
+        F3 pos, pErr, n, dpdu, wo;
+        sphereSurface(sp, F3(hv.y, hv.z, hv.w), xyz(P.rayD[p]), &pos, &pErr, &n, &dpdu, &wo);
+        float4* sg = sc.sphereGeom + (size_t)p * 4;
+        sg[0] = mk4(pos, pErr.x); sg[1] = mk4(n, pErr.y); sg[2] = mk4(dpdu, pErr.z); sg[3] = mk4(wo, __int_as_float((int)triMaterial(sp.mw)));
+    }
+}
+
+// A ray that has finished its walk through the triangles' BVH still has the scene's spheres to meet.  The traversal
+// kernels exist in two builds (template flag SPH): scenes without spheres run code that knows nothing of them -- with the
+// sphere test inlined, its registers cost the BVH walk a third of its speed.
+template <bool SPH>
+DEV void finishClosest(const DevScene& sc, const RaySetup& r, Hit* h) {
+    if (SPH) sphereClosest(sc, r.o, r.d, &h->tri, &h->t, &h->b0, &h->b1, &h->b2);
+}
+template <bool SPH>
+DEV bool isSpherePrim(const DevScene& sc, int prim) { return SPH && prim >= (int)sc.nTris; }
+// the second triangle word of a primitive of either kind
+template <bool SPH>
+DEV uint32_t primWord(const DevScene& sc, const float4* tris, int prim) {
+    return isSpherePrim<SPH>(sc, prim) ? sc.spheres[prim - (int)sc.nTris].mw : __float_as_uint(tris[(size_t)prim * 3 + 1].w);
 }
 
 // ---------------------------------------------------------------- kernels
@@ -317,7 +363,7 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 // MODE 2: the head of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:63-111): a ray that travels in a medium
 // samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
 // medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
-template <int LDSN, int OVF, bool LDS_SCENE, int MODE>
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
@@ -352,7 +398,8 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
                     uint32_t kind = 0;
-                    const Hit& h = w.h;
+                    Hit h = w.h;
+                    finishClosest<SPH>(sc, w.r, &h);
                     bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
                     if (VOL && stMedium(state) != 0) {
                         const DevMedium md = sc.media[stMedium(state) - 1u];
@@ -392,10 +439,11 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                     if (proceed && h.tri >= 0) {
                         uint32_t st = state;
                         uint32_t bounces = stBounces(st);
-                        const float4* tp = tris + (size_t)h.tri * 3;
+                        const bool sphere = isSpherePrim<SPH>(sc, h.tri); // no area light, nothing to fetch from the triangle array
+                        const float4* tp = tris + (size_t)(sphere ? 0 : h.tri) * 3;
                         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                        int lightIdx = __float_as_int(v2.w);
-                        uint32_t mw = __float_as_uint(v1.w);
+                        int lightIdx = sphere ? -1 : __float_as_int(v2.w);
+                        uint32_t mw = sphere ? sc.spheres[h.tri - (int)sc.nTris].mw : __float_as_uint(v1.w);
                         if ((DL || bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
                             const DevLight& lt = sc.lights[lightIdx];
                             F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
@@ -765,11 +813,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             float4 bv = P.beta[p];
             F3 beta = xyz(bv);
             float etaScale = bv.w;
-            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w, d, p);
             Bsdf bsdf;
             makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
             F3 ns = g.ns;
-            F3 woN = normalize(-d); // Interaction::m_wo, Enigma/Interaction.cpp:26
+            F3 woN = g.wo; // Interaction::m_wo
             // medium + 1 on either side of the surface: the triangle's MediumInterface if it is a transition, else
             // the medium the ray arrived in (GeometricPrimitive::intersect, Enigma/Primitive.cpp:155-160)
             uint32_t medIn = 0, medOut = 0;
@@ -936,11 +984,11 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             uint32_t px, py, slot;
             pathPixel(I, S, p, &px, &py, &slot);
             F3 beta = xyz(P.beta[p]);
-            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w, d, p);
             Bsdf bsdf;
             makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
             F3 ns = g.ns;
-            F3 woN = normalize(-d); // isect.m_wo
+            F3 woN = g.wo; // isect.m_wo
             const size_t raySlot0 = (size_t)p * I.raysPerPath;
             auto emit = [&](const DirectSample& ds, float div, int lightNum) { // div: sample count (all) or light-choice pdf (one)
                 if (ds.shadow) {
@@ -1047,7 +1095,7 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
     __shared__ uint32_t stack[LDSN * kBlock];
     __shared__ uint32_t poolNext;
@@ -1072,7 +1120,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             uint32_t nIdle = __popcll(idleMask);
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && p != kNoRay) {
-                    if (!w.occluded) {
+                    if (!w.occluded && !(SPH && sphereAny(sc, w.r.o, w.r.d, w.tMax))) {
                         if (shq.perPath == 1) { // the path's only ray in this kernel: nobody else touches its L
                             float4 L = P.L[p];
                             P.L[p] = make_float4(L.x + contrib.x, L.y + contrib.y, L.z + contrib.z, 0.f);
@@ -1106,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
 // the sampled light's triangle.  Few rays per bounce (only those that hit the light's own triangle
 // are queued), one per lane.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     extern __shared__ float4 sceneLds[];
@@ -1119,6 +1167,10 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
         Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
+        if (SPH) {
+            sphereClosest(sc, xyz(o), xyz(d), &h.tri, &h.t, &h.b0, &h.b1, &h.b2);
+            if (isSpherePrim<SPH>(sc, h.tri)) continue; // a sphere is no area light
+        }
         if (h.tri < 0) { // Li = light.Le(ray): only an infinite area light returns anything (Enigma/Integrator.cpp:194-195)
             const DevLight& lt = sc.lights[__float_as_int(d.w)];
             if (lt.type == 4) {

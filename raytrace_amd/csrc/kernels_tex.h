@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
         const uint32_t p = matQueue[i];
         const float4 hv = P.hit[p];
         const int tri = __float_as_int(hv.x);
+        if (sc.nSpheres && tri >= (int)sc.nTris) continue; // spheres carry no trilinear textures
         const float b0 = hv.y, b1 = hv.z, b2 = hv.w;
         const float4* tp = sc.tris + (size_t)tri * 3;
         const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];

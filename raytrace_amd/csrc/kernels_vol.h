@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
             float4 hv = P.hit[p];
             int tri = __float_as_int(hv.x);
             uint32_t st = __float_as_uint(rdv.w);
-            HitGeom g = hitGeometry(sc, sc.tris, tri, hv.y, hv.z, hv.w);
+            HitGeom g = hitGeometry(sc, sc.tris, tri, hv.y, hv.z, hv.w, d, p);
             P.rayO[p] = mk4(offsetRayOrigin(g.p, g.pError, g.n, d), 0.f); // isect.SpawnRay(ray.m_dir)
             P.rayD[p] = mk4(d, __uint_as_float(packState(mediumBeyond(sc, tri, stMedium(st), g.n, d), stDim(st), stBounces(st), stSpec(st)) | kStNoDifferentials));
         }
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
 // end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
 // without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
 // far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     extern __shared__ float4 sceneLds[];
@@ -207,16 +207,17 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
         }
         while (__ballot(active) != 0) {
             if (active && w.done()) {
-                const Hit& h = w.h;
+                Hit h = w.h;
+                finishClosest<SPH>(sc, w.r, &h);
                 bool hit = h.tri >= 0;
                 uint32_t kind = MK_NONE;
-                if (hit) kind = triKind(__float_as_uint(tris[(size_t)h.tri * 3 + 1].w));
+                if (hit) kind = triKind(primWord<SPH>(sc, tris, h.tri));
                 if (hit && kind != MK_NONE) { Tr = F3(0.f); active = false; }
                 else {
                     if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
                     if (!hit) active = false;
                     else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
-                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2);
+                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, p);
                         o = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
                         F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
                         d = target - o;
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
 // Scene::intersectTr for the MIS rays of one bounce: closest-hit queries through material-less surfaces
 // (isect.SpawnRay(ray.m_dir)), attenuated by the media on the way; the first surface with a material must be
 // the sampled light's triangle.  Every query counts as a MIS ray.
-template <int LDSN, int OVF, bool LDS_SCENE>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
     __shared__ uint32_t stack[2 * LDSN * kBlock];
     extern __shared__ float4 sceneLds[];
@@ -269,7 +270,8 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
         }
         while (__ballot(active) != 0) {
             if (active && w.done()) {
-                const Hit& h = w.h;
+                Hit h = w.h;
+                finishClosest<SPH>(sc, w.r, &h);
                 bool hit = h.tri >= 0;
                 if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : EDEV_INF);
                 if (!hit) {
@@ -280,6 +282,8 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                         float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
                         atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
                     }
+                } else if (isSpherePrim<SPH>(sc, h.tri)) {
+                    active = false; // a surface with a material that is no area light
                 } else {
                     const float4* tp = tris + (size_t)h.tri * 3;
                     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                             }
                         }
                     } else {
-                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2);
+                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, p);
                         o = offsetRayOrigin(g.p, g.pError, g.n, d);
                         med = mediumBeyond(sc, h.tri, med, g.n, d);
                         w.start(o, d, EDEV_INF);

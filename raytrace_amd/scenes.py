@@ -154,6 +154,10 @@ class MeshBuilder:
         self.interface = (-1, -1)   # MediumInterface (inside, outside) given to the triangles added next
         self.vn, self.vuv = [], []  # per-vertex normal / uv (zeros where the triangle has none)
         self.textures = []
+        self.spheres = []
+
+    def add_sphere(self, material, radius=1.0, object_to_world=None, **kw):
+        self.spheres.append(abi.sphere(material, radius, object_to_world, **kw))
 
     def add_texture(self, t):
         """Returns the value for a material's tex_* field (index + 1)."""
@@ -228,6 +232,9 @@ class MeshBuilder:
         return uniq, t.astype(np.uint32)
 
     def arrays(self, weld=True):
+        if not self.t:      # spheres (or lights) only
+            return abi.SceneArrays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32), [], [], self.materials, self.lights,
+                                   textures=self.textures, spheres=self.spheres)
         if weld:
             v, t = self.weld()
         else:
@@ -239,7 +246,7 @@ class MeshBuilder:
             shading["normals"] = v[:, 3:6]
         if any(f & abi.TRI_HAS_UVS for f in self.flags):
             shading["uvs"] = v[:, 6:8]
-        return abi.SceneArrays(v[:, :3], t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, textures=self.textures, **media, **shading)
+        return abi.SceneArrays(v[:, :3], t, self.mat, self.light, self.materials, self.lights, tri_flags=self.flags, textures=self.textures, spheres=self.spheres, **media, **shading)
 
 
 # ----------------------------------------------------------------------------- S1: Cornell box
@@ -387,6 +394,64 @@ def cornell_textured(trilinear=True, wrap=abi.WRAP_REPEAT):
             b.add_quad(f, m, toward=np.mean(f, axis=0) * 2 - centre, uvs=unit if name == "short" else None)
     b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
     return b.arrays()
+
+
+def _rotation(axis, degrees):
+    a = np.asarray(axis, dtype=np.float64)
+    a /= np.linalg.norm(a)
+    th = math.radians(degrees)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    m = np.eye(4)
+    m[:3, :3] = np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
+    return m
+
+
+def _translation(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def cornell_spheres(fog=False):
+    """The Cornell box with analytic Sphere shapes in place of the blocks: a matte sphere, a metal ellipsoid (rotated,
+    non-uniformly scaled), a smooth-glass sphere, a rough-glass bowl (z range and phi sweep cut open, ReverseOrientation)
+    and a plastic sphere under a mirroring transform.  fog: a scattering slab between camera and spheres (VolPath)."""
+    b = MeshBuilder()
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    c = CORNELL_CENTER
+    for name, m in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        b.add_quad(_CORNELL[name], m, toward=c)
+    b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
+    if fog:
+        med = b.add_medium(abi.homogeneous_medium((0.0005, 0.0005, 0.0005), (0.004, 0.005, 0.006), 0.2))
+        lo, hi = np.array([40.0, 150.0, 20.0]), np.array([520.0, 300.0, 120.0])
+        ctr = (lo + hi) / 2
+        b.medium_interface(med, -1)
+        for axis in range(3):
+            for side, val in ((-1, lo[axis]), (1, hi[axis])):
+                u, w = (axis + 1) % 3, (axis + 2) % 3
+                q = []
+                for du, dw in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                    p = np.zeros(3)
+                    p[axis] = val
+                    p[u] = hi[u] if du else lo[u]
+                    p[w] = hi[w] if dw else lo[w]
+                    q.append(tuple(p))
+                outward = ctr.copy()
+                outward[axis] = val + side * 100.0
+                b.add_quad(q, abi.NO_MATERIAL, toward=tuple(outward))
+        b.medium_interface(-1, -1)
+    b.add_sphere(b.add_material(abi.matte((0.6, 0.6, 0.2))), radius=60.0, object_to_world=_translation(120, 60, 140))
+    b.add_sphere(b.add_material(abi.metal(COPPER_ETA, COPPER_K, remap=False, uroughness=0.05, vroughness=0.25)), radius=1.0,
+                 object_to_world=_translation(400, 90, 330) @ _rotation((1, 2, 0.5), 35.0) @ np.diag([110.0, 70.0, 90.0, 1.0]))
+    b.add_sphere(b.add_material(abi.glass(1.5, 0.0, 0.0)), radius=70.0, object_to_world=_translation(260, 70, 200))
+    b.add_sphere(b.add_material(abi.glass(1.5, 0.1, 0.1)), radius=80.0, z_min=-80.0, z_max=30.0, phi_max=300.0, reverse_orientation=True,
+                 object_to_world=_translation(150, 330, 350) @ _rotation((1, 0, 0), -70.0))
+    b.add_sphere(b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05)), radius=55.0,
+                 object_to_world=_translation(420, 320, 300) @ np.diag([-1.0, 1.0, 1.0, 1.0]))
+    return b.arrays(weld=not fog)
 
 
 def cornell_fog(variant="diffuse", g=0.3):

@@ -424,6 +424,63 @@ def test_textures_change_the_picture_and_bad_ones_are_refused():
     assert e.value.code == -4
 
 
+@pytest.mark.parametrize("fog", [False, True])
+def test_image_parity_spheres(fog):
+    """Sphere shapes (Enigma/ShapeImp.cpp:13-203, eFloat.h, Transform.h:212-330): full, transformed, cut open, reversed and
+    mirrored spheres with all four materials beside the Cornell triangles; with fog, behind a scattering slab."""
+    sc = scenes.cornell_spheres(fog)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    integs = [scenes.volpath_desc(film, 16)] if fog else [scenes.integrator_desc(film, 16), scenes.direct_lighting_desc(film, 16, max_depth=4, strategy=abi.DL_SAMPLE_ONE),
+                                                          scenes.volpath_desc(film, 16)]
+    for integ in integs:
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert np.isfinite(r.image()).all()
+        assert common.mean_relative_error(r.image(), o.image()) < 2e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 2e-3 * so[k])
+        r.close(); o.close()
+
+
+def test_spheres_alone_and_refusals():
+    """A scene without a single triangle; more spheres than the limit, a sphere with a trilinear texture and the
+    intersection taps on a scene with spheres are refused."""
+    b = scenes.MeshBuilder()
+    b.add_sphere(b.add_material(abi.matte((0.5, 0.5, 0.5))), radius=5.0)
+    b.add_sphere(b.add_material(abi.glass(1.5, 0.0, 0.0)), radius=2.0, object_to_world=scenes._translation(0, 9, 0))
+    b.add_point_light((10, 30, 5), (3000.0, 3000.0, 3000.0))
+    b.add_distant_light((0.2, 1.0, 0.1), (0, 0, 0), (1.0, 1.0, 1.0))
+    sc = b.arrays()
+    cam, film = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, 48, 48), scenes.film_desc(48, 48)
+    integ = scenes.integrator_desc(film, 8, light_strategy=abi.LIGHTS_UNIFORM)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(0, 8); o.render(0, 8, threads=4)
+    assert r.image().max() > 0
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+    with pytest.raises(ra.EnigmaError) as e:
+        r.intersect(np.array([[0, 40, 0, 0, -1, 0, 1e30]], np.float32))
+    assert e.value.code == -4
+    r.close(); o.close()
+    many = scenes.MeshBuilder()
+    m = many.add_material(abi.matte((0.5, 0.5, 0.5)))
+    for i in range(abi.MAX_SPHERES + 1):
+        many.add_sphere(m, radius=1.0, object_to_world=scenes._translation(3.0 * i, 0, 0))
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(many.arrays(), cam, film, integ)
+    assert e.value.code == -4
+    tex = scenes.MeshBuilder()
+    m = tex.add_material(abi.matte((0.5, 0.5, 0.5)))
+    tex.materials[m].tex_kd = tex.add_texture(abi.image_texture(scenes.test_pattern(), trilinear=True))
+    tex.add_sphere(m, radius=1.0)
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(tex.arrays(), cam, film, integ)
+    assert e.value.code == -4
+
+
 def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
     """The uv axes orient the anisotropic tangent frame: a quarter turn of the uvs equals swapping u / v roughness
     (deterministic with a point light and depth 1)."""

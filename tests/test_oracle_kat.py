@@ -640,3 +640,107 @@ def test_texture_wrap_modes():
     want = 0.6 / math.pi * L
     assert np.allclose(out["repeat"], want[None, None, :], rtol=1e-4) and np.allclose(out["clamp"], want[None, None, :], rtol=1e-4)
     assert np.all(out["black"] == 0)
+
+
+# ------------------------------------------------------------------ spheres (oracle only, CPU)
+def _translate(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def _sphere_view(builder_fn, res=33, spp=16, light_dir=(0.0, 1.0, 0.0), strategy=abi.DL_SAMPLE_ALL):
+    """Camera 40 above the origin looking down (as _render_floor), distant light from above."""
+    b = scenes.MeshBuilder()
+    builder_fn(b)
+    b.add_distant_light(light_dir, (0, 0, 0), (2.0, 1.0, 0.5))
+    cam = scenes.camera_desc((0, 40, 0), (0, 0, 0), (0, 0, 1), 20.0, res, res)
+    film = scenes.film_desc(res, res)
+    o = orc.Oracle(b.arrays(), cam, film, scenes.direct_lighting_desc(film, spp, max_depth=1, strategy=strategy))
+    o.render(0, spp, threads=4)
+    img = o.image().astype(np.float64)
+    st = o.stats()
+    o.close()
+    return img, st
+
+
+def test_sphere_shades_like_its_closed_form():
+    """A matte unit-albedo-0.5 sphere of radius 5 under a distant light from +y, seen from +y: a pixel whose ray hits the
+    sphere at height y sees Kd/pi * L * (y / r) (normal = p / r); pixels outside the silhouette are black
+    (Sphere::intersect, Enigma/ShapeImp.cpp:36-143)."""
+    L = np.array([2.0, 1.0, 0.5])
+    r = 5.0
+
+    def build(b):
+        b.add_sphere(b.add_material(abi.matte((0.5, 0.5, 0.5))), radius=r)
+    img, st = _sphere_view(build, res=33, spp=16)
+    half = 40 * math.tan(math.radians(10.0))
+    c = (np.arange(33) + 0.5) / 33 * 2 - 1                       # pixel centres in [-1, 1]
+    # ray from (0, 40, 0) through the image plane point: direction (x, -40, z) * const; solve |o + t d| = r
+    dx, dz = np.meshgrid(c * half, c * half)
+    d = np.stack([dx, -40.0 * np.ones_like(dx), dz], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.array([0.0, 40.0, 0.0])
+    bq = 2 * (d @ o)
+    disc = bq * bq - 4 * (o @ o - r * r)
+    hit = disc > 0
+    t = np.where(hit, (-bq - np.sqrt(np.maximum(disc, 0))) / 2, 0)
+    y = o[1] + t * d[..., 1]
+    want = np.where(hit[..., None], (0.5 / math.pi) * L[None, None, :] * (y / r)[..., None], 0)
+    inner = disc > 0.25 * disc.max()                              # away from the silhouette, where a pixel straddles it
+    outer = disc < -0.25 * disc.max()
+    assert inner.sum() > 100 and outer.sum() > 100
+    assert np.allclose(img[inner], want[inner], rtol=0.02)
+    assert np.all(img[outer] == 0)
+    assert st["rays_shadow"] > 0                                  # the sphere's own shadow rays start above its surface: lit, not self-shadowed
+
+
+def test_sphere_matches_a_fine_tessellation_and_follows_its_transform():
+    """An analytic Sphere under a non-uniform scale and a translation against the same ellipsoid as a 20480-triangle
+    mesh with per-vertex normals: same picture to a few percent (the mesh's facets remain); a shadow on the floor below
+    comes from Sphere::intersectP."""
+    L = np.array([2.0, 1.0, 0.5])
+    m = _translate(1.0, 6.0, -0.5) @ np.diag([4.0, 2.0, 3.0, 1.0])
+
+    def floor(b):
+        grey = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+        b.add_quad([(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)], grey, toward=(0, 1, 0))
+        return grey
+
+    def analytic(b):
+        floor(b)
+        b.add_sphere(b.add_material(abi.matte((0.7, 0.6, 0.5))), radius=1.0, object_to_world=m)
+
+    def mesh(b):
+        floor(b)
+        mat = b.add_material(abi.matte((0.7, 0.6, 0.5)))
+        sv, sf = scenes._icosphere(5)
+        nrm = sv @ np.linalg.inv(m[:3, :3])                      # n * M^-1: the inverse transpose applied to the unit normals
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        pw = sv @ m[:3, :3].T + m[:3, 3]
+        for f in sf:
+            b.add_tri(pw[f[0]], pw[f[1]], pw[f[2]], mat, toward=pw[f[0]] + nrm[f[0]], normals=tuple(nrm[f]))
+    a, _ = _sphere_view(analytic, res=48, spp=16, light_dir=(0.3, 1.0, 0.2))
+    t, _ = _sphere_view(mesh, res=48, spp=16, light_dir=(0.3, 1.0, 0.2))
+    assert a.max() > 0
+    assert np.abs(a - t).mean() < 0.01 * t.mean()
+    dark = (t.sum(-1) == 0)
+    assert dark.sum() > 20 and (a[dark].sum(-1) == 0).mean() > 0.9   # the ellipsoid's shadow on the floor
+
+
+def test_partial_sphere_shows_its_inside_through_the_cut():
+    """zmax and phimax cut the sphere open (Enigma/ShapeImp.cpp:75-92): rays entering through the missing cap hit the
+    inner surface, which is lit from above through the opening; a full sphere of the same size hides it."""
+    def cut(b):
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1.0]])        # object +z -> world +y
+        b.add_sphere(b.add_material(abi.matte((0.5, 0.5, 0.5))), radius=5.0, object_to_world=rot, z_max=2.5)
+
+    def full(b):
+        b.add_sphere(b.add_material(abi.matte((0.5, 0.5, 0.5))), radius=5.0)
+    c, _ = _sphere_view(cut, res=33, spp=4)
+    f, _ = _sphere_view(full, res=33, spp=4)
+    centre_c, centre_f = c[16, 16, 0], f[16, 16, 0]
+    assert centre_f > 0 and centre_c > 0
+    assert abs(centre_c - centre_f) < 1e-3 * centre_f             # the bowl's bottom faces the light like the cap did (|n . w| = 1 both ways)
+    ring = c[16, 8, 0]                                            # a ray entering near the rim lands on the steep inner wall
+    assert 0 < ring < 0.9 * centre_c
