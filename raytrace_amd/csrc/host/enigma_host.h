@@ -262,6 +262,17 @@ public:
         m_textures.push_back(t);
         return (uint32_t)m_textures.size();
     }
+    // Sphere(o2w, w2o, reverseOrientation, radius, zMin, zMax, phiMax) with its GeometricPrimitive's material
+    // (Enigma/ShapeImp.cpp:13-27, Enigma/Api.cpp:843-874).  No area light and no medium interface on spheres.
+    void AddSphere(const Transform& objectToWorld, const Transform& worldToObject, bool reverseOrientation, bool transformSwapsHandedness,
+                   float radius, float zMin, float zMax, float phiMax, int materialIndex) {
+        EnigmaSphere s{};
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { s.object_to_world[4 * r + c] = objectToWorld.m_mat[r][c]; s.world_to_object[4 * r + c] = worldToObject.m_mat[r][c]; }
+        s.radius = radius; s.z_min = zMin; s.z_max = zMax; s.phi_max = phiMax;
+        s.material = (uint32_t)materialIndex;
+        s.flags = (reverseOrientation ^ transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u;
+        m_spheres.push_back(s);
+    }
     // HomogeneousMedium(sigma_a, sigma_s, g) (Enigma/Medium.cpp:69-76)
     int AddMedium(const EnigmaMedium& m) { m_media.push_back(m); return (int)m_media.size() - 1; }
     // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
@@ -309,6 +320,7 @@ public:
     std::vector<EnigmaMaterial> m_materials;
     std::vector<EnigmaMedium> m_media;
     std::vector<LightRec> m_lights;
+    std::vector<EnigmaSphere> m_spheres;
     std::vector<EnigmaTexture> m_textures;              // rgb pointers are filled in at Render time
     std::vector<std::vector<float>> m_textureTexels;
 private:
@@ -393,6 +405,7 @@ public:
         std::vector<EnigmaTexture> textures(scene.m_textures);
         for (size_t i = 0; i < textures.size(); ++i) textures[i].rgb = scene.m_textureTexels[i].data();
         sd.n_textures = (uint32_t)textures.size(); sd.textures = textures.empty() ? nullptr : textures.data();
+        sd.n_spheres = (uint32_t)scene.m_spheres.size(); sd.spheres = scene.m_spheres.empty() ? nullptr : scene.m_spheres.data();
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());

@@ -425,7 +425,8 @@ public:
     void pbrtAreaLightSource(const std::string& name, const ParamSet& p) { VerifyWorld("AreaLightSource"); m_gs.areaLight = name; m_gs.areaLightParams = p; }
     void pbrtShape(const std::string& name, const ParamSet& p) {
         VerifyWorld("Shape");
-        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh)");
+        if (name == "sphere") { MakeSphere(p); return; }
+        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh, sphere)");
         std::vector<int> vi = p.FindInt("indices");
         std::vector<double> P = p.FindPoint3("P");
         if (P.empty() || P.size() % 3) throw std::runtime_error("trianglemesh: \"point P\" missing or not a multiple of 3 values");
@@ -480,6 +481,19 @@ public:
             m.twoSided = ap.FindOneBool("twosided", false);
         }
         m_res->scene.AddTriangleMesh(m);
+        NoteUnused("Shape", p);
+    }
+    // CreateSphereShape (Enigma/ShapeImp.cpp:723-732) + the primitive MakeShapes wraps it in (Enigma/Api.cpp:843-874)
+    void MakeSphere(const ParamSet& p) {
+        const float radius = p.FindOneFloat("radius", 1.f);
+        const float zmin = p.FindOneFloat("zmin", -radius), zmax = p.FindOneFloat("zmax", radius), phimax = p.FindOneFloat("phimax", 360.f);
+        if (!m_gs.areaLight.empty()) throw std::runtime_error("Shape \"sphere\": an area light on a sphere is not supported");
+        if (!m_gs.currentInsideMedium.empty() || !m_gs.currentOutsideMedium.empty()) throw std::runtime_error("Shape \"sphere\": a MediumInterface on a sphere is not supported");
+        if (m_gs.currentMaterial == -2) throw std::runtime_error("Shape \"sphere\": a sphere without a material is not supported");
+        if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet());
+        const int material = m_gs.currentMaterial == -1 ? m_defaultMaterial : m_gs.currentMaterial;
+        Transform o2w = m_ctm.ToFloat(), w2o = m_ctm.Inverse().ToFloat();
+        m_res->scene.AddSphere(o2w, w2o, m_gs.reverseOrientation, m_ctm.SwapsHandedness(), radius, zmin, zmax, phimax, material);
         NoteUnused("Shape", p);
     }
     void pbrtObjectBegin(const std::string&) { throw std::runtime_error("ObjectBegin: object instancing is not supported"); }

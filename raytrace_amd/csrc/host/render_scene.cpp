@@ -68,6 +68,13 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         for (size_t k = 0; k < m.m_uv.size(); ++k) o << (k ? "," : "") << m.m_uv[k].x << "," << m.m_uv[k].y;
         o << "]}";
     }
+    o << "],\n\"spheres\":[";
+    for (size_t i = 0; i < R.scene.m_spheres.size(); ++i) {
+        const EnigmaSphere& s = R.scene.m_spheres[i];
+        o << (i ? "," : "") << "{\"o2w\":"; arr(s.object_to_world, 16); o << ",\"w2o\":"; arr(s.world_to_object, 16);
+        o << ",\"radius\":" << s.radius << ",\"zmin\":" << s.z_min << ",\"zmax\":" << s.z_max << ",\"phimax\":" << s.phi_max << ",\"material\":" << s.material
+          << ",\"flags\":" << s.flags << "}";
+    }
     o << "],\n\"textures\":[";
     for (size_t i = 0; i < R.scene.m_textures.size(); ++i) {
         const EnigmaTexture& t = R.scene.m_textures[i];

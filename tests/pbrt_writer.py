@@ -129,5 +129,17 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         out.append("AttributeEnd")
         t = e
     flush_points(1 << 30)
+    for i in range(getattr(sc, "n_spheres", 0)):
+        s = sc.spheres[i]
+        m = np.array(list(s.object_to_world), dtype=np.float64).reshape(4, 4)
+        swaps = np.linalg.det(m[:3, :3]) < 0
+        reverse = bool(s.flags & abi.TRI_FLIP_NORMAL) != bool(swaps)
+        out.append("AttributeBegin")
+        out.append("  ConcatTransform [%s]" % " ".join("%.9g" % v for v in m.T.reshape(-1)))      # the file holds the matrix column by column
+        out.append('  NamedMaterial "m%d"' % s.material)
+        if reverse:
+            out.append("  ReverseOrientation")
+        out.append('  Shape "sphere" "float radius" %.9g "float zmin" %.9g "float zmax" %.9g "float phimax" %.9g' % (s.radius, s.z_min, s.z_max, s.phi_max))
+        out.append("AttributeEnd")
     out.append("WorldEnd")
     return "\n".join(out) + "\n"

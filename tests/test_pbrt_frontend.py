@@ -169,7 +169,7 @@ WorldEnd
 
 
 @pytest.mark.parametrize("text,needle", [
-    ('WorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n', "sphere"),
+    ('WorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd\n', "cylinder"),
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
     ('WorldBegin\nMaterial "metal"\nWorldEnd\n', "eta"),
@@ -378,5 +378,44 @@ WorldEnd
                          ('Texture "x" "spectrum" "imagemap" "string filename" "one.png"', "PFM"),
                          ('Texture "x" "spectrum" "imagemap" "string filename" "missing.pfm"', "unable to read"),
                          ('Material "matte" "texture Kd" "nope"', "Couldn\'t find")):
+        err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
+        assert needle in err, err
+
+
+def test_sphere_shapes_reach_the_scene(tmp_path):
+    """Shape "sphere" (CreateSphereShape, Enigma/ShapeImp.cpp:723-732): both matrices of the CTM, the constructor's
+    parameters with their defaults, the orientation flag = ReverseOrientation ^ a mirroring CTM, the bound material."""
+    sc = scenes.cornell_spheres()
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4)
+    d = dump(tmp_path, text)
+    assert len(d["spheres"]) == sc.n_spheres
+    for got, ref in zip(d["spheres"], sc.spheres[: sc.n_spheres]):
+        assert np.allclose(got["o2w"], list(ref.object_to_world), rtol=1e-6, atol=1e-6)
+        assert np.allclose(got["w2o"], list(ref.world_to_object), rtol=1e-5, atol=1e-6)
+        assert np.allclose([got["radius"], got["zmin"], got["zmax"], got["phimax"]], [ref.radius, ref.z_min, ref.z_max, ref.phi_max])
+        assert got["material"] == ref.material and got["flags"] == ref.flags
+    head = '''
+LookAt 0 0 -5  0 0 0  0 1 0
+Camera "perspective" "float fov" 60
+Film "image" "integer xresolution" 8 "integer yresolution" 8
+Sampler "sobol" "integer pixelsamples" 1
+Integrator "path"
+WorldBegin
+'''
+    d = dump(tmp_path, head + '''
+AttributeBegin
+  Translate 1 2 3
+  Scale 2 2 -2
+  Shape "sphere" "float radius" 3
+AttributeEnd
+WorldEnd
+''')
+    s0 = d["spheres"][0]
+    assert (s0["radius"], s0["zmin"], s0["zmax"], s0["phimax"], s0["flags"]) == (3, -3, 3, 360, 1)           # the mirror alone flips the normal
+    assert np.allclose(np.array(s0["o2w"]).reshape(4, 4), [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, -2, 3], [0, 0, 0, 1]])
+    assert np.allclose(np.array(s0["o2w"]).reshape(4, 4) @ np.array(s0["w2o"]).reshape(4, 4), np.eye(4), atol=1e-6)
+    for body, needle in (('AreaLightSource "diffuse" "rgb L" [1 1 1]\nShape "sphere"', "area light"),
+                         ('Material "none"\nShape "sphere"', "without a material"),
+                         ('Shape "cylinder"', "not supported")):
         err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
         assert needle in err, err
