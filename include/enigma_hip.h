@@ -69,7 +69,7 @@ typedef struct EnigmaMaterial {
  * Enigma/MipMap.h:354-376) and every later ray reads level 0 bilinearly (SpawnRay drops the differentials). */
 enum { ENIGMA_WRAP_REPEAT = 0, ENIGMA_WRAP_BLACK = 1, ENIGMA_WRAP_CLAMP = 2 };
 typedef struct EnigmaTexture {
-    uint32_t width, height; /* power-of-two sides (the reference resamples other sizes first, MipMap.h:121-127) */
+    uint32_t width, height; /* other than power-of-two sides are zoomed first, as MipMap's constructor does (MipMap.h:121-127,155-237) */
     const float* rgb;       /* [height*width*3] as ReadImage returns them: top row first, before scale and gamma */
     float scale;            /* TexInfo::m_scale */
     float gamma;            /* TexInfo::m_gamma, the exponent (see above) */
@@ -98,8 +98,8 @@ typedef struct EnigmaLight {
     float world_to_light[9];  /* spot, infinite: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
     float light_to_world[9];  /* infinite: upper-left 3x3 of m_lightToWorld */
     /* infinite: the latitude-longitude radiance map the constructor reads (ReadImage -> RGB texels, row 0 = theta 0),
-     * multiplied by L; NULL = the 1 x 1 map of colour L (no "mapname").  Width and height must be powers of two: the
-     * reference resamples other sizes with a Lanczos filter first, which is left to the caller. */
+     * multiplied by L; NULL = the 1 x 1 map of colour L (no "mapname").  Sides that are not powers of two are zoomed with the
+     * reference's Lanczos filter first (MipMap::resizeImage, Enigma/MipMap.h:155-237). */
     uint32_t map_width, map_height;
     const float* map_rgb;     /* [map_height * map_width * 3] */
 } EnigmaLight;

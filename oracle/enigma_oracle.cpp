@@ -1501,7 +1501,66 @@ struct MipMapRGB {
     int wrap = 0;             // eImageWrapMode: 0 repeat, 1 black, 2 clamp
     bool doTrilinear = false; // m_doTrilinear
     int levels() const { return (int)level.size(); }
-    void build(int w, int h, const std::vector<Spectrum>& img) { // power-of-two sizes only (the resize step is not restated)
+    // MipMap::resizeImage / resampleWeights (MipMap.h:155-237): separable Lanczos zoom to power-of-two sides.  The signed
+    // "%" of the repeat mode leaves negative texel indices negative, and those taps are then dropped like the black mode's.
+    static float lanczos(float x, float tau = 2.f) { // MipMap.h:15-23
+        x = fabsf(x);
+        if (x < 1e-5) return 1;
+        if (x > 1.) return 0;
+        x *= 3.1415926535897932384f;
+        float s = sinf(x * tau) / (x * tau);
+        float l = sinf(x) / x;
+        return s * l;
+    }
+    struct ResampleWeight { int firstTexel; float weight[4]; };
+    static std::vector<ResampleWeight> resampleWeights(int oldWidth, int newWidth) {
+        std::vector<ResampleWeight> wt(newWidth);
+        float filterwidth = 2.f;
+        for (int i = 0; i < newWidth; ++i) {
+            float center = (i + .5f) * oldWidth / newWidth;
+            wt[i].firstTexel = (int)floorf((center - filterwidth) + 0.5f);
+            for (int j = 0; j < 4; ++j) { float pos = wt[i].firstTexel + j + .5f; wt[i].weight[j] = lanczos((pos - center) / filterwidth); }
+            float invSumWts = 1.f / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
+            for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
+        }
+        return wt;
+    }
+    static uint32_t roundUpPow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+    std::vector<Spectrum> resizeImage(const std::vector<Spectrum>& img, int oldWidth, int oldHeight, int* newWidth, int* newHeight) const {
+        const uint32_t sPow2 = roundUpPow2((uint32_t)oldWidth), tPow2 = roundUpPow2((uint32_t)oldHeight);
+        std::vector<ResampleWeight> sWeights = resampleWeights(oldWidth, (int)sPow2);
+        std::vector<Spectrum> out((size_t)sPow2 * tPow2, Spectrum(0.f));
+        for (uint32_t t = 0; t < (uint32_t)oldHeight; ++t)
+            for (uint32_t s = 0; s < sPow2; ++s) {
+                Spectrum acc = Spectrum(0.f);
+                for (int j = 0; j < 4; ++j) {
+                    int origS = sWeights[s].firstTexel + j;
+                    if (wrap == 0) origS = origS % oldWidth;
+                    else if (wrap == 2) origS = std::min(std::max(origS, 0), oldWidth - 1);
+                    if (origS >= 0 && origS < oldWidth) acc = acc + img[(size_t)t * oldWidth + origS] * sWeights[s].weight[j];
+                }
+                out[(size_t)t * sPow2 + s] = acc;
+            }
+        std::vector<ResampleWeight> tWeights = resampleWeights(oldHeight, (int)tPow2);
+        std::vector<Spectrum> work(tPow2);
+        for (uint32_t s = 0; s < sPow2; ++s) {
+            for (uint32_t t = 0; t < tPow2; ++t) {
+                Spectrum acc = Spectrum(0.f);
+                for (int j = 0; j < 4; ++j) {
+                    int offset = tWeights[t].firstTexel + j;
+                    if (wrap == 0) offset = offset % oldHeight;
+                    else if (wrap == 2) offset = std::min(std::max(offset, 0), oldHeight - 1);
+                    if (offset >= 0 && offset < oldHeight) acc = acc + out[(size_t)offset * sPow2 + s] * tWeights[t].weight[j];
+                }
+                work[t] = acc;
+            }
+            for (uint32_t t = 0; t < tPow2; ++t) out[(size_t)t * sPow2 + s] = work[t].Clamp();
+        }
+        *newWidth = (int)sPow2; *newHeight = (int)tPow2;
+        return out;
+    }
+    void build(int w, int h, std::vector<Spectrum> img) {
+        if ((w & (w - 1)) || (h & (h - 1))) { int nw, nh; img = resizeImage(img, w, h, &nw, &nh); w = nw; h = nh; }
         for (int i = 0; i < 128; ++i) { float alpha = 2; float r2 = float(i) / float(128 - 1); weightLut[i] = expf(-alpha * r2) - expf(-alpha); }
         int n = 1 + Log2Int(float(std::max(w, h)));
         level.assign(n, {}); lw.assign(n, 0); lh.assign(n, 0);
@@ -2537,7 +2596,7 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     for (uint32_t i = 0; i < s->n_textures; ++i) {
         const EnigmaTexture& t = s->textures[i];
         const int w = (int)t.width, hgt = (int)t.height;
-        if (w <= 0 || hgt <= 0 || (w & (w - 1)) || (hgt & (hgt - 1))) { h->o.error = "textures must have power-of-two sizes (MipMap::resizeImage is not restated)"; return -4; }
+        if (w <= 0 || hgt <= 0) { h->o.error = "empty texture"; return -1; }
         std::vector<Spectrum> px((size_t)w * hgt);
         for (size_t k = 0; k < px.size(); ++k) px[k] = Spectrum(t.rgb[3 * k], t.rgb[3 * k + 1], t.rgb[3 * k + 2]);
         for (int y = 0; y < hgt / 2; ++y)
@@ -2566,9 +2625,7 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         } else if (l.type == ENIGMA_LIGHT_DISTANT) {
             L.flags = 2; L.lightDir = Vec3(l.dir[0], l.dir[1], l.dir[2]);
         } else if (l.type == ENIGMA_LIGHT_INFINITE) {
-            if (l.map_rgb && ((l.map_width & (l.map_width - 1)) || (l.map_height & (l.map_height - 1)) || !l.map_width || !l.map_height)) {
-                h->o.error = "radiance maps must have power-of-two sizes (MipMap::resizeImage is not restated)"; return -4;
-            }
+            if (l.map_rgb && (!l.map_width || !l.map_height)) { h->o.error = "empty radiance map"; return -1; }
             L.flags = 8; L.inf.reset(new InfiniteData()); L.inf->build(l);
         } else { h->o.error = "light type is not restated"; return -4; }
     }

@@ -222,8 +222,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     for (uint32_t i = 0; i < s->n_textures; ++i) {
         const EnigmaTexture& t = s->textures[i];
         if (!t.rgb || !t.width || !t.height) return h->fail(ENIGMA_E_INVALID, "texture %u has no texels", i);
-        if ((t.width & (t.width - 1)) || (t.height & (t.height - 1)) || t.width > 32768u || t.height > 32768u)
-            return h->fail(ENIGMA_E_UNSUPPORTED, "texture %u is %u x %u: sides must be powers of two up to 32768 (the reference resamples other sizes)", i, t.width, t.height);
+        if (t.width > 32768u || t.height > 32768u) return h->fail(ENIGMA_E_UNSUPPORTED, "texture %u is %u x %u: sides up to 32768", i, t.width, t.height);
         if (t.wrap > 2u) return h->fail(ENIGMA_E_INVALID, "texture %u: unknown wrap mode %u", i, t.wrap);
         const int w = (int)t.width, hh = (int)t.height;
         std::vector<enigma::Rgb> px((size_t)w * hh);
@@ -238,7 +237,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         texConstant[i] = pyr.texel(pyr.levels() - 1, 0, 0);
         if (!t.trilinear) continue;
         DevTexture d{};
-        d.w = t.width; d.h = t.height; d.nLevels = (uint32_t)pyr.levels(); d.wrap = t.wrap;
+        d.w = (uint32_t)pyr.lw[0]; d.h = (uint32_t)pyr.lh[0]; d.nLevels = (uint32_t)pyr.levels(); d.wrap = t.wrap;
         d.su = t.su; d.sv = t.sv; d.du = t.du; d.dv = t.dv;
         for (int l = 0; l < pyr.levels(); ++l) {
             d.levelOff[l] = (uint32_t)texels.size();
@@ -465,8 +464,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             for (int c = 0; c < 3; ++c) P[c] = d.L[c] * PI * worldRadius * worldRadius;
             h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
         } else if (l.type == ENIGMA_LIGHT_INFINITE) {
-            if (l.map_rgb && (!l.map_width || !l.map_height || (l.map_width & (l.map_width - 1)) || (l.map_height & (l.map_height - 1))))
-                return h->fail(ENIGMA_E_UNSUPPORTED, "light %u: a radiance map of %u x %u texels is not a power of two on both sides", i, l.map_width, l.map_height);
+            if (l.map_rgb && (!l.map_width || !l.map_height)) return h->fail(ENIGMA_E_INVALID, "light %u: empty radiance map", i);
             if (l.map_rgb && (uint64_t)l.map_width * l.map_height > (1u << 26)) return h->fail(ENIGMA_E_UNSUPPORTED, "light %u: radiance map too large", i);
             enigma::HostEnvMap em;
             em.build(l.map_rgb, (int)l.map_width, (int)l.map_height, l.L);

@@ -25,7 +25,66 @@ struct EnvPyramid {
     float weightLut[128];
     int levels() const { return (int)level.size(); }
     static float log2f_(float x) { static const float invLog2 = 1.f / logf(2.f); return logf(x) * invLog2; } // Enigma/MathCommon.h:117-120
+    // MipMap::resizeImage / resampleWeights (Enigma/MipMap.h:155-237): separable Lanczos zoom to power-of-two sides.  The signed
+    // "%" of the repeat mode leaves negative texel indices negative, and those taps are then dropped like the black mode's.
+    static float lanczos(float x, float tau = 2.f) { // Enigma/MipMap.h:15-23
+        x = fabsf(x);
+        if (x < 1e-5) return 1;
+        if (x > 1.) return 0;
+        x *= 3.1415926535897932384f;
+        float s = sinf(x * tau) / (x * tau);
+        float l = sinf(x) / x;
+        return s * l;
+    }
+    struct ResampleWeight { int firstTexel; float weight[4]; };
+    static std::vector<ResampleWeight> resampleWeights(int oldWidth, int newWidth) {
+        std::vector<ResampleWeight> wt(newWidth);
+        float filterwidth = 2.f;
+        for (int i = 0; i < newWidth; ++i) {
+            float center = (i + .5f) * oldWidth / newWidth;
+            wt[i].firstTexel = (int)floorf((center - filterwidth) + 0.5f);
+            for (int j = 0; j < 4; ++j) { float pos = wt[i].firstTexel + j + .5f; wt[i].weight[j] = lanczos((pos - center) / filterwidth); }
+            float invSumWts = 1.f / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
+            for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
+        }
+        return wt;
+    }
+    static uint32_t roundUpPow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+    std::vector<Rgb> resizeImage(const std::vector<Rgb>& img, int oldWidth, int oldHeight, int* newWidth, int* newHeight) const {
+        const uint32_t sPow2 = roundUpPow2((uint32_t)oldWidth), tPow2 = roundUpPow2((uint32_t)oldHeight);
+        std::vector<ResampleWeight> sWeights = resampleWeights(oldWidth, (int)sPow2);
+        std::vector<Rgb> out((size_t)sPow2 * tPow2, Rgb{0.f, 0.f, 0.f});
+        for (uint32_t t = 0; t < (uint32_t)oldHeight; ++t)
+            for (uint32_t s = 0; s < sPow2; ++s) {
+                Rgb acc = Rgb{0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) {
+                    int origS = sWeights[s].firstTexel + j;
+                    if (wrap == 0) origS = origS % oldWidth;
+                    else if (wrap == 2) origS = std::min(std::max(origS, 0), oldWidth - 1);
+                    if (origS >= 0 && origS < oldWidth) acc = acc + img[(size_t)t * oldWidth + origS] * sWeights[s].weight[j];
+                }
+                out[(size_t)t * sPow2 + s] = acc;
+            }
+        std::vector<ResampleWeight> tWeights = resampleWeights(oldHeight, (int)tPow2);
+        std::vector<Rgb> work(tPow2);
+        for (uint32_t s = 0; s < sPow2; ++s) {
+            for (uint32_t t = 0; t < tPow2; ++t) {
+                Rgb acc = Rgb{0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) {
+                    int offset = tWeights[t].firstTexel + j;
+                    if (wrap == 0) offset = offset % oldHeight;
+                    else if (wrap == 2) offset = std::min(std::max(offset, 0), oldHeight - 1);
+                    if (offset >= 0 && offset < oldHeight) acc = acc + out[(size_t)offset * sPow2 + s] * tWeights[t].weight[j];
+                }
+                work[t] = acc;
+            }
+            for (uint32_t t = 0; t < tPow2; ++t) out[(size_t)t * sPow2 + s] = Rgb{std::max(work[t].r, 0.f), std::max(work[t].g, 0.f), std::max(work[t].b, 0.f)};
+        }
+        *newWidth = (int)sPow2; *newHeight = (int)tPow2;
+        return out;
+    }
     void build(int w, int h, std::vector<Rgb> img) {
+        if ((w & (w - 1)) || (h & (h - 1))) { int nw, nh; img = resizeImage(img, w, h, &nw, &nh); w = nw; h = nh; }
         for (int i = 0; i < 128; ++i) { float alpha = 2; float r2 = float(i) / float(128 - 1); weightLut[i] = expf(-alpha * r2) - expf(-alpha); }
         int n = 1 + (int)floorf(log2f_(float(std::max(w, h))));
         level.assign(n, {}); lw.assign(n, 0); lh.assign(n, 0);
@@ -136,9 +195,11 @@ struct HostEnvMap {
         for (size_t i = 0; i < tex.size(); ++i) tex[i] = map ? Rgb{map[3 * i] * L[0], map[3 * i + 1] * L[1], map[3 * i + 2] * L[2]} : Rgb{L[0], L[1], L[2]};
         EnvPyramid pyr;
         pyr.build(width, height, tex);
+        width = pyr.lw[0]; height = pyr.lh[0]; // power-of-two sides after MipMap::resizeImage
         w = width; h = height;
-        texels.resize(tex.size() * 4);
-        for (size_t i = 0; i < tex.size(); ++i) { texels[4 * i] = tex[i].r; texels[4 * i + 1] = tex[i].g; texels[4 * i + 2] = tex[i].b; texels[4 * i + 3] = 0.f; }
+        const std::vector<Rgb>& l0 = pyr.level[0];
+        texels.resize(l0.size() * 4);
+        for (size_t i = 0; i < l0.size(); ++i) { texels[4 * i] = l0[i].r; texels[4 * i + 1] = l0[i].g; texels[4 * i + 2] = l0[i].b; texels[4 * i + 3] = 0.f; }
         nu = 2 * width; nv = 2 * height;
         std::vector<float> img((size_t)nu * nv);
         for (int v = 0; v < nv; ++v) {

@@ -311,14 +311,17 @@ def test_image_parity_infinite_area_light(radiance_map):
         for k in ("rays_closest", "rays_shadow", "rays_mis"):
             assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
         r.close(); o.close()
-    # a map whose sides are not powers of two is refused (the reference resamples it first)
-    bad = abi.infinite_light((1, 1, 1), np.ones((6, 12, 3), np.float32))
+    # a map whose sides are not powers of two is resampled first (MipMap::resizeImage, Enigma/MipMap.h:155-237)
+    odd = abi.infinite_light((1, 1, 1), scenes.sky_map(12, 20), light_to_world=[[1, 0, 0], [0, 0, 1], [0, -1, 0]])
     base = scenes.cornell_box("diffuse")
     sc2 = abi.SceneArrays(base.vertices, base.indices, base.tri_material, base.tri_light, [base.materials[i] for i in range(base.n_materials)],
-                          [base.lights[0], base.lights[1], bad], tri_flags=base.tri_flags)
-    with pytest.raises(ra.EnigmaError) as e:
-        ra.Renderer(0).configure(sc2, cam, film, scenes.integrator_desc(film, 4))
-    assert e.value.code == -4
+                          [base.lights[0], base.lights[1], odd], tri_flags=base.tri_flags)
+    integ = scenes.integrator_desc(film, 16)
+    r = ra.Renderer(0).configure(sc2, cam, film, integ)
+    o = orc.Oracle(sc2, cam, film, integ)
+    r.render(0, 16); o.render(0, 16, threads=8)
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+    r.close(); o.close()
 
 
 def test_image_parity_shading_normals_and_uvs():
@@ -400,10 +403,14 @@ def test_textures_change_the_picture_and_bad_ones_are_refused():
     base = dict(vertices=sc.vertices, indices=sc.indices, tri_material=sc.tri_material, tri_light=sc.tri_light,
                 materials=[sc.materials[i] for i in range(sc.n_materials)], lights=[sc.lights[i] for i in range(sc.n_lights)],
                 tri_flags=sc.tri_flags, uvs=sc.uvs)
-    odd = abi.SceneArrays(**base, textures=[abi.image_texture(np.ones((6, 8, 3), np.float32))] * sc.n_textures)
-    with pytest.raises(ra.EnigmaError) as e:
-        ra.Renderer(0).configure(odd, cam, film, integ)
-    assert e.value.code == -4
+    # sides that are not powers of two are resampled first (MipMap::resizeImage), under each wrap mode
+    for wrap in (abi.WRAP_REPEAT, abi.WRAP_CLAMP, abi.WRAP_BLACK):
+        odd = abi.SceneArrays(**base, textures=[abi.image_texture(scenes.test_pattern(24, 40), trilinear=True, wrap=wrap, su=2.0, sv=2.0)] * sc.n_textures)
+        r = ra.Renderer(0).configure(odd, cam, film, integ)
+        o = orc.Oracle(odd, cam, film, integ)
+        r.render(0, 8); o.render(0, 8, threads=8)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        r.close(); o.close()
     missing = abi.SceneArrays(**base, textures=[sc.textures[0]])       # the materials index five textures
     with pytest.raises(ra.EnigmaError) as e:
         ra.Renderer(0).configure(missing, cam, film, integ)

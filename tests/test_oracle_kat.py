@@ -744,3 +744,24 @@ def test_partial_sphere_shows_its_inside_through_the_cut():
     assert abs(centre_c - centre_f) < 1e-3 * centre_f             # the bowl's bottom faces the light like the cap did (|n . w| = 1 both ways)
     ring = c[16, 8, 0]                                            # a ray entering near the rim lands on the steep inner wall
     assert 0 < ring < 0.9 * centre_c
+
+
+def test_textures_with_other_sides_are_resampled_to_powers_of_two():
+    """MipMap::resizeImage (Enigma/MipMap.h:155-237): a constant 6 x 6 image zoomed to 8 x 8 stays constant under the clamp
+    mode; under repeat the signed remainder leaves the taps left of / below the image negative and they are dropped
+    after the weights were normalised, so the first rows and columns come out darker; black drops them on both sides."""
+    L = np.array([2.0, 1.0, 0.5])
+    img = np.full((6, 6, 3), 0.6, np.float32)
+    want = 0.6 / math.pi * L
+    clamp = _textured_floor(abi.image_texture(img, trilinear=True, wrap=abi.WRAP_CLAMP, su=0.02, sv=0.02, du=0.5, dv=0.5), res=5)
+    assert np.allclose(clamp, want[None, None, :], rtol=1e-4)
+    # look at the resized image's texel (0, 0) and at its centre: uv window of a tenth of a texel around them
+    def at(wrap, u, v):
+        return _textured_floor(abi.image_texture(img, trilinear=True, wrap=wrap, su=1e-4, sv=1e-4, du=u, dv=v), res=3)[1, 1]
+    centre = (4.5 / 8, 4.5 / 8)
+    corner = (0.5 / 8, 0.5 / 8)
+    for wrap in (abi.WRAP_REPEAT, abi.WRAP_BLACK):
+        assert np.allclose(at(wrap, *centre), want, rtol=1e-4)
+        assert np.all(at(wrap, *corner) < 0.95 * want)
+    far_corner = (7.5 / 8, 0.5 / 8)                     # the last column: taps beyond the image wrap around (repeat) or vanish (black)
+    assert at(abi.WRAP_REPEAT, *far_corner)[0] > at(abi.WRAP_BLACK, *far_corner)[0]
