@@ -48,7 +48,8 @@ typedef struct EnigmaMaterial {
     float kt[3];              /* glass: Kt */
     float eta[3];             /* metal: eta (RGB) */
     float k[3];               /* metal: k (RGB) */
-    float sigma;              /* matte: Oren-Nayar sigma, must be 0 (Lambertian) */
+    float sigma;              /* matte: sigma in degrees, clamped to [0, 90]; 0 = LambertianReflection, else OrenNayer
+                                 (Enigma/Material.cpp:86-91) */
     float uroughness;         /* metal / glass: u roughness; plastic: roughness */
     float vroughness;         /* metal / glass: v roughness; plastic: roughness */
     float index;              /* glass: index of refraction */

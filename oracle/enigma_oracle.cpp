@@ -1193,6 +1193,29 @@ struct LambertianReflection : BxDF { // BxDF.cpp:729-732
     explicit LambertianReflection(const Spectrum& r) : BxDF(BSDF_REFLECTION | BSDF_DIFFUSE), R(r) {}
     Spectrum f(const Vec3&, const Vec3&) const override { return R * INV_PI; }
 };
+struct OrenNayer : BxDF { // BxDF.cpp:744-779; sampling and pdf are the base class's cosine hemisphere
+    Spectrum R; float A, B;
+    OrenNayer(const Spectrum& r, float sig) : BxDF(BSDF_REFLECTION | BSDF_DIFFUSE), R(r) {
+        float sigma = sig * (PI / 180.0f); // ToRadians
+        float sigma2 = sigma * sigma;
+        A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+        B = (0.45f * sigma2) / (sigma2 + 0.09f);
+    }
+    Spectrum f(const Vec3& wo, const Vec3& wi) const override {
+        float sinThetai = SinTheta(wi), sinThetao = SinTheta(wo);
+        float maxcos = 0.f;
+        if (sinThetai > 1e-4 && sinThetao > 1e-4) {
+            float sinphii = SinPhi(wi), cosphii = CosPhi(wi);
+            float sinphio = SinPhi(wo), cosphio = CosPhi(wo);
+            float dcos = cosphii * cosphio + sinphii * sinphio;
+            maxcos = std::max(0.f, dcos);
+        }
+        float sinalpha, tanbeta;
+        if (AbsCosTheta(wi) > AbsCosTheta(wo)) { sinalpha = sinThetao; tanbeta = sinThetai / AbsCosTheta(wi); }
+        else { sinalpha = sinThetai; tanbeta = sinThetao / AbsCosTheta(wo); }
+        return R * INV_PI * (A + B * maxcos * sinalpha * tanbeta);
+    }
+};
 struct SpecularReflection : BxDF { // BxDF.cpp:661-687
     Spectrum R; std::unique_ptr<Fresnel> fresnel;
     SpecularReflection(const Spectrum& r, Fresnel* fr) : BxDF(BSDF_REFLECTION | BSDF_SPECULAR), R(r), fresnel(fr) {}
@@ -1401,7 +1424,7 @@ static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceIn
         float sig = clampf(m.sigma, 0.f, 90.f);
         if (!r.IsBlack()) {
             if (sig == 0) bsdf->addBxDF(new LambertianReflection(r));
-            // Oren-Nayar (sigma != 0) is outside the restated path
+            else bsdf->addBxDF(new OrenNayer(r, sig));
         }
         return bsdf;
     }
@@ -2587,7 +2610,6 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         sc.triOutside.assign(s->tri_medium_outside, s->tri_medium_outside + s->n_triangles);
     }
     for (auto& m : sc.materials) {
-        if (m.type == ENIGMA_MAT_MATTE && m.sigma != 0) { h->o.error = "Oren-Nayar is not restated"; return -4; }
         for (uint32_t t : {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_eta, m.tex_k})
             if (t > s->n_textures) { h->o.error = "texture index out of range"; return -1; }
     }

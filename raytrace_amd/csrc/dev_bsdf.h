@@ -14,10 +14,10 @@
 namespace edev {
 
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR, LOBE_SPEC_REFL, LOBE_SPEC_TRANS };
+enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_OREN_NAYAR };
 
 DEV constexpr int lobeType(int k) {
-    return k == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
+    return (k == LOBE_LAMBERT || k == LOBE_OREN_NAYAR) ? (BSDF_REFLECTION | BSDF_DIFFUSE)
          : (k == LOBE_MICRO_REFL_CONDUCTOR || k == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
          : k == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
          : k == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
@@ -163,6 +163,7 @@ DEV F3 cosineSampleHemisphere(float ux, float uy) {
 // and keeps the struct in registers (no run-time indexed members).
 template <int MK, int I> struct LobeOf { static constexpr int kind = -1; };
 template <> struct LobeOf<MK_MATTE, 0> { static constexpr int kind = LOBE_LAMBERT; };
+template <> struct LobeOf<MK_MATTE_ROUGH, 0> { static constexpr int kind = LOBE_OREN_NAYAR; };
 template <> struct LobeOf<MK_METAL, 0> { static constexpr int kind = LOBE_MICRO_REFL_CONDUCTOR; };
 template <> struct LobeOf<MK_GLASS_SMOOTH, 0> { static constexpr int kind = LOBE_FRESNEL_SPECULAR; };
 template <> struct LobeOf<MK_GLASS_ROUGH, 0> { static constexpr int kind = LOBE_MICRO_REFL_DIELECTRIC; };
@@ -221,7 +222,7 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b, const fl
 }
 
 DEV constexpr bool lobeMatches(int kind, int flags) {
-    int t = kind == LOBE_LAMBERT ? (BSDF_REFLECTION | BSDF_DIFFUSE)
+    int t = (kind == LOBE_LAMBERT || kind == LOBE_OREN_NAYAR) ? (BSDF_REFLECTION | BSDF_DIFFUSE)
           : (kind == LOBE_MICRO_REFL_CONDUCTOR || kind == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
           : kind == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
           : kind == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
@@ -276,16 +277,31 @@ DEV float microTransPdf(const Bsdf& b, F3 wo, F3 wi) { // BxDF.cpp:1059-1073
     return trPdf(b.ax, b.ay, wo, wh) * dwh_dwi;
 }
 
+// OrenNayer::f, Enigma/BxDF.cpp:755-779; A and B (Enigma/BxDF.cpp:744-753) ride in the slots of the microfacet alphas
+DEV F3 orenNayarF(const Bsdf& b, F3 col, F3 wo, F3 wi) {
+    float sinThetai = sinTheta(wi), sinThetao = sinTheta(wo);
+    float maxcos = 0.f;
+    if (sinThetai > 1e-4 && sinThetao > 1e-4) {
+        float dcos = cosPhi(wi) * cosPhi(wo) + sinPhi(wi) * sinPhi(wo);
+        maxcos = smax(0.f, dcos);
+    }
+    float sinalpha, tanbeta;
+    if (absCosTheta(wi) > absCosTheta(wo)) { sinalpha = sinThetao; tanbeta = sinThetai / absCosTheta(wi); }
+    else { sinalpha = sinThetai; tanbeta = sinThetao / absCosTheta(wo); }
+    return col * kInvPi * (b.ax + b.ay * maxcos * sinalpha * tanbeta);
+}
+
 template <int KIND>
 DEV F3 lobeF(const Bsdf& b, F3 col, F3 wo, F3 wi) {
     if (KIND == LOBE_LAMBERT) return col * kInvPi;
+    if (KIND == LOBE_OREN_NAYAR) return orenNayarF(b, col, wo, wi);
     if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) return microReflF<KIND>(b, col, wo, wi);
     if (KIND == LOBE_MICRO_TRANS) return microTransF(b, col, wo, wi);
     return F3(0.f);
 }
 template <int KIND>
 DEV float lobePdf(const Bsdf& b, F3 wo, F3 wi) {
-    if (KIND == LOBE_LAMBERT) return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF.cpp:568-571
+    if (KIND == LOBE_LAMBERT || KIND == LOBE_OREN_NAYAR) return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF.cpp:568-571
     if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) return microReflPdf(b, wo, wi);
     if (KIND == LOBE_MICRO_TRANS) return microTransPdf(b, wo, wi);
     return 0.f;
@@ -293,7 +309,7 @@ DEV float lobePdf(const Bsdf& b, F3 wo, F3 wi) {
 // BxDF::sample_f of one lobe.  Returns f; *pdf stays 0 when the lobe fails to sample.
 template <int KIND>
 DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
-    if (KIND == LOBE_LAMBERT) { // BxDF.cpp:529-536
+    if (KIND == LOBE_LAMBERT || KIND == LOBE_OREN_NAYAR) { // BxDF.cpp:529-536
         *wi = cosineSampleHemisphere(u0, u1);
         if (wo.z < 0.f) wi->z *= -1.f;
         *pdf = lobePdf<KIND>(b, wo, *wi);

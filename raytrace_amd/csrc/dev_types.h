@@ -7,9 +7,10 @@ namespace edev {
 // Material kinds the shade kernels are sorted by.  ENIGMA_MAT_GLASS splits by roughness at
 // upload: a smooth glass is one FresnelSpecular lobe (allowMultipleLobes is always true on the
 // PathIntegrator path, Enigma/PathIntegrator.cpp:89, Enigma/Material.cpp:190-194).
-enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4, MK_COUNT = 5,
-                          MK_NONE = 5 /* a triangle without a material: a medium boundary (VolPathIntegrator) */,
-                          MK_DL_GLASS = 6 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
+enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4,
+                          MK_MATTE_ROUGH = 5 /* matte with sigma != 0: Oren-Nayar instead of Lambert */, MK_COUNT = 6,
+                          MK_NONE = 6 /* a triangle without a material: a medium boundary (VolPathIntegrator) */,
+                          MK_DL_GLASS = 7 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
 // One queue per material kind, then queue MK_COUNT: DirectLightingIntegrator paths that resume a pending branch /
 // VolPathIntegrator paths at a material-less surface; queue MK_COUNT + 1: VolPathIntegrator medium interactions.
 constexpr int kQueueKinds = MK_COUNT + 2;

@@ -71,12 +71,12 @@ struct EnigmaCtx {
     DevBuf<float4> sphereGeom;
     DevBuf<float4> texTexels, texColors;
     DevBuf<DevTexture> textures;
-    bool kindTextured[MK_COUNT] = {false, false, false, false, false};
+    bool kindTextured[MK_COUNT] = {};
     bool haveTrilinear = false, smoothGlass = false;
     bool haveNoMaterial = false; // some triangle has no material (a medium boundary): VolPathIntegrator only
     std::vector<DevLight> hostLights;
     std::vector<float> lightPower; // Light::Power().y() per light
-    bool kindPresent[MK_COUNT] = {false, false, false, false, false};
+    bool kindPresent[MK_COUNT] = {};
     bool haveAreaLights = false;
     uint32_t refillIdle = 16;
     DevScene scene{};
@@ -275,12 +275,21 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             (binds[b].slot ? d.tex1 : d.tex0) = texDevice[binds[b].tex - 1];
         }
         float ur = m.uroughness, vr = m.vroughness;
+        float orenA = 0.f, orenB = 0.f;
         bool specularGlass = false;
         switch (m.type) {
         case ENIGMA_MAT_MATTE:
-            if (m.sigma != 0.f) return h->fail(ENIGMA_E_UNSUPPORTED, "matte sigma != 0 (Oren-Nayar) is not supported");
             d.kind = MK_MATTE;
             for (int c = 0; c < 3; ++c) d.c0[c] = clamp01inf(m.kd[c]);
+            {   // sigma clamped to [0, 90] degrees; != 0 selects OrenNayer (Enigma/Material.cpp:86-91, Enigma/BxDF.cpp:744-753)
+                const float sig = std::min(std::max(m.sigma, 0.f), 90.f);
+                if (sig != 0.f) {
+                    d.kind = MK_MATTE_ROUGH;
+                    const float sigma = sig * (3.1415926535897932384f / 180.0f), sigma2 = sigma * sigma;
+                    orenA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                    orenB = (0.45f * sigma2) / (sigma2 + 0.09f);
+                }
+            }
             break;
         case ENIGMA_MAT_METAL:
             d.kind = MK_METAL;
@@ -305,6 +314,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         }
         d.alphax = std::max(float(0.001), ur); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
         d.alphay = std::max(float(0.001), vr);
+        if (d.kind == MK_MATTE_ROUGH) { d.alphax = orenA; d.alphay = orenB; } // the Oren-Nayar coefficients travel in the alpha slots
         bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f;
         bool nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
         if (d.tex0) nb0 = true; // decided per hit
@@ -838,6 +848,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
@@ -870,6 +881,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
@@ -904,6 +916,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {

@@ -488,6 +488,32 @@ def test_spheres_alone_and_refusals():
     assert e.value.code == -4
 
 
+def test_image_parity_oren_nayar():
+    """Matte with sigma != 0: the OrenNayer lobe (Enigma/BxDF.cpp:744-779) on the Cornell walls and blocks, under the three
+    integrators; sigma = 0 and negative sigma stay Lambertian."""
+    sc = scenes.cornell_box("diffuse")
+    sc.materials[0].sigma = 25.0        # white: walls, blocks
+    sc.materials[1].sigma = 60.0        # red
+    sc.materials[2].sigma = -5.0        # green: clamped to 0, Lambertian
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    for integ in (scenes.integrator_desc(film, 16), scenes.direct_lighting_desc(film, 16, max_depth=2, strategy=abi.DL_SAMPLE_ALL), scenes.volpath_desc(film, 16)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 1e-4 * so[k])
+        r.close(); o.close()
+    lam = scenes.cornell_box("diffuse")
+    integ = scenes.integrator_desc(film, 16)
+    a, b = ra.Renderer(0).configure(sc, cam, film, integ), ra.Renderer(0).configure(lam, cam, film, integ)
+    a.render(0, 16); b.render(0, 16)
+    assert common.mean_relative_error(a.image(), b.image()) > 0.02
+    a.close(); b.close()
+
+
 def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
     """The uv axes orient the anisotropic tangent frame: a quarter turn of the uvs equals swapping u / v roughness
     (deterministic with a point light and depth 1)."""
@@ -652,10 +678,10 @@ def test_error_conventions():
     assert e.value.code == -2                                  # ENIGMA_E_STATE: nothing configured
     sc, cam, film, integ = common.cornell_setup(res=16, spp=4)
     bad = scenes.cornell_box("diffuse")
-    bad.materials[0].sigma = 20.0
+    bad.materials[0].type = 17
     with pytest.raises(ra.EnigmaError) as e:
         r.upload_scene(bad)
-    assert e.value.code == -4                                  # ENIGMA_E_UNSUPPORTED: Oren-Nayar
+    assert e.value.code == -4                                  # ENIGMA_E_UNSUPPORTED: a material the path does not cover
     bad2 = scenes.cornell_box("diffuse")
     bad2.indices[3, 1] = 10 ** 6
     with pytest.raises(ra.EnigmaError) as e:

@@ -765,3 +765,22 @@ def test_textures_with_other_sides_are_resampled_to_powers_of_two():
         assert np.all(at(wrap, *corner) < 0.95 * want)
     far_corner = (7.5 / 8, 0.5 / 8)                     # the last column: taps beyond the image wrap around (repeat) or vanish (black)
     assert at(abi.WRAP_REPEAT, *far_corner)[0] > at(abi.WRAP_BLACK, *far_corner)[0]
+
+
+def test_oren_nayar_reduces_to_its_constant_term_at_normal_view():
+    """MatteMaterial with sigma != 0 makes an OrenNayer lobe (Enigma/Material.cpp:86-91, Enigma/BxDF.cpp:744-779): seen along the
+    normal (sin theta_o = 0) it is R/pi * A with A = 1 - sigma^2 / (2 (sigma^2 + 0.33)); sigma is clamped to 90 degrees."""
+    L = np.array([2.0, 1.0, 0.5])
+    w = np.array([0.3, 0.8, 0.1])
+    w = (w / np.linalg.norm(w)).astype(np.float32).astype(np.float64)
+    lam = _render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5))), light_dir=tuple(w), res=9, spp=16)
+    for sigma in (20.0, 90.0, 400.0):
+        s = math.radians(min(sigma, 90.0))
+        A = 1 - s * s / (2 * (s * s + 0.33))
+        B = 0.45 * s * s / (s * s + 0.09)
+        img = _render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5), sigma=sigma)), light_dir=tuple(w), res=9, spp=16)
+        assert np.allclose(img[4, 4] / lam[4, 4], A, rtol=2e-2)          # the centre pixel looks straight down (within the pixel's footprint)
+        # off-centre the view leaves the normal: the B term shows wherever the view's azimuth is on the light's side
+        ratio = img / lam
+        assert ratio.max() > A + 1e-4 and ratio.max() < A + B * 0.2
+    assert np.allclose(_render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5), sigma=-3.0)), light_dir=tuple(w), res=9, spp=16), lam, rtol=1e-6)
