@@ -161,7 +161,8 @@ def main():
         achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # the committed PMC passes were taken on the default workload only: other variants report no traffic
+        if os.path.exists(tpath) and args.variant == "microfacet" and args.integrator == "path":
             try:
                 traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
             except Exception:
