@@ -128,8 +128,7 @@ typedef struct EnigmaMedium {
 
 /* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or
  * partial (z range, phi sweep), any object-to-world transform.  Spheres are tested one by one beside the triangles'
- * BVH (at most ENIGMA_MAX_SPHERES of them); they cannot be area lights, carry no medium interface and their material
- * must not bind a trilinear texture. */
+ * BVH (at most ENIGMA_MAX_SPHERES of them); they cannot be area lights and always have a material. */
 #define ENIGMA_MAX_SPHERES 256u
 typedef struct EnigmaSphere {
     float object_to_world[16]; /* Shape::m_objectToWorld->m_mat, row-major m[r][c] */
@@ -138,6 +137,8 @@ typedef struct EnigmaSphere {
     uint32_t material;         /* index into materials */
     uint32_t flags;            /* ENIGMA_TRI_FLIP_NORMAL: m_reverseOrientation ^ m_transformSwapsHandedness */
     uint32_t prim_id;          /* Primitive::m_primitiveId; 0 = n_triangles + index + 1 */
+    int32_t medium_inside;     /* the primitive's MediumInterface as indices into media + 1, 0 = none (so that a zeroed */
+    int32_t medium_outside;    /* struct has no interface); read when the scene has media */
     uint32_t reserved;
 } EnigmaSphere;
 

@@ -2605,6 +2605,7 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     sc.materials.assign(s->materials, s->materials + s->n_materials);
     sc.media.assign(s->media, s->media + (s->media ? s->n_media : 0));
     sc.triInside.clear(); sc.triOutside.clear();
+    const bool haveMedia = (s->tri_medium_inside && s->tri_medium_outside) || (s->n_media > 0 && s->n_triangles == 0);
     if (s->tri_medium_inside && s->tri_medium_outside) {
         sc.triInside.assign(s->tri_medium_inside, s->tri_medium_inside + s->n_triangles);
         sc.triOutside.assign(s->tri_medium_outside, s->tri_medium_outside + s->n_triangles);
@@ -2659,9 +2660,6 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         const EnigmaSphere& e = s->spheres[i];
         if (e.material >= s->n_materials) { h->o.error = "sphere material index out of range"; return -1; }
         if (!(e.radius > 0)) { h->o.error = "sphere radius must be positive"; return -1; }
-        const EnigmaMaterial& m = s->materials[e.material];
-        for (uint32_t t : {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_eta, m.tex_k})
-            if (t && s->textures[t - 1].trilinear) { h->o.error = "trilinear textures on spheres are not restated"; return -4; }
         Sphere sp;
         memcpy(sp.o2w.m, e.object_to_world, 64); memcpy(sp.w2o.m, e.world_to_object, 64);
         sp.init(e.radius, e.z_min, e.z_max, e.phi_max);
@@ -2669,7 +2667,10 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         sc.spheres.push_back(sp);
         sc.triMaterial.push_back(e.material); sc.triLight.push_back(-1);
         sc.primId.push_back(e.prim_id ? e.prim_id : s->n_triangles + i + 1);
-        if (!sc.triInside.empty()) { sc.triInside.push_back(-1); sc.triOutside.push_back(-1); }
+        if (haveMedia) {
+            if (e.medium_inside < 0 || e.medium_inside > (int32_t)s->n_media || e.medium_outside < 0 || e.medium_outside > (int32_t)s->n_media) { h->o.error = "sphere medium index out of range"; return -1; }
+            sc.triInside.push_back(e.medium_inside - 1); sc.triOutside.push_back(e.medium_outside - 1);
+        }
         // Shape::worldBound = m_objectToWorld->transformBounds(objectBound()) (Transform.h:82-94, ShapeImp.cpp:29-34)
         const float lo[3] = {-sp.radius, -sp.radius, sp.zMin}, hi[3] = {sp.radius, sp.radius, sp.zMax};
         for (int c = 0; c < 8; ++c) {

@@ -48,7 +48,8 @@ MAX_SPHERES = 256
 class EnigmaSphere(C.Structure):
     _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
                 ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("phi_max", C.c_float),
-                ("material", C.c_uint32), ("flags", C.c_uint32), ("prim_id", C.c_uint32), ("reserved", C.c_uint32)]
+                ("material", C.c_uint32), ("flags", C.c_uint32), ("prim_id", C.c_uint32),
+                ("medium_inside", C.c_int32), ("medium_outside", C.c_int32), ("reserved", C.c_uint32)]
 
 
 class EnigmaSceneDesc(C.Structure):
@@ -155,7 +156,8 @@ class SceneArrays:
         return d
 
 
-def sphere(material, radius=1.0, object_to_world=None, z_min=None, z_max=None, phi_max=360.0, reverse_orientation=False):
+def sphere(material, radius=1.0, object_to_world=None, z_min=None, z_max=None, phi_max=360.0, reverse_orientation=False,
+           medium_inside=-1, medium_outside=-1):
     """CreateSphereShape (Enigma/ShapeImp.cpp) under a given object-to-world matrix (4 x 4, row-major; identity if omitted).
     The inverse is taken in double and rounded once, as the scene-description front end does."""
     s = EnigmaSphere()
@@ -167,6 +169,7 @@ def sphere(material, radius=1.0, object_to_world=None, z_min=None, z_max=None, p
     s.z_max = radius if z_max is None else z_max
     s.phi_max = phi_max
     s.material = material
+    s.medium_inside, s.medium_outside = medium_inside + 1, medium_outside + 1   # the ABI stores index + 1, 0 = none
     swaps = np.linalg.det(m[:3, :3]) < 0
     s.flags = TRI_FLIP_NORMAL if (bool(reverse_orientation) != bool(swaps)) else 0
     return s

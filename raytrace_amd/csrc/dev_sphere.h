@@ -137,7 +137,9 @@ DEV bool sphereAny(const DevScene& sc, F3 o, F3 d, float tMax) {
 
 // The SurfaceInteraction of a sphere hit in world space: p, pError, geometric normal, dpdu, and wo -- which the
 // reference transforms back to world space WITHOUT renormalising (Enigma/Transform.cpp:330)
-DEV void sphereSurface(const DevSphere& s, F3 pHit, F3 rayDirWorld, F3* p, F3* pError, F3* n, F3* dpdu, F3* wo) {
+// dpdv, uv: optional (the texture kernel asks for them)
+DEV void sphereSurface(const DevSphere& s, F3 pHit, F3 rayDirWorld, F3* p, F3* pError, F3* n, F3* dpdu, F3* wo, F3* dpdv = nullptr, float* u = nullptr,
+                       float* v = nullptr) {
     float theta = acosf(smin(smax(pHit.z / s.radius, -1.0f), 1.0f));
     float zRadius = sqrtf(pHit.x * pHit.x + pHit.y * pHit.y);
     float invZRadius = 1 / zRadius;
@@ -153,6 +155,13 @@ DEV void sphereSurface(const DevSphere& s, F3 pHit, F3 rayDirWorld, F3* p, F3* p
     *n = normalize(xfNormalByInverse(s.w2o, nObj));
     *wo = xfVec3(s.o2w, normalize(-dObj));
     *dpdu = xfVec3(s.o2w, dpduO);
+    if (dpdv) *dpdv = xfVec3(s.o2w, dpdvO);
+    if (u) { // Enigma/ShapeImp.cpp:72-73,95-97
+        float phi = atan2f(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * 3.14159265358979323846f;
+        *u = phi / s.phiMax;
+        *v = (theta - s.thetaMin) / (s.thetaMax - s.thetaMin);
+    }
 }
 
 } // namespace edev

@@ -191,7 +191,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->n_materials >= (1u << 24)) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 2^24 materials");
     for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
         if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
-    const bool haveMedia = s->tri_medium_inside && s->tri_medium_outside;
+    const bool haveMedia = (s->tri_medium_inside && s->tri_medium_outside) || (s->n_media > 0 && s->n_triangles == 0); // spheres only: their own fields
     if ((s->tri_medium_inside != nullptr) != (s->tri_medium_outside != nullptr)) return h->fail(ENIGMA_E_INVALID, "tri_medium_inside and tri_medium_outside go together");
     if (haveMedia && s->n_media && !s->media) return h->fail(ENIGMA_E_INVALID, "null media array");
     if (s->n_media >= 0xfffu) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 4094 media");
@@ -380,7 +380,6 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         const EnigmaSphere& e = s->spheres[i];
         if (e.material >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "sphere %u: material index out of range", i);
         if (!(e.radius > 0.f)) return h->fail(ENIGMA_E_INVALID, "sphere %u: radius must be positive", i);
-        if (mats[e.material].tex0 | mats[e.material].tex1) return h->fail(ENIGMA_E_UNSUPPORTED, "sphere %u: trilinear textures on spheres are not supported", i);
         for (int c = 0; c < 4; ++c)
             if (e.object_to_world[12 + c] != (c == 3 ? 1.f : 0.f) || e.world_to_object[12 + c] != (c == 3 ? 1.f : 0.f))
                 return h->fail(ENIGMA_E_UNSUPPORTED, "sphere %u: projective transforms are not supported", i);
@@ -517,7 +516,13 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             for (int c = 0; c < 3; ++c) { md[i].sigmaT[c] = m.sigma_s[c] + m.sigma_a[c]; md[i].sigmaS[c] = m.sigma_s[c]; }
             md[i].g = m.g; md[i].pad = 0.f;
         }
-        std::vector<uint32_t> tm(haveMedia ? std::max(1u, s->n_triangles) + s->n_spheres : 0, 0u); // spheres: no medium interface
+        std::vector<uint32_t> tm(haveMedia ? std::max(1u, s->n_triangles) + s->n_spheres : 0, 0u);
+        for (uint32_t i = 0; haveMedia && i < s->n_spheres; ++i) { // spheres follow the triangles; their ABI fields already hold index + 1
+            const EnigmaSphere& e = s->spheres[i];
+            if (e.medium_inside < 0 || e.medium_inside > (int32_t)s->n_media || e.medium_outside < 0 || e.medium_outside > (int32_t)s->n_media)
+                return h->fail(ENIGMA_E_INVALID, "sphere %u: medium index out of range", i);
+            tm[std::max(1u, s->n_triangles) + i] = (uint32_t)e.medium_inside | ((uint32_t)e.medium_outside << 16);
+        }
         for (uint32_t k = 0; k < (haveMedia ? s->n_triangles : 0u); ++k) {
             uint32_t t = bvh.triOrder[k];
             tm[k] = (uint32_t)(s->tri_medium_inside[t] + 1) | ((uint32_t)(s->tri_medium_outside[t] + 1) << 16);

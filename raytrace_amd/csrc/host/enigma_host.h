@@ -263,13 +263,14 @@ public:
         return (uint32_t)m_textures.size();
     }
     // Sphere(o2w, w2o, reverseOrientation, radius, zMin, zMax, phiMax) with its GeometricPrimitive's material
-    // (Enigma/ShapeImp.cpp:13-27, Enigma/Api.cpp:843-874).  No area light and no medium interface on spheres.
+    // and MediumInterface (registry indices, -1 = none) (Enigma/ShapeImp.cpp:13-27, Enigma/Api.cpp:843-874).  No area light on spheres.
     void AddSphere(const Transform& objectToWorld, const Transform& worldToObject, bool reverseOrientation, bool transformSwapsHandedness,
-                   float radius, float zMin, float zMax, float phiMax, int materialIndex) {
+                   float radius, float zMin, float zMax, float phiMax, int materialIndex, int mediumInside = -1, int mediumOutside = -1) {
         EnigmaSphere s{};
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { s.object_to_world[4 * r + c] = objectToWorld.m_mat[r][c]; s.world_to_object[4 * r + c] = worldToObject.m_mat[r][c]; }
         s.radius = radius; s.z_min = zMin; s.z_max = zMax; s.phi_max = phiMax;
         s.material = (uint32_t)materialIndex;
+        s.medium_inside = mediumInside + 1; s.medium_outside = mediumOutside + 1; // the ABI holds index + 1
         s.flags = (reverseOrientation ^ transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u;
         m_spheres.push_back(s);
     }

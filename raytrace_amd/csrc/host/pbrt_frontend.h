@@ -488,12 +488,12 @@ public:
         const float radius = p.FindOneFloat("radius", 1.f);
         const float zmin = p.FindOneFloat("zmin", -radius), zmax = p.FindOneFloat("zmax", radius), phimax = p.FindOneFloat("phimax", 360.f);
         if (!m_gs.areaLight.empty()) throw std::runtime_error("Shape \"sphere\": an area light on a sphere is not supported");
-        if (!m_gs.currentInsideMedium.empty() || !m_gs.currentOutsideMedium.empty()) throw std::runtime_error("Shape \"sphere\": a MediumInterface on a sphere is not supported");
         if (m_gs.currentMaterial == -2) throw std::runtime_error("Shape \"sphere\": a sphere without a material is not supported");
         if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet());
         const int material = m_gs.currentMaterial == -1 ? m_defaultMaterial : m_gs.currentMaterial;
         Transform o2w = m_ctm.ToFloat(), w2o = m_ctm.Inverse().ToFloat();
-        m_res->scene.AddSphere(o2w, w2o, m_gs.reverseOrientation, m_ctm.SwapsHandedness(), radius, zmin, zmax, phimax, material);
+        m_res->scene.AddSphere(o2w, w2o, m_gs.reverseOrientation, m_ctm.SwapsHandedness(), radius, zmin, zmax, phimax, material,
+                               LookupMedium(m_gs.currentInsideMedium), LookupMedium(m_gs.currentOutsideMedium));
         NoteUnused("Shape", p);
     }
     void pbrtObjectBegin(const std::string&) { throw std::runtime_error("ObjectBegin: object instancing is not supported"); }

@@ -73,7 +73,7 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         const EnigmaSphere& s = R.scene.m_spheres[i];
         o << (i ? "," : "") << "{\"o2w\":"; arr(s.object_to_world, 16); o << ",\"w2o\":"; arr(s.world_to_object, 16);
         o << ",\"radius\":" << s.radius << ",\"zmin\":" << s.z_min << ",\"zmax\":" << s.z_max << ",\"phimax\":" << s.phi_max << ",\"material\":" << s.material
-          << ",\"flags\":" << s.flags << "}";
+          << ",\"flags\":" << s.flags << ",\"medium_inside\":" << s.medium_inside - 1 << ",\"medium_outside\":" << s.medium_outside - 1 << "}";
     }
     o << "],\n\"textures\":[";
     for (size_t i = 0; i < R.scene.m_textures.size(); ++i) {

@@ -62,53 +62,64 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
         const uint32_t p = matQueue[i];
         const float4 hv = P.hit[p];
         const int tri = __float_as_int(hv.x);
-        if (sc.nSpheres && tri >= (int)sc.nTris) continue; // spheres carry no trilinear textures
-        const float b0 = hv.y, b1 = hv.z, b2 = hv.w;
-        const float4* tp = sc.tris + (size_t)tri * 3;
-        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-        const uint32_t mw = __float_as_uint(v1.w);
-        const DevMaterial& m = sc.materials[triMaterial(mw)];
-        if (!(m.tex0 | m.tex1)) continue;
-        const F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
-        // Triangle::intersect: uvs, dpdu / dpdv, hit point, geometric normal (Enigma/TriangleMesh.cpp:238-289)
-        float u0 = 0.f, w0 = 0.f, u1 = 1.f, w1 = 0.f, u2 = 1.f, w2 = 1.f; // getUVs default
-        const bool shaded = sc.triShade != nullptr;
-        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0;
-        if (shaded && (triHasUvs(mw) || triHasNormals(mw))) {
-            const float4* sp = sc.triShade + (size_t)tri * 4;
-            s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
-            if (triHasUvs(mw)) { float4 vv = sp[3]; u0 = s0.w; u1 = s1.w; u2 = s2.w; w0 = vv.x; w1 = vv.y; w2 = vv.z; }
-        }
-        const F3 dp02 = p0 - p2, dp12 = p1 - p2;
-        const float du02 = u0 - u2, dv02 = w0 - w2, du12 = u1 - u2, dv12 = w1 - w2;
-        const float determinant = du02 * dv12 - dv02 * du12;
-        const bool degenerateUV = fabsf(determinant) < 1e-8;
-        F3 dpdu(0.f), dpdv(0.f);
-        if (!degenerateUV) {
-            float invdet = 1 / determinant;
-            dpdu = (dv12 * dp02 - dv02 * dp12) * invdet;
-            dpdv = (-du12 * dp02 + du02 * dp12) * invdet;
-        }
-        if (degenerateUV || lengthSqr(cross(dpdu, dpdv)) == 0) {
-            F3 ng = cross(p2 - p0, p1 - p0);
-            coordinateSystem(normalize(ng), &dpdu, &dpdv);
-        }
-        const F3 pHit = b0 * p0 + b1 * p1 + b2 * p2;
-        const float uHit = b0 * u0 + b1 * u1 + b2 * u2, vHit = b0 * w0 + b1 * w1 + b2 * w2;
-        F3 n = triNormal(p0, p1, p2, triFlip(mw));
-        if (shaded && triHasNormals(mw)) { // the geometric normal faces the shading normal (SetShadingGeometry, Enigma/Interaction.cpp:139-141)
-            F3 ns = b0 * xyz(s0) + b1 * xyz(s1) + b2 * xyz(s2);
-            ns = lengthSqr(ns) > 0 ? normalize(ns) : n;
-            F3 ss = normalize(dpdu);
-            F3 ts = cross(ss, ns);
-            if (lengthSqr(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
-            else coordinateSystem(ns, &ss, &ts);
-            if (triReverse(mw)) ts = -ts;
-            if (dot(n, normalize(cross(ss, ts))) < 0.f) n = -n;
+        F3 pHit, n, dpdu(0.f), dpdv(0.f);
+        float uHit, vHit;
+        uint32_t tex0, tex1;
+        const float4 rdv = P.rayD[p];
+        if (sc.nSpheres && tri >= (int)sc.nTris) { // Sphere::intersect's parametrisation (Enigma/ShapeImp.cpp:94-107)
+            const DevSphere& sp = sc.spheres[tri - (int)sc.nTris];
+            const DevMaterial& m = sc.materials[triMaterial(sp.mw)];
+            if (!(m.tex0 | m.tex1)) continue;
+            tex0 = m.tex0; tex1 = m.tex1;
+            F3 pErr, wo;
+            sphereSurface(sp, F3(hv.y, hv.z, hv.w), xyz(rdv), &pHit, &pErr, &n, &dpdu, &wo, &dpdv, &uHit, &vHit);
+        } else {
+            const float b0 = hv.y, b1 = hv.z, b2 = hv.w;
+            const float4* tp = sc.tris + (size_t)tri * 3;
+            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            const uint32_t mw = __float_as_uint(v1.w);
+            const DevMaterial& m = sc.materials[triMaterial(mw)];
+            if (!(m.tex0 | m.tex1)) continue;
+            tex0 = m.tex0; tex1 = m.tex1;
+            const F3 p0 = xyz(v0), p1 = xyz(v1), p2 = xyz(v2);
+            // Triangle::intersect: uvs, dpdu / dpdv, hit point, geometric normal (Enigma/TriangleMesh.cpp:238-289)
+            float u0 = 0.f, w0 = 0.f, u1 = 1.f, w1 = 0.f, u2 = 1.f, w2 = 1.f; // getUVs default
+            const bool shaded = sc.triShade != nullptr;
+            float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0;
+            if (shaded && (triHasUvs(mw) || triHasNormals(mw))) {
+                const float4* sp = sc.triShade + (size_t)tri * 4;
+                s0 = sp[0]; s1 = sp[1]; s2 = sp[2];
+                if (triHasUvs(mw)) { float4 vv = sp[3]; u0 = s0.w; u1 = s1.w; u2 = s2.w; w0 = vv.x; w1 = vv.y; w2 = vv.z; }
+            }
+            const F3 dp02 = p0 - p2, dp12 = p1 - p2;
+            const float du02 = u0 - u2, dv02 = w0 - w2, du12 = u1 - u2, dv12 = w1 - w2;
+            const float determinant = du02 * dv12 - dv02 * du12;
+            const bool degenerateUV = fabsf(determinant) < 1e-8;
+            if (!degenerateUV) {
+                float invdet = 1 / determinant;
+                dpdu = (dv12 * dp02 - dv02 * dp12) * invdet;
+                dpdv = (-du12 * dp02 + du02 * dp12) * invdet;
+            }
+            if (degenerateUV || lengthSqr(cross(dpdu, dpdv)) == 0) {
+                F3 ng = cross(p2 - p0, p1 - p0);
+                coordinateSystem(normalize(ng), &dpdu, &dpdv);
+            }
+            pHit = b0 * p0 + b1 * p1 + b2 * p2;
+            uHit = b0 * u0 + b1 * u1 + b2 * u2; vHit = b0 * w0 + b1 * w1 + b2 * w2;
+            n = triNormal(p0, p1, p2, triFlip(mw));
+            if (shaded && triHasNormals(mw)) { // the geometric normal faces the shading normal (SetShadingGeometry, Enigma/Interaction.cpp:139-141)
+                F3 ns = b0 * xyz(s0) + b1 * xyz(s1) + b2 * xyz(s2);
+                ns = lengthSqr(ns) > 0 ? normalize(ns) : n;
+                F3 ss = normalize(dpdu);
+                F3 ts = cross(ss, ns);
+                if (lengthSqr(ts) > 0.f) { ts = normalize(ts); ss = cross(ts, ns); }
+                else coordinateSystem(ns, &ss, &ts);
+                if (triReverse(mw)) ts = -ts;
+                if (dot(n, normalize(cross(ss, ts))) < 0.f) n = -n;
+            }
         }
         // ComputeDifferentials: only the unmodified camera ray carries differentials (Enigma/Ray.cpp:44-47)
         float dudx = 0.f, dvdx = 0.f, dudy = 0.f, dvdy = 0.f;
-        const float4 rdv = P.rayD[p];
         const uint32_t st = __float_as_uint(rdv.w);
         if (stBounces(st) == 0u && !stNoDifferentials(st)) {
             const F3 o = xyz(P.rayO[p]), d = xyz(rdv);
@@ -155,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const uint32_t ti = k == 0 ? m.tex0 : m.tex1;
+            const uint32_t ti = k == 0 ? tex0 : tex1;
             if (!ti) continue;
             const DevTexture& t = sc.textures[ti - 1u];
             // UVMapping2D::map, then MipMap::lookup(st, dst0, dst1) with m_doTrilinear (Enigma/MipMap.h:369-376)

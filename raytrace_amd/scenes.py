@@ -234,7 +234,7 @@ class MeshBuilder:
     def arrays(self, weld=True):
         if not self.t:      # spheres (or lights) only
             return abi.SceneArrays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32), [], [], self.materials, self.lights,
-                                   textures=self.textures, spheres=self.spheres)
+                                   textures=self.textures, spheres=self.spheres, media=self.media)
         if weld:
             v, t = self.weld()
         else:
@@ -412,10 +412,12 @@ def _translation(x, y, z):
     return m
 
 
-def cornell_spheres(fog=False):
+def cornell_spheres(fog=False, textured=True):
     """The Cornell box with analytic Sphere shapes in place of the blocks: a matte sphere, a metal ellipsoid (rotated,
     non-uniformly scaled), a smooth-glass sphere, a rough-glass bowl (z range and phi sweep cut open, ReverseOrientation)
-    and a plastic sphere under a mirroring transform.  fog: a scattering slab between camera and spheres (VolPath)."""
+    and a plastic sphere under a mirroring transform.  fog: a scattering slab between camera and spheres and a tinted medium
+    inside the glass sphere (VolPath).  textured: the matte sphere's Kd comes from a trilinear image texture over its (phi, theta)
+    parametrisation."""
     b = MeshBuilder()
     white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
     red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
@@ -443,10 +445,14 @@ def cornell_spheres(fog=False):
                 outward[axis] = val + side * 100.0
                 b.add_quad(q, abi.NO_MATERIAL, toward=tuple(outward))
         b.medium_interface(-1, -1)
-    b.add_sphere(b.add_material(abi.matte((0.6, 0.6, 0.2))), radius=60.0, object_to_world=_translation(120, 60, 140))
+    globe = b.add_material(abi.matte((0.6, 0.6, 0.2), sigma=15.0))
+    if textured:
+        b.materials[globe].tex_kd = b.add_texture(abi.image_texture(test_pattern(), trilinear=True, su=2.0))   # u = phi / phimax, v over theta
+    b.add_sphere(globe, radius=60.0, object_to_world=_translation(120, 60, 140) @ _rotation((1, 0, 0), -90.0))
     b.add_sphere(b.add_material(abi.metal(COPPER_ETA, COPPER_K, remap=False, uroughness=0.05, vroughness=0.25)), radius=1.0,
                  object_to_world=_translation(400, 90, 330) @ _rotation((1, 2, 0.5), 35.0) @ np.diag([110.0, 70.0, 90.0, 1.0]))
-    b.add_sphere(b.add_material(abi.glass(1.5, 0.0, 0.0)), radius=70.0, object_to_world=_translation(260, 70, 200))
+    tint = b.add_medium(abi.homogeneous_medium((0.004, 0.008, 0.016), (0.002, 0.002, 0.002), 0.0)) if fog else -1
+    b.add_sphere(b.add_material(abi.glass(1.5, 0.0, 0.0)), radius=70.0, object_to_world=_translation(260, 70, 200), medium_inside=tint)
     b.add_sphere(b.add_material(abi.glass(1.5, 0.1, 0.1)), radius=80.0, z_min=-80.0, z_max=30.0, phi_max=300.0, reverse_orientation=True,
                  object_to_world=_translation(150, 330, 350) @ _rotation((1, 0, 0), -70.0))
     b.add_sphere(b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05)), radius=55.0,

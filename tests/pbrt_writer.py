@@ -137,6 +137,8 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         out.append("AttributeBegin")
         out.append("  ConcatTransform [%s]" % " ".join("%.9g" % v for v in m.T.reshape(-1)))      # the file holds the matrix column by column
         out.append('  NamedMaterial "m%d"' % s.material)
+        if n_media and (s.medium_inside or s.medium_outside):
+            out.append('  MediumInterface "%s" "%s"' % tuple("" if i <= 0 else "med%d" % (i - 1) for i in (s.medium_inside, s.medium_outside)))
         if reverse:
             out.append("  ReverseOrientation")
         out.append('  Shape "sphere" "float radius" %.9g "float zmin" %.9g "float zmax" %.9g "float phimax" %.9g' % (s.radius, s.z_min, s.z_max, s.phi_max))

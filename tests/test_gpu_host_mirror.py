@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -94,6 +94,8 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
         sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment: scene files carry no texels
     elif variant == "textured":
         sc = scenes.cornell_textured(True)  # Texture "imagemap" directives over PFM files, "texture Kd" bindings, uvs
+    elif variant == "spheres+fog":
+        sc = scenes.cornell_spheres(fog=True)   # a medium inside the glass sphere: MediumInterface before Shape "sphere"
     elif variant == "spheres":
         sc = scenes.cornell_spheres()       # Shape "sphere" under ConcatTransform, ReverseOrientation, zmin / zmax / phimax
     elif variant == "smooth":

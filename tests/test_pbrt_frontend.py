@@ -386,7 +386,7 @@ def test_sphere_shapes_reach_the_scene(tmp_path):
     """Shape "sphere" (CreateSphereShape, Enigma/ShapeImp.cpp:723-732): both matrices of the CTM, the constructor's
     parameters with their defaults, the orientation flag = ReverseOrientation ^ a mirroring CTM, the bound material."""
     sc = scenes.cornell_spheres()
-    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4)
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4, texture_dir=str(tmp_path))
     d = dump(tmp_path, text)
     assert len(d["spheres"]) == sc.n_spheres
     for got, ref in zip(d["spheres"], sc.spheres[: sc.n_spheres]):
@@ -394,6 +394,11 @@ def test_sphere_shapes_reach_the_scene(tmp_path):
         assert np.allclose(got["w2o"], list(ref.world_to_object), rtol=1e-5, atol=1e-6)
         assert np.allclose([got["radius"], got["zmin"], got["zmax"], got["phimax"]], [ref.radius, ref.z_min, ref.z_max, ref.phi_max])
         assert got["material"] == ref.material and got["flags"] == ref.flags
+    fog = scenes.cornell_spheres(fog=True)
+    d = dump(tmp_path, pbrt_writer.scene_text(fog, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4, texture_dir=str(tmp_path),
+                                               integrator='Integrator "volpath" "integer maxdepth" 5 "string lightsamplestrategy" "power"'))
+    assert [(s["medium_inside"], s["medium_outside"]) for s in d["spheres"]] == [(s.medium_inside - 1, s.medium_outside - 1) for s in fog.spheres[: fog.n_spheres]]
+    assert any(s["medium_inside"] >= 0 for s in d["spheres"])
     head = '''
 LookAt 0 0 -5  0 0 0  0 1 0
 Camera "perspective" "float fov" 60
