@@ -43,6 +43,8 @@ def main():
                          "fog (Cornell with a fog slab and a medium-filled glass block, for --integrator volpath)")
     ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one", "volpath"],
                     help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
+    ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
+                    help="lightsamplestrategy of the path / volpath integrators (the headline configuration names power)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=2, help="sample numbers per pixel the CPU baseline renders")
     args = ap.parse_args()
@@ -74,12 +76,13 @@ def main():
         scene, camera, cam_small, label = scenes.cornell_box(args.variant), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (%s)" % args.variant
     film = scenes.film_desc(XRES, YRES, "box")
     total_spp = pow2_at_least(max(1024, (K + 1) * N * SPP_PER_STEP + SPP_PER_STEP))
+    strategy = {"uniform": abi.LIGHTS_UNIFORM, "power": abi.LIGHTS_POWER, "spatial": abi.LIGHTS_SPATIAL}[args.light_strategy]
     if args.integrator == "path":
-        integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
-        integ_label = "PathIntegrator maxdepth 5, Sobol, box filter, power light sampling"
+        integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=strategy)
+        integ_label = "PathIntegrator maxdepth 5, Sobol, box filter, %s light sampling" % args.light_strategy
     elif args.integrator == "volpath":
-        integ = scenes.volpath_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=abi.LIGHTS_POWER)
-        integ_label = "VolPathIntegrator maxdepth 5, homogeneous media, Sobol, box filter, power light sampling"
+        integ = scenes.volpath_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=strategy)
+        integ_label = "VolPathIntegrator maxdepth 5, homogeneous media, Sobol, box filter, %s light sampling" % args.light_strategy
     else:
         strat = abi.DL_SAMPLE_ALL if args.integrator == "direct-all" else abi.DL_SAMPLE_ONE
         integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
@@ -162,7 +165,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # the committed PMC passes were taken on the default workload only: other variants report no traffic
-        if os.path.exists(tpath) and args.variant == "microfacet" and args.integrator == "path":
+        if os.path.exists(tpath) and args.variant == "microfacet" and args.integrator == "path" and args.light_strategy == "power":
             try:
                 traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
             except Exception:

@@ -195,7 +195,9 @@ typedef struct EnigmaFilmDesc {
     float max_sample_luminance;      /* +inf by default */
 } EnigmaFilmDesc;
 
-enum { ENIGMA_LIGHTS_UNIFORM = 0, ENIGMA_LIGHTS_POWER = 1 };
+enum { ENIGMA_LIGHTS_UNIFORM = 0, ENIGMA_LIGHTS_POWER = 1,
+       ENIGMA_LIGHTS_SPATIAL = 2 /* SpatialLightDistribution (Enigma/LightDist.cpp:80-267), the reference's default: one table per voxel
+                                    of a grid over the scene bounds; the library fills every voxel when the integrator is configured */ };
 
 /* PathIntegrator + SobolSampler parameters (Enigma/PathIntegrator.cpp:30-44,
  * 182-201; Enigma/Sampler.cpp:211-222). */

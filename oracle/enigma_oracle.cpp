@@ -28,6 +28,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1995,6 +1996,7 @@ static Spectrum EvaluateImageTexture(const TextureSet& ts, uint32_t index, const
 }
 
 struct Scene {
+    BBox3 worldBound; // the aggregate's bound (Scene.cpp:19-30)
     TextureSet textures;
     TriangleMesh mesh;
     std::vector<Triangle> tris;
@@ -2099,8 +2101,98 @@ static Spectrum UniformSampleOneLight(const SurfaceInteraction& it, const BSDF& 
     return EstimateDirect(it, bsdf, uScattering, light, uLight, scene) / lightPdf;
 }
 
+// RadicalInverse (SamplerInclude.h:44-62,2659-2680) for the five bases the spatial distribution uses
+template <int base>
+static float RadicalInverseSpecialized(uint64_t a) {
+    const float invBase = (float)1 / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        reversedDigits = reversedDigits * base + digit;
+        invBaseN *= invBase;
+        a = next;
+    }
+    return std::min(reversedDigits * invBaseN, OneMinusEpsilon);
+}
+static float RadicalInverse(int baseIndex, uint64_t a) {
+    switch (baseIndex) {
+    case 0: {
+        uint64_t r = 0;
+        for (int i = 0; i < 64; ++i) r |= ((a >> i) & 1ull) << (63 - i); // ReverseBits64
+        return (float)(r * 5.4210108624275222e-20);
+    }
+    case 1: return RadicalInverseSpecialized<3>(a);
+    case 2: return RadicalInverseSpecialized<5>(a);
+    case 3: return RadicalInverseSpecialized<7>(a);
+    default: return RadicalInverseSpecialized<11>(a);
+    }
+}
+// SpatialLightDistribution (LightDist.cpp:80-267).  The reference fills its hash table lazily under atomics; the table
+// a voxel gets does not depend on when it is computed, so a mutex-guarded map stands in for it.
+struct SpatialLightDistribution {
+    const Scene* scene; BBox3 wb; int nVoxels[3];
+    mutable std::mutex mu;
+    mutable std::unordered_map<uint64_t, std::unique_ptr<Distribution1D>> table;
+    SpatialLightDistribution(const Scene& sc, const BBox3& bounds, int maxVoxels = 64) : scene(&sc), wb(bounds) {
+        Vec3 diag = wb.mx - wb.mn;
+        int ext = (diag.x > diag.y && diag.x > diag.z) ? 0 : (diag.y > diag.z ? 1 : 2); // BBox3::maximumExtent
+        float bmax = diag[ext];
+        for (int i = 0; i < 3; ++i) nVoxels[i] = std::max(1, int(std::round(diag[i] / bmax * maxVoxels)));
+    }
+    static float LerpF(float a, float b, float t) { if (t < 0.f) return a; if (t > 1.f) return b; const float diff = (b - a) * t; return a + diff; } // MathCommon.h:31-39
+    Vec3 lerp(const Vec3& t) const { return Vec3(LerpF(wb.mn.x, wb.mx.x, t.x), LerpF(wb.mn.y, wb.mx.y, t.y), LerpF(wb.mn.z, wb.mx.z, t.z)); }
+    const Distribution1D* Lookup(const Vec3& p) const {
+        Vec3 o = p - wb.mn; // BBox3::offset, BBox.h:235-241
+        if (wb.mx.x > wb.mn.x) o.x /= wb.mx.x - wb.mn.x;
+        if (wb.mx.y > wb.mn.y) o.y /= wb.mx.y - wb.mn.y;
+        if (wb.mx.z > wb.mn.z) o.z /= wb.mx.z - wb.mn.z;
+        int pi[3];
+        for (int i = 0; i < 3; ++i) pi[i] = std::clamp(int(o[i] * nVoxels[i]), 0, nVoxels[i] - 1);
+        uint64_t packedPos = (uint64_t(pi[0]) << 40) | (uint64_t(pi[1]) << 20) | (uint64_t)pi[2];
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = table.find(packedPos);
+        if (it != table.end()) return it->second.get();
+        Distribution1D* d = ComputeDistribution(pi);
+        table[packedPos].reset(d);
+        return d;
+    }
+    Distribution1D* ComputeDistribution(const int pi[3]) const;
+};
+
+Distribution1D* SpatialLightDistribution::ComputeDistribution(const int pi[3]) const { // LightDist.cpp:210-266
+    Vec3 p0(float(pi[0]) / float(nVoxels[0]), float(pi[1]) / float(nVoxels[1]), float(pi[2]) / float(nVoxels[2]));
+    Vec3 p1(float(pi[0] + 1) / float(nVoxels[0]), float(pi[1] + 1) / float(nVoxels[1]), float(pi[2] + 1) / float(nVoxels[2]));
+    BBox3 voxel; voxel.mn = lerp(p0); voxel.mx = lerp(p1);
+    // BBox3(p, q) takes the componentwise min / max
+    for (int c = 0; c < 3; ++c) if (voxel.mn[c] > voxel.mx[c]) std::swap(voxel.mn[c], voxel.mx[c]);
+    const int nSamples = 128;
+    const size_t nl = scene->lights.size();
+    std::vector<float> lightContrib(nl, float(0));
+    for (int i = 0; i < nSamples; ++i) {
+        Vec3 t(RadicalInverse(0, i), RadicalInverse(1, i), RadicalInverse(2, i));
+        Vec3 po(LerpF(voxel.mn.x, voxel.mx.x, t.x), LerpF(voxel.mn.y, voxel.mx.y, t.y), LerpF(voxel.mn.z, voxel.mx.z, t.z));
+        Interaction intr; intr.p = po; intr.wo = Vec3(1, 0, 0); // normal and error bounds zero, time 0
+        Vec2 u(RadicalInverse(3, i), RadicalInverse(4, i));
+        for (size_t j = 0; j < nl; ++j) {
+            float pdf; Vec3 wi; Interaction p1i;
+            Spectrum Li = scene->lights[j].Sample_Li(intr, u, &wi, &pdf, &p1i);
+            if (pdf > 0) lightContrib[j] += Li.y() / pdf;
+        }
+    }
+    float sumContrib = 0;
+    for (float c : lightContrib) sumContrib += c; // std::accumulate with a float init
+    float avgContrib = sumContrib / (nSamples * lightContrib.size());
+    float minContrib = (avgContrib > 0) ? .001 * avgContrib : 1;
+    for (size_t i = 0; i < nl; ++i) lightContrib[i] = std::max(lightContrib[i], minContrib);
+    return new Distribution1D(&lightContrib[0], int(nl));
+}
+
 struct PathIntegrator {
     int maxDepth; float rrThreshold;
+    std::unique_ptr<SpatialLightDistribution> spatial; // lightsamplestrategy "spatial" with more than one light
+    const Distribution1D* Lookup(const Vec3& p) const { return spatial ? spatial->Lookup(p) : lightDistrib.get(); }
     std::unique_ptr<Distribution1D> lightDistrib; // Uniform/PowerLightDistribution::Lookup returns one table
     // PathIntegrator.cpp:46-179 (no BSSRDF, no media, no infinite lights in scope)
     Spectrum Li(const Ray& _ray, const Scene& scene, SobolSampler& sampler) const {
@@ -2119,7 +2211,7 @@ struct PathIntegrator {
             }
             if (!foundIntersection || bounces >= maxDepth) break;
             std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
-            const Distribution1D* distrib = lightDistrib.get();
+            const Distribution1D* distrib = Lookup(isect.p); // PathIntegrator.cpp:95
             if (bsdf->numComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                 Spectrum Ld = beta * UniformSampleOneLight(isect, *bsdf, scene, sampler, distrib);
                 L += Ld;
@@ -2324,7 +2416,8 @@ static Spectrum UniformSampleOneLightVol(const Interaction& it, const Vec3& shad
 
 struct VolPathIntegrator {
     int maxDepth = 5; float rrThreshold = 1;
-    const Distribution1D* lightDistrib = nullptr; // shared with the PathIntegrator's table
+    const PathIntegrator* tables = nullptr; // the light distribution is the PathIntegrator's (same CreateLightSampleDistribution)
+    const Distribution1D* Lookup(const Vec3& p) const { return tables ? tables->Lookup(p) : nullptr; }
     Spectrum Li(const Ray& _ray, const Scene& scene, SobolSampler& sampler) const {
         Spectrum L(0.f), beta(1.f);
         Ray ray(_ray);
@@ -2340,7 +2433,7 @@ struct VolPathIntegrator {
             if (beta.IsBlack()) break;
             if (mi.valid) {
                 if (bounces >= maxDepth) break;
-                L += beta * UniformSampleOneLightVol(mi, Vec3(0.f), nullptr, mi.g, scene, sampler, lightDistrib);
+                L += beta * UniformSampleOneLightVol(mi, Vec3(0.f), nullptr, mi.g, scene, sampler, Lookup(mi.p));
                 Vec3 wo = -ray.d, wi;
                 HGSample_p(mi.g, wo, &wi, sampler.Get2D());
                 ray = SpawnRayVol(mi, wi);
@@ -2357,7 +2450,7 @@ struct VolPathIntegrator {
                     continue;
                 }
                 std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
-                L += beta * UniformSampleOneLightVol(isect, isect.shading.n, bsdf.get(), 0.f, scene, sampler, lightDistrib);
+                L += beta * UniformSampleOneLightVol(isect, isect.shading.n, bsdf.get(), 0.f, scene, sampler, Lookup(isect.p));
                 Vec3 wo = -ray.d, wi;
                 float pdf = 0;
                 int flags = 0;
@@ -2691,6 +2784,7 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
             radius = inside ? Length(center - wb.mx) : 0.0f;
         }
         for (Light& L : sc.lights) L.worldRadius = radius;
+        sc.worldBound = wb;
     }
     return 0;
 }
@@ -2715,6 +2809,12 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     // CreateLightSampleDistribution (LightDist.cpp:20-38) + ComputeLightPowerDistribution (Integrator.cpp:30-38)
     size_t n = O.scene.lights.size();
     O.integrator.lightDistrib.reset();
+    O.integrator.spatial.reset();
+    if (d->light_strategy == ENIGMA_LIGHTS_SPATIAL && n > 1) { // one light: uniform (LightDist.cpp:22)
+        O.integrator.spatial.reset(new SpatialLightDistribution(O.scene, O.scene.worldBound));
+    } else if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL) {
+        h->o.error = "unknown light strategy"; return -4;
+    }
     if (n) {
         std::vector<float> w(n, 1.0f);
         if (!(d->light_strategy == ENIGMA_LIGHTS_UNIFORM || n == 1))
@@ -2741,7 +2841,7 @@ int oracle_volpath_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     if (rc) return rc;
     Oracle& O = h->o;
     O.volpath.maxDepth = d->max_depth; O.volpath.rrThreshold = d->rr_threshold;
-    O.volpath.lightDistrib = O.integrator.lightDistrib.get();
+    O.volpath.tables = &O.integrator;
     O.useVolPath = true;
     return 0;
 }

@@ -86,6 +86,11 @@ struct DevScene {
     const float4* tris;         // triangles in BVH order, 3 float4 each
     const DevMaterial* materials;
     const DevLight* lights;
+    // SpatialLightDistribution (Enigma/LightDist.cpp:80-267), every voxel filled: per voxel nLights func values, nLights + 1
+    // cdf values and funcInt; nullptr = one table for the whole scene (lightCdf / lightFunc below)
+    const float* spatialTable;
+    int nVoxels[3];
+    float boundMin[3], boundMax[3]; // Scene::worldBound()
     const float* lightCdf;      // Distribution1D::cdf, nLights + 1
     const float* lightFunc;     // Distribution1D::func, nLights
     const uint32_t* primId;     // reference m_primitiveId by original triangle index

@@ -68,6 +68,8 @@ struct EnigmaCtx {
     DevBuf<uint32_t> triMedium;
     DevBuf<float4> triShade;
     DevBuf<DevSphere> spheres;
+    DevBuf<float> spatialTable, halton;
+    float worldLo[3] = {0, 0, 0}, worldHi[3] = {0, 0, 0}; // Scene::worldBound(): the union of the primitives' bounds
     DevBuf<float4> sphereGeom;
     DevBuf<float4> texTexels, texColors;
     DevBuf<DevTexture> textures;
@@ -162,7 +164,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shRec.release();
-    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release(); h->spheres.release(); h->sphereGeom.release();
+    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release(); h->spheres.release(); h->sphereGeom.release(); h->spatialTable.release(); h->halton.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
@@ -421,6 +423,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
                 }
             }
         }
+        for (int c = 0; c < 3; ++c) { h->worldLo[c] = lo[c]; h->worldHi[c] = hi[c]; }
         float ctr[3], d2 = 0.f;
         bool inside = true;
         for (int c = 0; c < 3; ++c) { ctr[c] = (lo[c] * .5f) + (hi[c] * .5f); inside = inside && ctr[c] >= lo[c] && ctr[c] <= hi[c]; }
@@ -659,8 +662,8 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
     if (!h || !d) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
-    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
-        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
+    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
     // dimensions a path can consume: 5 (camera) + per bounce 1+2+2 (light) + 2 (BSDF) + 1 (roulette)
     int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u + 8u * (uint32_t)d->max_depth);
     if (rc) return rc;
@@ -682,8 +685,8 @@ extern "C" int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d
     // dimensions are not bounded by its depth: every dimension the 10-bit cursor can address is tabulated (the reference
     // aborts at dimension 1024)
     if (d->max_depth < 0 || d->max_depth > 60) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
-    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER)
-        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform and power are)", d->light_strategy);
+    if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
     int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 1023u);
     if (rc) return rc;
     h->integDesc = *d;
@@ -772,6 +775,45 @@ static int buildLightDistribution(EnigmaCtx* h) {
     HIPCHK(h, h->lightFunc.upload(func));
     h->scene.lightCdf = h->lightCdf.p;
     h->scene.lightFunc = h->lightFunc.p;
+    h->scene.spatialTable = nullptr;
+    if (h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && n > 1) { // one light: uniform (Enigma/LightDist.cpp:22)
+        // SpatialLightDistribution's constructor (Enigma/LightDist.cpp:80-103); the reference fills a voxel's table when a
+        // path first lands in it, here every voxel is filled now -- the table of a voxel does not depend on when it is made
+        float diag[3], bmax = 0.f;
+        for (int c = 0; c < 3; ++c) { diag[c] = h->worldHi[c] - h->worldLo[c]; }
+        const int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2); // BBox3::maximumExtent
+        bmax = diag[ext];
+        size_t total = 1;
+        for (int c = 0; c < 3; ++c) {
+            h->scene.nVoxels[c] = std::max(1, int(std::round(diag[c] / bmax * 64)));
+            h->scene.boundMin[c] = h->worldLo[c]; h->scene.boundMax[c] = h->worldHi[c];
+            total *= (size_t)h->scene.nVoxels[c];
+        }
+        const size_t stride = 2 * (size_t)n + 2;
+        if (total * stride * sizeof(float) > ((size_t)32 << 30))
+            return h->fail(ENIGMA_E_UNSUPPORTED, "the spatial light distribution of %d lights over %zu voxels needs more than 32 GB; use the power strategy", n, total);
+        std::vector<float> hal(5 * 128);
+        auto radical = [](int base, uint64_t a) { // RadicalInverseSpecialized, Enigma/SamplerInclude.h:49-62
+            const float invBase = (float)1 / (float)base;
+            uint64_t reversedDigits = 0;
+            float invBaseN = 1;
+            while (a) { uint64_t next = a / base; uint64_t digit = a - next * base; reversedDigits = reversedDigits * base + digit; invBaseN *= invBase; a = next; }
+            return std::min(reversedDigits * invBaseN, 0x1.fffffep-1f);
+        };
+        for (uint64_t i = 0; i < 128; ++i) {
+            uint64_t r = 0;
+            for (int b = 0; b < 64; ++b) r |= ((i >> b) & 1ull) << (63 - b); // ReverseBits64
+            hal[i] = (float)(r * 5.4210108624275222e-20);                    // Enigma/SamplerInclude.h:2664
+            hal[128 + i] = radical(3, i); hal[256 + i] = radical(5, i); hal[384 + i] = radical(7, i); hal[512 + i] = radical(11, i);
+        }
+        HIPCHK(h, h->halton.upload(hal));
+        HIPCHK(h, h->spatialTable.alloc(total * stride));
+        const size_t work = total * (size_t)n;
+        k_spatial_contrib<<<(unsigned)((work + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(h->scene, h->halton.p, h->spatialTable.p, (uint32_t)total);
+        k_spatial_finish<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(h->spatialTable.p, (uint32_t)n, (uint32_t)total);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->scene.spatialTable = h->spatialTable.p;
+    }
     h->lightDistDirty = false;
     return ENIGMA_OK;
 }
@@ -957,7 +999,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
-    const bool ldsScene = h->scene.nSpheres == 0 && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    const bool ldsScene = h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;

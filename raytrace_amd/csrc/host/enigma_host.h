@@ -475,8 +475,7 @@ protected:
         id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
         if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
         else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
-        else if (nLights == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
-        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
+        else id.light_strategy = ENIGMA_LIGHTS_SPATIAL; // "spatial", and unknown names fall back to it (Enigma/LightDist.cpp:28-37); one light is uniform inside the library
         FillSamplerFields(id, sob);
         return enigma_integrator_config(h, &id);
     }
@@ -499,8 +498,7 @@ protected:
         id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
         if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
         else if (m_lightSampleStrategy == "power") id.light_strategy = ENIGMA_LIGHTS_POWER;
-        else if (nLights == 1) id.light_strategy = ENIGMA_LIGHTS_UNIFORM; // one light: always uniform (Enigma/LightDist.cpp:22)
-        else throw std::runtime_error("lightsamplestrategy \"" + m_lightSampleStrategy + "\" is not supported on the GPU path (uniform, power)");
+        else id.light_strategy = ENIGMA_LIGHTS_SPATIAL; // "spatial", and unknown names fall back to it (Enigma/LightDist.cpp:28-37); one light is uniform inside the library
         FillSamplerFields(id, sob);
         return enigma_volpath_config(h, &id);
     }

@@ -526,6 +526,19 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
     }
 }
 
+// SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the table of the voxel that holds p
+DEV const float* spatialLookup(const DevScene& sc, F3 p) {
+    F3 o = p - F3(sc.boundMin[0], sc.boundMin[1], sc.boundMin[2]); // BBox3::offset, Enigma/BBox.h:235-241
+    if (sc.boundMax[0] > sc.boundMin[0]) o.x /= sc.boundMax[0] - sc.boundMin[0];
+    if (sc.boundMax[1] > sc.boundMin[1]) o.y /= sc.boundMax[1] - sc.boundMin[1];
+    if (sc.boundMax[2] > sc.boundMin[2]) o.z /= sc.boundMax[2] - sc.boundMin[2];
+    int px = min(max((int)(o.x * sc.nVoxels[0]), 0), sc.nVoxels[0] - 1);
+    int py = min(max((int)(o.y * sc.nVoxels[1]), 0), sc.nVoxels[1] - 1);
+    int pz = min(max((int)(o.z * sc.nVoxels[2]), 0), sc.nVoxels[2] - 1);
+    size_t voxel = ((size_t)px * sc.nVoxels[1] + py) * sc.nVoxels[2] + pz;
+    return sc.spatialTable + voxel * (2 * (size_t)sc.nLights + 2);
+}
+
 // Distribution1D::SampleDiscrete, Enigma/MonteCarlo.h:61-69 (std::upper_bound on the cdf)
 DEV int sampleDiscrete(const float* lightCdf, const float* lightFunc, float lightFuncInt, int n, float u, float* pdf) {
     int lo = 0, len = n + 1; // first element > u in cdf[0..n]
@@ -833,7 +846,14 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
             // ---- UniformSampleOneLight (Enigma/Integrator.cpp:71-92) ----
             if ((VOL || numComponents<MK>(bsdf, kNonSpecular) > 0) && sc.nLights > 0) {
                 float pick;
-                int lightNum = sampleDiscrete(lightCdf, lightFunc, sc.lightFuncInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
+                // m_lightDistribution->Lookup(isect.m_p), Enigma/PathIntegrator.cpp:95.  The per-voxel tables are read by the
+                // build of this kernel that keeps its tables in global memory (scenes with a spatial distribution are run
+                // through it); the LDS build knows nothing of them and keeps its registers -- seven more cost it a wave per SIMD
+                const float* pickFunc = lightFunc;
+                const float* pickCdf = lightCdf;
+                float pickInt = sc.lightFuncInt;
+                if (!LDS_SCENE && sc.spatialTable) { pickFunc = spatialLookup(sc, g.p); pickCdf = pickFunc + sc.nLights; pickInt = pickFunc[2 * sc.nLights + 1]; }
+                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
                 dim += 1;
                 if (pick != 0) {
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);

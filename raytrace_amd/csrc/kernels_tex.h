@@ -176,4 +176,49 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
     }
 }
 
+// ---------------------------------------------------------------- SpatialLightDistribution, every voxel (Enigma/LightDist.cpp:210-266)
+// halton: RadicalInverse(b, i) for b = 0..4 and i = 0..127, [b * 128 + i]
+__global__ void __launch_bounds__(kBlock) k_spatial_contrib(DevScene sc, const float* halton, float* table, uint32_t nVoxelsTotal) {
+    const size_t id = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t nl = (uint32_t)sc.nLights;
+    if (id >= (size_t)nVoxelsTotal * nl) return;
+    const uint32_t voxel = (uint32_t)(id / nl), j = (uint32_t)(id % nl);
+    const int pz = (int)(voxel % (uint32_t)sc.nVoxels[2]), py = (int)((voxel / (uint32_t)sc.nVoxels[2]) % (uint32_t)sc.nVoxels[1]),
+              px = (int)(voxel / ((uint32_t)sc.nVoxels[2] * (uint32_t)sc.nVoxels[1]));
+    auto lerp1 = [](float a, float b, float t) { if (t < 0.f) return a; if (t > 1.f) return b; const float diff = (b - a) * t; return a + diff; }; // Enigma/MathCommon.h:31-39
+    float lo[3], hi[3];
+    const int pi[3] = {px, py, pz};
+    for (int c = 0; c < 3; ++c) {
+        float a = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c]) / float(sc.nVoxels[c]));
+        float b = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c] + 1) / float(sc.nVoxels[c]));
+        lo[c] = smin(a, b); hi[c] = smax(a, b);
+    }
+    const DevLight& lt = sc.lights[j];
+    float contrib = 0.f;
+    for (int i = 0; i < 128; ++i) {
+        F3 po(lerp1(lo[0], hi[0], halton[i]), lerp1(lo[1], hi[1], halton[128 + i]), lerp1(lo[2], hi[2], halton[256 + i]));
+        LightSample s = sampleLight(sc, lt, sc.tris, po, halton[384 + i], halton[512 + i]);
+        if (s.pdf > 0) contrib += (0.212671f * s.Li.x + 0.715160f * s.Li.y + 0.072169f * s.Li.z) / s.pdf;
+    }
+    table[(size_t)voxel * (2 * (size_t)nl + 2) + j] = contrib;
+}
+__global__ void __launch_bounds__(kBlock) k_spatial_finish(float* table, uint32_t nl, uint32_t nVoxelsTotal) {
+    const uint32_t voxel = blockIdx.x * kBlock + threadIdx.x;
+    if (voxel >= nVoxelsTotal) return;
+    float* func = table + (size_t)voxel * (2 * (size_t)nl + 2);
+    float* cdf = func + nl;
+    float sumContrib = 0.f;
+    for (uint32_t i = 0; i < nl; ++i) sumContrib += func[i];
+    const float avgContrib = sumContrib / (float)(128u * nl); // the reference divides by a size_t product
+    const float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
+    for (uint32_t i = 0; i < nl; ++i) func[i] = smax(func[i], minContrib);
+    // Distribution1D (Enigma/MonteCarlo.h:17-38)
+    cdf[0] = 0.f;
+    for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)nl;
+    const float funcInt = cdf[nl];
+    if (funcInt == 0.f) for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = float(i) / float(nl);
+    else for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] /= funcInt;
+    cdf[nl + 1] = funcInt;
+}
+
 } // namespace edev

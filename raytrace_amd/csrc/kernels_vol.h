@@ -82,7 +82,13 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
             // ---- UniformSampleOneLight + EstimateDirect for a medium interaction (Enigma/Integrator.cpp:71-204) ----
             if (sc.nLights > 0) {
                 float pick;
-                int lightNum = sampleDiscrete(lightCdf, lightFunc, sc.lightFuncInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
+                const float* pickFunc = lightFunc;
+                const float* pickCdf = lightCdf;
+                float pickInt = sc.lightFuncInt;
+                if (!LDS_SCENE && sc.spatialTable) { // lightDistrib->Lookup(mi.m_p), Enigma/VolPathIntegrator.cpp:76 (global-memory build only)
+                    pickFunc = spatialLookup(sc, pm); pickCdf = pickFunc + sc.nLights; pickInt = pickFunc[2 * sc.nLights + 1];
+                }
+                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
                 dim += 1;
                 if (pick != 0) {
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);

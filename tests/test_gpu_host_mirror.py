@@ -122,14 +122,21 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     o.close()
 
 
-def test_scene_description_unsupported_default_light_strategy_is_reported(tmp_path):
-    """lightsamplestrategy defaults to "spatial" (Enigma/PathIntegrator.cpp:199), which the GPU path refuses with several lights."""
+def test_scene_description_default_light_strategy_is_spatial(tmp_path):
+    """lightsamplestrategy defaults to "spatial" (Enigma/PathIntegrator.cpp:199): a scene file that does not name a strategy
+    renders like the oracle under ENIGMA_LIGHTS_SPATIAL."""
     import math
     import pbrt_writer
     sc = scenes.cornell_box("diffuse")
-    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), 39.0, 16, 16, 1, integrator='Integrator "path"')
-    scene_file = str(tmp_path / "c.pbrt")
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, 48, 48, 8, integrator='Integrator "path"')
+    scene_file, out_file = str(tmp_path / "c.pbrt"), str(tmp_path / "o.pfm")
     with open(scene_file, "w") as f:
         f.write(text)
-    p = subprocess.run([EXE, scene_file, str(tmp_path / "o.pfm")], capture_output=True, text=True, timeout=120)
-    assert p.returncode != 0 and "spatial" in p.stderr
+    p = subprocess.run([EXE, scene_file, out_file], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 8, light_strategy=abi.LIGHTS_SPATIAL))
+    o.render(0, 8, threads=4)
+    assert common.mean_relative_error(_read_pfm(out_file), o.image()) < 1e-3
+    o.close()

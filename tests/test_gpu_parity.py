@@ -516,6 +516,36 @@ def test_image_parity_oren_nayar():
     a.close(); b.close()
 
 
+def test_image_parity_spatial_light_distribution():
+    """lightsamplestrategy "spatial", the reference's default (Enigma/LightDist.cpp:80-267): one table per voxel from 128 Halton
+    points x every light's Sample_Li.  The library fills every voxel at configuration time, the oracle when a path first lands
+    in it; the tables are the same either way.  Two lights (Cornell), many lights with the path and the VolPath integrator."""
+    cases = [(scenes.cornell_box("microfacet"), "path"), (scenes.many_lights(n_quads=24, n_points=8), "path"), (scenes.cornell_fog("diffuse"), "volpath"),
+             (scenes.cornell_box("diffuse", delta_lights=True), "path")]
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    for sc, kind in cases:
+        integ = (scenes.volpath_desc if kind == "volpath" else scenes.integrator_desc)(film, 16, light_strategy=abi.LIGHTS_SPATIAL)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16)
+        o.render(0, 16, threads=8)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[k] - so[k]) <= max(3, 1e-3 * so[k])
+        r.close(); o.close()
+    # the tables matter: with many lights the spatial pick differs from the power pick sample by sample, yet both are unbiased
+    sc = scenes.many_lights(n_quads=24, n_points=8)
+    imgs = []
+    for strat in (abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL):
+        r = ra.Renderer(0).configure(sc, cam, film, scenes.integrator_desc(film, 256, light_strategy=strat))
+        r.render(0, 256)
+        imgs.append(r.image().astype(np.float64))
+        r.close()
+    assert not np.allclose(imgs[0], imgs[1], rtol=1e-3)
+    assert abs(imgs[0].mean() - imgs[1].mean()) < 0.03 * imgs[0].mean()
+
+
 def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
     """The uv axes orient the anisotropic tangent frame: a quarter turn of the uvs equals swapping u / v roughness
     (deterministic with a point light and depth 1)."""
@@ -693,10 +723,10 @@ def test_error_conventions():
     with pytest.raises(ra.EnigmaError):
         r.render(0, 99)                                        # beyond samples_per_pixel
     integ2 = scenes.integrator_desc(film, 4)
-    integ2.light_strategy = 2
+    integ2.light_strategy = 7
     with pytest.raises(ra.EnigmaError) as e:
         r.set_integrator(integ2)
-    assert e.value.code == -4                                  # spatial light distribution: out of scope
+    assert e.value.code == -4                                  # no such light distribution
     r.render(0, 4)                                             # still usable after errors
     assert np.isfinite(r.image()).all()
     r.close()
