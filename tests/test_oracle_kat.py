@@ -784,3 +784,37 @@ def test_oren_nayar_reduces_to_its_constant_term_at_normal_view():
         ratio = img / lam
         assert ratio.max() > A + 1e-4 and ratio.max() < A + B * 0.2
     assert np.allclose(_render_floor(_shaded_floor(abi.matte((0.5, 0.5, 0.5), sigma=-3.0)), light_dir=tuple(w), res=9, spp=16), lam, rtol=1e-6)
+
+
+def test_spatial_light_distribution_is_unbiased_and_prefers_near_lights():
+    """SpatialLightDistribution (Enigma/LightDist.cpp:80-267): whatever table a voxel gets, the estimate stays unbiased, so the
+    three strategies agree in the mean; and with two equal point lights far apart, shading points next to one of them pick
+    that one most of the time, which shows as less noise than the uniform pick has."""
+    sc = scenes.many_lights(n_quads=6, n_points=3)
+    cam, film = scenes.cornell_camera(32, 32), scenes.film_desc(32, 32)
+    means = {}
+    for name, strat in (("uniform", abi.LIGHTS_UNIFORM), ("power", abi.LIGHTS_POWER), ("spatial", abi.LIGHTS_SPATIAL)):
+        o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 64, light_strategy=strat))
+        o.render(0, 64, threads=8)
+        means[name] = float(o.image().astype(np.float64).mean())
+        o.close()
+    assert abs(means["spatial"] - means["uniform"]) < 0.03 * means["uniform"]
+    assert abs(means["power"] - means["uniform"]) < 0.03 * means["uniform"]
+    b = scenes.MeshBuilder()
+    grey = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([(-50, 0, -5), (-50, 0, 5), (50, 0, 5), (50, 0, -5)], grey, toward=(0, 1, 0))
+    b.add_point_light((-45, 2, 0), (100.0, 100.0, 100.0))
+    b.add_point_light((45, 2, 0), (100.0, 100.0, 100.0))
+    cam2, film2 = scenes.camera_desc((0, 120, 0), (0, 0, 0), (0, 0, 1), 45.0, 64, 8), scenes.film_desc(64, 8)
+    var = {}
+    for name, strat in (("uniform", abi.LIGHTS_UNIFORM), ("spatial", abi.LIGHTS_SPATIAL)):
+        o = orc.Oracle(b.arrays(), cam2, film2, scenes.integrator_desc(film2, 256, max_depth=1, light_strategy=strat))
+        o.render(0, 256, threads=4, moments=True)
+        m = o.moments().astype(np.float64)
+        n = np.maximum(m[..., 6], 1)
+        mean = m[..., 0] / n
+        var[name] = float((m[..., 3] / n - mean * mean).sum())
+        means[name + "2"] = float(mean.sum())
+        o.close()
+    assert abs(means["spatial2"] - means["uniform2"]) < 0.05 * means["uniform2"]
+    assert var["spatial"] < 0.5 * var["uniform"]
