@@ -178,6 +178,23 @@ inline Mat4d LookAtD(const double e[3], const double l[3], const double u[3]) { 
     return c2w.Inverse();
 }
 
+class LanczosSincFilter : public Filter { // Enigma/Filter.h:63-88, Enigma/Filter.cpp:18-21: the argument is already divided by the radius
+public:
+    LanczosSincFilter(const Vector2f& r, float tau) : Filter(r), m_tau(tau) {}
+    float Evaluate(const Vector2f& p) const override { return Sinc1D(p.x * m_invRadius.x) * Sinc1D(p.y * m_invRadius.y); }
+private:
+    float Sinc1D(float x) const {
+        x = fabsf(x);
+        if (x < 1e-5) return 1.f;
+        if (x > 1.) return 0.f;
+        x *= 3.1415926535897932384f;
+        float sinc = sinf(x) / x;
+        float lanczos = sinf(x * m_tau) / (x * m_tau);
+        return sinc * lanczos;
+    }
+    const float m_tau;
+};
+
 class MitchellFilter : public Filter { // Enigma/Filter.h:78-103
 public:
     MitchellFilter(const Vector2f& r, float B, float C) : Filter(r), m_B(B), m_C(C) {}
@@ -514,8 +531,11 @@ public:
             float xw = fp.FindOneFloat("xwidth", 2.f), yw = fp.FindOneFloat("ywidth", 2.f);
             float B = fp.FindOneFloat("B", 1.f / 3.f), C = fp.FindOneFloat("C", 1.f / 3.f);
             filter.reset(new MitchellFilter(Vector2f(xw, yw), B, C));
+        } else if (m_opt.FilterName == "sinc") { // CreateSincFilter, Enigma/Filter.cpp:62-68
+            float xw = fp.FindOneFloat("xwidth", 4.f), yw = fp.FindOneFloat("ywidth", 4.f);
+            filter.reset(new LanczosSincFilter(Vector2f(xw, yw), fp.FindOneFloat("tau", 3.f)));
         } else if (m_opt.FilterName == "triangle") filter.reset(new TriangleFilter(Vector2f(fp.FindOneFloat("xwidth", 2.f), fp.FindOneFloat("ywidth", 2.f))));
-        else throw std::runtime_error("Filter \"" + m_opt.FilterName + "\" is not supported (box, gaussian, mitchell, triangle)");
+        else throw std::runtime_error("Filter \"" + m_opt.FilterName + "\" is not supported (box, gaussian, mitchell, sinc, triangle)");
         R.filterName = m_opt.FilterName;
         // film (Enigma/Film.cpp:330-372)
         if (m_opt.FilmName != "image") throw std::runtime_error("Film \"" + m_opt.FilmName + "\" unknown.");

@@ -77,12 +77,26 @@ def _filter_eval(kind, x, y, rx, ry, params):
                 return F32(((-b - 6 * c) * v * v * v + (6 * b + 30 * c) * v * v + (-12 * b - 48 * c) * v + (8 * b + 24 * c)) * F32(1.0 / 6.0))
             return F32(((12 - 9 * b - 6 * c) * v * v * v + (-18 + 12 * b + 6 * c) * v * v + (6 - 2 * b)) * F32(1.0 / 6.0))
         return F32(m1(x * (F32(1) / rx)) * m1(y * (F32(1) / ry)))
+    if kind == "sinc":      # LanczosSincFilter::Evaluate / Sinc1D (Enigma/Filter.cpp:18-21, Enigma/Filter.h:74-82)
+        tau = F32(params.get("tau", 3.0))
+
+        def s1(v):
+            v = F32(abs(v))
+            if v < 1e-5:
+                return F32(1)
+            if v > 1.0:
+                return F32(0)
+            v = F32(v * F32(math.pi))
+            sinc = F32(F32(np.sin(v)) / v)
+            lanczos = F32(F32(np.sin(F32(v * tau))) / F32(v * tau))
+            return F32(sinc * lanczos)
+        return F32(s1(x * (F32(1) / rx)) * s1(y * (F32(1) / ry)))
     raise ValueError(kind)
 
 
 def film_desc(xres, yres, filter_kind="box", radius=None, crop=(0.0, 1.0, 0.0, 1.0), max_sample_luminance=float("inf"), **params):
     """Film constructor state (Enigma/Film.cpp:39-71): cropped pixel bounds + 16x16 filter table."""
-    default_r = {"box": 0.5, "triangle": 2.0, "gaussian": 2.0, "mitchell": 2.0}[filter_kind]
+    default_r = {"box": 0.5, "triangle": 2.0, "gaussian": 2.0, "mitchell": 2.0, "sinc": 4.0}[filter_kind]
     rx, ry = (default_r, default_r) if radius is None else radius
     f = abi.EnigmaFilmDesc()
     f.full_resolution[:] = [xres, yres]

@@ -186,7 +186,7 @@ def test_degenerate_rays():
     r.close(); o.close()
 
 
-@pytest.mark.parametrize("kind", ["box", "triangle", "gaussian", "mitchell"])
+@pytest.mark.parametrize("kind", ["box", "triangle", "gaussian", "mitchell", "sinc"])
 def test_film_footprint_bit_exact(kind):
     g = np.load(os.path.join(GOLD, "film_footprints.npz"))
     sc, cam, film, integ = common.cornell_setup(res=64, spp=16, filter_kind=kind)
@@ -242,7 +242,7 @@ def test_image_parity_cornell(variant):
     r.close()
 
 
-@pytest.mark.parametrize("kind,variant", [("gaussian", "diffuse"), ("triangle", "microfacet"), ("mitchell", "diffuse")])
+@pytest.mark.parametrize("kind,variant", [("gaussian", "diffuse"), ("triangle", "microfacet"), ("mitchell", "diffuse"), ("sinc", "diffuse")])
 def test_image_parity_wide_filters(kind, variant):
     setup = common.cornell_setup(res=48, spp=16, variant=variant, filter_kind=kind, crop=(0.1, 0.9, 0.1, 0.9))
     r, o = pair(setup)

@@ -424,3 +424,24 @@ WorldEnd
                          ('Shape "cylinder"', "not supported")):
         err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
         assert needle in err, err
+
+
+def test_sinc_pixel_filter_table(tmp_path):
+    """PixelFilter "sinc" (CreateSincFilter, Enigma/Filter.cpp:62-68; LanczosSincFilter, Enigma/Filter.h:63-88): radius 4, tau 3 by
+    default, the 16 x 16 table of Film's constructor with its negative lobes."""
+    text = '''
+Camera "perspective"
+PixelFilter "sinc" "float tau" 2.5
+Film "image" "integer xresolution" 32 "integer yresolution" 16
+Sampler "sobol"
+Integrator "path"
+WorldBegin
+Shape "trianglemesh" "point P" [0 0 5  1 0 5  0 1 5]
+WorldEnd
+'''
+    d = dump(tmp_path, text)
+    film = scenes.film_desc(32, 16, "sinc", tau=2.5)
+    assert d["film"]["filter"] == "sinc"
+    table = np.array(d["film"]["filter_table"])
+    assert np.allclose(table, list(film.filter_table), rtol=1e-4, atol=1e-6)
+    assert table.min() < 0 < table.max()

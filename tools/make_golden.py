@@ -56,7 +56,7 @@ def film_footprints():
     out = {}
     rng = np.random.RandomState(7)
     pf = np.concatenate([rng.uniform(-1, 66, size=(24, 2)), np.array([[0, 0], [10, 10], [10.5, 10.5], [63.999, 63.999], [64, 64], [31.0, 17.25], [0.5, 63.5], [5.0, 5.5]])]).astype(np.float32)
-    for kind in ("box", "triangle", "gaussian", "mitchell"):
+    for kind in ("box", "triangle", "gaussian", "mitchell", "sinc"):
         sc, cam, film, integ = common.cornell_setup(res=64, spp=16, filter_kind=kind)
         o = orc.Oracle(sc, cam, film, integ)
         pix, w, cnt = o.film_footprint(pf, 32)
@@ -134,6 +134,8 @@ if __name__ == "__main__":
         direct_lighting_images()
     elif len(sys.argv) > 1 and sys.argv[1] == "delta":
         delta_light_images()
+    elif len(sys.argv) > 1 and sys.argv[1] == "film":
+        film_footprints()
     else:
         sobol_and_camera(); primary_hits(); film_footprints(); bsdf_points(); images(); direct_lighting_images(); delta_light_images()
     for f in sorted(os.listdir(G)):
