@@ -154,8 +154,10 @@ typedef struct EnigmaSceneDesc {
                                      (Enigma/Primitive.cpp:19-26); NULL = i+1 */
     const float* normals;         /* [n_vertices*3] world-space per-vertex normals (as the TriangleMesh constructor leaves
                                      them), read for triangles flagged ENIGMA_TRI_HAS_NORMALS; may be NULL otherwise.
-                                     Per-vertex tangents (m_s) are not supported.  An emissive triangle must not carry
-                                     normals (its DiffuseAreaLight would need them in Triangle::sample too). */
+                                     Per-vertex tangents (m_s) are not supported.  The three normals of an emissive
+                                     triangle must lie on one side of its plane (Triangle::sample turns the sampled
+                                     point's normal to them, Enigma/TriangleMesh.cpp:618-623); otherwise
+                                     ENIGMA_E_UNSUPPORTED. */
     const float* uvs;             /* [n_vertices*2] per-vertex uvs for triangles flagged ENIGMA_TRI_HAS_UVS */
     uint32_t n_materials;
     uint32_t n_lights;

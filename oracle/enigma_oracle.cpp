@@ -644,7 +644,10 @@ struct Triangle {
         Interaction it;
         it.p = b[0] * p0 + b[1] * p1 + (1 - b[0] - b[1]) * p2;
         it.n = Normalize(Cross(p1 - p0, p2 - p0));
-        if (flip) it.n *= -1;
+        if (hasN) { // :618-623, FaceForward to the interpolated normal; the orientation flags are not looked at
+            Vec3 ns = b[0] * mesh->n[v[0]] + b[1] * mesh->n[v[1]] + (1 - b[0] - b[1]) * mesh->n[v[2]];
+            if (Dot(it.n, ns) < 0.f) it.n *= -1;
+        } else if (flip) it.n *= -1;
         Vec3 pAbsSum = Abs(b[0] * p0) + Abs(b[1] * p1) + Abs((1 - b[0] - b[1]) * p2);
         it.pError = gamma(6) * pAbsSum;
         *pdf = 1 / area();
@@ -2692,7 +2695,6 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         sc.tris[i] = Triangle{&sc.mesh, &sc.mesh.idx[3 * (size_t)i], (fl & ENIGMA_TRI_FLIP_NORMAL) != 0};
         sc.tris[i].hasN = (fl & ENIGMA_TRI_HAS_NORMALS) && s->normals; sc.tris[i].hasUV = (fl & ENIGMA_TRI_HAS_UVS) && s->uvs;
         sc.tris[i].reverse = (fl & ENIGMA_TRI_REVERSE_ORIENTATION) != 0;
-        if (sc.tris[i].hasN && s->tri_light[i] >= 0) { h->o.error = "an emissive triangle with per-vertex normals is not restated"; return -4; }
         sc.primId[i] = s->tri_prim_id ? s->tri_prim_id[i] : i + 1;
     }
     sc.materials.assign(s->materials, s->materials + s->n_materials);

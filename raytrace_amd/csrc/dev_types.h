@@ -41,7 +41,7 @@ struct DevLight {           // 144 bytes
     float cosTotalWidth;    // spot
     float w2l0[3]; float cosFalloffStart; // spot: rows of the upper 3x3 of m_worldToLight
     float w2l1[3]; float worldRadius;     // distant: radius of the scene's bounding sphere (Light::Preprocess)
-    float w2l2[3]; float pad;
+    float w2l2[3]; float sampleFlip;      // area: 1 when a sampled point's normal is -Cross(p1 - p0, p2 - p0) (Enigma/TriangleMesh.cpp:615-625)
     float l2w0[3]; float pad2;             // infinite: rows of the upper 3x3 of m_lightToWorld (its m_worldToLight sits in w2l0..2,
     float l2w1[3]; float pad3;             // its radiance map and sampling distribution in DevScene::envMaps[tri])
     float l2w2[3]; float pad4;

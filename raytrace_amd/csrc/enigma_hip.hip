@@ -180,6 +180,26 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
 
 extern "C" const char* enigma_last_error(const EnigmaCtx* h) { return h ? h->error.c_str() : "null context"; }
 
+// An emissive triangle of a mesh with normals: the side of its plane that its vertex normals lie on, +1 for the side of
+// Cross(p1 - p0, p2 - p0), -1 for the other, 0 when they disagree or graze the plane.  Triangle::sample and
+// Triangle::intersect turn the geometric normal to face the interpolated one (Enigma/TriangleMesh.cpp:618-623,
+// Enigma/Interaction.cpp:139-141); with all three on one side that is the same turn at every point of the triangle.
+static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
+    const float* p[3]; const float* n[3];
+    for (int k = 0; k < 3; ++k) { p[k] = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + k]]; n[k] = &s->normals[3 * (size_t)s->indices[3 * (size_t)t + k]]; }
+    const double e1[3] = {(double)p[1][0] - p[0][0], (double)p[1][1] - p[0][1], (double)p[1][2] - p[0][2]};
+    const double e2[3] = {(double)p[2][0] - p[0][0], (double)p[2][1] - p[0][1], (double)p[2][2] - p[0][2]};
+    const double g[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double gl = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    int pos = 0, neg = 0;
+    for (int k = 0; k < 3; ++k) {
+        const double nl = std::sqrt((double)n[k][0] * n[k][0] + (double)n[k][1] * n[k][1] + (double)n[k][2] * n[k][2]);
+        const double c = (g[0] * n[k][0] + g[1] * n[k][1] + g[2] * n[k][2]) / (gl * nl);
+        if (c > 1e-3) ++pos; else if (c < -1e-3) ++neg; // NaN (a zero normal or a degenerate triangle) counts for neither
+    }
+    return pos == 3 ? 1 : neg == 3 ? -1 : 0;
+}
+
 extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (!h || !s) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -207,8 +227,8 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
         if ((fl & ENIGMA_TRI_HAS_NORMALS) && !s->normals) return h->fail(ENIGMA_E_INVALID, "triangle %u is flagged to have normals but the normals array is null", t);
         if ((fl & ENIGMA_TRI_HAS_UVS) && !s->uvs) return h->fail(ENIGMA_E_INVALID, "triangle %u is flagged to have uvs but the uvs array is null", t);
-        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0)
-            return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light on a mesh with per-vertex normals is not supported", t);
+        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0 && emitterNormalSide(s, t) == 0)
+            return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light whose vertex normals lie on both sides of (or in) its plane is not supported", t);
         if (haveMedia && (s->tri_medium_inside[t] < -1 || s->tri_medium_inside[t] >= (int32_t)s->n_media || s->tri_medium_outside[t] < -1 ||
                           s->tri_medium_outside[t] >= (int32_t)s->n_media))
             return h->fail(ENIGMA_E_INVALID, "medium index out of range at triangle %u", t);
@@ -347,7 +367,10 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         uint32_t t = bvh.triOrder[k];
         newPos[t] = k;
         const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
-        const uint32_t bits = ((fl & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u) | ((fl & ENIGMA_TRI_HAS_NORMALS) ? 1u << 27 : 0u) |
+        bool flip = (fl & ENIGMA_TRI_FLIP_NORMAL) != 0;
+        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0) // what FaceForward(n, shading.n) leaves, shading.n = -ns under ReverseOrientation;
+            flip = (emitterNormalSide(s, t) < 0) != ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) != 0); // the emission tests read it, the shading path turns n itself
+        const uint32_t bits = (flip ? 1u << 31 : 0u) | ((fl & ENIGMA_TRI_HAS_NORMALS) ? 1u << 27 : 0u) |
                               ((fl & ENIGMA_TRI_HAS_UVS) ? 1u << 28 : 0u) | ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
         const bool noMat = s->tri_material[t] == ENIGMA_NO_MATERIAL;
         uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | bits : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | bits, (uint32_t)s->tri_light[t]};
@@ -447,6 +470,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             if (s->tri_light[l.triangle] != (int32_t)i) return h->fail(ENIGMA_E_INVALID, "light %u: triangle %u does not point back at it", i, l.triangle);
             h->haveAreaLights = true;
             d.type = 1; d.tri = newPos[l.triangle]; d.twoSided = l.two_sided ? 1u : 0u;
+            {   // the normal of a sampled point: reversed by the orientation flags, or turned to the vertex normals' side (Enigma/TriangleMesh.cpp:615-625)
+                const uint32_t fl = s->tri_flags ? s->tri_flags[l.triangle] : 0u;
+                const bool sampleFlip = (fl & ENIGMA_TRI_HAS_NORMALS) ? emitterNormalSide(s, l.triangle) < 0 : (fl & ENIGMA_TRI_FLIP_NORMAL) != 0;
+                d.sampleFlip = sampleFlip ? 1.f : 0.f;
+            }
             const float* a = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle]];
             const float* b = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle + 1]];
             const float* c = &s->vertices[3 * (size_t)s->indices[3 * (size_t)l.triangle + 2]];

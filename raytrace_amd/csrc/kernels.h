@@ -630,7 +630,7 @@ DEV LightSample sampleLight(const DevScene& sc, const DevLight& lt, const float4
         const float4* tp = tris + (size_t)lt.tri * 3;
         float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
         q0 = xyz(a0); q1 = xyz(a1); q2 = xyz(a2);
-        lflip = triFlip(__float_as_uint(a1.w));
+        lflip = lt.sampleFlip != 0.f;
         // Triangle::sample (Enigma/TriangleMesh.cpp:604-632)
         float su1 = sqrtf(ulx);
         float tb0 = 1.f - su1, tb1 = uly * su1;

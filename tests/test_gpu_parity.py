@@ -350,7 +350,7 @@ def test_image_parity_shading_normals_and_uvs():
     a.render(0, 16); b.render(0, 16)
     assert common.mean_relative_error(a.image(), b.image()) > 0.02
     a.close(); b.close()
-    # flags without their arrays, and an emissive triangle with normals, are refused
+    # flags without their arrays, and an emissive triangle whose normals (zero here) pick no side of its plane, are refused
     bad = abi.SceneArrays(sc.vertices, sc.indices, sc.tri_material, sc.tri_light, [sc.materials[i] for i in range(sc.n_materials)],
                           [sc.lights[i] for i in range(sc.n_lights)], tri_flags=sc.tri_flags)
     with pytest.raises(ra.EnigmaError) as e:
@@ -363,6 +363,38 @@ def test_image_parity_shading_normals_and_uvs():
     with pytest.raises(ra.EnigmaError) as e:
         ra.Renderer(0).configure(bad, cam, film, integ)
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("normal,reverse", [((0.0, -1.0, 0.0), False), ((0.3, 1.0, 0.2), False), ((0.3, 1.0, 0.2), True)])
+def test_image_parity_emissive_triangles_with_normals(normal, reverse):
+    """A DiffuseAreaLight on a mesh with normals: Triangle::sample turns the sampled normal to the vertex normals
+    (Enigma/TriangleMesh.cpp:618-623), Triangle::intersect turns the hit normal to shading.n, which ReverseOrientation
+    flips (:369, Enigma/Interaction.cpp:139-141).  The one-sided panel of the oracle's known-answer test under the
+    three integrators and the spatial light distribution; normals that straddle the panel's plane are refused."""
+    from test_oracle_kat import _panel_scene
+    sc = _panel_scene(normal=normal, reverse=reverse)
+    cam, film = scenes.camera_desc((0, 60, 0), (0, 0, 0), (0, 0, 1), 40.0, 32, 32), scenes.film_desc(32, 32)
+    for integ in (scenes.integrator_desc(film, 64), scenes.integrator_desc(film, 64, light_strategy=abi.LIGHTS_SPATIAL),
+                  scenes.direct_lighting_desc(film, 64, max_depth=1, strategy=abi.DL_SAMPLE_ALL), scenes.volpath_desc(film, 64)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 64)
+        o.render(0, 64, threads=8)
+        assert np.isfinite(r.image()).all()
+        assert o.image().max() > 1e-3         # every variant shows its light somewhere (the last only through BSDF sampling)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):   # the panel's own top samples points in its own plane: a cosine of +-1 ulp decides those few rays
+            assert abs(st[k] - so[k]) <= max(16, 1e-3 * so[k])
+        r.close(); o.close()
+    if reverse:
+        return
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_tri((0, 0, 0), (1, 0, 0), (0, 0, 1), m, emit=(1.0, 1.0, 1.0), normals=((0, 1, 0), (0, 1, 0), (0, -1, 0)))
+    with pytest.raises(ra.EnigmaError) as e:
+        ra.Renderer(0).configure(b.arrays(), cam, film, scenes.integrator_desc(film, 4))
+    assert e.value.code == -4 and "normals" in str(e.value)
 
 
 @pytest.mark.parametrize("trilinear,wrap", [(True, abi.WRAP_REPEAT), (True, abi.WRAP_CLAMP), (True, abi.WRAP_BLACK), (False, abi.WRAP_REPEAT)])

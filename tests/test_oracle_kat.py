@@ -818,3 +818,53 @@ def test_spatial_light_distribution_is_unbiased_and_prefers_near_lights():
         o.close()
     assert abs(means["spatial2"] - means["uniform2"]) < 0.05 * means["uniform2"]
     assert var["spatial"] < 0.5 * var["uniform"]
+
+
+# ------------------------------------------------------------------ emissive triangles with per-vertex normals
+def _panel_scene(normal=None, reverse=False, two_sided=False):
+    """A matte floor at y = 0 under a 10 x 10 one-sided emissive panel at y = 10 whose geometric normal faces down."""
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([np.array(p, float) for p in ((-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50))], m, toward=(0, 1, 0))
+    q = [np.array(p, float) for p in ((-5, 10, -5), (-5, 10, 5), (5, 10, 5), (5, 10, -5))]
+    for tri in ((0, 1, 2), (0, 2, 3)):
+        b.add_tri(q[tri[0]], q[tri[1]], q[tri[2]], m, toward=(0, 0, 0), emit=(10.0, 8.0, 6.0), two_sided=two_sided,
+                  normals=None if normal is None else (normal,) * 3, reverse_orientation=reverse)
+    return b.arrays()
+
+
+def _render_panel(sc, integ_fn, spp=256, res=16):
+    cam = scenes.camera_desc((0, 60, 0), (0, 0, 0), (0, 0, 1), 40.0, res, res)
+    film = scenes.film_desc(res, res)
+    o = orc.Oracle(sc, cam, film, integ_fn(film, spp))
+    o.render(0, spp, threads=4)
+    img = o.image().astype(np.float64)
+    o.close()
+    return img
+
+
+def test_emissive_triangle_turns_its_normal_to_its_vertex_normals():
+    """Triangle::sample face-forwards the sampled point's normal to the interpolated vertex normal and ignores the
+    orientation flags (Enigma/TriangleMesh.cpp:618-623); Triangle::intersect face-forwards to shading.n, which
+    ReverseOrientation has turned (:369, Enigma/Interaction.cpp:139-141).  A one-sided panel over a floor, seen from
+    above: normals along the geometric normal change nothing; normals against it send the light upward (dark floor,
+    bright panel); with ReverseOrientation on top, light sampling still finds a dark back side while BSDF-sampled
+    rays meet an emitting front, so the floor keeps only the BSDF-sampling share of the estimate."""
+    dl = lambda film, spp: scenes.direct_lighting_desc(film, spp, max_depth=1, strategy=abi.DL_SAMPLE_ALL)
+    plain = _render_panel(_panel_scene(), dl)
+    down = _render_panel(_panel_scene(normal=(0.0, -1.0, 0.0)), dl)
+    up = _render_panel(_panel_scene(normal=(0.0, 1.0, 0.0)), dl)
+    up_rev = _render_panel(_panel_scene(normal=(0.0, 1.0, 0.0), reverse=True), dl)
+    centre = (slice(7, 9), slice(7, 9))       # the panel covers the middle of the view
+    corner = (slice(0, 3), slice(0, 3))       # floor
+    assert np.allclose(plain, down, rtol=1e-5, atol=1e-6)
+    assert plain[corner].mean() > 0.01 and np.all(plain[centre] < 1e-6)          # lit floor, the panel's dark back
+    assert np.all(up[corner] < 1e-6) and np.allclose(up[centre], (10.0, 8.0, 6.0))
+    assert np.all(up_rev[centre] < 1e-6)
+    near = (slice(5, 6), slice(6, 10))        # floor next to the panel's outline, where a cosine lobe often finds it
+    share = up_rev[near].mean() / plain[near].mean()      # the power heuristic leaves BSDF sampling well under a tenth here
+    assert 1e-3 < share < 0.05, share
+    # a two-sided panel does not care
+    both = _render_panel(_panel_scene(two_sided=True), dl)
+    both_up = _render_panel(_panel_scene(normal=(0.0, 1.0, 0.0), two_sided=True), dl)
+    assert np.allclose(both, both_up, rtol=1e-5, atol=1e-6)
