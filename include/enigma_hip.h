@@ -82,11 +82,13 @@ typedef struct EnigmaTexture {
 /* Light kinds: PointLight (Enigma/Lights.cpp:89-129), DiffuseAreaLight (:560-651), SpotLight (:133-190),
  * DistantLight (:656-708).  One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
 enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT = 2, ENIGMA_LIGHT_DISTANT = 3,
-       ENIGMA_LIGHT_INFINITE = 4 /* InfiniteAreaLight, Enigma/Lights.cpp:395-546 */ };
+       ENIGMA_LIGHT_INFINITE = 4 /* InfiniteAreaLight, Enigma/Lights.cpp:395-546 */,
+       ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE = 5 /* a DiffuseAreaLight whose shape is a Sphere (Sphere::sample / pdf,
+                                               Enigma/ShapeImp.cpp:205-310): `triangle` is the index into spheres */ };
 
 typedef struct EnigmaLight {
     uint32_t type;      /* ENIGMA_LIGHT_* */
-    uint32_t triangle;  /* area light: index of its triangle */
+    uint32_t triangle;  /* area light: index of its triangle (of its sphere for ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) */
     uint32_t two_sided; /* area light: twosided flag */
     uint32_t n_samples; /* Light::m_nSamples ("samples"/"nsamples", default 1; 0 means 1): read only by
                            DirectLightingIntegrator's UniformSampleAll strategy (Enigma/DirectLightingIntegrator.cpp:76-77) */
@@ -128,18 +130,21 @@ typedef struct EnigmaMedium {
 
 /* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or
  * partial (z range, phi sweep), any object-to-world transform.  Spheres are tested one by one beside the triangles'
- * BVH (at most ENIGMA_MAX_SPHERES of them); they cannot be area lights and always have a material. */
+ * BVH (at most ENIGMA_MAX_SPHERES of them) and always have a material.  A sphere may carry a DiffuseAreaLight
+ * (`light`); its sampling routines are the reference's: they cover the whole sphere whatever the z range and sweep,
+ * and compare the object-space radius with world-space distances (Enigma/ShapeImp.cpp:210-310). */
 #define ENIGMA_MAX_SPHERES 256u
 typedef struct EnigmaSphere {
     float object_to_world[16]; /* Shape::m_objectToWorld->m_mat, row-major m[r][c] */
     float world_to_object[16]; /* Shape::m_worldToObject->m_mat */
     float radius, z_min, z_max, phi_max; /* the constructor's arguments (phi_max in degrees) */
     uint32_t material;         /* index into materials */
-    uint32_t flags;            /* ENIGMA_TRI_FLIP_NORMAL: m_reverseOrientation ^ m_transformSwapsHandedness */
+    uint32_t flags;            /* ENIGMA_TRI_FLIP_NORMAL: m_reverseOrientation ^ m_transformSwapsHandedness;
+                                  ENIGMA_TRI_REVERSE_ORIENTATION: m_reverseOrientation alone (read by Sphere::sample) */
     uint32_t prim_id;          /* Primitive::m_primitiveId; 0 = n_triangles + index + 1 */
     int32_t medium_inside;     /* the primitive's MediumInterface as indices into media + 1, 0 = none (so that a zeroed */
     int32_t medium_outside;    /* struct has no interface); read when the scene has media */
-    uint32_t reserved;
+    uint32_t light;            /* index into lights + 1 of its ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE, 0 = not emissive */
 } EnigmaSphere;
 
 typedef struct EnigmaSceneDesc {

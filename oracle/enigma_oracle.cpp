@@ -1731,8 +1731,12 @@ struct InfiniteData {
     }
 };
 
+struct Sphere;
+static Interaction SphereSampleFrom(const Sphere& s, const Interaction& ref, const Vec2& u, float* pdf);
+static float SpherePdfFrom(const Sphere& s, const Interaction& ref, const Vec3& wi);
 struct Light {
     int nSamples = 1; // Light::m_nSamples
+    const Sphere* sphere = nullptr; // a DiffuseAreaLight whose shape is a Sphere (shape stays null)
     std::shared_ptr<InfiniteData> inf; // InfiniteAreaLight (flags & 8)
     int flags; // 1 = delta position, 2 = delta direction, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
@@ -1768,7 +1772,7 @@ struct Light {
     // Lights.cpp:117-124 / 634-645.  vis endpoints returned in p1.
     Spectrum Sample_Li(const Interaction& ref, const Vec2& u, Vec3* wi, float* pdf, Interaction* p1) const {
         if (flags & 4) {
-            Interaction pShape = shape->sample(ref, u, pdf);
+            Interaction pShape = sphere ? SphereSampleFrom(*sphere, ref, u, pdf) : shape->sample(ref, u, pdf);
             if (*pdf == 0 || LengthSqr(pShape.p - ref.p) == 0) { *pdf = 0; return 0.f; }
             *wi = Normalize(pShape.p - ref.p);
             *p1 = pShape;
@@ -1811,7 +1815,7 @@ struct Light {
             const float INV_TWO_PI = 1.0f / (PI * 2.0f);
             return inf->dist->Pdf(phi * INV_TWO_PI, theta * INV_TWO_PI) / (2 * PI * PI * sinTheta);
         }
-        return (flags & 4) ? shape->pdf(ref, w) : 0;
+        return (flags & 4) ? (sphere ? SpherePdfFrom(*sphere, ref, w) : shape->pdf(ref, w)) : 0;
     }
 };
 
@@ -1904,6 +1908,7 @@ struct Sphere {
     Mat4 o2w, w2o;
     float radius, zMin, zMax, thetaMin, thetaMax, phiMax;
     bool flip = false; // m_reverseOrientation ^ m_transformSwapsHandedness
+    bool reverse = false; // m_reverseOrientation alone: what the sampling routines look at
     void init(float r, float z0, float z1, float phiDeg) { // ShapeImp.cpp:13-27
         radius = r;
         zMin = clampf(std::min(z0, z1), -radius, radius);
@@ -1986,7 +1991,88 @@ struct Sphere {
         *tHit = t;
         return true;
     }
+    float area() const { return phiMax * radius * (zMax - zMin); } // ShapeImp.cpp:205-208
+    // ShapeImp.cpp:210-222: the whole sphere whatever the z range and sweep; the normal is the sampled point pushed
+    // through the POINT transform (translation included) and normalised
+    Interaction sample(const Vec2& u, float* pdf) const {
+        float z = 1.f - 2.f * u[0]; // UniformSampleSphere, MonteCarlo.cpp:97-105
+        float r = sqrtf(std::max(0.f, 1.f - z * z));
+        float phi = 2.f * PI * u[1];
+        Vec3 pObj = Vec3(0, 0, 0) + radius * Vec3(r * cosf(phi), r * sinf(phi), z);
+        Interaction it;
+        Vec3 unused;
+        it.n = Normalize(TransformPointErr(o2w, pObj, &unused));
+        if (reverse) it.n *= -1;
+        pObj *= radius / Distance(pObj, Vec3(0, 0, 0));
+        Vec3 pObjError = gamma(5) * Abs(pObj);
+        it.p = TransformPointErr(o2w, pObj, pObjError, &it.pError);
+        *pdf = 1 / area();
+        return it;
+    }
+    // ShapeImp.cpp:224-293: m_radius is compared with world-space distances (a scaled sphere is sampled as if unscaled)
+    Interaction sample(const Interaction& ref, const Vec2& u, float* pdf) const {
+        Vec3 unused;
+        Vec3 pCenter = TransformPointErr(o2w, Vec3(0.0f), &unused);
+        Vec3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
+        if (DistanceSqr(pOrigin, pCenter) <= radius * radius) {
+            Interaction intr = sample(u, pdf);
+            Vec3 wi = intr.p - ref.p;
+            if (LengthSqr(wi) == 0) *pdf = 0;
+            else {
+                wi = Normalize(wi);
+                *pdf *= DistanceSqr(ref.p, intr.p) / AbsDot(intr.n, -wi);
+            }
+            if (std::isinf(*pdf)) *pdf = 0.f;
+            return intr;
+        }
+        float dc = Distance(ref.p, pCenter);
+        float invDc = 1 / dc;
+        Vec3 wc = (pCenter - ref.p) * invDc;
+        Vec3 wcX, wcY;
+        CoordinateSystem(wc, &wcX, &wcY);
+        float sinThetaMax = radius * invDc;
+        float sinThetaMax2 = sinThetaMax * sinThetaMax;
+        float invSinThetaMax = 1 / sinThetaMax;
+        float cosThetaMax = std::sqrt(std::max(0.f, 1 - sinThetaMax2));
+        float cosTheta = (cosThetaMax - 1) * u[0] + 1;
+        float sinTheta2 = 1 - cosTheta * cosTheta;
+        if (sinThetaMax2 < 0.00068523f) {
+            sinTheta2 = sinThetaMax2 * u[0];
+            cosTheta = std::sqrt(1 - sinTheta2);
+        }
+        float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * std::sqrt(std::max(0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
+        float sinAlpha = std::sqrt(std::max(0.f, 1.f - cosAlpha * cosAlpha));
+        float phi = u[1] * 2 * PI;
+        Vec3 nWorld = (sinAlpha * cosf(phi) * (-wcX)) + (sinAlpha * sinf(phi) * (-wcY)) + (cosAlpha * (-wc)); // SphericalDirection, MathCommon.cpp:18-23
+        Vec3 pWorld = pCenter + radius * Vec3(nWorld.x, nWorld.y, nWorld.z);
+        Interaction it;
+        it.p = pWorld;
+        it.pError = gamma(5) * Abs(pWorld);
+        it.n = nWorld;
+        if (reverse) it.n *= -1;
+        *pdf = 1 / (2 * PI * (1 - cosThetaMax));
+        return it;
+    }
+    // ShapeImp.cpp:297-310, Shape::pdf (Shape.cpp:80-98) from inside
+    float pdf(const Interaction& ref, const Vec3& wi) const {
+        Vec3 unused;
+        Vec3 pCenter = TransformPointErr(o2w, Vec3(0, 0, 0), &unused);
+        Vec3 pOrigin = OffsetRayOrigin(ref.p, ref.pError, ref.n, pCenter - ref.p);
+        if (DistanceSqr(pOrigin, pCenter) <= radius * radius) {
+            Ray ray = ref.SpawnRay(wi);
+            float tHit; SurfaceInteraction isectLight;
+            if (!intersect(ray, &tHit, &isectLight)) return 0;
+            float pdf = DistanceSqr(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * area());
+            if (std::isinf(pdf)) pdf = 0.f;
+            return pdf;
+        }
+        float sinThetaMax2 = radius * radius / DistanceSqr(ref.p, pCenter);
+        float cosThetaMax = std::sqrt(std::max(0.f, 1 - sinThetaMax2));
+        return 1.f / (2.f * PI * (1.f - cosThetaMax)); // UniformConePdf, MonteCarlo.cpp:112-115
+    }
 };
+static Interaction SphereSampleFrom(const Sphere& s, const Interaction& ref, const Vec2& u, float* pdf) { return s.sample(ref, u, pdf); }
+static float SpherePdfFrom(const Sphere& s, const Interaction& ref, const Vec3& wi) { return s.pdf(ref, wi); }
 
 // ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (Texture.h:313-415, Texture.cpp:22-29,412-453)
 struct ImageTex { MipMapRGB mip; float su = 1, sv = 1, du = 0, dv = 0; };
@@ -2734,6 +2820,9 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         L.nSamples = l.n_samples ? (int)l.n_samples : 1;
         if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA) {
             L.flags = 4; L.shape = &sc.tris[l.triangle]; L.twoSided = l.two_sided != 0; L.area = L.shape->area();
+        } else if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) {
+            if (l.triangle >= s->n_spheres || s->spheres[l.triangle].light != i + 1) { h->o.error = "sphere light and sphere do not point at each other"; return -1; }
+            L.flags = 4; L.twoSided = l.two_sided != 0; // shape and area follow the spheres below
         } else if (l.type == ENIGMA_LIGHT_POINT || l.type == ENIGMA_LIGHT_SPOT) {
             L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]);
             if (l.type == ENIGMA_LIGHT_SPOT) {
@@ -2759,8 +2848,12 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         memcpy(sp.o2w.m, e.object_to_world, 64); memcpy(sp.w2o.m, e.world_to_object, 64);
         sp.init(e.radius, e.z_min, e.z_max, e.phi_max);
         sp.flip = (e.flags & ENIGMA_TRI_FLIP_NORMAL) != 0;
+        sp.reverse = (e.flags & ENIGMA_TRI_REVERSE_ORIENTATION) != 0;
+        if (e.light > s->n_lights || (e.light && (s->lights[e.light - 1].type != ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE || s->lights[e.light - 1].triangle != i))) {
+            h->o.error = "sphere light index out of range or not a sphere light"; return -1;
+        }
         sc.spheres.push_back(sp);
-        sc.triMaterial.push_back(e.material); sc.triLight.push_back(-1);
+        sc.triMaterial.push_back(e.material); sc.triLight.push_back((int32_t)e.light - 1);
         sc.primId.push_back(e.prim_id ? e.prim_id : s->n_triangles + i + 1);
         if (haveMedia) {
             if (e.medium_inside < 0 || e.medium_inside > (int32_t)s->n_media || e.medium_outside < 0 || e.medium_outside > (int32_t)s->n_media) { h->o.error = "sphere medium index out of range"; return -1; }
@@ -2773,6 +2866,8 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
             sphereBounds.addPoint(q);
         }
     }
+    for (size_t i = 0; i < sc.spheres.size(); ++i) // the vector no longer grows: its elements stay where they are
+        if (s->spheres[i].light) { Light& L = sc.lights[s->spheres[i].light - 1]; L.sphere = &sc.spheres[i]; L.area = sc.spheres[i].area(); }
     sc.accel.reset(new BVHAccel(&sc.tris, max_node_prims, split_method == 1 ? SplitMethod::HLBVH : SplitMethod::SAH));
     {   // Scene::Scene (Scene.cpp:19-30): every light's Preprocess sees the aggregate's world bound;
         // BBox3::getBoundingSphere (BBox.h:322-326), getCenter (BBox.h:263-265)

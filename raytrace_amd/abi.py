@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
-LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3, 4
+LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE = 0, 1, 2, 3, 4, 5
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
@@ -49,7 +49,7 @@ class EnigmaSphere(C.Structure):
     _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
                 ("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("phi_max", C.c_float),
                 ("material", C.c_uint32), ("flags", C.c_uint32), ("prim_id", C.c_uint32),
-                ("medium_inside", C.c_int32), ("medium_outside", C.c_int32), ("reserved", C.c_uint32)]
+                ("medium_inside", C.c_int32), ("medium_outside", C.c_int32), ("light", C.c_uint32)]
 
 
 class EnigmaSceneDesc(C.Structure):
@@ -171,8 +171,15 @@ def sphere(material, radius=1.0, object_to_world=None, z_min=None, z_max=None, p
     s.material = material
     s.medium_inside, s.medium_outside = medium_inside + 1, medium_outside + 1   # the ABI stores index + 1, 0 = none
     swaps = np.linalg.det(m[:3, :3]) < 0
-    s.flags = TRI_FLIP_NORMAL if (bool(reverse_orientation) != bool(swaps)) else 0
+    s.flags = (TRI_FLIP_NORMAL if (bool(reverse_orientation) != bool(swaps)) else 0) | (TRI_REVERSE_ORIENTATION if reverse_orientation else 0)
     return s
+
+
+def sphere_area_light(sphere_index, L, two_sided=False, n_samples=1):
+    """The DiffuseAreaLight of an emissive sphere; the sphere's `light` field must hold this light's index + 1."""
+    l = area_light(sphere_index, L, two_sided, n_samples)
+    l.type = LIGHT_DIFFUSE_AREA_SPHERE
+    return l
 
 
 def image_texture(rgb, trilinear=False, gamma=True, scale=1.0, wrap=WRAP_REPEAT, su=1.0, sv=1.0, du=0.0, dv=0.0):

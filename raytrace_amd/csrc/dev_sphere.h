@@ -164,4 +164,80 @@ DEV void sphereSurface(const DevSphere& s, F3 pHit, F3 rayDirWorld, F3* p, F3* p
     }
 }
 
+// Sphere::sample(ref, u) (Enigma/ShapeImp.cpp:210-293) as Shape-side half of DiffuseAreaLight::Sample_Li: the sampled
+// point as an Interaction and the pdf over solid angle at the reference point.  The reference compares its object-space
+// radius with world-space distances and samples the whole sphere whatever its z range and sweep; so does this.
+DEV void sphereSampleFrom(const DevSphere& s, F3 refP, F3 refErr, F3 refN, float u0, float u1, F3* lp, F3* lpErr, F3* ln, float* pdfOut) {
+    const float kPiS = 3.14159265358979323846f;
+    const bool reverse = (s.mw >> 29) & 1u; // m_reverseOrientation alone
+    const F3 pCenter(s.o2w[3], s.o2w[7], s.o2w[11]);
+    F3 pOrigin = offsetRayOrigin(refP, refErr, refN, pCenter - refP);
+    if (lengthSqr(pOrigin - pCenter) <= s.radius * s.radius) { // inside: the whole sphere by area, Sphere::sample(u)
+        float z = 1.f - 2.f * u0; // UniformSampleSphere, Enigma/MonteCarlo.cpp:97-105
+        float r = sqrtf(smax(0.f, 1.f - z * z));
+        float phi = 2.f * kPiS * u1;
+        F3 pObj = F3(0.f, 0.f, 0.f) + s.radius * F3(r * cosf(phi), r * sinf(phi), z);
+        F3 unused;
+        F3 n = normalize(xfPointErr(s.o2w, pObj, &unused)); // sic: the point transform, translation included (:214)
+        if (reverse) n = -n;
+        pObj *= s.radius / length(pObj - F3(0.f, 0.f, 0.f));
+        F3 pObjError = gammaf(5) * fabs3(pObj);
+        F3 p = xfPointErr2(s.o2w, pObj, pObjError, lpErr);
+        float pdf = 1 / (s.phiMax * s.radius * (s.zMax - s.zMin));
+        F3 wi = p - refP;
+        if (lengthSqr(wi) == 0) pdf = 0;
+        else {
+            wi = normalize(wi);
+            pdf *= lengthSqr(refP - p) / absdot(n, -wi);
+        }
+        if (isinf(pdf)) pdf = 0.f;
+        *lp = p; *ln = n; *pdfOut = pdf;
+        return;
+    }
+    float dc = length(refP - pCenter);
+    float invDc = 1 / dc;
+    F3 wc = (pCenter - refP) * invDc;
+    F3 wcX, wcY;
+    coordinateSystem(wc, &wcX, &wcY);
+    float sinThetaMax = s.radius * invDc;
+    float sinThetaMax2 = sinThetaMax * sinThetaMax;
+    float invSinThetaMax = 1 / sinThetaMax;
+    float cosThetaMax = sqrtf(smax(0.f, 1 - sinThetaMax2));
+    float cosTheta = (cosThetaMax - 1) * u0 + 1;
+    float sinTheta2 = 1 - cosTheta * cosTheta;
+    if (sinThetaMax2 < 0.00068523f) {
+        sinTheta2 = sinThetaMax2 * u0;
+        cosTheta = sqrtf(1 - sinTheta2);
+    }
+    float cosAlpha = sinTheta2 * invSinThetaMax + cosTheta * sqrtf(smax(0.f, 1.f - sinTheta2 * invSinThetaMax * invSinThetaMax));
+    float sinAlpha = sqrtf(smax(0.f, 1.f - cosAlpha * cosAlpha));
+    float phi = u1 * 2 * kPiS;
+    F3 nWorld = (sinAlpha * cosf(phi) * (-wcX)) + (sinAlpha * sinf(phi) * (-wcY)) + (cosAlpha * (-wc)); // SphericalDirection, Enigma/MathCommon.cpp:18-23
+    F3 pWorld = pCenter + s.radius * nWorld;
+    *lp = pWorld;
+    *lpErr = gammaf(5) * fabs3(pWorld);
+    *ln = reverse ? -nWorld : nWorld;
+    *pdfOut = 1 / (2 * kPiS * (1 - cosThetaMax));
+}
+
+// Sphere::pdf(ref, wi) (Enigma/ShapeImp.cpp:297-310): the cone's pdf from outside (whether or not wi meets the sphere),
+// Shape::pdf (Enigma/Shape.cpp:80-98) over the ray (rayO, wi) = ref.SpawnRay(wi) from inside
+DEV float spherePdfFrom(const DevSphere& s, F3 refP, F3 refErr, F3 refN, F3 rayO, F3 wi) {
+    const float kPiS = 3.14159265358979323846f;
+    const F3 pCenter(s.o2w[3], s.o2w[7], s.o2w[11]);
+    F3 pOrigin = offsetRayOrigin(refP, refErr, refN, pCenter - refP);
+    if (lengthSqr(pOrigin - pCenter) <= s.radius * s.radius) {
+        F3 pHit, dObj; float t;
+        if (!sphereHit(s, rayO, wi, EDEV_INF, &pHit, &dObj, &t)) return 0.f;
+        F3 p, pErr, n, dpdu, wo;
+        sphereSurface(s, pHit, wi, &p, &pErr, &n, &dpdu, &wo, nullptr, nullptr, nullptr);
+        float pdf = lengthSqr(refP - p) / (absdot(n, -wi) * (s.phiMax * s.radius * (s.zMax - s.zMin)));
+        if (isinf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+    float sinThetaMax2 = s.radius * s.radius / lengthSqr(refP - pCenter);
+    float cosThetaMax = sqrtf(smax(0.f, 1 - sinThetaMax2));
+    return 1.f / (2.f * kPiS * (1.f - cosThetaMax)); // UniformConePdf, Enigma/MonteCarlo.cpp:112-115
+}
+
 } // namespace edev

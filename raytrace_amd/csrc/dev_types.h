@@ -32,8 +32,8 @@ struct DevMaterial {        // 64 bytes
 static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
 
 struct DevLight {           // 144 bytes
-    uint32_t type;          // 0 point, 1 diffuse area, 2 spot, 3 distant, 4 infinite area
-    uint32_t tri;           // area: triangle position in the device (BVH) order
+    uint32_t type;          // 0 point, 1 diffuse area, 2 spot, 3 distant, 4 infinite area, 5 diffuse area on a sphere
+    uint32_t tri;           // area: triangle position in the device (BVH) order; type 5: index into DevScene::spheres
     uint32_t twoSided;
     float area;             // Triangle::area() (Enigma/TriangleMesh.cpp:438-446)
     float L[3]; uint32_t nSamples;  // Light::m_nSamples (DirectLightingIntegrator, strategy all)
@@ -77,8 +77,8 @@ struct DevTexture {         // a trilinear ImageTexture: the MipMap pyramid (lev
 struct DevSphere {          // 128 bytes: a Sphere shape and its primitive
     float o2w[12], w2o[12]; // rows 0..2 of Shape::m_objectToWorld / m_worldToObject (affine)
     float radius, zMin, zMax, thetaMin, thetaMax, phiMax; // Sphere's members (Enigma/ShapeImp.cpp:13-27)
-    uint32_t mw;            // the second triangle word's layout: material | kind << 24 | flip-normal << 31
-    uint32_t pad;
+    uint32_t mw;            // the second triangle word's layout: material | kind << 24 | reverseOrientation << 29 | flip-normal << 31
+    uint32_t light;         // index + 1 of its DiffuseAreaLight (DevLight type 5), 0 = not emissive
 };
 
 struct DevScene {

@@ -417,8 +417,10 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         d.thetaMin = std::acos(clampf(d.zMin / d.radius, -1.f, 1.f));
         d.thetaMax = std::acos(clampf(d.zMax / d.radius, -1.f, 1.f));
         d.phiMax = (3.14159265358979323846f / 180.f) * clampf(e.phi_max, 0.0f, 360.0f);
-        d.mw = e.material | (mats[e.material].kind << 24) | ((e.flags & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u);
-        d.pad = 0;
+        d.mw = e.material | (mats[e.material].kind << 24) | ((e.flags & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u) | ((e.flags & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
+        if (e.light > s->n_lights || (e.light && (s->lights[e.light - 1].type != ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE || s->lights[e.light - 1].triangle != i)))
+            return h->fail(ENIGMA_E_INVALID, "sphere %u: its light index is out of range or names no light on this sphere", i);
+        d.light = e.light;
         sphereTable.push_back(d);
     }
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
@@ -482,6 +484,15 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
             float cx = e1[1] * e2[2] - e2[1] * e1[2], cy = e1[2] * e2[0] - e2[2] * e1[0], cz = e1[0] * e2[1] - e2[0] * e1[1];
             d.area = std::sqrt(cx * cx + cy * cy + cz * cz) * 0.5f;
+            float scale = d.twoSided ? 2.0f : 1.0f;
+            float k = d.area * PI * scale; // DiffuseAreaLight::Power, Enigma/Lights.cpp:647-651
+            h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
+        } else if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) {
+            if (l.triangle >= s->n_spheres || s->spheres[l.triangle].light != i + 1) return h->fail(ENIGMA_E_INVALID, "light %u: sphere %u does not point back at it", i, l.triangle);
+            h->haveAreaLights = true;
+            const DevSphere& sp = sphereTable[l.triangle];
+            d.type = 5; d.tri = l.triangle; d.twoSided = l.two_sided ? 1u : 0u;
+            d.area = sp.phiMax * sp.radius * (sp.zMax - sp.zMin); // Sphere::area, Enigma/ShapeImp.cpp:205-208
             float scale = d.twoSided ? 2.0f : 1.0f;
             float k = d.area * PI * scale; // DiffuseAreaLight::Power, Enigma/Lights.cpp:647-651
             h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
@@ -918,12 +929,12 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     launchTextures(h, P, gridShade);
-    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
@@ -951,13 +962,13 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     launchTextures(h, P, gridShade);
-    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->scene.triMedium) k_shade_medium<LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
         k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
@@ -986,12 +997,12 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     launchTextures(h, P, gridShade);
-    if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {

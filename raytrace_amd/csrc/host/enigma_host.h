@@ -263,15 +263,23 @@ public:
         return (uint32_t)m_textures.size();
     }
     // Sphere(o2w, w2o, reverseOrientation, radius, zMin, zMax, phiMax) with its GeometricPrimitive's material
-    // and MediumInterface (registry indices, -1 = none) (Enigma/ShapeImp.cpp:13-27, Enigma/Api.cpp:843-874).  No area light on spheres.
+    // and MediumInterface (registry indices, -1 = none) (Enigma/ShapeImp.cpp:13-27, Enigma/Api.cpp:843-874).  emission: the
+    // radiance of its DiffuseAreaLight (CreateDiffuseAreaLight, Enigma/Lights.cpp:812-822), which takes its place among
+    // the scene's lights in creation order; nullptr = not emissive.
     void AddSphere(const Transform& objectToWorld, const Transform& worldToObject, bool reverseOrientation, bool transformSwapsHandedness,
-                   float radius, float zMin, float zMax, float phiMax, int materialIndex, int mediumInside = -1, int mediumOutside = -1) {
+                   float radius, float zMin, float zMax, float phiMax, int materialIndex, int mediumInside = -1, int mediumOutside = -1,
+                   const Spectrum* emission = nullptr, bool twoSided = false, int nSamples = 1) {
         EnigmaSphere s{};
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { s.object_to_world[4 * r + c] = objectToWorld.m_mat[r][c]; s.world_to_object[4 * r + c] = worldToObject.m_mat[r][c]; }
         s.radius = radius; s.z_min = zMin; s.z_max = zMax; s.phi_max = phiMax;
         s.material = (uint32_t)materialIndex;
         s.medium_inside = mediumInside + 1; s.medium_outside = mediumOutside + 1; // the ABI holds index + 1
-        s.flags = (reverseOrientation ^ transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u;
+        s.flags = ((reverseOrientation ^ transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u) | (reverseOrientation ? ENIGMA_TRI_REVERSE_ORIENTATION : 0u);
+        if (emission) { // the sphere's `light` field is filled when the lights are laid out in order
+            EnigmaLight l{}; l.type = ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE; l.triangle = (uint32_t)m_spheres.size(); l.two_sided = twoSided; l.n_samples = (uint32_t)std::max(1, nSamples);
+            l.L[0] = (*emission)[0]; l.L[1] = (*emission)[1]; l.L[2] = (*emission)[2];
+            AddLight(l);
+        }
         m_spheres.push_back(s);
     }
     // HomogeneousMedium(sigma_a, sigma_s, g) (Enigma/Medium.cpp:69-76)
@@ -367,10 +375,14 @@ public:
         struct Guard { EnigmaCtx* h; ~Guard() { enigma_ctx_destroy(h); } } guard{h};
         auto check = [&](int rc) { if (rc != ENIGMA_OK) throw std::runtime_error(std::string("enigma: ") + enigma_last_error(h)); };
         // flatten the registry
+        std::vector<EnigmaSphere> spheres(scene.m_spheres);
         std::vector<float> verts, normals, uvs; std::vector<uint32_t> idx, triMat, triFlags; std::vector<int32_t> triLight, triIn, triOut; std::vector<EnigmaLight> lights;
         size_t pl = 0;
         auto flushPointLights = [&](int upTo) {
-            for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) lights.push_back(scene.m_lights[pl].light);
+            for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) {
+                lights.push_back(scene.m_lights[pl].light);
+                if (lights.back().type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) spheres[lights.back().triangle].light = (uint32_t)lights.size();
+            }
         };
         for (size_t mi = 0; mi < scene.m_meshes.size(); ++mi) {
             flushPointLights((int)mi);
@@ -406,7 +418,7 @@ public:
         std::vector<EnigmaTexture> textures(scene.m_textures);
         for (size_t i = 0; i < textures.size(); ++i) textures[i].rgb = scene.m_textureTexels[i].data();
         sd.n_textures = (uint32_t)textures.size(); sd.textures = textures.empty() ? nullptr : textures.data();
-        sd.n_spheres = (uint32_t)scene.m_spheres.size(); sd.spheres = scene.m_spheres.empty() ? nullptr : scene.m_spheres.data();
+        sd.n_spheres = (uint32_t)spheres.size(); sd.spheres = spheres.empty() ? nullptr : spheres.data();
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());

@@ -504,13 +504,22 @@ public:
     void MakeSphere(const ParamSet& p) {
         const float radius = p.FindOneFloat("radius", 1.f);
         const float zmin = p.FindOneFloat("zmin", -radius), zmax = p.FindOneFloat("zmax", radius), phimax = p.FindOneFloat("phimax", 360.f);
-        if (!m_gs.areaLight.empty()) throw std::runtime_error("Shape \"sphere\": an area light on a sphere is not supported");
         if (m_gs.currentMaterial == -2) throw std::runtime_error("Shape \"sphere\": a sphere without a material is not supported");
         if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet());
         const int material = m_gs.currentMaterial == -1 ? m_defaultMaterial : m_gs.currentMaterial;
         Transform o2w = m_ctm.ToFloat(), w2o = m_ctm.Inverse().ToFloat();
+        Spectrum Le(0.f); bool emissive = false, twoSided = false; int nSamples = 1;
+        if (!m_gs.areaLight.empty()) {
+            if (m_gs.areaLight != "diffuse" && m_gs.areaLight != "area") throw std::runtime_error("AreaLightSource \"" + m_gs.areaLight + "\" is not supported (diffuse)");
+            const ParamSet& ap = m_gs.areaLightParams; // CreateDiffuseAreaLight, Enigma/Lights.cpp:812-822
+            Spectrum L = ap.FindOneSpectrum("L", Spectrum(1.f)), sc = ap.FindOneSpectrum("scale", Spectrum(1.f));
+            emissive = true;
+            Le = Spectrum(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]);
+            nSamples = ap.FindOneInt("samples", ap.FindOneInt("nsamples", 1));
+            twoSided = ap.FindOneBool("twosided", false);
+        }
         m_res->scene.AddSphere(o2w, w2o, m_gs.reverseOrientation, m_ctm.SwapsHandedness(), radius, zmin, zmax, phimax, material,
-                               LookupMedium(m_gs.currentInsideMedium), LookupMedium(m_gs.currentOutsideMedium));
+                               LookupMedium(m_gs.currentInsideMedium), LookupMedium(m_gs.currentOutsideMedium), emissive ? &Le : nullptr, twoSided, nSamples);
         NoteUnused("Shape", p);
     }
     void pbrtObjectBegin(const std::string&) { throw std::runtime_error("ObjectBegin: object instancing is not supported"); }

@@ -439,14 +439,18 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                     if (proceed && h.tri >= 0) {
                         uint32_t st = state;
                         uint32_t bounces = stBounces(st);
-                        const bool sphere = isSpherePrim<SPH>(sc, h.tri); // no area light, nothing to fetch from the triangle array
+                        const bool sphere = isSpherePrim<SPH>(sc, h.tri); // nothing to fetch from the triangle array
                         const float4* tp = tris + (size_t)(sphere ? 0 : h.tri) * 3;
                         float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                        int lightIdx = sphere ? -1 : __float_as_int(v2.w);
+                        int lightIdx = sphere ? (int)sc.spheres[h.tri - (int)sc.nTris].light - 1 : __float_as_int(v2.w);
                         uint32_t mw = sphere ? sc.spheres[h.tri - (int)sc.nTris].mw : __float_as_uint(v1.w);
                         if ((DL || bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
                             const DevLight& lt = sc.lights[lightIdx];
-                            F3 n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
+                            F3 n;
+                            if (SPH && sphere) {
+                                F3 ps, pe, dpdu, wo;
+                                sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), w.r.d, &ps, &pe, &n, &dpdu, &wo);
+                            } else n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
                             if (lt.twoSided || dot(n, -w.r.d) > 0) {
                                 float4 L = P.L[p], be = P.beta[p];
                                 F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
@@ -620,7 +624,10 @@ struct DirectSample {
 // Light::Sample_Li for a reference point (Enigma/Lights.cpp:117-124,165-172,634-645,696-703): direction, radiance,
 // pdf and the sampled point as an Interaction; q0..q2 are the area light's vertices (read again by Shape::pdf).
 struct LightSample { F3 wi, Li, lp, lpErr, ln, q0, q1, q2; float pdf; };
-DEV LightSample sampleLight(const DevScene& sc, const DevLight& lt, const float4* tris, F3 refP, float ulx, float uly) {
+// SPHL: lights on spheres are compiled in (the builds for scenes with spheres);
+// refErr / refN: the reference point's error bounds and normal, which Sphere::sample offsets it by (zero for a medium point)
+template <bool SPHL = false>
+DEV LightSample sampleLight(const DevScene& sc, const DevLight& lt, const float4* tris, F3 refP, float ulx, float uly, F3 refErr = F3(0.f), F3 refN = F3(0.f)) {
     LightSample s;
     F3 wi(0.f), Li(0.f), lp(0.f), lpErr(0.f), ln(0.f);
     float lightPdf = 0.f;
@@ -648,6 +655,13 @@ DEV LightSample sampleLight(const DevScene& sc, const DevLight& lt, const float4
             if (isinf(lightPdf)) lightPdf = 0.f;
         }
         // DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
+        if (lightPdf == 0 || lengthSqr(lp - refP) == 0) lightPdf = 0;
+        else {
+            wi = normalize(lp - refP);
+            if (lt.twoSided || dot(ln, -wi) > 0) Li = F3(lt.L[0], lt.L[1], lt.L[2]);
+        }
+    } else if (SPHL && lt.type == 5) { // Sphere::sample(ref, u) under DiffuseAreaLight::Sample_Li (Enigma/Lights.cpp:634-645)
+        sphereSampleFrom(sc.spheres[lt.tri], refP, refErr, refN, ulx, uly, &lp, &lpErr, &ln, &lightPdf);
         if (lightPdf == 0 || lengthSqr(lp - refP) == 0) lightPdf = 0;
         else {
             wi = normalize(lp - refP);
@@ -711,14 +725,14 @@ DEV float lightTrianglePdf(F3 o, F3 refP, F3 wi, F3 q0, F3 q1, F3 q2, float area
     }
     return pdf;
 }
-template <int MK>
+template <int MK, bool SPHL = false>
 DEV DirectSample estimateDirect(const DevScene& sc, const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
                                 float ulx, float uly, float usx, float usy) {
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     DirectSample r;
     r.shadow = false; r.mis = false;
     // ---- light sampling (Enigma/Integrator.cpp:104-148) ----
-    LightSample ls = sampleLight(sc, lt, tris, g.p, ulx, uly);
+    LightSample ls = sampleLight<SPHL>(sc, lt, tris, g.p, ulx, uly, g.pError, g.n);
     F3 wi = ls.wi, Li = ls.Li, lp = ls.lp, lpErr = ls.lpErr, ln = ls.ln, q0 = ls.q0, q1 = ls.q1, q2 = ls.q2;
     float lightPdf = ls.pdf;
     if (lightPdf > 0 && !isBlack(Li)) {
@@ -744,7 +758,9 @@ DEV DirectSample estimateDirect(const DevScene& sc, const Bsdf& bsdf, const HitG
         if (!isBlack(f2) && scatPdf2 > 0) {
             // light.Pdf_Li -> Shape::pdf (Enigma/Shape.cpp:80-98): intersect the light's own triangle
             F3 o2 = offsetRayOrigin(g.p, g.pError, g.n, wi2);
-            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2) : lightTrianglePdf(o2, g.p, wi2, q0, q1, q2, lt.area);
+            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2)
+                              : (SPHL && lt.type == 5) ? spherePdfFrom(sc.spheres[lt.tri], g.p, g.pError, g.n, o2, wi2)
+                                                       : lightTrianglePdf(o2, g.p, wi2, q0, q1, q2, lt.area);
             if (lightPdf2 != 0) {
                 float weight = powerHeuristic(scatPdf2, lightPdf2);
                 r.miO = o2; r.miD = wi2;
@@ -797,7 +813,8 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
 // VOL: the surface branch of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:113-136): direct lighting is
 // sampled for every BSDF (no test for non-specular lobes), and every ray leaving the surface takes the medium on
 // its side of the surface (Interaction::GetMedium, Enigma/Interaction.cpp:72-75).
-template <int MK, bool LDS_SCENE, bool VOL = false>
+// SPH: the build for scenes with spheres, the only one that can sample a light on a sphere
+template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
@@ -859,7 +876,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSa
                     float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
-                    DirectSample ds = estimateDirect<MK>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    DirectSample ds = estimateDirect<MK, SPH>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
                         if (VOL) storeShadowRay(shq, p, ds.shO, ds.shD, beta * (ds.Ld / pick));
                         else { shRayO = ds.shO; shRayD = ds.shD; shRayW = beta * (ds.Ld / pick); } // stored at its queue position below
@@ -976,7 +993,7 @@ DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrato
 // of one material kind: direct lighting from all lights (sample arrays) or one uniformly chosen light,
 // then SpecularReflect / SpecularTransmit.  Smooth glass carries two specular lobes here (allowMultipleLobes
 // is false on this path).  A path's shadow / MIS rays go to its raysPerPath ray slots, packed from slot 0.
-template <int MK, bool LDS_SCENE>
+template <int MK, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevDirect D, DevRayQueue shq,
                                                          DevRayQueue misq, const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx,
                                                          DevCounters* ctr) {
@@ -1034,7 +1051,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                             unsigned long long sn = sampleNum * n + k; // entry of the array that belongs to this sample
                             float ulx = sampleDimensionOf(S, px, py, sn, dimL), uly = sampleDimensionOf(S, px, py, sn, dimL + 1);
                             float usx = sampleDimensionOf(S, px, py, sn, dimS), usy = sampleDimensionOf(S, px, py, sn, dimS + 1);
-                            DirectSample ds = estimateDirect<MKD>(sc, bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
+                            DirectSample ds = estimateDirect<MKD, SPH>(sc, bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
                             emit(ds, (float)n, l);
                         }
                     }
@@ -1046,7 +1063,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                     float ulx = sampleDimension(S, px, py, slot, dim + 1), uly = sampleDimension(S, px, py, slot, dim + 2);
                     float usx = sampleDimension(S, px, py, slot, dim + 3), usy = sampleDimension(S, px, py, slot, dim + 4);
                     dim += 5;
-                    DirectSample ds = estimateDirect<MKD>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
+                    DirectSample ds = estimateDirect<MKD, SPH>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     emit(ds, lightPdf, lightNum);
                 }
             }
@@ -1189,7 +1206,19 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
         Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
         if (SPH) {
             sphereClosest(sc, xyz(o), xyz(d), &h.tri, &h.t, &h.b0, &h.b1, &h.b2);
-            if (isSpherePrim<SPH>(sc, h.tri)) continue; // a sphere is no area light
+            if (isSpherePrim<SPH>(sc, h.tri)) { // lightIsect.Le(-wi) of an emissive sphere, if it is the sampled light
+                const DevSphere& sp = sc.spheres[h.tri - (int)sc.nTris];
+                if ((int)sp.light - 1 != __float_as_int(d.w)) continue;
+                const DevLight& lt = sc.lights[sp.light - 1];
+                F3 ps, pe, n, dpdu, wo;
+                sphereSurface(sp, F3(h.b0, h.b1, h.b2), xyz(d), &ps, &pe, &n, &dpdu, &wo);
+                if (lt.twoSided || dot(n, -xyz(d)) > 0) {
+                    F3 add = xyz(misq.w[p]) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                    float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
+                    atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
+                }
+                continue;
+            }
         }
         if (h.tri < 0) { // Li = light.Le(ray): only an infinite area light returns anything (Enigma/Integrator.cpp:194-195)
             const DevLight& lt = sc.lights[__float_as_int(d.w)];

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_spatial_contrib(DevScene sc, const f
     float contrib = 0.f;
     for (int i = 0; i < 128; ++i) {
         F3 po(lerp1(lo[0], hi[0], halton[i]), lerp1(lo[1], hi[1], halton[128 + i]), lerp1(lo[2], hi[2], halton[256 + i]));
-        LightSample s = sampleLight(sc, lt, sc.tris, po, halton[384 + i], halton[512 + i]);
+        LightSample s = sampleLight<true>(sc, lt, sc.tris, po, halton[384 + i], halton[512 + i]);
         if (s.pdf > 0) contrib += (0.212671f * s.Li.x + 0.715160f * s.Li.y + 0.072169f * s.Li.z) / s.pdf;
     }
     table[(size_t)voxel * (2 * (size_t)nl + 2) + j] = contrib;

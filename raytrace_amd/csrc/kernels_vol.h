@@ -50,7 +50,7 @@ DEV F3 mediumTr(const DevMedium& m, F3 d, float tMax) {
 
 // The medium branch for the paths of the medium-interaction queue.  A medium interaction has no normal and no
 // error bounds: rays start at the point itself and stay in the interaction's medium.
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                          const uint32_t* queue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
                     float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
                     dim += 4;
                     const DevLight& lt = lights[lightNum];
-                    LightSample ls = sampleLight(sc, lt, tris, pm, ulx, uly);
+                    LightSample ls = sampleLight<SPH>(sc, lt, tris, pm, ulx, uly);
                     if (ls.pdf > 0 && !isBlack(ls.Li)) {
                         float ph = phaseHG(dot(wo, ls.wi), g);
                         if (ph != 0.f) {
@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
                         F3 wi2(0.f);
                         float ph2 = hgSample(g, wo, &wi2, usx, usy);
                         if (ph2 != 0.f && ph2 > 0) {
-                            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2) : lightTrianglePdf(pm, pm, wi2, ls.q0, ls.q1, ls.q2, lt.area);
+                            float lightPdf2 = lt.type == 4 ? infinitePdfLi(sc, lt, wi2)
+                                              : (SPH && lt.type == 5) ? spherePdfFrom(sc.spheres[lt.tri], pm, F3(0.f), F3(0.f), pm, wi2)
+                                                                             : lightTrianglePdf(pm, pm, wi2, ls.q0, ls.q1, ls.q2, lt.area);
                             if (lightPdf2 != 0) {
                                 float weight = powerHeuristic(ph2, lightPdf2);
                                 misq.o[p] = mk4(pm, __uint_as_float(med));
@@ -289,7 +291,18 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                         atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
                     }
                 } else if (isSpherePrim<SPH>(sc, h.tri)) {
-                    active = false; // a surface with a material that is no area light
+                    active = false; // a surface with a material: the chain ends here, with lightIsect.Le(-wi) if it is the sampled light
+                    const DevSphere& sp = sc.spheres[h.tri - (int)sc.nTris];
+                    if ((int)sp.light - 1 == wantLight) {
+                        const DevLight& lt = sc.lights[wantLight];
+                        F3 ps, pe, n, dpdu, wo;
+                        sphereSurface(sp, F3(h.b0, h.b1, h.b2), d, &ps, &pe, &n, &dpdu, &wo);
+                        if (lt.twoSided || dot(n, -d) > 0) {
+                            F3 add = xyz(misq.w[p]) * F3(lt.L[0], lt.L[1], lt.L[2]) * Tr;
+                            float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
+                            atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
+                        }
+                    }
                 } else {
                     const float4* tp = tris + (size_t)h.tri * 3;
                     float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];

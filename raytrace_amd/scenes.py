@@ -170,8 +170,13 @@ class MeshBuilder:
         self.textures = []
         self.spheres = []
 
-    def add_sphere(self, material, radius=1.0, object_to_world=None, **kw):
-        self.spheres.append(abi.sphere(material, radius, object_to_world, **kw))
+    def add_sphere(self, material, radius=1.0, object_to_world=None, emit=None, two_sided=False, n_samples=1, **kw):
+        """emit: radiance of the sphere's DiffuseAreaLight (AreaLightSource "diffuse" in front of the shape)."""
+        sp = abi.sphere(material, radius, object_to_world, **kw)
+        if emit is not None:
+            self.lights.append(abi.sphere_area_light(len(self.spheres), emit, two_sided, n_samples))
+            sp.light = len(self.lights)
+        self.spheres.append(sp)
 
     def add_texture(self, t):
         """Returns the value for a material's tex_* field (index + 1)."""
@@ -426,12 +431,12 @@ def _translation(x, y, z):
     return m
 
 
-def cornell_spheres(fog=False, textured=True):
+def cornell_spheres(fog=False, textured=True, lamp=False):
     """The Cornell box with analytic Sphere shapes in place of the blocks: a matte sphere, a metal ellipsoid (rotated,
     non-uniformly scaled), a smooth-glass sphere, a rough-glass bowl (z range and phi sweep cut open, ReverseOrientation)
     and a plastic sphere under a mirroring transform.  fog: a scattering slab between camera and spheres and a tinted medium
     inside the glass sphere (VolPath).  textured: the matte sphere's Kd comes from a trilinear image texture over its (phi, theta)
-    parametrisation."""
+    parametrisation.  lamp: a small emissive sphere (a DiffuseAreaLight on a Sphere, 2 samples) hangs under the ceiling."""
     b = MeshBuilder()
     white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
     red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
@@ -471,6 +476,8 @@ def cornell_spheres(fog=False, textured=True):
                  object_to_world=_translation(150, 330, 350) @ _rotation((1, 0, 0), -70.0))
     b.add_sphere(b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05)), radius=55.0,
                  object_to_world=_translation(420, 320, 300) @ np.diag([-1.0, 1.0, 1.0, 1.0]))
+    if lamp:
+        b.add_sphere(white, radius=25.0, object_to_world=_translation(330, 430, 200), emit=(40.0, 40.0, 60.0), n_samples=2)
     return b.arrays(weld=not fog)
 
 

@@ -71,7 +71,10 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
     med = lambda k: (int(sc.tri_medium_inside[k]), int(sc.tri_medium_outside[k])) if n_media else (-1, -1)
     nT = sc.indices.shape[0]
     # point lights keep their position among the area lights: emit each before the first triangle whose light index is larger
-    point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type != abi.LIGHT_DIFFUSE_AREA]
+    point = [(i, sc.lights[i]) for i in range(sc.n_lights) if sc.lights[i].type not in (abi.LIGHT_DIFFUSE_AREA, abi.LIGHT_DIFFUSE_AREA_SPHERE)]
+    # spheres are written last, so their lights must be the last ones and in sphere order
+    on_spheres = [i for i in range(sc.n_lights) if sc.lights[i].type == abi.LIGHT_DIFFUSE_AREA_SPHERE]
+    assert on_spheres == list(range(sc.n_lights - len(on_spheres), sc.n_lights)) and [sc.lights[i].triangle for i in on_spheres] == sorted(sc.lights[i].triangle for i in on_spheres)
     emitted = 0
 
     def flush_points(upto):
@@ -141,6 +144,9 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
             out.append('  MediumInterface "%s" "%s"' % tuple("" if i <= 0 else "med%d" % (i - 1) for i in (s.medium_inside, s.medium_outside)))
         if reverse:
             out.append("  ReverseOrientation")
+        if s.light:
+            l = sc.lights[s.light - 1]
+            out.append('  AreaLightSource "diffuse" %s "bool twosided" "%s" "integer samples" %d' % (_rgb("L", l.L), "true" if l.two_sided else "false", max(1, l.n_samples)))
         out.append('  Shape "sphere" "float radius" %.9g "float zmin" %.9g "float zmax" %.9g "float phimax" %.9g' % (s.radius, s.z_min, s.z_max, s.phi_max))
         out.append("AttributeEnd")
     out.append("WorldEnd")

@@ -95,7 +95,7 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     elif variant == "textured":
         sc = scenes.cornell_textured(True)  # Texture "imagemap" directives over PFM files, "texture Kd" bindings, uvs
     elif variant == "spheres+fog":
-        sc = scenes.cornell_spheres(fog=True)   # a medium inside the glass sphere: MediumInterface before Shape "sphere"
+        sc = scenes.cornell_spheres(fog=True, lamp=True)   # a medium inside the glass sphere: MediumInterface before Shape "sphere"; AreaLightSource on a sphere
     elif variant == "spheres":
         sc = scenes.cornell_spheres()       # Shape "sphere" under ConcatTransform, ReverseOrientation, zmin / zmax / phimax
     elif variant == "smooth":

@@ -485,6 +485,36 @@ def test_image_parity_spheres(fog):
         r.close(); o.close()
 
 
+def test_image_parity_sphere_area_lights():
+    """DiffuseAreaLight on a Sphere (Sphere::sample / pdf, Enigma/ShapeImp.cpp:205-310): the oracle's closed-form scenes --
+    cone sampling from outside (also the small-angle series), area sampling from inside a two-sided sphere -- and a
+    lamp sphere in the Cornell box with spheres, with and without fog, under the three integrators and both
+    light-selection tables that read Power()."""
+    from test_oracle_kat import _sphere_light_scene
+    cam, film = scenes.camera_desc((0.0, 3.0, -40.0), (0, 2.5, 0), (0, 1, 0), 25.0, 48, 48), scenes.film_desc(48, 48)
+    cases = [(_sphere_light_scene(2.0, (0.0, 5.0, 0.0)), cam, film), (_sphere_light_scene(0.1, (0.0, 20.0, 0.0)), cam, film),
+             (_sphere_light_scene(50.0, (0.0, 0.0, 0.0), two_sided=True), cam, film)]
+    ccam, cfilm = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    cases += [(scenes.cornell_spheres(textured=False, lamp=True), ccam, cfilm), (scenes.cornell_spheres(fog=True, textured=False, lamp=True), ccam, cfilm)]
+    for k, (sc, cm, fl) in enumerate(cases):
+        integs = [scenes.integrator_desc(fl, 16), scenes.direct_lighting_desc(fl, 16, max_depth=1, strategy=abi.DL_SAMPLE_ALL), scenes.volpath_desc(fl, 16)]
+        if k == 3:
+            integs += [scenes.integrator_desc(fl, 16, light_strategy=abi.LIGHTS_SPATIAL), scenes.direct_lighting_desc(fl, 16, max_depth=1, strategy=abi.DL_SAMPLE_ONE)]
+        if k == 4:
+            integs = [scenes.volpath_desc(fl, 16), scenes.volpath_desc(fl, 16, light_strategy=abi.LIGHTS_SPATIAL)]
+        for integ in integs:
+            r = ra.Renderer(0).configure(sc, cm, fl, integ)
+            o = orc.Oracle(sc, cm, fl, integ)
+            r.render(0, 16)
+            o.render(0, 16, threads=8)
+            assert np.isfinite(r.image()).all() and o.image().max() > 1e-6
+            assert common.mean_relative_error(r.image(), o.image()) < 2e-3, (k, common.mean_relative_error(r.image(), o.image()))
+            so, st = o.stats(), r.stats()
+            for key in ("rays_closest", "rays_shadow", "rays_mis"):
+                assert abs(st[key] - so[key]) <= max(8, 1e-3 * so[key]), (k, key, st[key], so[key])
+            r.close(); o.close()
+
+
 def test_spheres_alone_and_refusals():
     """A scene without a single triangle; more spheres than the limit, a sphere with a trilinear texture and the
     intersection taps on a scene with spheres are refused."""

@@ -868,3 +868,57 @@ def test_emissive_triangle_turns_its_normal_to_its_vertex_normals():
     both = _render_panel(_panel_scene(two_sided=True), dl)
     both_up = _render_panel(_panel_scene(normal=(0.0, 1.0, 0.0), two_sided=True), dl)
     assert np.allclose(both, both_up, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ spheres as area lights
+def _sphere_light_scene(radius, centre, two_sided=False, quad=5.0, n_samples=1):
+    """A small matte quad at the origin (normal +y) and an emissive sphere."""
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([np.array(p, float) for p in ((-quad, 0, -quad), (-quad, 0, quad), (quad, 0, quad), (quad, 0, -quad))], m, toward=(0, 1, 0))
+    b.add_sphere(m, radius, _translate(*centre), emit=(4.0, 2.0, 1.0), two_sided=two_sided, n_samples=n_samples)
+    return b.arrays()
+
+
+def _centre_radiance(sc, integ_fn, eye, spp=256, res=5):
+    cam = scenes.camera_desc(eye, (0, 0, 0), (0, 1, 0) if abs(eye[1]) < abs(eye[2]) else (0, 0, 1), 1.0, res, res)
+    film = scenes.film_desc(res, res)
+    o = orc.Oracle(sc, cam, film, integ_fn(film, spp))
+    o.render(0, spp, threads=4)
+    img = o.image().astype(np.float64)
+    o.close()
+    return img[res // 2, res // 2]
+
+
+def test_sphere_area_light_matches_its_closed_forms():
+    """Sphere::sample(ref, u) / pdf (Enigma/ShapeImp.cpp:224-310) behind DiffuseAreaLight::Sample_Li: from outside the
+    cone of directions the sphere subtends is sampled uniformly, so a matte point facing a sphere of radius r at
+    distance d radiates Kd/pi * L * pi (r/d)^2; from inside the whole sphere is sampled by area and a two-sided
+    sphere is a furnace, Kd/pi * L * pi.  Both hold for light sampling alone, BSDF sampling alone (through the MIS
+    weights summing to one) and the path integrator's first bounce."""
+    L = np.array([4.0, 2.0, 1.0])
+    dl = lambda film, spp: scenes.direct_lighting_desc(film, spp, max_depth=1, strategy=abi.DL_SAMPLE_ALL)
+    one = lambda film, spp: scenes.direct_lighting_desc(film, spp, max_depth=1, strategy=abi.DL_SAMPLE_ONE)
+    path = lambda film, spp: scenes.integrator_desc(film, spp, max_depth=1)
+    for r, d in ((1.0, 10.0), (2.0, 5.0), (0.1, 20.0)):          # the last takes the small-angle series (sin^2 < 0.00068523)
+        want = 0.5 * L * (r / d) ** 2
+        for integ in (dl, one, path):
+            got = _centre_radiance(_sphere_light_scene(r, (0.0, d, 0.0)), integ, (0.0, 3.0, -40.0))
+            assert np.allclose(got, want, rtol=0.03), (r, d, got, want)
+    # inside a two-sided sphere of radius 50 around the origin: a furnace
+    for integ in (dl, path):
+        got = _centre_radiance(_sphere_light_scene(50.0, (0.0, 0.0, 0.0), two_sided=True), integ, (0.0, 3.0, -40.0), spp=1024)
+        assert np.allclose(got, 0.5 * L, rtol=0.03), got
+    # one-sided, seen from inside: the outward normal faces away, nothing arrives
+    got = _centre_radiance(_sphere_light_scene(50.0, (0.0, 0.0, 0.0)), dl, (0.0, 3.0, -40.0))
+    assert np.all(got == 0.0)
+    # the light is seen directly, and several samples per light change only the noise
+    sc = _sphere_light_scene(2.0, (0.0, 5.0, 0.0), n_samples=4)
+    cam = scenes.camera_desc((0.0, 5.0, -40.0), (0, 5.0, 0), (0, 1, 0), 1.0, 5, 5)
+    film = scenes.film_desc(5, 5)
+    o = orc.Oracle(sc, cam, film, dl(film, 16))
+    o.render(0, 16, threads=2)
+    assert np.allclose(o.image()[2, 2], L)
+    o.close()
+    got = _centre_radiance(sc, dl, (0.0, 3.0, -40.0), spp=64)
+    assert np.allclose(got, 0.5 * L * (2.0 / 5.0) ** 2, rtol=0.03)

@@ -385,10 +385,14 @@ WorldEnd
 def test_sphere_shapes_reach_the_scene(tmp_path):
     """Shape "sphere" (CreateSphereShape, Enigma/ShapeImp.cpp:723-732): both matrices of the CTM, the constructor's
     parameters with their defaults, the orientation flag = ReverseOrientation ^ a mirroring CTM, the bound material."""
-    sc = scenes.cornell_spheres()
+    sc = scenes.cornell_spheres(lamp=True)
     text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 32, 32, 4, texture_dir=str(tmp_path))
     d = dump(tmp_path, text)
     assert len(d["spheres"]) == sc.n_spheres
+    (lamp,) = d["lights"]             # AreaLightSource in front of Shape "sphere": a DiffuseAreaLight on the last sphere, after the mesh lights
+    ref = sc.lights[sc.n_lights - 1]
+    assert (lamp["type"], lamp["sphere"], lamp["nsamples"], lamp["twosided"]) == (abi.LIGHT_DIFFUSE_AREA_SPHERE, sc.n_spheres - 1, 2, 0) and np.allclose(lamp["I"], list(ref.L))
+    assert lamp["order"] == len(d["meshes"])
     for got, ref in zip(d["spheres"], sc.spheres[: sc.n_spheres]):
         assert np.allclose(got["o2w"], list(ref.object_to_world), rtol=1e-6, atol=1e-6)
         assert np.allclose(got["w2o"], list(ref.world_to_object), rtol=1e-5, atol=1e-6)
@@ -419,7 +423,7 @@ WorldEnd
     assert (s0["radius"], s0["zmin"], s0["zmax"], s0["phimax"], s0["flags"]) == (3, -3, 3, 360, 1)           # the mirror alone flips the normal
     assert np.allclose(np.array(s0["o2w"]).reshape(4, 4), [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, -2, 3], [0, 0, 0, 1]])
     assert np.allclose(np.array(s0["o2w"]).reshape(4, 4) @ np.array(s0["w2o"]).reshape(4, 4), np.eye(4), atol=1e-6)
-    for body, needle in (('AreaLightSource "diffuse" "rgb L" [1 1 1]\nShape "sphere"', "area light"),
+    for body, needle in (('AreaLightSource "spot" "rgb L" [1 1 1]\nShape "sphere"', "not supported (diffuse)"),
                          ('Material "none"\nShape "sphere"', "without a material"),
                          ('Shape "cylinder"', "not supported")):
         err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
