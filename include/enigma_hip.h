@@ -130,7 +130,7 @@ typedef struct EnigmaMedium {
 
 /* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or
  * partial (z range, phi sweep), any object-to-world transform.  Spheres are tested one by one beside the triangles'
- * BVH (at most ENIGMA_MAX_SPHERES of them) and always have a material.  A sphere may carry a DiffuseAreaLight
+ * BVH (at most ENIGMA_MAX_SPHERES of them).  A sphere may carry a DiffuseAreaLight
  * (`light`); its sampling routines are the reference's: they cover the whole sphere whatever the z range and sweep,
  * and compare the object-space radius with world-space distances (Enigma/ShapeImp.cpp:210-310). */
 #define ENIGMA_MAX_SPHERES 256u
@@ -138,7 +138,7 @@ typedef struct EnigmaSphere {
     float object_to_world[16]; /* Shape::m_objectToWorld->m_mat, row-major m[r][c] */
     float world_to_object[16]; /* Shape::m_worldToObject->m_mat */
     float radius, z_min, z_max, phi_max; /* the constructor's arguments (phi_max in degrees) */
-    uint32_t material;         /* index into materials */
+    uint32_t material;         /* index into materials, or ENIGMA_NO_MATERIAL: a medium boundary (VolPathIntegrator) */
     uint32_t flags;            /* ENIGMA_TRI_FLIP_NORMAL: m_reverseOrientation ^ m_transformSwapsHandedness;
                                   ENIGMA_TRI_REVERSE_ORIENTATION: m_reverseOrientation alone (read by Sphere::sample) */
     uint32_t prim_id;          /* Primitive::m_primitiveId; 0 = n_triangles + index + 1 */

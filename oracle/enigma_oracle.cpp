@@ -2842,7 +2842,8 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     if (s->n_spheres > ENIGMA_MAX_SPHERES) { h->o.error = "too many spheres"; return -4; }
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const EnigmaSphere& e = s->spheres[i];
-        if (e.material >= s->n_materials) { h->o.error = "sphere material index out of range"; return -1; }
+        if (e.material != ENIGMA_NO_MATERIAL && e.material >= s->n_materials) { h->o.error = "sphere material index out of range"; return -1; }
+        if (e.material == ENIGMA_NO_MATERIAL && e.light) { h->o.error = "an area light on a surface without a material is not restated"; return -4; }
         if (!(e.radius > 0)) { h->o.error = "sphere radius must be positive"; return -1; }
         Sphere sp;
         memcpy(sp.o2w.m, e.object_to_world, 64); memcpy(sp.w2o.m, e.world_to_object, 64);

@@ -403,7 +403,10 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->n_spheres && !s->spheres) return h->fail(ENIGMA_E_INVALID, "null sphere array");
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const EnigmaSphere& e = s->spheres[i];
-        if (e.material >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "sphere %u: material index out of range", i);
+        const bool noMat = e.material == ENIGMA_NO_MATERIAL; // a medium boundary, as for triangles
+        if (!noMat && e.material >= s->n_materials) return h->fail(ENIGMA_E_INVALID, "sphere %u: material index out of range", i);
+        if (noMat && e.light) return h->fail(ENIGMA_E_UNSUPPORTED, "sphere %u: an area light on a surface without a material is not supported", i);
+        if (noMat) h->haveNoMaterial = true;
         if (!(e.radius > 0.f)) return h->fail(ENIGMA_E_INVALID, "sphere %u: radius must be positive", i);
         for (int c = 0; c < 4; ++c)
             if (e.object_to_world[12 + c] != (c == 3 ? 1.f : 0.f) || e.world_to_object[12 + c] != (c == 3 ? 1.f : 0.f))
@@ -417,7 +420,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         d.thetaMin = std::acos(clampf(d.zMin / d.radius, -1.f, 1.f));
         d.thetaMax = std::acos(clampf(d.zMax / d.radius, -1.f, 1.f));
         d.phiMax = (3.14159265358979323846f / 180.f) * clampf(e.phi_max, 0.0f, 360.0f);
-        d.mw = e.material | (mats[e.material].kind << 24) | ((e.flags & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u) | ((e.flags & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
+        d.mw = (noMat ? (uint32_t)MK_NONE << 24 : e.material | (mats[e.material].kind << 24)) | ((e.flags & ENIGMA_TRI_FLIP_NORMAL) ? 1u << 31 : 0u) | ((e.flags & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
         if (e.light > s->n_lights || (e.light && (s->lights[e.light - 1].type != ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE || s->lights[e.light - 1].triangle != i)))
             return h->fail(ENIGMA_E_INVALID, "sphere %u: its light index is out of range or names no light on this sphere", i);
         d.light = e.light;
@@ -906,6 +909,7 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
     if (h->scene.nSpheres) // the surface interactions of this bounce's sphere hits
         for (int k = 0; k < MK_COUNT; ++k)
             if (h->kindPresent[k]) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[k].p, k, h->counters.p);
+    if (h->scene.nSpheres && h->haveNoMaterial) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, h->counters.p);
     if (!h->haveTrilinear) return;
     const float diffScale = 1 / std::sqrt((float)h->spp); // RayDifferential::scaleDifferentials, Enigma/Integrator.cpp:276
     for (int k = 0; k < MK_COUNT; ++k)

@@ -272,7 +272,7 @@ public:
         EnigmaSphere s{};
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { s.object_to_world[4 * r + c] = objectToWorld.m_mat[r][c]; s.world_to_object[4 * r + c] = worldToObject.m_mat[r][c]; }
         s.radius = radius; s.z_min = zMin; s.z_max = zMax; s.phi_max = phiMax;
-        s.material = (uint32_t)materialIndex;
+        s.material = materialIndex < 0 ? ENIGMA_NO_MATERIAL : (uint32_t)materialIndex; // no material: a medium boundary
         s.medium_inside = mediumInside + 1; s.medium_outside = mediumOutside + 1; // the ABI holds index + 1
         s.flags = ((reverseOrientation ^ transformSwapsHandedness) ? ENIGMA_TRI_FLIP_NORMAL : 0u) | (reverseOrientation ? ENIGMA_TRI_REVERSE_ORIENTATION : 0u);
         if (emission) { // the sphere's `light` field is filled when the lights are laid out in order

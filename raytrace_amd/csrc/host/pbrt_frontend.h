@@ -504,9 +504,8 @@ public:
     void MakeSphere(const ParamSet& p) {
         const float radius = p.FindOneFloat("radius", 1.f);
         const float zmin = p.FindOneFloat("zmin", -radius), zmax = p.FindOneFloat("zmax", radius), phimax = p.FindOneFloat("phimax", 360.f);
-        if (m_gs.currentMaterial == -2) throw std::runtime_error("Shape \"sphere\": a sphere without a material is not supported");
         if (m_gs.currentMaterial == -1 && m_defaultMaterial < 0) m_defaultMaterial = MakeMaterial("matte", ParamSet());
-        const int material = m_gs.currentMaterial == -1 ? m_defaultMaterial : m_gs.currentMaterial;
+        const int material = m_gs.currentMaterial == -1 ? m_defaultMaterial : (m_gs.currentMaterial == -2 ? -1 : m_gs.currentMaterial); // -1: Material "none"
         Transform o2w = m_ctm.ToFloat(), w2o = m_ctm.Inverse().ToFloat();
         Spectrum Le(0.f); bool emissive = false, twoSided = false; int nSamples = 1;
         if (!m_gs.areaLight.empty()) {

@@ -181,6 +181,19 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
     }
 }
 
+// Position, error bounds and normal of a hit on a surface without a material, for the rays that are not the path's own
+// (their sphere hits have no record from k_sphere_surface: worked out here).
+template <bool SPH>
+DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, F3 d, uint32_t path, F3* gp, F3* ge, F3* gn) {
+    if (isSpherePrim<SPH>(sc, h.tri)) {
+        F3 dpdu, wo;
+        sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), d, gp, ge, gn, &dpdu, &wo);
+    } else {
+        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, path);
+        *gp = g.p; *ge = g.pError; *gn = g.n;
+    }
+}
+
 // VisibilityTester::Tr for the shadow rays of one bounce.  A shadow ray is a chain of segments towards the same
 // end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
 // without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
@@ -225,11 +238,12 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
                     if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
                     if (!hit) active = false;
                     else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
-                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, p);
-                        o = offsetRayOrigin(g.p, g.pError, g.n, lp - g.p);
+                        F3 gp, ge, gn;
+                        boundaryGeometry<SPH>(sc, tris, h, d, p, &gp, &ge, &gn);
+                        o = offsetRayOrigin(gp, ge, gn, lp - gp);
                         F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
                         d = target - o;
-                        med = mediumBeyond(sc, h.tri, med, g.n, d);
+                        med = mediumBeyond(sc, h.tri, med, gn, d);
                         w.start(o, d, 1 - kShadowEpsilon);
                         ++nQueries;
                     }
@@ -290,7 +304,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                         float* L = reinterpret_cast<float*>(P.L + p / misq.perPath);
                         atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
                     }
-                } else if (isSpherePrim<SPH>(sc, h.tri)) {
+                } else if (isSpherePrim<SPH>(sc, h.tri) && triKind(sc.spheres[h.tri - (int)sc.nTris].mw) != MK_NONE) {
                     active = false; // a surface with a material: the chain ends here, with lightIsect.Le(-wi) if it is the sampled light
                     const DevSphere& sp = sc.spheres[h.tri - (int)sc.nTris];
                     if ((int)sp.light - 1 == wantLight) {
@@ -304,10 +318,10 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                         }
                     }
                 } else {
-                    const float4* tp = tris + (size_t)h.tri * 3;
-                    float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    uint32_t mw = __float_as_uint(v1.w);
+                    uint32_t mw = primWord<SPH>(sc, tris, h.tri); // a triangle, or a sphere without a material
                     if (triKind(mw) != MK_NONE) {
+                        const float4* tp = tris + (size_t)h.tri * 3;
+                        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                         active = false;
                         int lightIdx = __float_as_int(v2.w);
                         if (lightIdx == wantLight) { // lightIsect.m_primitive->getAreaLight() == &light
@@ -320,9 +334,10 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
                             }
                         }
                     } else {
-                        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, p);
-                        o = offsetRayOrigin(g.p, g.pError, g.n, d);
-                        med = mediumBeyond(sc, h.tri, med, g.n, d);
+                        F3 gp, ge, gn;
+                        boundaryGeometry<SPH>(sc, tris, h, d, p, &gp, &ge, &gn);
+                        o = offsetRayOrigin(gp, ge, gn, d);
+                        med = mediumBeyond(sc, h.tri, med, gn, d);
                         w.start(o, d, EDEV_INF);
                         ++nQueries;
                     }

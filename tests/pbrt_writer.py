@@ -139,7 +139,7 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
         reverse = bool(s.flags & abi.TRI_FLIP_NORMAL) != bool(swaps)
         out.append("AttributeBegin")
         out.append("  ConcatTransform [%s]" % " ".join("%.9g" % v for v in m.T.reshape(-1)))      # the file holds the matrix column by column
-        out.append('  NamedMaterial "m%d"' % s.material)
+        out.append('  Material "none"' if s.material == abi.NO_MATERIAL else '  NamedMaterial "m%d"' % s.material)
         if n_media and (s.medium_inside or s.medium_outside):
             out.append('  MediumInterface "%s" "%s"' % tuple("" if i <= 0 else "med%d" % (i - 1) for i in (s.medium_inside, s.medium_outside)))
         if reverse:

@@ -515,6 +515,33 @@ def test_image_parity_sphere_area_lights():
             r.close(); o.close()
 
 
+def test_image_parity_spheres_without_material():
+    """A Sphere with Material "none" bounds a medium (Enigma/VolPathIntegrator.cpp:105-111): a scattering ball in front
+    of an emissive wall, with and without a lamp sphere above it, under the VolPathIntegrator with both light tables;
+    the camera rays, the shadow-ray chains and the MIS rays all cross the ball.  The other integrators refuse."""
+    from test_oracle_kat import _fog_ball_scene
+    cam, film = scenes.camera_desc((0, 5, -40), (0, 2, 0), (0, 1, 0), 40.0, 48, 48), scenes.film_desc(48, 48)
+    for lamp in (False, True):
+        sc = _fog_ball_scene((0.02, 0.03, 0.05), (0.15, 0.15, 0.12), g=0.3, lamp=lamp)
+        for strategy in (abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL):
+            integ = scenes.volpath_desc(film, 32, light_strategy=strategy)
+            r = ra.Renderer(0).configure(sc, cam, film, integ)
+            o = orc.Oracle(sc, cam, film, integ)
+            r.render(0, 32)
+            o.render(0, 32, threads=8)
+            assert np.isfinite(r.image()).all() and o.image().max() > 0.5
+            assert common.mean_relative_error(r.image(), o.image()) < 2e-3, common.mean_relative_error(r.image(), o.image())
+            so, st = o.stats(), r.stats()
+            for key in ("rays_closest", "rays_shadow", "rays_mis"):
+                assert abs(st[key] - so[key]) <= max(8, 1e-3 * so[key]), (key, st[key], so[key])
+            r.close(); o.close()
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.integrator_desc(film, 4))
+    with pytest.raises(ra.EnigmaError) as e:       # refused when a render is asked for, as for triangles without a material
+        r.render(0, 4)
+    assert e.value.code == -4
+    r.close()
+
+
 def test_spheres_alone_and_refusals():
     """A scene without a single triangle; more spheres than the limit, a sphere with a trilinear texture and the
     intersection taps on a scene with spheres are refused."""

@@ -922,3 +922,38 @@ def test_sphere_area_light_matches_its_closed_forms():
     o.close()
     got = _centre_radiance(sc, dl, (0.0, 3.0, -40.0), spp=64)
     assert np.allclose(got, 0.5 * L * (2.0 / 5.0) ** 2, rtol=0.03)
+
+
+# ------------------------------------------------------------------ spheres without a material: medium boundaries
+def _fog_ball_scene(sigma_a, sigma_s, g=0.0, radius=5.0, lamp=False):
+    """An emissive wall behind a ball of medium (a Sphere with Material "none" and a medium inside), over a matte floor."""
+    b = scenes.MeshBuilder()
+    m = b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    b.add_quad([np.array(p, float) for p in ((-30, -10, 20), (-30, 30, 20), (30, 30, 20), (30, -10, 20))], m, toward=(0, 0, -40), emit=(2.0, 1.0, 0.5))
+    b.add_quad([np.array(p, float) for p in ((-30, -10, -60), (-30, -10, 20), (30, -10, 20), (30, -10, -60))], m, toward=(0, 0, 0))
+    med = b.add_medium(abi.homogeneous_medium(sigma_a, sigma_s, g))
+    b.add_sphere(abi.NO_MATERIAL, radius, _translate(0.0, 0.0, 0.0), medium_inside=med)
+    if lamp:
+        b.add_sphere(m, 2.0, _translate(0.0, 12.0, 0.0), emit=(30.0, 30.0, 30.0))
+    return b.arrays(weld=False)
+
+
+def test_sphere_without_material_bounds_its_medium():
+    """A GeometricPrimitive without a material is passed through and switches the ray's medium
+    (Enigma/VolPathIntegrator.cpp:105-111, Enigma/Interaction.cpp:72-75); for a Sphere the crossing points come from
+    Sphere::intersect.  Through the centre of an absorbing ball of radius r the wall behind it keeps exp(-sigma_a 2r)
+    of its radiance, beside the ball all of it; the other integrators refuse such a scene."""
+    L = np.array([2.0, 1.0, 0.5])
+    sa = np.array([0.05, 0.1, 0.2])
+    sc = _fog_ball_scene(tuple(sa), (0.0, 0.0, 0.0))
+    cam = scenes.camera_desc((0, 0, -40), (0, 0, 0), (0, 1, 0), 30.0, 45, 45)
+    film = scenes.film_desc(45, 45)
+    o = orc.Oracle(sc, cam, film, scenes.volpath_desc(film, 1024, max_depth=1))
+    o.render(0, 1024, threads=8)
+    img = o.image().astype(np.float64)
+    o.close()
+    # HomogeneousMedium::Sample estimates the transmittance (a path survives with probability mean Tr): noise, not bias
+    assert np.allclose(img[22, 22], L * np.exp(-sa * 10.0), rtol=0.02), img[22, 22]
+    assert np.allclose(img[22, 0], L, rtol=1e-5) and np.allclose(img[5, 44], L, rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 16)).render(0, 1, threads=1)

@@ -423,8 +423,9 @@ WorldEnd
     assert (s0["radius"], s0["zmin"], s0["zmax"], s0["phimax"], s0["flags"]) == (3, -3, 3, 360, 1)           # the mirror alone flips the normal
     assert np.allclose(np.array(s0["o2w"]).reshape(4, 4), [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, -2, 3], [0, 0, 0, 1]])
     assert np.allclose(np.array(s0["o2w"]).reshape(4, 4) @ np.array(s0["w2o"]).reshape(4, 4), np.eye(4), atol=1e-6)
+    d = dump(tmp_path, head + 'Material "none"\nShape "sphere"\nWorldEnd\n')       # a medium boundary
+    assert d["spheres"][0]["material"] == abi.NO_MATERIAL
     for body, needle in (('AreaLightSource "spot" "rgb L" [1 1 1]\nShape "sphere"', "not supported (diffuse)"),
-                         ('Material "none"\nShape "sphere"', "without a material"),
                          ('Shape "cylinder"', "not supported")):
         err = dump(tmp_path, head + body + "\nWorldEnd\n", expect_fail=True)
         assert needle in err, err
