@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: PathIntegrator on the Cornell box at 1920x1080 (BASELINE.json configs[1]).
+"""Headline benchmark: the PathIntegrator at 1920x1080 on the MI355X.
 
-A "step" renders 16 samples per pixel of the whole 1080p film on every rank (33.2 M camera
-samples per rank and step); the 1024-spp job of the config is 64 such steps.  Ranks take disjoint
-sample numbers (spp sharding), the per-rank films are summed onto rank 0 with one RCCL reduce
-inside the timed region.  value = rays traced by all ranks / wall time (max over ranks).
+The line's `value` is BASELINE.json configs[1]: the Cornell box with Lambertian + microfacet BxDFs.  The same JSON
+object carries, under "bigmesh", configs[2]: the 1.18 M-triangle scene with conductor / dielectric microfacet
+materials (the scene the north star's target is stated on), measured the same way with fewer steps.
+
+A "step" renders 16 samples per pixel of the whole 1080p film on every rank (33.2 M camera samples per rank and
+step); the 1024-spp job of the configs is 64 such steps.  Ranks take disjoint sample numbers (spp sharding) and the
+per-rank films are summed onto rank 0 by ONE ncclReduce inside the library (enigma_film_reduce), inside the timed
+region.  value = rays traced by all ranks / wall time (max over ranks).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (one child process per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,11 +26,81 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-
 SPP_PER_STEP = 16
 XRES, YRES = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+# bytes the closest-hit kernel moves per ray besides the tree: the 64-byte path record read, the 16-byte hit record
+# written, the queue word read and the material-queue word written
+RAY_IO_BYTES = 64 + 16 + 8
+TRIANGLE_BYTES = 48
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--variant", default="default",
+                    help="default = the Cornell microfacet line with the bigmesh object inside it; one workload only: microfacet | diffuse | specular | "
+                         "bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3]) | fog (Cornell with a fog slab, for --integrator volpath)")
+    ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one", "volpath"],
+                    help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
+    ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
+                    help="lightsamplestrategy of the path / volpath integrators (the headline configuration names power)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="sample numbers per pixel the CPU baseline renders (0 = 8 for Cornell scenes, 1 for bigmesh)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every CPU this process may run on)")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------- ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """One child process per GPU, started before this process has touched torch or the GPU; rank 0's line is relayed."""
+    port = free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("ranks exited with %s" % codes)
+
+
+# ---------------------------------------------------------------- host description
+def host_cpus():
+    """CPUs this process may use: the affinity mask, cut down to the cgroup's CPU quota if it has one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        pass
+    return n, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def pow2_at_least(v):
@@ -33,47 +110,25 @@ def pow2_at_least(v):
     return p
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--variant", default="microfacet",
-                    help="workload: microfacet (Cornell, configs[1], the default) | diffuse | specular | bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3]) | "
-                         "fog (Cornell with a fog slab and a medium-filled glass block, for --integrator volpath)")
-    ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one", "volpath"],
-                    help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
-    ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
-                    help="lightsamplestrategy of the path / volpath integrators (the headline configuration names power)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="sample numbers per pixel the CPU baseline renders")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-
+# ---------------------------------------------------------------- one workload
+def run_workload(args, variant, steps, ctx):
+    """Renders `steps` timed steps of one scene on every rank; returns the rank-0 dictionary (None on other ranks)."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     import raytrace_amd as ra
-    from raytrace_amd import abi, distributed, scenes
+    from raytrace_amd import abi, scenes
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    K, W, N = args.steps, args.warmup, world
-    if args.variant == "bigmesh":
-        scene, camera, cam_small, label = scenes.big_mesh(), scenes.big_mesh_camera(XRES, YRES), scenes.big_mesh_camera(480, 270), "BigMesh (terrain + spheres, conductor/dielectric microfacet)"
-    elif args.variant == "manylights":
-        scene, camera, cam_small, label = scenes.many_lights(), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "ManyLights (512 emissive triangles + 64 point lights)"
-    elif args.variant == "fog":
-        scene, camera, cam_small, label = scenes.cornell_fog("microfacet"), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (microfacet) with a fog slab and a medium-filled glass block"
+    rank, world, dev = ctx["rank"], ctx["world"], ctx["dev"]
+    K, W, N = steps, args.warmup, world
+    if variant == "bigmesh":
+        scene, camera, label = scenes.big_mesh(), scenes.big_mesh_camera(XRES, YRES), "BigMesh (terrain + spheres, 1.18 M triangles, conductor/dielectric microfacet)"
+    elif variant == "manylights":
+        scene, camera, label = scenes.many_lights(), scenes.cornell_camera(XRES, YRES), "ManyLights (512 emissive triangles + 64 point lights)"
+    elif variant == "fog":
+        scene, camera, label = scenes.cornell_fog("microfacet"), scenes.cornell_camera(XRES, YRES), "Cornell box (microfacet) with a fog slab and a medium-filled glass block"
     else:
-        scene, camera, cam_small, label = scenes.cornell_box(args.variant), scenes.cornell_camera(XRES, YRES), scenes.cornell_camera(480, 270), "Cornell box (%s)" % args.variant
+        scene, camera, label = scenes.cornell_box(variant), scenes.cornell_camera(XRES, YRES), "Cornell box (%s)" % variant
     film = scenes.film_desc(XRES, YRES, "box")
     total_spp = pow2_at_least(max(1024, (K + 1) * N * SPP_PER_STEP + SPP_PER_STEP))
     strategy = {"uniform": abi.LIGHTS_UNIFORM, "power": abi.LIGHTS_POWER, "spatial": abi.LIGHTS_SPATIAL}[args.light_strategy]
@@ -87,8 +142,14 @@ def main():
         strat = abi.DL_SAMPLE_ALL if args.integrator == "direct-all" else abi.DL_SAMPLE_ONE
         integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
         integ_label = "DirectLightingIntegrator maxdepth 5 strategy %s, Sobol, box filter" % ("all" if strat == abi.DL_SAMPLE_ALL else "one")
-    r = ra.Renderer(local_rank).configure(scene, camera, film, integ)
-    film_t = distributed.film_tensor(r, dev)
+    r = ra.Renderer(ctx["local_rank"]).configure(scene, camera, film, integ)
+    if world > 1:  # the library's own communicator: rank 0 makes the id, torch's process group only carries the 128 bytes
+        ident = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(ra.Renderer.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        r.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+    rccl_rank, rccl_world = r.comm_info()
 
     def barrier():
         torch.cuda.synchronize()
@@ -96,115 +157,169 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up: the last sample numbers of the range, film cleared afterwards
-    for w in range(W):
+    # warm-up: the last sample numbers of the range (and one reduce, which sets the communicator's channels up), then a clean film
+    for _ in range(W):
         r.render(total_spp - SPP_PER_STEP, total_spp)
-    if world > 1:
-        distributed.reduce_film(film_t.clone())  # warm the communicator
+    r.film_reduce(0)
     r.clear()
     s_before = r.stats()
 
     barrier()
     t0 = time.perf_counter()
-    ms_intersect, launches = 0.0, 0
+    ms_closest = ms_shadow = 0.0
+    n_closest = n_shadow = 0
     for i in range(K):
         s0 = (i * N + rank) * SPP_PER_STEP
         r.render(s0, s0 + SPP_PER_STEP)
         st = r.stats()
-        ms_intersect += st["ms_intersect"]
-        launches += st["intersect_launches"]
-    distributed.reduce_film(film_t, dst=0)
+        ms_closest += st["ms_intersect"]; n_closest += st["intersect_launches"]
+        ms_shadow += st["ms_shadow"]; n_shadow += st["shadow_launches"]
+    r.film_reduce(0)
     barrier()
     elapsed = time.perf_counter() - t0
 
     s_after = r.stats()
-    counts = torch.tensor([s_after[k] - s_before[k] for k in ("camera_samples", "rays_closest", "rays_shadow", "rays_mis")],
-                          dtype=torch.float64, device=dev)
+    keys = ("camera_samples", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow")
+    counts = torch.tensor([s_after[k] - s_before[k] for k in keys], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    samples, rc, rs, rm = [float(v) for v in counts.tolist()]
+    samples, rc, rs, rm, nodes_c, tris_c, nodes_s, tris_s = [float(v) for v in counts.tolist()]
     rays = rc + rs + rm
+    if rank != 0:
+        r.close()
+        return None
+
+    out = {
+        "value": rays / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "msamples_per_s": samples / elapsed / 1e6,
+        "steps": K,
+        "ms_per_step": elapsed / K * 1e3,
+        # the 1024-spp job of the config on these N GPUs (strong scaling): 64 / N steps per rank
+        "job_1024spp_seconds": elapsed / K * (1024.0 / SPP_PER_STEP) / N,
+        "config": {"workload": "%s 1920x1080, %s; %d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
+                   "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP,
+                   "parallelism": "spp-shard x%d + one ncclReduce of the film" % N},
+        "rccl_ranks": rccl_world,
+        "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
+    }
+
+    # ---- roofline of the dominant kernel (k_intersect_closest): the bytes ITS OWN traversal needs, from the device tallies
+    node_bytes = float(s_after["bvh_node_bytes"])
+    in_lds = bool(s_after["scene_in_lds"])
+    npr, tpr = nodes_c / max(1.0, rc), tris_c / max(1.0, rc)
+    # a scene staged into LDS is read from HBM once per block, not once per visit: only the ray records stream
+    b_ray = RAY_IO_BYTES + (0.0 if in_lds else node_bytes * npr + TRIANGLE_BYTES * tpr)
+    rays_per_launch = rc / N / max(1, n_closest)  # this rank's launches; ranks are symmetric
+    avg_ms = ms_closest / max(1, n_closest)
+    achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, pmc = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    wl_key = "%s_%s_%s" % (variant, args.integrator, args.light_strategy)
+    if os.path.exists(tpath):
+        try:
+            entry = json.load(open(tpath)).get(wl_key)
+            if entry:
+                traffic = entry.get("k_intersect_closest_bytes_per_launch")
+                pmc = {k: entry[k] for k in ("valu_issue_share", "valu_lane_use", "l2_hit", "source") if k in entry}
+        except Exception:
+            pass
+    out["roofline"] = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel": "k_intersect_closest", "avg_launch_ms": avg_ms, "launches": n_closest, "rays_per_launch": rays_per_launch,
+        "bytes_per_ray": b_ray, "nodes_per_ray": npr, "triangles_per_ray": tpr, "node_bytes": node_bytes, "scene_in_lds": in_lds,
+        "pmc": pmc,
+        "note": "achieved = algorithmic bytes of this build's own traversal per launch (per ray: %d B of path record, hit record and queue words%s; "
+                "visit counts tallied on the device) / the launch's duration from HIP events on the library's stream"
+                % (RAY_IO_BYTES, "" if not in_lds else "; tree and triangles are staged into LDS once per block and cost no HBM bytes per visit"
+                   ) + ("" if in_lds else " + node_bytes x nodes fetched + 48 B x triangles tested"),
+    }
+    if n_shadow:
+        nps, tps = nodes_s / max(1.0, rs), tris_s / max(1.0, rs)
+        b_sh = 36 + 4 + 16 + (0.0 if in_lds else node_bytes * nps + TRIANGLE_BYTES * tps)  # ray + queue word read, radiance read-modify-write
+        avg_sh = ms_shadow / n_shadow
+        ach_sh = b_sh * (rs / N / n_shadow) / (avg_sh * 1e-3) / 1e9
+        out["roofline_shadow"] = {"bound": "hbm", "kernel": "k_shadow", "achieved": ach_sh, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_sh / HBM_PEAK_GBS,
+                                  "avg_launch_ms": avg_sh, "launches": n_shadow, "bytes_per_ray": b_sh, "nodes_per_ray": nps, "triangles_per_ray": tps}
+
+    # ---- CPU baseline: the restated reference renderer on the host cores, a bounded sample of the same workload
+    if N == 1 and not args.no_cpu:
+        import orc
+        avail, quota = host_cpus()
+        cores = args.cpu_threads or avail
+        cpu_spp = args.cpu_spp or (1 if variant == "bigmesh" else 8)
+        o = orc.Oracle(scene, camera, film, integ, fast=True)
+        o.render(0, cpu_spp, threads=cores)
+        sc = o.stats()
+        cpu_rays = sc["rays_closest"] + sc["rays_shadow"] + sc["rays_mis"]
+        cpu_s = sc["ms_render"] * 1e-3
+        ref_img = o.image()
+        o.close()
+        ref_nodes = sc["nodes_closest"] / max(1, sc["rays_closest"])
+        ref_tris = sc["tris_closest"] / max(1, sc["rays_closest"])
+        out["cpu_baseline"] = {"value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "msamples_per_s": sc["samples"] / cpu_s / 1e6, "seconds": cpu_s,
+                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "usable_cpus": avail, "cgroup_cpu_quota": quota,
+                               "sample": "same scene/camera/film, sample numbers [0,%d) of every 1080p pixel (%.1f M samples), "
+                                         "oracle built -O3 -march=x86-64-v3 -ffp-contract=off, the reference's HLBVH / 128-primitive tree, 32x32 tile tasks on %d threads"
+                                         % (cpu_spp, sc["samples"] / 1e6, cores)}
+        # what the REFERENCE's traversal would have to stream for the same rays (its 32-byte nodes, up to 127 primitives per leaf)
+        out["roofline"]["ref_nodes_per_ray"] = ref_nodes
+        out["roofline"]["ref_tris_per_ray"] = ref_tris
+        out["roofline"]["ref_bytes_per_ray"] = 32.0 * ref_nodes + 48.0 * ref_tris + 48.0
+        # image agreement on exactly that sample range (GPU re-render, untimed)
+        r.clear()
+        r.render(0, cpu_spp)
+        gpu_img = r.image()
+        diff = gpu_img - ref_img
+        out["rmse_vs_cpu"] = float(np.sqrt(np.mean(diff * diff)))
+        out["mre_vs_cpu"] = float(np.mean(np.abs(diff) / np.maximum(ref_img, 1e-3)))
+    r.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)  # no torch, no GPU in this process
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev}
+
+    first = "microfacet" if args.variant == "default" else args.variant
+    main_res = run_workload(args, first, args.steps, ctx)
+    big_res = None
+    if args.variant == "default" and args.integrator == "path":
+        big_res = run_workload(args, "bigmesh", max(4, args.steps // 4), ctx)
 
     if rank == 0:
-        import orc
-
-        out = {
-            "metric": "Mrays/s",
-            "value": rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "msamples_per_s": samples / elapsed / 1e6,
-            "n_gpus": N, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s 1920x1080, %s; "
-                                   "%d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
-                       "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP, "parallelism": "spp-shard x%d + RCCL film reduce" % N},
-            "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
-        }
-        # --- algorithmic bytes per ray from the reference traversal (HLBVH, <=127 prims per leaf) on a small sample
-        small = scenes.film_desc(480, 270, "box")
-        small_integ = (scenes.integrator_desc(small, 16) if args.integrator == "path" else scenes.volpath_desc(small, 16) if args.integrator == "volpath"
-                       else scenes.direct_lighting_desc(small, 16, max_depth=5, strategy=integ.strategy))
-        o_small = orc.Oracle(scene, cam_small, small, small_integ, fast=True)
-        o_small.render(0, 1, threads=min(16, os.cpu_count() or 1))
-        so = o_small.stats()
-        n_nodes = so["nodes_closest"] / max(1, so["rays_closest"])
-        n_tris = so["tris_closest"] / max(1, so["rays_closest"])
-        o_small.close()
-        b_ray = 32.0 * n_nodes + 36.0 * n_tris + 12.0 * n_tris + 32.0 + 16.0
-        rays_per_launch = rc / N / max(1, launches)  # this rank's launches; ranks are symmetric
-        avg_ms = ms_intersect / max(1, launches)
-        achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        # the committed PMC passes were taken on the default workload only: other variants report no traffic
-        if os.path.exists(tpath) and args.variant == "microfacet" and args.integrator == "path" and args.light_strategy == "power":
-            try:
-                traffic = json.load(open(tpath)).get("k_intersect_closest_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "k_intersect_closest", "avg_launch_ms": avg_ms, "launches": launches,
-                           "bytes_per_ray": b_ray, "ref_nodes_per_ray": n_nodes, "ref_tris_per_ray": n_tris,
-                           "rays_per_launch": rays_per_launch,
-                           "note": "achieved = the reference traversal's bytes (32 B/node + 48 B/triangle + 48 B ray/hit, its own HLBVH visit "
-                                   "counts) per launch / measured launch time; a scene that fits LDS/L2 is not streamed from HBM, so frac can exceed 1 "
-                                   "there -- traffic is what the PMC counters saw"}
-        # --- CPU baseline: the restated reference renderer on the host cores, bounded sample of the same workload
-        if N == 1 and not args.no_cpu:
-            cores = min(16, os.cpu_count() or 1)
-            cpu_spp = args.cpu_spp
-            o = orc.Oracle(scene, camera, film, integ, fast=True)
-            o.render(0, cpu_spp, threads=cores)
-            sc = o.stats()
-            cpu_rays = sc["rays_closest"] + sc["rays_shadow"] + sc["rays_mis"]
-            cpu_s = sc["ms_render"] * 1e-3
-            ref_img = o.image()
-            o.close()
-            out["cpu_baseline"] = {"value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "msamples_per_s": sc["samples"] / cpu_s / 1e6,
-                                   "sample": "same scene/camera/film, sample numbers [0,%d) of every 1080p pixel (%.1f M samples), "
-                                             "oracle built -O3 -march=x86-64-v3 -ffp-contract=off, reference HLBVH/128 tree, 32x32 tile tasks on %d threads"
-                                             % (cpu_spp, sc["samples"] / 1e6, cores)}
-            # image agreement on exactly that sample range (GPU re-render, untimed)
-            r.clear()
-            r.render(0, cpu_spp)
-            gpu_img = r.image()
-            diff = gpu_img - ref_img
-            out["rmse_vs_cpu"] = float(np.sqrt(np.mean(diff * diff)))
-            out["mre_vs_cpu"] = float(np.mean(np.abs(diff) / np.maximum(ref_img, 1e-3)))
-        print(json.dumps(out))
+        line = {"metric": "Mrays/s", "value": main_res.pop("value"), "unit": main_res.pop("unit"),
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res.pop("ms_per_step"),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        main_res.pop("steps")
+        line.update(main_res)
+        if big_res is not None:
+            big_res["metric"] = "Mrays/s"
+            line["bigmesh"] = big_res
+        print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    r.close()
 
 
 if __name__ == "__main__":

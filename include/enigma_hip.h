@@ -241,6 +241,15 @@ typedef struct EnigmaStats {
     uint64_t bvh_nodes;       /* device BVH size */
     uint64_t bvh_depth;
     double ms_bvh_build;
+    /* Work the traversal kernels did since the handle was created, per kind of query: tree nodes fetched and
+     * triangles tested (Enigma/BVH.cpp:639-722 visits a node / calls Primitive::intersect once per such count). */
+    uint64_t nodes_closest, tris_closest; /* path rays */
+    uint64_t nodes_shadow, tris_shadow;   /* shadow rays */
+    uint64_t nodes_mis, tris_mis;         /* BSDF-sampled MIS rays */
+    uint64_t bvh_node_bytes;              /* size of one device tree node */
+    uint64_t scene_in_lds;                /* last call: 1 when the traversal kernels ran on a copy of the scene in LDS */
+    double ms_shadow;                     /* device time of the shadow-ray kernel launches, last call */
+    uint64_t shadow_launches;
 } EnigmaStats;
 
 typedef struct EnigmaCtx EnigmaCtx;
@@ -290,6 +299,25 @@ int enigma_film_clear(EnigmaCtx* h);
 /* Device pointer of the film accumulators (float4 per pixel) and their float count,
  * for in-place reductions across ranks (e.g. an RCCL reduce by the caller). */
 int enigma_film_device_ptr(EnigmaCtx* h, void** dev_ptr, uint64_t* n_floats);
+/* ---- multi-GPU: samples-per-pixel sharding, one film reduce ----
+ * The reference renders on one host (tile tasks on a thread pool, Enigma/Integrator.cpp:310-320; films merged under a
+ * mutex, Enigma/Film.cpp:101-125) and has no multi-process path.  Here every rank (one process per GPU, a full scene
+ * replica each) renders a disjoint range of sample numbers with enigma_render into its own film, and one
+ * ncclReduce(sum, float32) over RCCL/xGMI on the library's stream adds the films onto the root's: the device-side
+ * counterpart of MergeFilmTile across ranks.  No other exchange exists on the path.
+ *   rank 0:  enigma_comm_unique_id(id)  -> the caller ships the 128 bytes to every rank (file, socket, MPI, ...)
+ *   all:     enigma_comm_init(h, rank, world, id); enigma_render(h, my_begin, my_end); enigma_film_reduce(h, 0);
+ *   rank 0:  enigma_film_read(h, ...)
+ * RCCL is loaded when the first of these calls is made; without it they return ENIGMA_E_DEVICE. */
+#define ENIGMA_COMM_ID_BYTES 128
+int enigma_comm_unique_id(void* id_out /* ENIGMA_COMM_ID_BYTES */);
+int enigma_comm_init(EnigmaCtx* h, int rank, int world, const void* unique_id);
+/* rank and size as the communicator reports them (0 and 1 for a handle outside any communicator) */
+int enigma_comm_info(EnigmaCtx* h, int* rank_out, int* world_out);
+/* Sums the films of all ranks onto the film of `root`; blocking; collective (every rank calls it). */
+int enigma_film_reduce(EnigmaCtx* h, int root);
+int enigma_comm_destroy(EnigmaCtx* h);
+
 /* Film::WriteImage normalisation (Enigma/Film.cpp:157-209) on a host rgbw buffer:
  * rgb = max(0, XYZToRGB(RGBToXYZ(sum)) / weight) * scale.  Host code, no device work. */
 int enigma_film_resolve(const float* rgbw, uint64_t n_pixels, float scale, float* rgb_out);
@@ -314,6 +342,15 @@ int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy,
 int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
                            uint32_t* prim_id_out, float* t_out, float* bary_out);
 int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out);
+/* enigma_debug_intersect for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the rays
+ * and results are staged in a fixed array inside the library (13 words per ray, ENIGMA_NOALLOC_MAX_RAYS rays, 6.5 MiB
+ * held on every GPU the library runs on until the process ends) instead of buffers allocated per call: no
+ * hipMalloc / hipFree happens here.  More rays than ENIGMA_NOALLOC_MAX_RAYS: ENIGMA_E_INVALID.  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (other handles, other threads) race. */
+#define ENIGMA_NOALLOC_MAX_RAYS 131072u
+int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
+                                   uint32_t* prim_id_out, float* t_out, float* bary_out);
 /* FilmTile::AddSample footprint (Enigma/Film.cpp:269-292) for n film positions:
  * up to max_per (pixel x, pixel y) pairs and filter weights each, count in counts. */
 int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per,

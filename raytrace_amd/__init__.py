@@ -20,7 +20,8 @@ SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
     "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
-    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint",
+    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc",
+    "enigma_comm_unique_id", "enigma_comm_init", "enigma_comm_info", "enigma_film_reduce", "enigma_comm_destroy",
 ]
 
 _lib = None
@@ -45,9 +46,15 @@ def load_library():
         for name in ("enigma_scene_upload", "enigma_camera_set", "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_get_stats"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.enigma_film_clear.argtypes = [C.c_void_p]
+        L.enigma_comm_unique_id.argtypes = [C.c_void_p]
+        L.enigma_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.enigma_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.enigma_film_reduce.argtypes = [C.c_void_p, C.c_int]
+        L.enigma_comm_destroy.argtypes = [C.c_void_p]
         L.enigma_debug_sobol.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.enigma_debug_camera_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.enigma_debug_intersect_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.enigma_debug_film_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -127,6 +134,28 @@ class Renderer:
         self._chk(self.L.enigma_film_read(self.h, abi.ptr(out), out.size))
         return out
 
+    # ---- multi-GPU (RCCL inside the library) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId; rank 0 makes them, every rank passes them to comm_init."""
+        buf = C.create_string_buffer(abi.COMM_ID_BYTES)
+        rc = load_library().enigma_comm_unique_id(buf)
+        if rc != 0:
+            raise EnigmaError(rc, "enigma_comm_unique_id failed (RCCL not loadable?)")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == abi.COMM_ID_BYTES
+        self._chk(self.L.enigma_comm_init(self.h, rank, world, C.create_string_buffer(unique_id, abi.COMM_ID_BYTES)))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._chk(self.L.enigma_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def film_reduce(self, root=0):
+        self._chk(self.L.enigma_film_reduce(self.h, root))
+
     def film_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.L.enigma_film_device_ptr(self.h, C.byref(p), C.byref(n)))
@@ -159,14 +188,17 @@ class Renderer:
         self._chk(self.L.enigma_debug_camera_rays(self.h, n, abi.ptr(pixels), abi.ptr(sn), abi.ptr(rays), abi.ptr(pf)))
         return rays, pf
 
-    def intersect(self, rays7):
+    def intersect(self, rays7, noalloc=False):
+        """Scene::intersect for rays (o, d, tMax); noalloc=True goes through the entry point that stages in the
+        library's fixed device array instead of allocating."""
         rays7 = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)
         n = rays7.shape[0]
         tri = np.zeros(n, dtype=np.int32)
         pid = np.zeros(n, dtype=np.uint32)
         t = np.zeros(n, dtype=np.float32)
         bary = np.zeros((n, 3), dtype=np.float32)
-        self._chk(self.L.enigma_debug_intersect(self.h, n, abi.ptr(rays7), abi.ptr(tri), abi.ptr(pid), abi.ptr(t), abi.ptr(bary)))
+        fn = self.L.enigma_debug_intersect_noalloc if noalloc else self.L.enigma_debug_intersect
+        self._chk(fn(self.h, n, abi.ptr(rays7), abi.ptr(tri), abi.ptr(pid), abi.ptr(t), abi.ptr(bary)))
         return dict(tri=tri, prim_id=pid, t=t, bary=bary)
 
     def intersect_any(self, rays7):

@@ -12,6 +12,7 @@ TRI_HAS_NORMALS = 2
 TRI_HAS_UVS = 4
 TRI_REVERSE_ORIENTATION = 8
 NO_MATERIAL = 0xFFFFFFFF
+COMM_ID_BYTES = 128
 
 
 class EnigmaMaterial(C.Structure):
@@ -92,7 +93,10 @@ class EnigmaStats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("rays_mis", C.c_uint64), ("ms_render", C.c_double), ("ms_intersect", C.c_double),
                 ("intersect_launches", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64),
-                ("ms_bvh_build", C.c_double)]
+                ("ms_bvh_build", C.c_double),
+                ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
+                ("nodes_mis", C.c_uint64), ("tris_mis", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
+                ("scene_in_lds", C.c_uint64), ("ms_shadow", C.c_double), ("shadow_launches", C.c_uint64)]
 
 
 def ptr(a):

@@ -128,6 +128,31 @@ DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, flo
 
 struct Hit { int tri; float t, b0, b1, b2; };
 
+// Per-launch tallies of the traversal work: for each kind of ray query (closest hit of path rays, any hit of shadow
+// rays, closest hit of MIS rays) the nodes fetched and the triangles tested, summed per block into one of kVisitSlots
+// slots (block b adds to slot b mod kVisitSlots; the adds of different blocks go to different words as long as a
+// grid has at most kVisitSlots blocks, which the launch code keeps).  Layout: [kind][0 = nodes, 1 = triangles][slot].
+constexpr uint32_t kVisitSlots = 8192;
+enum VisitKind : uint32_t { kVisitClosest = 0, kVisitShadow = 1, kVisitMis = 2, kVisitKinds = 3 };
+DEV void blockZeroVisits(uint32_t* column, int rows, int stride) { column[rows * stride] = 0u; column[(rows + 1) * stride] = 0u; }
+// every thread of the block calls it once, after its last traversal step; red: 2 * (block size / 64) words of LDS
+DEV void blockFlushVisits(const uint32_t* column, int rows, int stride, unsigned long long* visits, uint32_t kind, uint32_t* red) {
+    if (!visits) return;
+    uint32_t n = column[rows * stride], t = column[(rows + 1) * stride];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { n += __shfl_xor(n, d); t += __shfl_xor(t, d); }
+    const uint32_t wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { red[wid] = n; red[nw + wid] = t; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sn = 0, stt = 0;
+        for (uint32_t w = 0; w < nw; ++w) { sn += red[w]; stt += red[nw + w]; }
+        const uint32_t slot = blockIdx.x % kVisitSlots;
+        atomicAdd(&visits[((size_t)kind * 2 + 0) * kVisitSlots + slot], sn);
+        atomicAdd(&visits[((size_t)kind * 2 + 1) * kVisitSlots + slot], stt);
+    }
+}
+
 // One 4-wide node (see bvh_build.h): child boxes in structure-of-arrays form, seven float4 loads.
 // Planes come out as near / far along the ray: the float4 index of "near x" is 0 or 3 by the sign of d.x, etc.
 struct Node4 { float4 nx, ny, nz, fx, fy, fz; int c0, c1, c2, c3; };
@@ -159,13 +184,20 @@ DEV void orderPair(float& ta, int& ca, float& tb, int& cb) {
 // (tMin < ray.m_maxT, Enigma/BBox.h:294).
 constexpr int kTraverseDone = (int)0x80000000; // never a valid leaf reference (nTris < 2^28); also the unused-slot marker of a node
 
+// Behind the stack planes every lane owns two more LDS words (rows kRows and kRows + 1 of its column): the number of
+// tree nodes it has fetched and of triangles it has tested since the block zeroed them.  ds_add without return, no
+// register lives across steps for them; the block sums them up once, when it ends (blockFlushVisits).
 template <int LDSN, int OVF, int STRIDE, bool DIST>
 struct LaneStack {
+    static constexpr int kRows = DIST ? 2 * LDSN : LDSN; // words of a column used by the stack itself
+    static constexpr int kWords = kRows + 2;             // ... and with the two visit counters
     uint32_t* lds;
     uint32_t* ovN;   // spill arrays live in the caller's frame as objects of their own: inside this struct
     float* ovT;      // their run-time indexing would drag every other member into scratch memory with them
     int sp;
     DEV LaneStack(uint32_t* column, uint32_t* spillNodes, float* spillDist) : lds(column), ovN(spillNodes), ovT(spillDist), sp(0) {}
+    DEV void countNode() { atomicAdd(&lds[kRows * STRIDE], 1u); }
+    DEV void countTriangle() { atomicAdd(&lds[(kRows + 1) * STRIDE], 1u); }
     DEV void push(int node, float t) {
         if (sp < LDSN) {
             lds[sp * STRIDE] = (uint32_t)node;
@@ -222,6 +254,7 @@ struct ClosestWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
+            st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             // children the ray misses (or unused slots) get entry distance +inf and sort to the back
             float t0, t1, t2, t3;
@@ -242,6 +275,7 @@ struct ClosestWalker {
             uint32_t leaf = ~(uint32_t)cur;
             uint32_t tri = leaf >> 3, left = leaf & 7u;
             for (int rep = 0;; ++rep) { // up to kLeafTrisPerStep triangles of the leaf
+                st.countTriangle();
                 const float4* tp = tris + (size_t)tri * 3;
                 float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                 float t, b0, b1, b2;
@@ -265,6 +299,7 @@ struct ClosestWalker {
     // do in the shallow tree of a scene small enough to be traversed out of LDS.
     DEV void round(const float4* nodes, const float4* tris) {
         while (cur >= 0) {
+            st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float t0, t1, t2, t3;
             if (!(q.c0 != kTraverseDone && slabTestNF(r, h.t, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &t0))) t0 = EDEV_INF;
@@ -284,6 +319,7 @@ struct ClosestWalker {
         uint32_t leaf = ~(uint32_t)cur;
         uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
         for (uint32_t i = 0; i < cnt; ++i) {
+            st.countTriangle();
             const float4* tp = tris + (size_t)(first + i) * 3;
             float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
             float t, b0, b1, b2;
@@ -323,6 +359,7 @@ struct AnyWalker {
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
             if (!atNode) return;
+            st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float te;
             bool h0 = q.c0 != kTraverseDone && slabTestNF(r, tMax, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &te);
@@ -340,6 +377,7 @@ struct AnyWalker {
             uint32_t leaf = ~(uint32_t)cur;
             uint32_t tri = leaf >> 3, left = leaf & 7u;
             for (int rep = 0;; ++rep) { // up to kLeafTrisPerStep triangles of the leaf
+                st.countTriangle();
                 const float4* tp = tris + (size_t)tri * 3;
                 float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                 float t, b0, b1, b2;
@@ -353,6 +391,7 @@ struct AnyWalker {
     }
     DEV void round(const float4* nodes, const float4* tris) { // see ClosestWalker::round
         while (cur >= 0) {
+            st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
             float te;
             bool h0 = q.c0 != kTraverseDone && slabTestNF(r, tMax, q.nx.x, q.ny.x, q.nz.x, q.fx.x, q.fy.x, q.fz.x, &te);
@@ -370,6 +409,7 @@ struct AnyWalker {
         uint32_t leaf = ~(uint32_t)cur;
         uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
         for (uint32_t i = 0; i < cnt; ++i) {
+            st.countTriangle();
             const float4* tp = tris + (size_t)(first + i) * 3;
             float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
             float t, b0, b1, b2;

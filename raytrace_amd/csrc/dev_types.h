@@ -106,6 +106,7 @@ struct DevScene {
                                 // (p | pError.x) (n | pError.y) (dpdu | pError.z) (wo | material index)
     const DevTexture* textures; // trilinear image textures; nullptr = none
     float4* texColors;          // two float4 per path: the textured colours k_texture evaluated at the path's hit
+    unsigned long long* visits; // tallies of nodes fetched / triangles tested per kind of ray query (dev_trace.h), nullptr = not kept
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;
     int nLights;

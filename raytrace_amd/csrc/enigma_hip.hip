@@ -10,6 +10,9 @@
 #include <memory>
 #include "sobol_host.h"
 
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -119,10 +122,16 @@ struct EnigmaCtx {
     DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
     DevBuf<float2> pfilm;
     DevBuf<DevCounters> counters;
+    DevBuf<unsigned long long> visits; // [kVisitKinds][2][kVisitSlots], see dev_trace.h
+
+    // multi-GPU: the communicator this handle's rank belongs to (enigma_comm_init), nullptr = single GPU
+    ncclComm_t comm = nullptr;
+    int commRank = 0, commWorld = 1;
 
     // stats
     EnigmaStats stats{};
-    std::vector<hipEvent_t> evPool;
+    std::vector<hipEvent_t> evPool;      // four per traversal step of a render call: closest-hit kernel begin / end, shadow kernel begin / end
+    std::vector<uint8_t> shadowTimed;   // per step: the shadow kernel was launched (its two events were recorded)
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -141,17 +150,33 @@ struct EnigmaCtx {
         if (e__ != hipSuccess) return (h)->fail(ENIGMA_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+static hipError_t resolveScratch(int device);
+extern "C" int enigma_comm_destroy(EnigmaCtx* h);
+
+// No C++ exception may cross the C boundary: a failed allocation of a host-side table becomes an error code.
+template <class F>
+static int guarded(EnigmaCtx* h, F body) {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return h->fail(ENIGMA_E_DEVICE, "out of host memory"); }
+    catch (const std::exception& e) { return h->fail(ENIGMA_E_DEVICE, "%s", e.what()); }
+    catch (...) { return h->fail(ENIGMA_E_DEVICE, "unknown exception"); }
+}
+
 extern "C" int enigma_ctx_create(int device_id, EnigmaCtx** out) {
     if (!out) return ENIGMA_E_INVALID;
     *out = nullptr;
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0 || device_id < 0 || device_id >= nDev) return ENIGMA_E_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return ENIGMA_E_DEVICE;
+    if (resolveScratch(device_id) != hipSuccess) return ENIGMA_E_DEVICE;
     EnigmaCtx* h = new EnigmaCtx();
     h->device = device_id;
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
     if (h->counters.alloc(1) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
     (void)hipMemset(h->counters.p, 0, sizeof(DevCounters));
+    if (h->visits.alloc((size_t)kVisitKinds * 2 * kVisitSlots) != hipSuccess) { h->counters.release(); delete h; return ENIGMA_E_DEVICE; }
+    (void)hipMemset(h->visits.p, 0, h->visits.n * sizeof(unsigned long long));
+    h->scene.visits = h->visits.p;
     *out = h;
     return ENIGMA_OK;
 }
@@ -160,6 +185,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    (void)enigma_comm_destroy(h);
     for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
@@ -172,7 +198,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
     h->extQ[0].release(); h->extQ[1].release();
     for (auto& q : h->matQ) q.release();
-    h->pfilm.release(); h->counters.release(); h->shIdx.release(); h->miIdx.release();
+    h->pfilm.release(); h->counters.release(); h->visits.release(); h->shIdx.release(); h->miIdx.release();
     h->bitConst.release(); h->arrayOff.release(); h->pendCount.release(); h->pendO.release(); h->pendD.release(); h->pendB.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -200,9 +226,11 @@ static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
     return pos == 3 ? 1 : neg == 3 ? -1 : 0;
 }
 
-extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
-    if (!h || !s) return ENIGMA_E_INVALID;
+static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     HIPCHK(h, hipSetDevice(h->device));
+    // the context holds no scene until this upload has succeeded: a failure part-way leaves host flags and device
+    // tables of two different scenes behind, and enigma_render must refuse to run on that mixture
+    h->haveScene = false;
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
     if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
     if (s->n_materials == 0 && s->n_triangles) {
@@ -213,8 +241,12 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->n_materials >= (1u << 24)) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 2^24 materials");
     for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
         if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
-    const bool haveMedia = (s->tri_medium_inside && s->tri_medium_outside) || (s->n_media > 0 && s->n_triangles == 0); // spheres only: their own fields
+    // a scene has media when it lists any; triangles without the per-triangle arrays have no interface (-1 on both sides),
+    // the spheres carry their own fields
+    const bool haveMedia = s->n_media > 0;
+    const bool triMedia = s->tri_medium_inside && s->tri_medium_outside;
     if ((s->tri_medium_inside != nullptr) != (s->tri_medium_outside != nullptr)) return h->fail(ENIGMA_E_INVALID, "tri_medium_inside and tri_medium_outside go together");
+    if (triMedia && !haveMedia) return h->fail(ENIGMA_E_INVALID, "per-triangle medium arrays without media");
     if (haveMedia && s->n_media && !s->media) return h->fail(ENIGMA_E_INVALID, "null media array");
     if (s->n_media >= 0xfffu) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 4094 media");
     h->haveNoMaterial = false;
@@ -229,7 +261,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         if ((fl & ENIGMA_TRI_HAS_UVS) && !s->uvs) return h->fail(ENIGMA_E_INVALID, "triangle %u is flagged to have uvs but the uvs array is null", t);
         if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0 && emitterNormalSide(s, t) == 0)
             return h->fail(ENIGMA_E_UNSUPPORTED, "triangle %u: an area light whose vertex normals lie on both sides of (or in) its plane is not supported", t);
-        if (haveMedia && (s->tri_medium_inside[t] < -1 || s->tri_medium_inside[t] >= (int32_t)s->n_media || s->tri_medium_outside[t] < -1 ||
+        if (triMedia && (s->tri_medium_inside[t] < -1 || s->tri_medium_inside[t] >= (int32_t)s->n_media || s->tri_medium_outside[t] < -1 ||
                           s->tri_medium_outside[t] >= (int32_t)s->n_media))
             return h->fail(ENIGMA_E_INVALID, "medium index out of range at triangle %u", t);
     }
@@ -568,7 +600,7 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
                 return h->fail(ENIGMA_E_INVALID, "sphere %u: medium index out of range", i);
             tm[std::max(1u, s->n_triangles) + i] = (uint32_t)e.medium_inside | ((uint32_t)e.medium_outside << 16);
         }
-        for (uint32_t k = 0; k < (haveMedia ? s->n_triangles : 0u); ++k) {
+        for (uint32_t k = 0; k < ((haveMedia && triMedia) ? s->n_triangles : 0u); ++k) { // tm is sized by haveMedia
             uint32_t t = bvh.triOrder[k];
             tm[k] = (uint32_t)(s->tri_medium_inside[t] + 1) | ((uint32_t)(s->tri_medium_outside[t] + 1) << 16);
         }
@@ -610,6 +642,11 @@ extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->lightDistDirty = true;
     h->haveScene = true;
     return ENIGMA_OK;
+}
+
+extern "C" int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
+    if (!h || !s) return ENIGMA_E_INVALID;
+    return guarded(h, [&] { return sceneUpload(h, s); });
 }
 
 extern "C" int enigma_camera_set(EnigmaCtx* h, const EnigmaCameraDesc* c) {
@@ -656,8 +693,12 @@ extern "C" int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* f) {
 // SobolSampler construction + the pixels the tile loop visits; shared by both integrators.
 static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32_t* sb, const int32_t* pixel_bounds, uint32_t nDims) {
     if (samples_per_pixel <= 0 || samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
-    int dx = sb[2] - sb[0], dy = sb[3] - sb[1];
-    if (dx <= 0 || dy <= 0) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
+    if (sb[2] <= sb[0] || sb[3] <= sb[1]) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
+    const int64_t dx64 = (int64_t)sb[2] - sb[0], dy64 = (int64_t)sb[3] - sb[1];
+    if (dx64 > 65535 || dy64 > 65535) return h->fail(ENIGMA_E_INVALID, "sample bounds wider than 65535");
+    int dx = (int)dx64, dy = (int)dy64;
+    if (sb[0] < sb[1]) return h->fail(ENIGMA_E_UNSUPPORTED, "sample bounds with min.x < min.y make the reference's tile loop (Integrator.cpp:254) "
+                                                          "start above the sample bounds; its result is undefined");
     // SobolSampler ctor, Enigma/Sampler.cpp:211-222
     h->spp = (int64_t)roundUpPow2((uint32_t)samples_per_pixel);
     h->resolution = roundUpPow2((uint32_t)std::max(dx, dy));
@@ -665,6 +706,10 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     if ((1u << h->log2Res) != h->resolution) return h->fail(ENIGMA_E_INVALID, "Log2Int(resolution) is inexact for %u", h->resolution);
     if (nDims > (uint32_t)enigma::kNumSobolDimensions) return h->fail(ENIGMA_E_INVALID, "the integrator needs %u Sobol dimensions (> 1024)", nDims);
     if (nDims > 1023u) return h->fail(ENIGMA_E_INVALID, "dimension cursor overflow");
+    // the Sobol' index of (pixel, sample number) has 2 * log2Res + log2(spp) bits; the matrices have 52 columns
+    // (Enigma/SobolMatrices.h:6-11, Enigma/SamplerInclude.h:2627-2637)
+    if (h->spp > (1ll << (52 - 2 * (int)h->log2Res)))
+        return h->fail(ENIGMA_E_INVALID, "%lld samples per pixel at resolution %u exceed the 52-bit Sobol' index", (long long)h->spp, h->resolution);
     h->nDims = nDims;
     enigma::SobolPixelTables T;
     enigma::build_pixel_tables(h->log2Res, nDims, &T);
@@ -689,20 +734,17 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     // render region: the pixels the reference's tile loop visits (Enigma/Integrator.cpp:233-265).  Tile rows start
     // at sampleBounds.m_min.x, not m_min.y (:254): with a crop window whose x and y origins differ, the rows
     // [min.y, min.x) are never rendered.  Kept, because the film must match the reference's.
-    if (sb[0] < sb[1]) return h->fail(ENIGMA_E_UNSUPPORTED, "sample bounds with min.x < min.y make the reference's tile loop (Integrator.cpp:254) "
-                                                          "start above the sample bounds; its result is undefined");
     int nTilesY = (dy + 31) / 32;
     int tileY0 = sb[0], tileY1 = std::min(sb[0] + nTilesY * 32, sb[3]);
     int rx0 = std::max(sb[0], pixel_bounds[0]), ry0 = std::max(tileY0, pixel_bounds[1]);
     int rx1 = std::min(sb[2], pixel_bounds[2]), ry1 = std::min(tileY1, pixel_bounds[3]);
     h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
-    if (dx > 65535 || dy > 65535) return h->fail(ENIGMA_E_INVALID, "sample bounds wider than 65535");
     return ENIGMA_OK;
 }
 
-extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
-    if (!h || !d) return ENIGMA_E_INVALID;
+static int integratorConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
+    h->haveInteg = false; // a reconfiguration that fails leaves no half-updated integrator behind
     if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
     if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
         return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
@@ -720,9 +762,9 @@ extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc
     return ENIGMA_OK;
 }
 
-extern "C" int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
-    if (!h || !d) return ENIGMA_E_INVALID;
+static int volpathConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
+    h->haveInteg = false; // a reconfiguration that fails leaves no half-updated integrator behind
     // every ray segment inside a medium draws two more samples and boundaries do not count as bounces, so a path's
     // dimensions are not bounded by its depth: every dimension the 10-bit cursor can address is tabulated (the reference
     // aborts at dimension 1024)
@@ -742,9 +784,9 @@ extern "C" int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d
     return ENIGMA_OK;
 }
 
-extern "C" int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLightingDesc* d) {
-    if (!h || !d) return ENIGMA_E_INVALID;
+static int directLightingConfigImpl(EnigmaCtx* h, const EnigmaDirectLightingDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
+    h->haveInteg = false;
     if (d->max_depth < 0 || d->max_depth > 30) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
     if (d->strategy != ENIGMA_DL_SAMPLE_ALL && d->strategy != ENIGMA_DL_SAMPLE_ONE) return h->fail(ENIGMA_E_INVALID, "unknown strategy %d", d->strategy);
     if (d->samples_per_pixel <= 0 || d->samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
@@ -757,9 +799,23 @@ extern "C" int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLig
     h->useDirect = true;
     h->useVolPath = false;
     h->directDirty = true; // finished against the scene at render time (Preprocess needs the lights)
-    h->haveInteg = true;
     // the sampler part does not depend on the scene: report its errors now
-    return configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u);
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u);
+    h->haveInteg = rc == ENIGMA_OK;
+    return rc;
+}
+
+extern "C" int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    return guarded(h, [&] { return integratorConfigImpl(h, d); });
+}
+extern "C" int enigma_volpath_config(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    return guarded(h, [&] { return volpathConfigImpl(h, d); });
+}
+extern "C" int enigma_direct_lighting_config(EnigmaCtx* h, const EnigmaDirectLightingDesc* d) {
+    if (!h || !d) return ENIGMA_E_INVALID;
+    return guarded(h, [&] { return directLightingConfigImpl(h, d); });
 }
 
 // DirectLightingIntegrator::Preprocess against the current scene (Enigma/DirectLightingIntegrator.cpp:71-87): the
@@ -788,7 +844,7 @@ static int finishDirectLighting(EnigmaCtx* h) {
     if ((uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res)))
         return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the Sobol' index width", maxN, (long long)h->spp);
     int rc = configureSampler(h, d.samples_per_pixel, d.sample_bounds, d.pixel_bounds, (uint32_t)nDims);
-    if (rc) return rc;
+    if (rc) { h->haveInteg = false; return rc; } // the sampler tables are half rebuilt
     h->integ.maxDepth = d.max_depth;
     h->integ.rrThreshold = 0.f;
     h->integ.dlStrategy = d.strategy;
@@ -903,6 +959,21 @@ static size_t shadeLdsBytes(const EnigmaCtx* h) {
     return ((size_t)h->scene.nTris * 3 + (size_t)h->scene.nMaterials * 4 + (size_t)h->scene.nLights * kLightVec4) * sizeof(float4) + (2 * (size_t)h->scene.nLights + 1) * sizeof(float);
 }
 
+// Events that bracket the two traversal kernels of a step, on the library's stream.
+struct StepEvents { hipEvent_t c0, c1, s0, s1; uint8_t* shadowTimed; };
+static int acquireStepEvents(EnigmaCtx* h, StepEvents* ev) {
+    const size_t i = h->stats.intersect_launches;
+    while (h->evPool.size() < (i + 1) * 4) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->evPool.push_back(e);
+    }
+    if (h->shadowTimed.size() < i + 1) h->shadowTimed.resize(i + 1);
+    h->shadowTimed[i] = 0;
+    *ev = StepEvents{h->evPool[4 * i], h->evPool[4 * i + 1], h->evPool[4 * i + 2], h->evPool[4 * i + 3], &h->shadowTimed[i]};
+    return ENIGMA_OK;
+}
+
 // Evaluates the trilinear image textures at this bounce's hits (the material queues of the kinds that have a textured
 // material), between the closest-hit kernel and the shade kernels.
 static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
@@ -918,7 +989,7 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
 
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
-                         int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
+                         int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
     uint32_t cur = (uint32_t)bounce & 1u;
     hipStream_t s = h->stream;
@@ -927,9 +998,9 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
-    (void)hipEventRecord(e0, s);
+    (void)hipEventRecord(ev.c0, s);
     k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
-    (void)hipEventRecord(e1, s);
+    (void)hipEventRecord(ev.c1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     launchTextures(h, P, gridShade);
@@ -941,7 +1012,10 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
+        (void)hipEventRecord(ev.s0, s);
         k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        (void)hipEventRecord(ev.s1, s);
+        *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
@@ -950,7 +1024,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
 // trace + medium sampling, then the surface, medium and boundary branches, then the shadow and MIS rays.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int iter, int gridTrace,
-                            int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
+                            int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
     uint32_t cur = (uint32_t)iter & 1u;
     hipStream_t s = h->stream;
@@ -959,10 +1033,10 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
-    (void)hipEventRecord(e0, s);
+    (void)hipEventRecord(ev.c0, s);
     k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                               h->refillIdle, nullptr);
-    (void)hipEventRecord(e1, s);
+    (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     launchTextures(h, P, gridShade);
@@ -975,7 +1049,10 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
+        (void)hipEventRecord(ev.s0, s);
         k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        (void)hipEventRecord(ev.s1, s);
+        *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
@@ -985,7 +1062,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
 // of the paths that missed, then the shadow and MIS rays of this step.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths,
-                             int step, int gridTrace, int gridShadow, int gridShade, hipEvent_t e0, hipEvent_t e1) {
+                             int step, int gridTrace, int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
     uint32_t cur = (uint32_t)step & 1u;
     hipStream_t s = h->stream;
@@ -994,10 +1071,10 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
-    (void)hipEventRecord(e0, s);
+    (void)hipEventRecord(ev.c0, s);
     k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                                  h->refillIdle, D.pendCount);
-    (void)hipEventRecord(e1, s);
+    (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     launchTextures(h, P, gridShade);
@@ -1010,13 +1087,15 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
+        (void)hipEventRecord(ev.s0, s);
         k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        (void)hipEventRecord(ev.s1, s);
+        *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
-extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
-    if (!h) return ENIGMA_E_INVALID;
+static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (!h->haveScene || !h->haveCamera || !h->haveFilm || !h->haveInteg) return h->fail(ENIGMA_E_STATE, "scene, camera, film and integrator must be configured before render");
     if (sample_begin < 0 || sample_end < sample_begin || sample_end > h->spp) return h->fail(ENIGMA_E_INVALID, "sample range [%lld, %lld) outside [0, %lld)", (long long)sample_begin, (long long)sample_end, (long long)h->spp);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1025,6 +1104,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     auto wall0 = std::chrono::steady_clock::now();
     const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
     h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
+    h->stats.ms_shadow = 0; h->stats.shadow_launches = 0;
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
     // passes of k sample numbers over all pixels, ~32M paths in flight (capped by the 12-bit sample slot)
     const bool direct = h->useDirect, vol = h->useVolPath && !h->useDirect;
@@ -1043,6 +1123,7 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
     const bool ldsScene = h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    h->stats.scene_in_lds = ldsScene ? 1 : 0;
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1087,17 +1168,12 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             // DirectLightingIntegrator: one step per level of the recursion still alive; the host reads the number of
             // continuing paths after each step (a camera sample is a chain of <= maxDepth steps, or a tree with glass)
             for (int step = 0; direct; ++step) {
-                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
-                while (h->evPool.size() < need) {
-                    hipEvent_t e;
-                    HIPCHK(h, hipEventCreate(&e));
-                    h->evPool.push_back(e);
-                }
-                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (h->scene.nSpheres) launchDirectStep<12, 52, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
-                else launchDirectStep<12, 52, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, e0, e1);
+                StepEvents ev;
+                { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
+                if (h->scene.nSpheres) launchDirectStep<12, 52, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else launchDirectStep<11, 53, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
                 uint32_t alive = 0;
                 HIPCHK(h, hipMemcpyAsync(&alive, &h->counters.p->extCount[(step & 1) ^ 1].v, sizeof(alive), hipMemcpyDeviceToHost, h->stream));
@@ -1108,17 +1184,12 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
             // VolPathIntegrator: crossing a medium boundary is an iteration of Li's loop that is not a bounce, so the number
             // of iterations is not known beforehand; the host reads the number of continuing paths after each one
             for (int iter = 0; vol; ++iter) {
-                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
-                while (h->evPool.size() < need) {
-                    hipEvent_t e;
-                    HIPCHK(h, hipEventCreate(&e));
-                    h->evPool.push_back(e);
-                }
-                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (h->scene.nSpheres) launchVolBounce<12, 52, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
-                else launchVolBounce<12, 52, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, e0, e1);
+                StepEvents ev;
+                { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
+                if (h->scene.nSpheres) launchVolBounce<12, 52, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else launchVolBounce<11, 53, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
                 uint32_t alive = 0;
                 HIPCHK(h, hipMemcpyAsync(&alive, &h->counters.p->extCount[(iter & 1) ^ 1].v, sizeof(alive), hipMemcpyDeviceToHost, h->stream));
@@ -1127,17 +1198,12 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
                 if (iter > 4096) return h->fail(ENIGMA_E_DEVICE, "VolPathIntegrator: paths still alive after 4096 iterations");
             }
             for (int b = 0; !direct && !vol && b <= h->integ.maxDepth; ++b) {
-                size_t need = (size_t)(h->stats.intersect_launches + 1) * 2;
-                while (h->evPool.size() < need) {
-                    hipEvent_t e;
-                    HIPCHK(h, hipEventCreate(&e));
-                    h->evPool.push_back(e);
-                }
-                hipEvent_t e0 = h->evPool[h->stats.intersect_launches * 2], e1 = h->evPool[h->stats.intersect_launches * 2 + 1];
-                if (h->scene.nSpheres) launchBounce<12, 52, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
-                else launchBounce<12, 52, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, e0, e1);
+                StepEvents ev;
+                { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
+                if (h->scene.nSpheres) launchBounce<12, 52, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
             }
             k_film_splat<<<(nPixels + kBlock - 1) / kBlock, kBlock, 0, h->stream>>>(P, h->film, h->integ, nPixels, ks);
@@ -1148,10 +1214,16 @@ extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (uint64_t i = 0; i < h->stats.intersect_launches; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->evPool[i * 2], h->evPool[i * 2 + 1]) == hipSuccess) h->stats.ms_intersect += ms;
+        if (hipEventElapsedTime(&ms, h->evPool[i * 4], h->evPool[i * 4 + 1]) == hipSuccess) h->stats.ms_intersect += ms;
+        if (h->shadowTimed[i] && hipEventElapsedTime(&ms, h->evPool[i * 4 + 2], h->evPool[i * 4 + 3]) == hipSuccess) { h->stats.ms_shadow += ms; h->stats.shadow_launches++; }
     }
     h->stats.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return ENIGMA_OK;
+}
+
+extern "C" int enigma_render(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
+    if (!h) return ENIGMA_E_INVALID;
+    return guarded(h, [&] { return renderImpl(h, sample_begin, sample_end); });
 }
 
 extern "C" int enigma_film_read(EnigmaCtx* h, float* rgbw, uint64_t n_floats) {
@@ -1168,6 +1240,113 @@ extern "C" int enigma_film_device_ptr(EnigmaCtx* h, void** dev_ptr, uint64_t* n_
     if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
     *dev_ptr = h->filmPixels.p;
     *n_floats = h->filmPixels.n * 4;
+    return ENIGMA_OK;
+}
+
+
+// ---------------------------------------------------------------- multi-GPU: one film reduce over RCCL
+// Ranks render disjoint sample numbers of every pixel into their own films (one process per GPU, a full scene replica
+// each); the films are float4 sums, so one ncclReduce(sum) over xGMI onto the root rank is the whole exchange.  RCCL is
+// bound at run time (dlopen) the first time a communicator call is made: a single-GPU user never loads it, and a
+// process that has already loaded an RCCL (PyTorch's) shares that copy.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*getUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*commInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*commCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*commUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*errorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    if (api.lib || !api.error.empty()) return &api;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { api.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"); return &api; }
+    struct { const char* name; void** slot; } syms[] = {
+        {"ncclGetUniqueId", (void**)&api.getUniqueId}, {"ncclCommInitRank", (void**)&api.commInitRank}, {"ncclCommDestroy", (void**)&api.commDestroy},
+        {"ncclCommCount", (void**)&api.commCount}, {"ncclCommUserRank", (void**)&api.commUserRank}, {"ncclReduce", (void**)&api.reduce},
+        {"ncclGetErrorString", (void**)&api.errorString}};
+    for (auto& sym : syms) {
+        *sym.slot = dlsym(api.lib, sym.name);
+        if (!*sym.slot) { api.error = std::string("librccl lacks ") + sym.name; dlclose(api.lib); api.lib = nullptr; return &api; }
+    }
+    return &api;
+}
+} // namespace
+
+#define RCCLCHK(h, api, expr)                                                                              \
+    do {                                                                                                   \
+        ncclResult_t r__ = (expr);                                                                         \
+        if (r__ != ncclSuccess) return (h)->fail(ENIGMA_E_DEVICE, "%s: %s", #expr, (api)->errorString(r__)); \
+    } while (0)
+
+extern "C" int enigma_comm_unique_id(void* id_out) {
+    if (!id_out) return ENIGMA_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == ENIGMA_COMM_ID_BYTES, "the ABI hands the id over as 128 opaque bytes");
+    RcclApi* api = rccl();
+    if (!api->lib) return ENIGMA_E_DEVICE;
+    ncclUniqueId id;
+    if (api->getUniqueId(&id) != ncclSuccess) return ENIGMA_E_DEVICE;
+    memcpy(id_out, &id, sizeof(id));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_comm_init(EnigmaCtx* h, int rank, int world, const void* unique_id) {
+    if (!h || !unique_id) return ENIGMA_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return h->fail(ENIGMA_E_INVALID, "rank %d of %d", rank, world);
+    if (h->comm) return h->fail(ENIGMA_E_STATE, "the handle already belongs to a communicator");
+    RcclApi* api = rccl();
+    if (!api->lib) return h->fail(ENIGMA_E_DEVICE, "%s", api->error.c_str());
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    RCCLCHK(h, api, api->commInitRank(&h->comm, world, id, rank));
+    // what the communicator itself says, not what the caller passed
+    RCCLCHK(h, api, api->commCount(h->comm, &h->commWorld));
+    RCCLCHK(h, api, api->commUserRank(h->comm, &h->commRank));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_comm_info(EnigmaCtx* h, int* rank_out, int* world_out) {
+    if (!h || !rank_out || !world_out) return ENIGMA_E_INVALID;
+    *rank_out = h->commRank;
+    *world_out = h->comm ? h->commWorld : 1;
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_film_reduce(EnigmaCtx* h, int root) {
+    if (!h) return ENIGMA_E_INVALID;
+    if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
+    if (!h->comm) { // one rank: the film is already the sum
+        if (root != 0) return h->fail(ENIGMA_E_INVALID, "root %d of a single rank", root);
+        return ENIGMA_OK;
+    }
+    if (root < 0 || root >= h->commWorld) return h->fail(ENIGMA_E_INVALID, "root %d of %d ranks", root, h->commWorld);
+    RcclApi* api = rccl();
+    HIPCHK(h, hipSetDevice(h->device));
+    // in place on every rank; only the root's film holds the sum afterwards (the others keep their partial films)
+    RCCLCHK(h, api, api->reduce(h->filmPixels.p, h->filmPixels.p, h->filmPixels.n * 4, ncclFloat, ncclSum, root, h->comm, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_comm_destroy(EnigmaCtx* h) {
+    if (!h) return ENIGMA_E_INVALID;
+    if (!h->comm) return ENIGMA_OK;
+    RcclApi* api = rccl();
+    HIPCHK(h, hipSetDevice(h->device));
+    (void)hipStreamSynchronize(h->stream);
+    ncclResult_t r = api->commDestroy(h->comm);
+    h->comm = nullptr; h->commRank = 0; h->commWorld = 1;
+    if (r != ncclSuccess) return h->fail(ENIGMA_E_DEVICE, "ncclCommDestroy: %s", api->errorString(r));
     return ENIGMA_OK;
 }
 
@@ -1205,8 +1384,19 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     h->stats.rays_closest = c.raysClosest;
     h->stats.rays_shadow = c.raysShadow;
     h->stats.rays_mis = c.raysMis;
+    {   // traversal tallies: one slot per block of a launch, summed here
+        std::vector<unsigned long long> v(h->visits.n);
+        HIPCHK(h, hipMemcpy(v.data(), h->visits.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        uint64_t* out6[6] = {&h->stats.nodes_closest, &h->stats.tris_closest, &h->stats.nodes_shadow, &h->stats.tris_shadow, &h->stats.nodes_mis, &h->stats.tris_mis};
+        for (int k = 0; k < 6; ++k) {
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < kVisitSlots; ++i) sum += v[(size_t)k * kVisitSlots + i];
+            *out6[k] = sum;
+        }
+    }
     h->stats.bvh_nodes = h->bvhNodes;
     h->stats.bvh_depth = h->bvhDepth;
+    h->stats.bvh_node_bytes = sizeof(enigma::Bvh4Node);
     h->stats.ms_bvh_build = h->msBvhBuild;
     *out = h->stats;
     return ENIGMA_OK;
@@ -1234,6 +1424,7 @@ static int debugSlots(EnigmaCtx* h, uint32_t n, const int32_t* pixels, const int
 
 extern "C" int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums, uint32_t n_dims, uint64_t* index_out, float* dims_out) {
     if (!h || !pixels_xy || !sample_nums || !dims_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     if (n == 0) return ENIGMA_OK;
     if (n_dims > h->nDims) return h->fail(ENIGMA_E_INVALID, "n_dims %u exceeds the %u dimensions tabulated for this max_depth", n_dims, h->nDims);
@@ -1255,10 +1446,12 @@ extern "C" int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixel
     }
     dPix.release(); dSlots.release(); dOut.release();
     return rc;
+    });
 }
 
 extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums, float* out_ray, float* out_pfilm) {
     if (!h || !pixels_xy || !sample_nums || !out_ray || !out_pfilm) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->haveCamera) return h->fail(ENIGMA_E_STATE, "camera not configured");
     if (n == 0) return ENIGMA_OK;
@@ -1277,6 +1470,27 @@ extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t*
     }
     dPix.release(); dSlots.release(); dRay.release(); dPf.release();
     return rc;
+    });
+}
+
+// Launches the intersection tap over rays already on the device and brings the results back; the staging buffers
+// are the caller's (device memory of the call, or the fixed scratch array of the entry point that allocates nothing).
+static hipError_t debugIntersectRun(EnigmaCtx* h, uint32_t n, const float* dRays, int anyHit, int32_t* dTri, uint32_t* dPrim, float* dT, float* dB,
+                                    int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
+    if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    else if (h->bvhStack <= 12) k_debug_intersect<12, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    else k_debug_intersect<12, 52><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(triOut, dTri, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && !anyHit) {
+        e = hipMemcpyAsync(primOut, dPrim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(tOut, dT, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(baryOut, dB, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    }
+    hipError_t es = hipStreamSynchronize(h->stream);
+    return e != hipSuccess ? e : es;
 }
 
 static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyHit, int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
@@ -1290,39 +1504,74 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
     if (e == hipSuccess) e = dB.alloc((size_t)n * 3);
     if (e == hipSuccess) e = dTri.alloc(n);
     if (e == hipSuccess) e = dPrim.alloc(n);
-    if (e == hipSuccess) {
-        int grid = (int)((n + kBlock - 1) / kBlock);
-        // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
-        if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
-        else if (h->bvhStack <= 12) k_debug_intersect<12, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
-        else k_debug_intersect<12, 52><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p);
-        e = hipStreamSynchronize(h->stream);
-        if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && !anyHit) {
-            e = hipMemcpy(primOut, dPrim.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(tOut, dT.p, n * sizeof(float), hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(baryOut, dB.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
-        }
-    }
+    if (e == hipSuccess) e = debugIntersectRun(h, n, dRays.p, anyHit, dTri.p, dPrim.p, dT.p, dB.p, triOut, primOut, tOut, baryOut);
     dRays.release(); dT.release(); dB.release(); dTri.release(); dPrim.release();
     if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_intersect: %s", hipGetErrorString(e));
     return ENIGMA_OK;
 }
 
-extern "C" int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
+// ---- the entry point that allocates nothing ----
+// Staging for enigma_debug_intersect_noalloc: per ray 7 words in (o, d, tMax) and 6 words out (triangle, primitive id,
+// t, barycentrics).  One copy of the array lives on every GPU the library runs on, for the life of the process.
+constexpr uint32_t kNoAllocWordsPerRay = 13;
+static __device__ __align__(256) uint32_t scratch[(size_t)ENIGMA_NOALLOC_MAX_RAYS * kNoAllocWordsPerRay];
+// Device address of `scratch` per GPU.  In host code the array's name is only a handle for hipGetSymbolAddress; every
+// use of the memory below goes through the address resolved here, with that GPU current.
+constexpr int kMaxDevices = 64;
+static uint32_t* g_scratchPtr[kMaxDevices] = {};
+
+static hipError_t resolveScratch(int device) { // caller has made `device` current
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (g_scratchPtr[device]) return hipSuccess;
+    uint32_t* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratchPtr[device] = ptr;
+    return hipSuccess;
+}
+
+extern "C" int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
     if (!h || !rays7 || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
+    if (h->scene.nSpheres) return h->fail(ENIGMA_E_UNSUPPORTED, "the intersection taps cover triangles only; the scene has spheres");
+    if (n > ENIGMA_NOALLOC_MAX_RAYS) return h->fail(ENIGMA_E_INVALID, "%u rays exceed the %u the fixed staging array holds", n, (unsigned)ENIGMA_NOALLOC_MAX_RAYS);
+    if (n == 0) return ENIGMA_OK;
+    uint32_t* base = (h->device >= 0 && h->device < kMaxDevices) ? g_scratchPtr[h->device] : nullptr;
+    if (!base) return h->fail(ENIGMA_E_STATE, "the staging array of device %d was not resolved when the context was created", h->device);
+    // carve the array: every region starts on a 256-byte boundary for any n (the ray region is sized for the maximum)
+    float* dRays = reinterpret_cast<float*>(base);
+    int32_t* dTri = reinterpret_cast<int32_t*>(base + (size_t)ENIGMA_NOALLOC_MAX_RAYS * 7);
+    uint32_t* dPrim = base + (size_t)ENIGMA_NOALLOC_MAX_RAYS * 8;
+    float* dT = reinterpret_cast<float*>(base + (size_t)ENIGMA_NOALLOC_MAX_RAYS * 9);
+    float* dB = reinterpret_cast<float*>(base + (size_t)ENIGMA_NOALLOC_MAX_RAYS * 10);
+    // every output word of rays [0, n) is written by the kernel, so nothing of the previous call's contents is read
+    hipError_t e = hipMemcpyAsync(dRays, rays7, (size_t)n * 7 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = debugIntersectRun(h, n, dRays, 0, dTri, dPrim, dT, dB, tri_out, prim_id_out, t_out, bary_out);
+    if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_intersect_noalloc: %s", hipGetErrorString(e));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
+    if (!h || !rays7 || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
+    HIPCHK(h, hipSetDevice(h->device));
     return debugIntersect(h, n, rays7, 0, tri_out, prim_id_out, t_out, bary_out);
+    });
 }
 
 extern "C" int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out) {
     if (!h || !rays7 || !hit_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     return debugIntersect(h, n, rays7, 1, hit_out, nullptr, nullptr, nullptr);
+    });
 }
 
 extern "C" int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per, int32_t* pixels_xy_out, float* weights_out, uint32_t* counts_out) {
     if (!h || !pfilm_xy || !pixels_xy_out || !weights_out || !counts_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->haveFilm) return h->fail(ENIGMA_E_STATE, "film not configured");
     if (n == 0) return ENIGMA_OK;
@@ -1342,5 +1591,6 @@ extern "C" int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float
     dPf.release(); dW.release(); dPix.release(); dCnt.release();
     if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_film_footprint: %s", hipGetErrorString(e));
     return ENIGMA_OK;
+    });
 }
 

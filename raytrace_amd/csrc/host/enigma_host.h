@@ -20,6 +20,7 @@
 //    deposits the film through ONE FilmTile covering the cropped pixel bounds + MergeFilmTile +
 //    WriteImage, exactly like the reference's tile tasks do (Enigma/Integrator.cpp:295-321).
 #pragma once
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -442,7 +443,13 @@ public:
         if (!sob) throw std::runtime_error("the GPU integrators need a SobolSampler");
         check(ConfigureIntegrator(h, lights.size(), *sob));
 
-        check(enigma_render(h, 0, sob->m_samplesPerPixel));
+        // one process per GPU: this rank's share of the sample numbers, then the films are summed onto rank 0
+        const int64_t spp = sob->m_samplesPerPixel;
+        if (m_world > 1) check(enigma_comm_init(h, m_rank, m_world, m_commId));
+        check(enigma_render(h, spp * m_rank / m_world, spp * (m_rank + 1) / m_world));
+        check(enigma_film_reduce(h, 0));
+        check(enigma_get_stats(h, &m_stats));
+        if (m_rank != 0) return; // the film lives on rank 0
 
         // deposit: one FilmTile over the cropped bounds, then the reference's own merge + write
         std::vector<float> rgbw((size_t)4 * std::max(0, cb.area()));
@@ -457,9 +464,15 @@ public:
             }
         film.MergeFilmTile(std::move(tile));
         film.WriteImage(1.0f / sob->m_samplesPerPixel);
-        check(enigma_get_stats(h, &m_stats));
     }
     const EnigmaStats& GetStats() const { return m_stats; }
+    // Several GPUs, one process each: every process builds the same scene and integrator, names its rank, and passes
+    // the 128 bytes rank 0 got from enigma_comm_unique_id (shipped by whatever channel the application has).  Render
+    // then takes sample numbers [spp * rank / world, spp * (rank + 1) / world) and rank 0 ends up with the whole film.
+    void SetRanks(int rank, int world, const void* commId) {
+        m_rank = rank; m_world = world;
+        std::memcpy(m_commId, commId, ENIGMA_COMM_ID_BYTES);
+    }
 protected:
     virtual int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) = 0;
     template <class DESC> void FillSamplerFields(DESC& id, const SobolSampler& sob) const {
@@ -471,6 +484,8 @@ protected:
     }
 private:
     const int m_device;
+    int m_rank = 0, m_world = 1;
+    unsigned char m_commId[ENIGMA_COMM_ID_BYTES] = {};
     EnigmaStats m_stats{};
 };
 

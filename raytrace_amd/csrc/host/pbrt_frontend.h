@@ -619,6 +619,7 @@ public:
         }
         if (R.scene.getNumLights() == 0) Warn("No light sources defined in scene; rendering a black image.");
         m_inWorld = false;
+        if (m_world > 1) R.integrator->SetRanks(m_rank, m_world, m_commId);
         if (m_render) R.integrator->Render(R.scene);
     }
 
@@ -636,6 +637,8 @@ public:
     void pbrtParseString(const std::string& s) { Parse(s, ""); }
 
     void SetImageFile(const std::string& f) { m_imageFile = f; } // Options::imageFile overrides the Film's filename
+    // one process per GPU: see GpuSamplerIntegrator::SetRanks (the device index is the constructor's)
+    void SetRanks(int rank, int world, const void* commId) { m_rank = rank; m_world = world; std::memcpy(m_commId, commId, ENIGMA_COMM_ID_BYTES); }
     FrontEndResult& Result() { return *m_res; }
     std::unique_ptr<FrontEndResult> TakeResult() { return std::move(m_res); }
 
@@ -835,6 +838,8 @@ private:
     }
 
     bool m_render;
+    int m_rank = 0, m_world = 1;
+    unsigned char m_commId[ENIGMA_COMM_ID_BYTES] = {};
     int m_device;
     bool m_inWorld = false;
     Mat4d m_ctm;

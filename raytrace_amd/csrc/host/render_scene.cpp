@@ -6,6 +6,8 @@
 //   enigma_render <scene.bin> <out.f32>
 //   enigma_render <scene.pbrt> [out.pfm | out.f32]      scene description through the pbrt front end (pbrt_frontend.h)
 //   enigma_render --dump <scene.pbrt> <out.json>        parse only (no GPU): what the front end hands to the integrator
+//   enigma_render --gpus N <scene> <out>                 one child process per GPU (ranks 0..N-1 on devices 0..N-1): each renders its
+//                                                        share of the sample numbers, RCCL sums the films onto rank 0, which writes <out>
 // scene.bin (little endian): "ESC1", then int32 {xres, yres, spp, maxDepth, integrator (PathIntegrator: 0 uniform / 1 power
 //   light distribution; DirectLightingIntegrator: 2 strategy all / 3 strategy one),
 //   nVerts, nTris, nMaterials}, float {rrThreshold, lensRadius, focalDistance}, float[16] rasterToCamera,
@@ -14,9 +16,14 @@
 #include "enigma_host.h"
 #include "pbrt_frontend.h"
 
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <thread>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 using namespace RayTrace;
 
@@ -108,10 +115,57 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o << "]}\n";
 }
 
+// ---- one process per GPU ----
+// The parent forks the ranks before anything touches the GPU; rank 0 asks the library for the communicator id and leaves
+// it in a file beside the output, the other ranks wait for that file.
+struct Ranks { int rank = 0, world = 1; unsigned char id[ENIGMA_COMM_ID_BYTES] = {}; };
+static Ranks g_ranks;
+
+static bool exchangeCommId(const std::string& path, Ranks* r) {
+    if (r->rank == 0) {
+        if (enigma_comm_unique_id(r->id) != ENIGMA_OK) { std::cerr << "enigma_comm_unique_id failed (RCCL not loadable)\n"; return false; }
+        const std::string tmp = path + ".part";
+        { std::ofstream o(tmp, std::ios::binary); o.write(reinterpret_cast<const char*>(r->id), sizeof(r->id)); if (!o) return false; }
+        return rename(tmp.c_str(), path.c_str()) == 0; // appears whole or not at all
+    }
+    for (int tries = 0; tries < 6000; ++tries) { // up to a minute
+        std::ifstream f(path, std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(r->id), sizeof(r->id))) return true;
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    std::cerr << "rank " << r->rank << ": no communicator id from rank 0\n";
+    return false;
+}
+
+// returns -1 in a child (which goes on to render as g_ranks.rank), else the parent's exit code
+static int forkRanks(int world, const std::string& out) {
+    const std::string idFile = out + ".commid";
+    unlink(idFile.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        pid_t pid = fork();
+        if (pid < 0) { std::cerr << "fork failed\n"; return 1; }
+        if (pid == 0) {
+            g_ranks.rank = r; g_ranks.world = world;
+            if (!exchangeCommId(idFile, &g_ranks)) _exit(3);
+            return -1;
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    unlink(idFile.c_str());
+    return rc;
+}
+
 // Scene description file -> front end -> GPU integrator, like pbrtParseFile + pbrtWorldEnd in Enigma/Main.h.
 static int runPbrt(const std::string& scene, const std::string& out, bool dumpOnly) {
     try {
-        PbrtApi api(!dumpOnly);
+        PbrtApi api(!dumpOnly, g_ranks.rank);
+        if (g_ranks.world > 1) api.SetRanks(g_ranks.rank, g_ranks.world, g_ranks.id);
         if (!dumpOnly && endsWith(out, ".pfm")) api.SetImageFile(out);
         api.pbrtParseFile(scene);
         FrontEndResult& R = api.Result();
@@ -122,6 +176,7 @@ static int runPbrt(const std::string& scene, const std::string& out, bool dumpOn
             dumpJson(R, o);
             return o ? 0 : 1;
         }
+        if (g_ranks.rank != 0) return 0; // the film is rank 0's
         if (!out.empty() && !endsWith(out, ".pfm")) {
             const std::vector<float>& rgb = R.camera->m_film->GetRGB();
             std::ofstream o(out, std::ios::binary);
@@ -138,6 +193,15 @@ static int runPbrt(const std::string& scene, const std::string& out, bool dumpOn
 
 int main(int argc, char** argv) {
     if (argc >= 4 && std::string(argv[1]) == "--dump") return runPbrt(argv[2], argv[3], true);
+    if (argc >= 5 && std::string(argv[1]) == "--gpus") {
+        const int world = atoi(argv[2]);
+        if (world < 1 || world > 64) { std::cerr << "--gpus takes 1..64\n"; return 2; }
+        argv += 2; argc -= 2;
+        if (world > 1) {
+            int rc = forkRanks(world, argv[2]);
+            if (rc >= 0) return rc; // the parent; children fall through with g_ranks set
+        }
+    }
     if (argc >= 2 && endsWith(argv[1], ".pbrt")) return runPbrt(argv[1], argc >= 3 ? argv[2] : "", false);
     if (argc < 3) { std::cerr << "usage: enigma_render scene.bin out.f32 | scene.pbrt [out.pfm|out.f32] | --dump scene.pbrt out.json\n"; return 2; }
     std::ifstream f(argv[1], std::ios::binary);
@@ -187,14 +251,16 @@ int main(int argc, char** argv) {
     if (strat >= 2)
         integrator.reset(new GpuDirectLightingIntegrator(strat == 2 ? GpuDirectLightingIntegrator::eLightStrategy::UniformSampleAll
                                                                     : GpuDirectLightingIntegrator::eLightStrategy::UniformSampleOne,
-                                                         maxDepth, camera, sampler, filmPtr->GetSampleBounds()));
-    else integrator.reset(new GpuPathIntegrator(maxDepth, camera, sampler, filmPtr->GetSampleBounds(), fl[0], strat ? "power" : "uniform"));
+                                                         maxDepth, camera, sampler, filmPtr->GetSampleBounds(), g_ranks.rank));
+    else integrator.reset(new GpuPathIntegrator(maxDepth, camera, sampler, filmPtr->GetSampleBounds(), fl[0], strat ? "power" : "uniform", g_ranks.rank));
+    if (g_ranks.world > 1) integrator->SetRanks(g_ranks.rank, g_ranks.world, g_ranks.id);
     try {
         integrator->Render(scene);
     } catch (const std::exception& e) {
         std::cerr << e.what() << "\n";
         return 1;
     }
+    if (g_ranks.rank != 0) return 0; // the film is rank 0's
     const std::vector<float>& rgb = filmPtr->GetRGB();
     std::ofstream o(argv[2], std::ios::binary);
     o.write(reinterpret_cast<const char*>(rgb.data()), rgb.size() * sizeof(float));

@@ -369,7 +369,8 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     constexpr int NK = MODE == 0 ? MK_COUNT : (MODE == 1 ? MK_COUNT + 1 : kQueueKinds);
-    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
+    __shared__ uint32_t stack[Stack::kWords * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];
     __shared__ uint32_t binBase[kQueueKinds];
     __shared__ uint32_t poolNext;
@@ -382,6 +383,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
@@ -528,6 +530,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         }
         __syncthreads(); // binCnt / binBase / kindOf / poolNext are rewritten by the next chunk
     }
+    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitClosest, binCnt);
 }
 
 // SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the table of the voxel that holds p
@@ -1134,8 +1137,10 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
-    __shared__ uint32_t stack[LDSN * kBlock];
+    using Stack = LaneStack<LDSN, OVF, kBlock, false>;
+    __shared__ uint32_t stack[Stack::kWords * kBlock];
     __shared__ uint32_t poolNext;
+    __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     uint32_t spillNodes[OVF > 0 ? OVF : 1];
     const uint32_t count = ctr->shadowCount.v;
@@ -1143,6 +1148,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
@@ -1186,6 +1192,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
         }
         __syncthreads(); // poolNext is rewritten by the next chunk
     }
+    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitShadow, red);
 }
 
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
@@ -1193,13 +1200,16 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
 // are queued), one per lane.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
+    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     const uint32_t count = ctr->misCount.v;
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
@@ -1242,6 +1252,7 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
             atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
         }
     }
+    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitMis, red); // every thread gets here
 }
 
 // FilmTile::AddSample footprint (Enigma/Film.cpp:263-300).  SINK(x, y, weight) per covered pixel.
@@ -1344,7 +1355,7 @@ __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int3
 template <int LDSN, int OVF>
 __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
                                                             uint32_t* primOut, float* tOut, float* baryOut) {
-    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    __shared__ uint32_t stack[LaneStack<LDSN, OVF, kBlock, true>::kWords * kBlock]; // the walkers tally into the last two rows
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;

@@ -200,7 +200,9 @@ DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, 
 // far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
-    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
+    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     uint32_t spillNodes[OVF > 0 ? OVF : 1];
     float spillDist[OVF > 0 ? OVF : 1];
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
@@ -259,6 +262,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
     if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysShadow, (unsigned long long)nQueries);
+    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitShadow, red);
 }
 
 // Scene::intersectTr for the MIS rays of one bounce: closest-hit queries through material-less surfaces
@@ -266,7 +270,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
 // the sampled light's triangle.  Every query counts as a MIS ray.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    __shared__ uint32_t stack[2 * LDSN * kBlock];
+    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
+    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     uint32_t spillNodes[OVF > 0 ? OVF : 1];
     float spillDist[OVF > 0 ? OVF : 1];
@@ -275,6 +281,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
+    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
@@ -348,6 +355,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
     if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysMis, (unsigned long long)nQueries);
+    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitMis, red);
 }
 
 } // namespace edev

@@ -5,11 +5,12 @@ The path shards by sample number: sample k of pixel p is addressable directly
 Enigma/Sampler.cpp:184-189), paths never interact and the film is a plain sum
 (Enigma/Film.cpp:117-120,296-297).  Every rank holds a full scene replica, renders a disjoint
 range of sample numbers for all pixels into its own film, and ONE sum-reduce of the
-{r, g, b, weight} accumulators (RCCL over xGMI on GPUs, gloo in the CPU tests) produces the film
-on rank 0.  No other exchange exists.
+{r, g, b, weight} accumulators produces the film on rank 0.  No other exchange exists.
+
+On GPUs that reduce is the library's own (enigma_comm_init / enigma_film_reduce: ncclReduce over RCCL/xGMI on the
+library's stream; Renderer.comm_init / film_reduce).  The torch helpers below are the cross-check of it and the CPU
+stand-in (gloo) of the tests; torch is imported only when they are used.
 """
-import torch
-import torch.distributed as dist
 
 
 def shard_range(begin, end, rank, world):
@@ -29,12 +30,14 @@ class _DeviceArray:
 
 def film_tensor(renderer, device):
     """torch view (no copy) of the renderer's device film accumulators."""
+    import torch
     ptr, n = renderer.film_device_ptr()
     return torch.as_tensor(_DeviceArray(ptr, n), device=device)
 
 
 def reduce_film(t, dst=0):
     """Sum-reduce a film tensor onto rank dst (in place on dst)."""
+    import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return t

@@ -6,6 +6,7 @@ import socket
 
 import numpy as np
 import pytest
+import torch  # before the library: the PyTorch wheel brings its own HIP runtime, and the one that is loaded first serves the process
 
 import common
 import raytrace_amd as ra
@@ -51,3 +52,46 @@ def test_film_view_aliases_device_film_and_rccl_accepts_it():
     finally:
         dist.destroy_process_group()
     r.close(); r2.close()
+
+
+def test_native_communicator_of_one_rank():
+    """enigma_comm_* with a single rank: RCCL loads, the communicator reports itself, the reduce leaves the film as it is."""
+    sc, cam, film, integ = common.cornell_setup(res=32, spp=4, variant="diffuse")
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    assert r.comm_info() == (0, 1)
+    r.render(0, 4)
+    before = r.film()
+    r.film_reduce(0)                                   # no communicator: a no-op
+    ident = ra.Renderer.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    r.comm_init(0, 1, ident)
+    assert r.comm_info() == (0, 1)
+    r.film_reduce(0)
+    assert np.array_equal(r.film(), before)
+    with pytest.raises(ra.EnigmaError) as e:
+        r.comm_init(0, 1, ident)                       # a handle joins one communicator
+    assert e.value.code == -2
+    with pytest.raises(ra.EnigmaError) as e:
+        r.film_reduce(3)
+    assert e.value.code == -1
+    r.close()
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_two_rank_native_reduce_matches_single_render(tmp_path):
+    """Two processes, two GPUs: each renders half of the sample numbers, enigma_film_reduce (RCCL inside the library)
+    sums the films onto rank 0, which must hold what one process renders alone.  Skipped on a one-GPU box."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idfile, result = tmp_path / "commid", tmp_path / "result.txt"
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "comm_worker.py"), str(rank), "2", str(idfile), str(result)]) for rank in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    assert result.read_text() == "ok"
