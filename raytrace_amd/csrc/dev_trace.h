@@ -241,7 +241,10 @@ struct ClosestWalker {
     Hit h;
     int cur;
     LaneStack<LDSN, OVF, STRIDE, true> st;
+    static constexpr int kWords = LaneStack<LDSN, OVF, STRIDE, true>::kWords, kRows = LaneStack<LDSN, OVF, STRIDE, true>::kRows;
     DEV ClosestWalker(uint32_t* column, uint32_t* spillNodes, float* spillDist) : cur(kTraverseDone), st(column, spillNodes, spillDist) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
+    // one spill array of 2 * max(OVF, 1) words in the caller's frame: node references, then entry distances
+    DEV ClosestWalker(uint32_t* column, uint32_t* spill) : ClosestWalker(column, spill, reinterpret_cast<float*>(spill + (OVF > 0 ? OVF : 1))) {}
     DEV void start(F3 o, F3 d, float tMax) {
         r = setupRay(o, d);
         h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
@@ -345,6 +348,7 @@ struct AnyWalker {
     int cur;
     bool occluded;
     LaneStack<LDSN, OVF, STRIDE, false> st;
+    static constexpr int kWords = LaneStack<LDSN, OVF, STRIDE, false>::kWords, kRows = LaneStack<LDSN, OVF, STRIDE, false>::kRows;
     DEV AnyWalker(uint32_t* column, uint32_t* spillNodes) : tMax(0.f), cur(kTraverseDone), occluded(false), st(column, spillNodes, nullptr) {}
     DEV void start(F3 o, F3 d, float tMaxRay) {
         r = setupRay(o, d);
@@ -419,23 +423,5 @@ struct AnyWalker {
     }
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
-
-template <int LDSN, int OVF, int STRIDE, int NS = 8>
-DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
-    float spillDist[OVF > 0 ? OVF : 1];
-    ClosestWalker<LDSN, OVF, STRIDE, NS> w(column, spillNodes, spillDist);
-    w.start(o, d, tMax);
-    while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
-    return w.h;
-}
-template <int LDSN, int OVF, int STRIDE>
-DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
-    AnyWalker<LDSN, OVF, STRIDE> w(column, spillNodes);
-    w.start(o, d, tMax);
-    while (__ballot(!w.done()) != 0) w.step(nodes, tris);
-    return w.occluded;
-}
 
 } // namespace edev

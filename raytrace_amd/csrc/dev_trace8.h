@@ -1,0 +1,300 @@
+// Traversal of the 8-wide compressed tree (bvh_build.h, Bvh8Node).
+//
+// Replaces BVHAccel::intersect / intersectP (Enigma/BVH.cpp:639-722) like dev_trace.h does, with the same triangle
+// test (Triangle::intersects, operation for operation), so hits, t and barycentrics stay bit-identical; only the
+// culling differs, and culling here is conservative by construction:
+//  - child boxes are stored rounded outwards (8-bit offsets from the node's corner);
+//  - the slab distances are one fused multiply-add per plane, t = q * (2^e / d) + (corner - o) / d, evaluated with a
+//    slack that bounds its rounding error: entry distances are lowered and exit distances raised by
+//    2^-21 * (|(corner - o) / d| + 256 * |2^e / d|), four times the worst case of the three roundings involved;
+//  - 1 / d is clamped to +-2^80, which keeps every product finite (a ray parallel to a slab gets entry / exit
+//    distances of the right sign and astronomic size, i.e. the slab does not constrain it while the origin is inside).
+// A box that the exact ray meets within [0, tMax] is therefore never culled; the reference's own slab test gives the
+// same guarantee through its 1 + 2 gamma(3) factor (Enigma/BBox.h:267-295).
+//
+// Children are visited near to far without sorting: slots are laid out by octant at build time, the hit children of
+// a node form a bit mask whose bit order is the visiting order for this ray (slot ^ octant), and what is left of a
+// node's children waits on the stack as ONE entry (first child index + mask).  The stack is as deep as the tree, not
+// three entries per level.  Triangles of the hit leaves of a node form a 24-bit mask over the node's triangle range.
+#pragma once
+#include "dev_trace.h"
+
+namespace edev {
+
+constexpr int kNode8Vec4 = 5;      // 16-byte pieces per node in global memory
+constexpr uint32_t kNodeHits = 0xff000000u;
+// The middle sixteen bits of a node group's second word hold a lower bound of the entry distances of its children: the
+// upper half of the float (positive, so cutting the mantissa rounds down).  A group that comes off the stack after the
+// ray has found a nearer hit is dropped unfetched, the decision the reference takes when it visits such a node
+// (tMin < ray.m_maxT, Enigma/BBox.h:294).
+constexpr uint32_t kGroupBound = 0x00ffff00u;
+DEV float groupBound(uint32_t gy) { return __uint_as_float((gy << 8) & 0xffff0000u); }
+
+struct Ray8 { float ox, oy, oz, ix, iy, iz; uint32_t oct4; bool nx, ny, nz; };
+
+DEV float clampInv(float v) { // keeps the sign of +-inf and of +-0's reciprocal
+    const float k = 0x1p80f;
+    return v > k ? k : (v < -k ? -k : v);
+}
+DEV Ray8 makeRay8(const RaySetup& r) {
+    Ray8 q;
+    q.ox = r.o.x; q.oy = r.o.y; q.oz = r.o.z;
+    q.ix = clampInv(r.invDir.x); q.iy = clampInv(r.invDir.y); q.iz = clampInv(r.invDir.z);
+    q.nx = r.negX; q.ny = r.negY; q.nz = r.negZ;
+    q.oct4 = ((r.negX ? 1u : 0u) | (r.negY ? 2u : 0u) | (r.negZ ? 4u : 0u)) * 0x01010101u;
+    return q;
+}
+
+DEV float ubyteToFloat(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); } // v_cvt_f32_ubyte<b>
+
+// One node against the ray: the node group (first inner child, hit bits in visiting order | inner mask) and the
+// triangle group (first triangle, one bit per triangle of the hit leaves).
+template <int NS, bool BOUND>
+DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, float tMax, uint32_t* gx, uint32_t* gy, uint32_t* tx, uint32_t* ty) {
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + (size_t)index * NS);
+    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    const uint32_t ew = n0.w;
+    const float Ax = __uint_as_float((ew & 0xffu) << 23) * r.ix;
+    const float Ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * r.iy;
+    const float Az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * r.iz;
+    const float Bx = (__uint_as_float(n0.x) - r.ox) * r.ix;
+    const float By = (__uint_as_float(n0.y) - r.oy) * r.iy;
+    const float Bz = (__uint_as_float(n0.z) - r.oz) * r.iz;
+    const float kSlack = 0x1p-21f;
+    const float sx = __builtin_fmaf(256.f, fabsf(Ax), fabsf(Bx)), sy = __builtin_fmaf(256.f, fabsf(Ay), fabsf(By)), sz = __builtin_fmaf(256.f, fabsf(Az), fabsf(Bz));
+    const float Bnx = __builtin_fmaf(-kSlack, sx, Bx), Bny = __builtin_fmaf(-kSlack, sy, By), Bnz = __builtin_fmaf(-kSlack, sz, Bz);
+    const float Bfx = __builtin_fmaf(kSlack, sx, Bx), Bfy = __builtin_fmaf(kSlack, sy, By), Bfz = __builtin_fmaf(kSlack, sz, Bz);
+    // the plane a ray enters a slab through is the low one unless it travels in the negative direction
+    const uint32_t nxw[2] = {r.nx ? n3.z : n2.x, r.nx ? n3.w : n2.y}, fxw[2] = {r.nx ? n2.x : n3.z, r.nx ? n2.y : n3.w};
+    const uint32_t nyw[2] = {r.ny ? n4.x : n2.z, r.ny ? n4.y : n2.w}, fyw[2] = {r.ny ? n2.z : n4.x, r.ny ? n2.w : n4.y};
+    const uint32_t nzw[2] = {r.nz ? n4.z : n3.x, r.nz ? n4.w : n3.y}, fzw[2] = {r.nz ? n3.x : n4.z, r.nz ? n3.y : n4.w};
+    const uint32_t metaw[2] = {n1.z, n1.w};
+    uint32_t hitmask = 0;
+    float tLow = EDEV_INF; // smallest entry distance among the hit children
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t meta4 = metaw[half];
+        const uint32_t isInner4 = (meta4 & (meta4 << 1)) & 0x10101010u;   // low five bits >= 24: an inner node
+        const uint32_t innerMask4 = (isInner4 >> 4) * 0xffu;
+        const uint32_t bitIndex4 = (meta4 ^ (r.oct4 & innerMask4)) & 0x1f1f1f1fu; // inner: 24 + (slot ^ octant); leaf: its triangle offset
+        const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;                 // inner: 1; leaf: one bit per triangle
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float tnx = __builtin_fmaf(ubyteToFloat(nxw[half], b), Ax, Bnx), tfx = __builtin_fmaf(ubyteToFloat(fxw[half], b), Ax, Bfx);
+            const float tny = __builtin_fmaf(ubyteToFloat(nyw[half], b), Ay, Bny), tfy = __builtin_fmaf(ubyteToFloat(fyw[half], b), Ay, Bfy);
+            const float tnz = __builtin_fmaf(ubyteToFloat(nzw[half], b), Az, Bnz), tfz = __builtin_fmaf(ubyteToFloat(fzw[half], b), Az, Bfz);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tMax));
+            if (tn <= tf) {
+                hitmask |= ((childBits4 >> (8 * b)) & 0xffu) << ((bitIndex4 >> (8 * b)) & 0xffu);
+                if (BOUND) tLow = fminf(tLow, tn);
+            }
+        }
+    }
+    *gx = n1.x; *gy = (hitmask & kNodeHits) | (BOUND ? (__float_as_uint(tLow) >> 8) & kGroupBound : 0u) | (ew >> 24);
+    *tx = n1.y; *ty = hitmask & ~kNodeHits;
+}
+
+// Per-lane stack of node groups, two words an entry; the first LDSN levels in LDS (entry l of a lane at words
+// (2l) * STRIDE and (2l + 1) * STRIDE of its column: a lane always uses bank lane % 32), deeper levels in a private
+// array.  Behind the stack rows sit the lane's two visit tallies, as in LaneStack.
+template <int LDSN, int OVF, int STRIDE>
+struct GroupStack {
+    static constexpr int kRows = 2 * LDSN;
+    static constexpr int kWords = kRows + 2;
+    uint32_t* lds;
+    uint32_t* ov; // [2 * OVF], caller's frame
+    int sp;
+    DEV GroupStack(uint32_t* column, uint32_t* spill) : lds(column), ov(spill), sp(0) {}
+    DEV void countNode() { atomicAdd(&lds[kRows * STRIDE], 1u); }
+    DEV void countTriangle() { atomicAdd(&lds[(kRows + 1) * STRIDE], 1u); }
+    DEV void push(uint32_t x, uint32_t y) {
+        if (sp < LDSN) { lds[(2 * sp) * STRIDE] = x; lds[(2 * sp + 1) * STRIDE] = y; ++sp; }
+        else if (OVF > 0 && sp < LDSN + OVF) { ov[2 * (sp - LDSN)] = x; ov[2 * (sp - LDSN) + 1] = y; ++sp; }
+        // deeper than LDSN + OVF cannot happen: the host refuses trees that deep
+    }
+    DEV bool pop(uint32_t* x, uint32_t* y) {
+        if (sp == 0) return false;
+        --sp;
+        if (OVF > 0 && sp >= LDSN) { *x = ov[2 * (sp - LDSN)]; *y = ov[2 * (sp - LDSN) + 1]; }
+        else { *x = lds[(2 * sp) * STRIDE]; *y = lds[(2 * sp + 1) * STRIDE]; }
+        return true;
+    }
+};
+
+// Common state machine of the two walkers.  A lane holds a node group G (children still to visit) and a triangle
+// group T (triangles still to test); T is emptied before the lane takes its next node.  done: both empty, stack empty.
+template <int LDSN, int OVF, int STRIDE, int NS>
+struct Walker8Base {
+    RaySetup r;
+    Ray8 q;
+    uint32_t gx, gy, tx, ty;
+    GroupStack<LDSN, OVF, STRIDE> st;
+    DEV Walker8Base(uint32_t* column, uint32_t* spill) : gx(0), gy(0), tx(0), ty(0), st(column, spill) {}
+    DEV void begin(F3 o, F3 d) {
+        r = setupRay(o, d);
+        q = makeRay8(r);
+        st.sp = 0;
+        gx = 0; gy = 0x80000000u; // the root as the only child of a group without siblings (bound 0, inner mask 0)
+        tx = 0; ty = 0;
+    }
+    DEV void finish() { gy = 0; ty = 0; st.sp = 0; }
+    DEV bool done() const { return ty == 0 && (gy & kNodeHits) == 0; }
+    DEV bool atTriangles() const { return ty != 0; }
+    DEV bool atNode() const { return ty == 0 && (gy & kNodeHits) != 0; }
+    // takes the nearest unvisited child of G, leaves the rest of G on the stack, and intersects the child's node
+    template <bool BOUND>
+    DEV void nodeStep(const float4* nodes, float tMax) {
+        st.countNode();
+        const uint32_t hits = gy & kNodeHits;
+        const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
+        const uint32_t rest = gy & ~(1u << bit);
+        const uint32_t slot = (bit - 24u) ^ (q.oct4 & 7u);
+        const uint32_t child = gx + __popc(rest & 0xffu & ((1u << slot) - 1u)); // inner slots below it
+        if (rest & kNodeHits) st.push(gx, rest);
+        intersectNode8<NS, BOUND>(nodes, child, q, tMax, &gx, &gy, &tx, &ty);
+    }
+    // when G and T are both empty: the next group from the stack whose children can still lie before tMax, if any
+    template <bool BOUND>
+    DEV void refill(float tMax) {
+        if (ty == 0 && (gy & kNodeHits) == 0) {
+            for (;;) {
+                if (!st.pop(&gx, &gy)) { gy = 0; break; }
+                if (!BOUND || groupBound(gy) <= tMax) break;
+            }
+        }
+    }
+    DEV uint32_t takeTriangle() { // lowest set bit of T
+        const uint32_t b = (uint32_t)__ffs((int)ty) - 1u;
+        ty &= ty - 1u;
+        st.countTriangle();
+        return tx + b;
+    }
+};
+
+// degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
+DEV bool triangleAccepted(F3 p0, F3 p1, F3 p2) {
+    F3 dpdu = (p1 - p2) - (p0 - p2);
+    F3 dpdv = -(p1 - p2);
+    if (lengthSqr(cross(dpdu, dpdv)) == 0) return lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
+    return true;
+}
+
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4>
+struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
+    using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
+    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
+    Hit h;
+    DEV ClosestWalker8(uint32_t* column, uint32_t* spill) : Base(column, spill) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
+    DEV void start(F3 o, F3 d, float tMax) {
+        Base::begin(o, d);
+        h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
+    }
+    DEV void testOne(const float4* tris) {
+        const uint32_t tri = Base::takeTriangle();
+        const float4* tp = tris + (size_t)tri * 3;
+        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        float t, b0, b1, b2;
+        if (triangleTest(this->r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2) && triangleAccepted(xyz(v0), xyz(v1), xyz(v2))) {
+            h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2;
+        }
+    }
+    // one kind of work per wave step, whichever has more lanes waiting (see ClosestWalker::step)
+    DEV void step(const float4* nodes, const float4* tris) {
+        const bool n = Base::atNode(), t = Base::atTriangles();
+        if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+            if (!n) return;
+            Base::template nodeStep<true>(nodes, h.t);
+        } else {
+            if (!t) return;
+            testOne(tris);
+            if (this->ty != 0) testOne(tris);
+        }
+        Base::template refill<true>(h.t);
+    }
+    // descend until the lane holds triangles (or is through), then test them all
+    DEV void round(const float4* nodes, const float4* tris) {
+        while (Base::atNode()) { Base::template nodeStep<true>(nodes, h.t); Base::template refill<true>(h.t); }
+        while (this->ty != 0) testOne(tris);
+        Base::template refill<true>(h.t);
+    }
+    template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
+};
+
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4>
+struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
+    using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
+    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
+    float tMax;
+    bool occluded;
+    DEV AnyWalker8(uint32_t* column, uint32_t* spill) : Base(column, spill), tMax(0.f), occluded(false) {}
+    DEV void start(F3 o, F3 d, float tMaxRay) {
+        Base::begin(o, d);
+        tMax = tMaxRay;
+        occluded = false;
+    }
+    DEV void testOne(const float4* tris) { // Triangle::intersectP
+        const uint32_t tri = Base::takeTriangle();
+        const float4* tp = tris + (size_t)tri * 3;
+        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        float t, b0, b1, b2;
+        if (triangleTest(this->r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) { occluded = true; Base::finish(); }
+    }
+    DEV void step(const float4* nodes, const float4* tris) {
+        const bool n = Base::atNode(), t = Base::atTriangles();
+        if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+            if (!n) return;
+            Base::template nodeStep<false>(nodes, tMax);
+        } else {
+            if (!t) return;
+            testOne(tris);
+            if (this->ty != 0) testOne(tris);
+        }
+        Base::template refill<false>(tMax);
+    }
+    DEV void round(const float4* nodes, const float4* tris) {
+        while (Base::atNode()) { Base::template nodeStep<false>(nodes, tMax); Base::template refill<false>(tMax); }
+        while (this->ty != 0) testOne(tris);
+        Base::template refill<false>(tMax);
+    }
+    template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
+};
+
+// ---- which tree a kernel walks ----
+// W = 4: the 128-byte nodes with full-precision child boxes (dev_trace.h); W = 8: the compressed nodes above.
+// NS: 16-byte pieces between consecutive nodes (a copy of the scene in LDS staggers the wide nodes over the banks).
+template <int W> struct TreeLayout;
+template <> struct TreeLayout<4> { static constexpr int kNodeVec4 = 8, kLdsPitch = 9; };
+template <> struct TreeLayout<8> { static constexpr int kNodeVec4 = kNode8Vec4, kLdsPitch = kNode8Vec4; };
+template <int W, int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel;
+template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel<4, LDSN, OVF, STRIDE, LDS_SCENE> {
+    static constexpr int NS = LDS_SCENE ? TreeLayout<4>::kLdsPitch : TreeLayout<4>::kNodeVec4;
+    using Closest = ClosestWalker<LDSN, OVF, STRIDE, NS>;
+    using Any = AnyWalker<LDSN, OVF, STRIDE, NS>;
+};
+template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel<8, LDSN, OVF, STRIDE, LDS_SCENE> {
+    static constexpr int NS = LDS_SCENE ? TreeLayout<8>::kLdsPitch : TreeLayout<8>::kNodeVec4;
+    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS>;
+    using Any = AnyWalker8<LDSN, OVF, STRIDE, NS>;
+};
+constexpr int spillWords(int ovf) { return 2 * (ovf > 0 ? ovf : 1); }
+
+// one ray per lane, start to finish (kernels that do not pool rays); column: the lane's LDS column of Closest::kWords rows
+template <int W, int LDSN, int OVF, int STRIDE, bool LDS_SCENE = false>
+DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+    uint32_t spill[spillWords(OVF)];
+    typename WalkerSel<W, LDSN, OVF, STRIDE, LDS_SCENE>::Closest w(column, spill);
+    w.start(o, d, tMax);
+    while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
+    return w.h;
+}
+template <int W, int LDSN, int OVF, int STRIDE>
+DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+    uint32_t spill[spillWords(OVF)];
+    typename WalkerSel<W, LDSN, OVF, STRIDE, false>::Any w(column, spill);
+    w.start(o, d, tMax);
+    while (__ballot(!w.done()) != 0) w.step(nodes, tris);
+    return w.occluded;
+}
+
+} // namespace edev

@@ -86,6 +86,7 @@ struct EnigmaCtx {
     uint32_t refillIdle = 16;
     DevScene scene{};
     uint32_t bvhDepth = 0, bvhNodes = 0, bvhStack = 0;
+    int bvhWidth = 8; // 8: compressed 80-byte nodes (dev_trace8.h); 4: 128-byte nodes with full-precision boxes (scenes with spheres)
     double msBvhBuild = 0;
 
     // camera / film / integrator
@@ -228,9 +229,6 @@ static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
 
 static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     HIPCHK(h, hipSetDevice(h->device));
-    // the context holds no scene until this upload has succeeded: a failure part-way leaves host flags and device
-    // tables of two different scenes behind, and enigma_render must refuse to run on that mixture
-    h->haveScene = false;
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
     if (s->n_triangles >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many triangles");
     if (s->n_materials == 0 && s->n_triangles) {
@@ -249,6 +247,10 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (triMedia && !haveMedia) return h->fail(ENIGMA_E_INVALID, "per-triangle medium arrays without media");
     if (haveMedia && s->n_media && !s->media) return h->fail(ENIGMA_E_INVALID, "null media array");
     if (s->n_media >= 0xfffu) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 4094 media");
+    // From here on the context's scene state is rewritten piece by piece.  It holds no scene until this upload has
+    // succeeded: a failure part-way leaves host flags and device tables of two different scenes behind, and
+    // enigma_render must refuse to run on that mixture.  (A description rejected above leaves the old scene in place.)
+    h->haveScene = false;
     h->haveNoMaterial = false;
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (s->tri_material[t] == ENIGMA_NO_MATERIAL) {
@@ -381,17 +383,28 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->kindPresent[d.kind] = true;
         mats[i] = d;
     }
-    // BVH + triangle reorder
+    // BVH + triangle reorder.  Scenes with spheres keep the 4-wide tree: their kernels test the spheres beside it.
     auto t0 = std::chrono::steady_clock::now();
+    int width = s->n_spheres ? 4 : 8;
+    if (const char* e = getenv("ENIGMA_BVH_WIDTH")) width = atoi(e) == 4 ? 4 : width; // measurement knob: the 4-wide tree for any scene
     enigma::BvhResult bvh;
-    uint32_t maxLeaf = 4;
-    if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
-    enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
+    enigma::Bvh8Result bvh8;
+    if (width == 8) {
+        enigma::build_bvh8(s->vertices, s->indices, s->n_triangles, &bvh8);
+        bvh.triOrder = bvh8.triOrder;
+        bvh.maxDepth = bvh8.maxDepth;
+        bvh.stackNeed = bvh8.maxDepth; // one stack entry per level
+    } else {
+        uint32_t maxLeaf = 4;
+        if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
+        enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
+    }
     h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (bvh.stackNeed > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH needs %u traversal stack entries (limit 64)", bvh.stackNeed);
+    h->bvhWidth = width;
     h->bvhDepth = bvh.maxDepth;
     h->bvhStack = bvh.stackNeed;
-    h->bvhNodes = (uint32_t)bvh.nodes.size();
+    h->bvhNodes = (uint32_t)(width == 8 ? bvh8.nodes.size() : bvh.nodes.size());
     std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> newPos(s->n_triangles);
     std::vector<float4> shadeData; // filled when some triangle has per-vertex normals or uvs
@@ -425,8 +438,14 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             triData[(size_t)k * 3 + v] = make_float4(p[0], p[1], p[2], wf);
         }
     }
-    std::vector<float4> nodeData(bvh.nodes.size() * 8);
-    memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh4Node));
+    std::vector<float4> nodeData;
+    if (width == 8) {
+        nodeData.resize(bvh8.nodes.size() * kNode8Vec4);
+        memcpy(nodeData.data(), bvh8.nodes.data(), bvh8.nodes.size() * sizeof(enigma::Bvh8Node));
+    } else {
+        nodeData.resize(bvh.nodes.size() * 8);
+        memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh4Node));
+    }
     std::vector<uint32_t> prim(std::max(1u, s->n_triangles));
     for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
     // spheres (Enigma/ShapeImp.cpp:13-27): tested one by one beside the BVH, primitive index n_triangles + i
@@ -637,7 +656,7 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->scene.primId = h->primId.p;
     h->scene.nLights = (int)s->n_lights;
     h->scene.nTris = std::max(1u, s->n_triangles);
-    h->scene.nNodes = (uint32_t)bvh.nodes.size();
+    h->scene.nNodes = h->bvhNodes;
     h->scene.nMaterials = s->n_materials;
     h->lightDistDirty = true;
     h->haveScene = true;
@@ -699,6 +718,9 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     int dx = (int)dx64, dy = (int)dy64;
     if (sb[0] < sb[1]) return h->fail(ENIGMA_E_UNSUPPORTED, "sample bounds with min.x < min.y make the reference's tile loop (Integrator.cpp:254) "
                                                           "start above the sample bounds; its result is undefined");
+    // Arguments rejected above leave the configured integrator as it was.  From here on the sampler state is rewritten;
+    // a failure below leaves it half rebuilt, so the handle has no integrator until the caller's configuration succeeds.
+    h->haveInteg = false;
     // SobolSampler ctor, Enigma/Sampler.cpp:211-222
     h->spp = (int64_t)roundUpPow2((uint32_t)samples_per_pixel);
     h->resolution = roundUpPow2((uint32_t)std::max(dx, dy));
@@ -744,7 +766,6 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
 
 static int integratorConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
-    h->haveInteg = false; // a reconfiguration that fails leaves no half-updated integrator behind
     if (d->max_depth < 0 || d->max_depth > 120) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
     if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
         return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
@@ -764,7 +785,6 @@ static int integratorConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
 
 static int volpathConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
-    h->haveInteg = false; // a reconfiguration that fails leaves no half-updated integrator behind
     // every ray segment inside a medium draws two more samples and boundaries do not count as bounces, so a path's
     // dimensions are not bounded by its depth: every dimension the 10-bit cursor can address is tabulated (the reference
     // aborts at dimension 1024)
@@ -786,11 +806,11 @@ static int volpathConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
 
 static int directLightingConfigImpl(EnigmaCtx* h, const EnigmaDirectLightingDesc* d) {
     HIPCHK(h, hipSetDevice(h->device));
-    h->haveInteg = false;
     if (d->max_depth < 0 || d->max_depth > 30) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
     if (d->strategy != ENIGMA_DL_SAMPLE_ALL && d->strategy != ENIGMA_DL_SAMPLE_ONE) return h->fail(ENIGMA_E_INVALID, "unknown strategy %d", d->strategy);
     if (d->samples_per_pixel <= 0 || d->samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
     if (d->sample_bounds[2] <= d->sample_bounds[0] || d->sample_bounds[3] <= d->sample_bounds[1]) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
+    h->haveInteg = false; // rewritten from here on; true again only if everything below succeeds
     h->directDesc = *d;
     h->integDesc.max_depth = d->max_depth;
     memcpy(h->integDesc.pixel_bounds, d->pixel_bounds, sizeof(d->pixel_bounds));
@@ -852,6 +872,7 @@ static int finishDirectLighting(EnigmaCtx* h) {
     h->integ.raysPerPath = (int)raysPerPath;
     h->integ.pendingLevels = std::max(1, d.max_depth - 1);
     h->directDirty = false;
+    h->haveInteg = true; // configureSampler cleared it while it rebuilt the tables
     return ENIGMA_OK;
 }
 
@@ -952,7 +973,10 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
 
 // Scenes up to this many bytes of nodes + triangles are traversed out of LDS (see stageSceneToLds).
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
-static size_t sceneLdsBytes(const EnigmaCtx* h) { return ((size_t)h->scene.nNodes * kLdsNodePitch + (size_t)h->scene.nTris * 3) * sizeof(float4); }
+static size_t sceneLdsBytes(const EnigmaCtx* h) {
+    const size_t pitch = h->bvhWidth == 8 ? TreeLayout<8>::kLdsPitch : TreeLayout<4>::kLdsPitch;
+    return ((size_t)h->scene.nNodes * pitch + (size_t)h->scene.nTris * 3) * sizeof(float4);
+}
 
 // triangles + materials + lights + light distribution, as k_shade stages them
 static size_t shadeLdsBytes(const EnigmaCtx* h) {
@@ -987,7 +1011,7 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
         if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
 }
 
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -999,7 +1023,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(ev.c1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1013,16 +1037,16 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One iteration of VolPathIntegrator::Li's loop for every path in flight (Enigma/VolPathIntegrator.cpp:63-174):
 // trace + medium sampling, then the surface, medium and boundary branches, then the shadow and MIS rays.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int iter, int gridTrace,
                             int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -1034,7 +1058,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                               h->refillIdle, nullptr);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1050,17 +1074,17 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One step of the depth-first walk of DirectLightingIntegrator::Li's recursion for every path in flight:
 // trace the current rays, shade the hits (direct lighting + the specular children), resume pending branches
 // of the paths that missed, then the shadow and MIS rays of this step.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths,
                              int step, int gridTrace, int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -1072,7 +1096,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                                  h->refillIdle, D.pendCount);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1088,10 +1112,10 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
@@ -1171,6 +1195,11 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchDirectStep<12, 52, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhWidth == 8) {
+                    if (ldsScene) launchDirectStep<12, 0, true, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                    else if (h->bvhStack <= 11) launchDirectStep<11, 0, false, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                    else launchDirectStep<11, 53, false, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 else launchDirectStep<11, 53, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
@@ -1187,6 +1216,11 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchVolBounce<12, 52, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhWidth == 8) {
+                    if (ldsScene) launchVolBounce<12, 0, true, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                    else if (h->bvhStack <= 11) launchVolBounce<11, 0, false, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                    else launchVolBounce<11, 53, false, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 else launchVolBounce<11, 53, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
@@ -1201,6 +1235,11 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchBounce<12, 52, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhWidth == 8) {
+                    if (ldsScene) launchBounce<12, 0, true, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                    else if (h->bvhStack <= 11) launchBounce<11, 0, false, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                    else launchBounce<11, 53, false, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
@@ -1396,7 +1435,7 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     }
     h->stats.bvh_nodes = h->bvhNodes;
     h->stats.bvh_depth = h->bvhDepth;
-    h->stats.bvh_node_bytes = sizeof(enigma::Bvh4Node);
+    h->stats.bvh_node_bytes = h->bvhWidth == 8 ? sizeof(enigma::Bvh8Node) : sizeof(enigma::Bvh4Node);
     h->stats.ms_bvh_build = h->msBvhBuild;
     *out = h->stats;
     return ENIGMA_OK;
@@ -1479,7 +1518,12 @@ static hipError_t debugIntersectRun(EnigmaCtx* h, uint32_t n, const float* dRays
                                     int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
     int grid = (int)((n + kBlock - 1) / kBlock);
     // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
-    if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    if (h->bvhWidth == 8) {
+        if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+        else if (h->bvhStack <= 12) k_debug_intersect<12, 0, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+        else k_debug_intersect<12, 52, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    }
+    else if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
     else if (h->bvhStack <= 12) k_debug_intersect<12, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
     else k_debug_intersect<12, 52><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
     hipError_t e = hipGetLastError();

@@ -19,7 +19,7 @@
 // per-wave totals scanned through LDS so a block issues one atomic per queue.
 #pragma once
 #include "dev_bsdf.h"
-#include "dev_trace.h"
+#include "dev_trace8.h"
 #include "dev_sphere.h"
 
 namespace edev {
@@ -160,11 +160,12 @@ static_assert(kWavesPerBlock == 4, "blockReserve3 lays its counts out for four w
 // which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 9 float4 apart][tris: 3 float4 each].
 // Nodes sit 9 float4 apart in LDS (144 bytes = 36 banks): lanes at different nodes then read from
 // different banks, where a 128-byte pitch would put every other node on the same ones.
-constexpr uint32_t kLdsNodePitch = 9;
+template <int W>
 DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
-    const uint32_t nN = sc.nNodes * 8u, nT = sc.nTris * 3u;
-    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[(i >> 3) * kLdsNodePitch + (i & 7u)] = sc.nodes[i];
-    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[sc.nNodes * kLdsNodePitch + i] = sc.tris[i];
+    constexpr uint32_t kVec = TreeLayout<W>::kNodeVec4, kPitch = TreeLayout<W>::kLdsPitch;
+    const uint32_t nN = sc.nNodes * kVec, nT = sc.nTris * 3u;
+    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[(i / kVec) * kPitch + (i % kVec)] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[sc.nNodes * kPitch + i] = sc.tris[i];
     __syncthreads();
 }
 
@@ -363,34 +364,33 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 // MODE 2: the head of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:63-111): a ray that travels in a medium
 // samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
 // medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
-template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false, int W = 4>
 __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     constexpr int NK = MODE == 0 ? MK_COUNT : (MODE == 1 ? MK_COUNT + 1 : kQueueKinds);
-    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
-    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];
     __shared__ uint32_t binBase[kQueueKinds];
     __shared__ uint32_t poolNext;
     __shared__ uint8_t kindOf[kTraceChunk]; // material kind + 1 of the path at a pool position, 0 = path ended
     extern __shared__ float4 sceneLds[];
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
-    float spillDist[OVF > 0 ? OVF : 1];
+    uint32_t spill[spillWords(OVF)];
     const uint32_t count = countPtr ? *countPtr : countImm;
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
-    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
+    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
+        Walker w(stack + threadIdx.x, spill);
         uint32_t pos = kNoRay, p = 0, state = 0;
         bool exhausted = false;
         for (;;) {
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         }
         __syncthreads(); // binCnt / binBase / kindOf / poolNext are rewritten by the next chunk
     }
-    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitClosest, binCnt);
+    blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitClosest, binCnt);
 }
 
 // SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the table of the voxel that holds p
@@ -1135,25 +1135,25 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
-    using Stack = LaneStack<LDSN, OVF, kBlock, false>;
-    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Any;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t poolNext;
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
+    uint32_t spill[spillWords(OVF)];
     const uint32_t count = ctr->shadowCount.v;
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
-    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
+    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        AnyWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes);
+        Walker w(stack + threadIdx.x, spill);
         uint32_t p = kNoRay;
         F3 contrib(0.f); // fetched with the ray: no dependent load when the ray is through
         bool exhausted = false;
@@ -1192,28 +1192,28 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
         }
         __syncthreads(); // poolNext is rewritten by the next chunk
     }
-    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitShadow, red);
+    blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitShadow, red);
 }
 
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
 // the sampled light's triangle.  Few rays per bounce (only those that hit the light's own triangle
 // are queued), one per lane.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
-    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     const uint32_t count = ctr->misCount.v;
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
-    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
+    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
-        Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
+        Hit h = traceClosest<W, LDSN, OVF, kBlock, LDS_SCENE>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
         if (SPH) {
             sphereClosest(sc, xyz(o), xyz(d), &h.tri, &h.t, &h.b0, &h.b1, &h.b2);
             if (isSpherePrim<SPH>(sc, h.tri)) { // lightIsect.Le(-wi) of an emissive sphere, if it is the sampled light
@@ -1252,7 +1252,7 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
             atomicAdd(L + 0, add.x); atomicAdd(L + 1, add.y); atomicAdd(L + 2, add.z);
         }
     }
-    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitMis, red); // every thread gets here
+    blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitMis, red); // every thread gets here
 }
 
 // FilmTile::AddSample footprint (Enigma/Film.cpp:263-300).  SINK(x, y, weight) per covered pixel.
@@ -1352,19 +1352,19 @@ __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int3
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
     outPfilm[2 * (size_t)i] = fx; outPfilm[2 * (size_t)i + 1] = fy;
 }
-template <int LDSN, int OVF>
+template <int LDSN, int OVF, int W = 4>
 __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
                                                             uint32_t* primOut, float* tOut, float* baryOut) {
-    __shared__ uint32_t stack[LaneStack<LDSN, OVF, kBlock, true>::kWords * kBlock]; // the walkers tally into the last two rows
+    __shared__ uint32_t stack[WalkerSel<W, LDSN, OVF, kBlock, false>::Closest::kWords * kBlock]; // the walkers tally into the last two rows
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
     F3 o(r[0], r[1], r[2]), d(r[3], r[4], r[5]);
     if (anyHit) {
-        triOut[i] = traceAny<LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
+        triOut[i] = traceAny<W, LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
         return;
     }
-    Hit h = traceClosest<LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
+    Hit h = traceClosest<W, LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
     int orig = -1;
     if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
     triOut[i] = orig;

@@ -198,25 +198,24 @@ DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, 
 // end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
 // without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
 // far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
-    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
-    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
-    float spillDist[OVF > 0 ? OVF : 1];
+    uint32_t spill[spillWords(OVF)];
     const uint32_t count = ctr->shadowCount.v;
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
-    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
+    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;
-        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
+        Walker w(stack + threadIdx.x, spill);
         uint32_t p = 0, med = 0;
         F3 o(0.f), d(0.f), contrib(0.f), Tr(1.f), lp(0.f), lpErr(0.f), ln(0.f);
         if (active) {
@@ -262,31 +261,30 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
     if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysShadow, (unsigned long long)nQueries);
-    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitShadow, red);
+    blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitShadow, red);
 }
 
 // Scene::intersectTr for the MIS rays of one bounce: closest-hit queries through material-less surfaces
 // (isect.SpawnRay(ray.m_dir)), attenuated by the media on the way; the first surface with a material must be
 // the sampled light's triangle.  Every query counts as a MIS ray.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
 __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    using Stack = LaneStack<LDSN, OVF, kBlock, true>;
-    __shared__ uint32_t stack[Stack::kWords * kBlock];
+    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
-    uint32_t spillNodes[OVF > 0 ? OVF : 1];
-    float spillDist[OVF > 0 ? OVF : 1];
+    uint32_t spill[spillWords(OVF)];
     const uint32_t count = ctr->misCount.v;
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
-    blockZeroVisits(stack + threadIdx.x, Stack::kRows, kBlock);
+    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;
-        ClosestWalker<LDSN, OVF, kBlock, LDS_SCENE ? (int)kLdsNodePitch : 8> w(stack + threadIdx.x, spillNodes, spillDist);
+        Walker w(stack + threadIdx.x, spill);
         uint32_t p = 0, med = 0;
         int wantLight = -1;
         F3 o(0.f), d(0.f), Tr(1.f);
@@ -355,7 +353,7 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
     if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysMis, (unsigned long long)nQueries);
-    blockFlushVisits(stack + threadIdx.x, Stack::kRows, kBlock, sc.visits, kVisitMis, red);
+    blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitMis, red);
 }
 
 } // namespace edev
