@@ -179,14 +179,15 @@ def run_workload(args, variant, steps, ctx):
     elapsed = time.perf_counter() - t0
 
     s_after = r.stats()
-    keys = ("camera_samples", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow")
+    keys = ("camera_samples", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
+            "node_steps_closest", "tri_steps_closest", "node_steps_shadow", "tri_steps_shadow")
     counts = torch.tensor([s_after[k] - s_before[k] for k in keys], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    samples, rc, rs, rm, nodes_c, tris_c, nodes_s, tris_s = [float(v) for v in counts.tolist()]
+    samples, rc, rs, rm, nodes_c, tris_c, nodes_s, tris_s, nsteps_c, tsteps_c, nsteps_s, tsteps_s = [float(v) for v in counts.tolist()]
     rays = rc + rs + rm
     if rank != 0:
         r.close()
@@ -232,6 +233,10 @@ def run_workload(args, variant, steps, ctx):
         "kernel": "k_intersect_closest", "avg_launch_ms": avg_ms, "launches": n_closest, "rays_per_launch": rays_per_launch,
         "bytes_per_ray": b_ray, "nodes_per_ray": npr, "triangles_per_ray": tpr, "node_bytes": node_bytes, "scene_in_lds": in_lds,
         "pmc": pmc,
+        # lanes of a wave that had work in a step (from the device's own step tallies; 0 where the kernel does not step wave-wide)
+        "lanes_busy_node_step": nodes_c / (64.0 * nsteps_c) if nsteps_c else None,
+        "triangles_per_tri_step": tris_c / tsteps_c if tsteps_c else None,
+        "wave_steps_per_ray": (nsteps_c + tsteps_c) * 64.0 / max(1.0, rc),
         "note": "achieved = algorithmic bytes of this build's own traversal per launch (per ray: %d B of path record, hit record and queue words%s; "
                 "visit counts tallied on the device) / the launch's duration from HIP events on the library's stream"
                 % (RAY_IO_BYTES, "" if not in_lds else "; tree and triangles are staged into LDS once per block and cost no HBM bytes per visit"
@@ -243,7 +248,10 @@ def run_workload(args, variant, steps, ctx):
         avg_sh = ms_shadow / n_shadow
         ach_sh = b_sh * (rs / N / n_shadow) / (avg_sh * 1e-3) / 1e9
         out["roofline_shadow"] = {"bound": "hbm", "kernel": "k_shadow", "achieved": ach_sh, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_sh / HBM_PEAK_GBS,
-                                  "avg_launch_ms": avg_sh, "launches": n_shadow, "bytes_per_ray": b_sh, "nodes_per_ray": nps, "triangles_per_ray": tps}
+                                  "avg_launch_ms": avg_sh, "launches": n_shadow, "bytes_per_ray": b_sh, "nodes_per_ray": nps, "triangles_per_ray": tps,
+                                  "lanes_busy_node_step": nodes_s / (64.0 * nsteps_s) if nsteps_s else None,
+                                  "triangles_per_tri_step": tris_s / tsteps_s if tsteps_s else None,
+                                  "wave_steps_per_ray": (nsteps_s + tsteps_s) * 64.0 / max(1.0, rs)}
 
     # ---- CPU baseline: the restated reference renderer on the host cores, a bounded sample of the same workload
     if N == 1 and not args.no_cpu:

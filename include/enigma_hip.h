@@ -250,6 +250,9 @@ typedef struct EnigmaStats {
     uint64_t scene_in_lds;                /* last call: 1 when the traversal kernels ran on a copy of the scene in LDS */
     double ms_shadow;                     /* device time of the shadow-ray kernel launches, last call */
     uint64_t shadow_launches;
+    /* Wave-wide steps of the pooled traversal kernels: a step either fetches a node in every lane that is at one or
+     * tests triangles in every lane that holds some.  nodes / (64 * node steps) = lanes busy in a node step. */
+    uint64_t node_steps_closest, tri_steps_closest, node_steps_shadow, tri_steps_shadow;
 } EnigmaStats;
 
 typedef struct EnigmaCtx EnigmaCtx;

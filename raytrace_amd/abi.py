@@ -96,7 +96,8 @@ class EnigmaStats(C.Structure):
                 ("ms_bvh_build", C.c_double),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
                 ("nodes_mis", C.c_uint64), ("tris_mis", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
-                ("scene_in_lds", C.c_uint64), ("ms_shadow", C.c_double), ("shadow_launches", C.c_uint64)]
+                ("scene_in_lds", C.c_uint64), ("ms_shadow", C.c_double), ("shadow_launches", C.c_uint64),
+                ("node_steps_closest", C.c_uint64), ("tri_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64), ("tri_steps_shadow", C.c_uint64)]
 
 
 def ptr(a):

@@ -22,10 +22,11 @@ DEV F3 permuteK(F3 v, bool kz0, bool kz1) {
     return F3(kz0 ? v.y : (kz1 ? v.z : v.x), kz0 ? v.z : (kz1 ? v.x : v.y), kz0 ? v.x : (kz1 ? v.y : v.z));
 }
 
-DEV RaySetup setupRay(F3 o, F3 d) {
+// invDir: 1 / d as the slab test in use needs it (the reference's own test takes the correctly rounded quotient)
+DEV RaySetup setupRayWith(F3 o, F3 d, F3 invDir) {
     RaySetup r;
     r.o = o; r.d = d;
-    r.invDir = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);      // Inverted(), MathCommon.h:225-230
+    r.invDir = invDir;
     r.negX = r.invDir.x < 0; r.negY = r.invDir.y < 0; r.negZ = r.invDir.z < 0;
     // MaxDimension(Abs(d)), MathCommon.h:342-353
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
@@ -37,6 +38,7 @@ DEV RaySetup setupRay(F3 o, F3 d) {
     r.Sx = -dp.x / dp.z; r.Sy = -dp.y / dp.z; r.Sz = 1.f / dp.z;
     return r;
 }
+DEV RaySetup setupRay(F3 o, F3 d) { return setupRayWith(o, d, F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)); } // Inverted(), MathCommon.h:225-230
 
 // BBox3::intersectP(ray, invDir, dirIsNeg), Enigma/BBox.h:267-295.  tEntry = the final tMin.
 DEV bool slabTest(const RaySetup& r, float tMaxRay, F3 lo, F3 hi, float* tEntry) {
@@ -136,6 +138,14 @@ constexpr uint32_t kVisitSlots = 8192;
 enum VisitKind : uint32_t { kVisitClosest = 0, kVisitShadow = 1, kVisitMis = 2, kVisitKinds = 3 };
 DEV void blockZeroVisits(uint32_t* column, int rows, int stride) { column[rows * stride] = 0u; column[(rows + 1) * stride] = 0u; }
 // every thread of the block calls it once, after its last traversal step; red: 2 * (block size / 64) words of LDS
+constexpr uint32_t kVisitTallies = 4;
+// a wave's step counts (uniform values: one lane adds them)
+DEV void waveFlushSteps(unsigned long long* visits, uint32_t kind, uint32_t nodeSteps, uint32_t triSteps) {
+    if (!visits || (threadIdx.x & 63u) != 0) return;
+    const uint32_t slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kVisitSlots;
+    atomicAdd(&visits[((size_t)kind * kVisitTallies + 2) * kVisitSlots + slot], (unsigned long long)nodeSteps);
+    atomicAdd(&visits[((size_t)kind * kVisitTallies + 3) * kVisitSlots + slot], (unsigned long long)triSteps);
+}
 DEV void blockFlushVisits(const uint32_t* column, int rows, int stride, unsigned long long* visits, uint32_t kind, uint32_t* red) {
     if (!visits) return;
     uint32_t n = column[rows * stride], t = column[(rows + 1) * stride];
@@ -148,8 +158,8 @@ DEV void blockFlushVisits(const uint32_t* column, int rows, int stride, unsigned
         unsigned long long sn = 0, stt = 0;
         for (uint32_t w = 0; w < nw; ++w) { sn += red[w]; stt += red[nw + w]; }
         const uint32_t slot = blockIdx.x % kVisitSlots;
-        atomicAdd(&visits[((size_t)kind * 2 + 0) * kVisitSlots + slot], sn);
-        atomicAdd(&visits[((size_t)kind * 2 + 1) * kVisitSlots + slot], stt);
+        atomicAdd(&visits[((size_t)kind * kVisitTallies + 0) * kVisitSlots + slot], sn);
+        atomicAdd(&visits[((size_t)kind * kVisitTallies + 1) * kVisitSlots + slot], stt);
     }
 }
 
@@ -240,6 +250,7 @@ struct ClosestWalker {
     RaySetup r;
     Hit h;
     int cur;
+    uint32_t nodeSteps = 0, triSteps = 0; // wave steps of either kind (the same in every lane of the wave)
     LaneStack<LDSN, OVF, STRIDE, true> st;
     static constexpr int kWords = LaneStack<LDSN, OVF, STRIDE, true>::kWords, kRows = LaneStack<LDSN, OVF, STRIDE, true>::kRows;
     DEV ClosestWalker(uint32_t* column, uint32_t* spillNodes, float* spillDist) : cur(kTraverseDone), st(column, spillNodes, spillDist) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
@@ -256,6 +267,7 @@ struct ClosestWalker {
         const bool atNode = cur >= 0;
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
+            ++nodeSteps;
             if (!atNode) return;
             st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
@@ -274,6 +286,7 @@ struct ClosestWalker {
             if (t1 != EDEV_INF) st.push(q.c1, t1);
             cur = q.c0;
         } else {
+            ++triSteps;
             if (!atLeaf) return;
             uint32_t leaf = ~(uint32_t)cur;
             uint32_t tri = leaf >> 3, left = leaf & 7u;
@@ -347,6 +360,7 @@ struct AnyWalker {
     float tMax;
     int cur;
     bool occluded;
+    uint32_t nodeSteps = 0, triSteps = 0;
     LaneStack<LDSN, OVF, STRIDE, false> st;
     static constexpr int kWords = LaneStack<LDSN, OVF, STRIDE, false>::kWords, kRows = LaneStack<LDSN, OVF, STRIDE, false>::kRows;
     DEV AnyWalker(uint32_t* column, uint32_t* spillNodes) : tMax(0.f), cur(kTraverseDone), occluded(false), st(column, spillNodes, nullptr) {}
@@ -362,6 +376,7 @@ struct AnyWalker {
         const bool atNode = cur >= 0;
         const bool atLeaf = cur < 0 && cur != kTraverseDone;
         if (__popcll(__ballot(atNode)) >= __popcll(__ballot(atLeaf))) {
+            ++nodeSteps;
             if (!atNode) return;
             st.countNode();
             Node4 q = loadNode4(nodes + (size_t)cur * NS, r);
@@ -377,6 +392,7 @@ struct AnyWalker {
             if (h0) { if (next != kTraverseDone) st.push(next, 0.f); next = q.c0; }
             cur = (next != kTraverseDone) ? next : st.pop(0.f);
         } else {
+            ++triSteps;
             if (!atLeaf) return;
             uint32_t leaf = ~(uint32_t)cur;
             uint32_t tri = leaf >> 3, left = leaf & 7u;

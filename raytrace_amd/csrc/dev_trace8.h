@@ -6,7 +6,8 @@
 //  - child boxes are stored rounded outwards (8-bit offsets from the node's corner);
 //  - the slab distances are one fused multiply-add per plane, t = q * (2^e / d) + (corner - o) / d, evaluated with a
 //    slack that bounds its rounding error: entry distances are lowered and exit distances raised by
-//    2^-21 * (|(corner - o) / d| + 256 * |2^e / d|), four times the worst case of the three roundings involved;
+//    2^-21 * (|(corner - o) / d| + 256 * |2^e / d|), more than twice the worst case of the roundings involved
+//    (1 / d from the hardware reciprocal, one ulp; the difference, the product and the fused multiply-add, half an ulp each);
 //  - 1 / d is clamped to +-2^80, which keeps every product finite (a ray parallel to a slab gets entry / exit
 //    distances of the right sign and astronomic size, i.e. the slab does not constrain it while the origin is inside).
 // A box that the exact ray meets within [0, tMax] is therefore never culled; the reference's own slab test gives the
@@ -129,10 +130,13 @@ struct Walker8Base {
     RaySetup r;
     Ray8 q;
     uint32_t gx, gy, tx, ty;
+    uint32_t nodeSteps, triSteps; // wave steps of either kind this walker has made (the same in every lane of the wave)
     GroupStack<LDSN, OVF, STRIDE> st;
-    DEV Walker8Base(uint32_t* column, uint32_t* spill) : gx(0), gy(0), tx(0), ty(0), st(column, spill) {}
+    DEV Walker8Base(uint32_t* column, uint32_t* spill) : gx(0), gy(0), tx(0), ty(0), nodeSteps(0), triSteps(0), st(column, spill) {}
     DEV void begin(F3 o, F3 d) {
-        r = setupRay(o, d);
+        // the hardware reciprocal (one ulp) is enough for the box distances: their slack covers it; the shear constants
+        // of the triangle test stay correctly rounded quotients
+        r = setupRayWith(o, d, F3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)));
         q = makeRay8(r);
         st.sp = 0;
         gx = 0; gy = 0x80000000u; // the root as the only child of a group without siblings (bound 0, inner mask 0)
@@ -203,9 +207,11 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
         if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+            ++this->nodeSteps;
             if (!n) return;
             Base::template nodeStep<true>(nodes, h.t);
         } else {
+            ++this->triSteps;
             if (!t) return;
             testOne(tris);
             if (this->ty != 0) testOne(tris);
@@ -243,9 +249,11 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
         if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+            ++this->nodeSteps;
             if (!n) return;
             Base::template nodeStep<false>(nodes, tMax);
         } else {
+            ++this->triSteps;
             if (!t) return;
             testOne(tris);
             if (this->ty != 0) testOne(tris);

@@ -123,7 +123,7 @@ struct EnigmaCtx {
     DevBuf<uint32_t> extQ[2], matQ[kQueueKinds];
     DevBuf<float2> pfilm;
     DevBuf<DevCounters> counters;
-    DevBuf<unsigned long long> visits; // [kVisitKinds][2][kVisitSlots], see dev_trace.h
+    DevBuf<unsigned long long> visits; // [kVisitKinds][kVisitTallies][kVisitSlots], see dev_trace.h
 
     // multi-GPU: the communicator this handle's rank belongs to (enigma_comm_init), nullptr = single GPU
     ncclComm_t comm = nullptr;
@@ -175,7 +175,7 @@ extern "C" int enigma_ctx_create(int device_id, EnigmaCtx** out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
     if (h->counters.alloc(1) != hipSuccess) { delete h; return ENIGMA_E_DEVICE; }
     (void)hipMemset(h->counters.p, 0, sizeof(DevCounters));
-    if (h->visits.alloc((size_t)kVisitKinds * 2 * kVisitSlots) != hipSuccess) { h->counters.release(); delete h; return ENIGMA_E_DEVICE; }
+    if (h->visits.alloc((size_t)kVisitKinds * kVisitTallies * kVisitSlots) != hipSuccess) { h->counters.release(); delete h; return ENIGMA_E_DEVICE; }
     (void)hipMemset(h->visits.p, 0, h->visits.n * sizeof(unsigned long long));
     h->scene.visits = h->visits.p;
     *out = h;
@@ -1426,11 +1426,14 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     {   // traversal tallies: one slot per block of a launch, summed here
         std::vector<unsigned long long> v(h->visits.n);
         HIPCHK(h, hipMemcpy(v.data(), h->visits.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        uint64_t* out6[6] = {&h->stats.nodes_closest, &h->stats.tris_closest, &h->stats.nodes_shadow, &h->stats.tris_shadow, &h->stats.nodes_mis, &h->stats.tris_mis};
-        for (int k = 0; k < 6; ++k) {
+        uint64_t dummy[2];
+        uint64_t* outs[kVisitKinds * kVisitTallies] = {&h->stats.nodes_closest, &h->stats.tris_closest, &h->stats.node_steps_closest, &h->stats.tri_steps_closest,
+                                                       &h->stats.nodes_shadow, &h->stats.tris_shadow, &h->stats.node_steps_shadow, &h->stats.tri_steps_shadow,
+                                                       &h->stats.nodes_mis, &h->stats.tris_mis, &dummy[0], &dummy[1]};
+        for (uint32_t k = 0; k < kVisitKinds * kVisitTallies; ++k) {
             uint64_t sum = 0;
             for (uint32_t i = 0; i < kVisitSlots; ++i) sum += v[(size_t)k * kVisitSlots + i];
-            *out6[k] = sum;
+            *outs[k] = sum;
         }
     }
     h->stats.bvh_nodes = h->bvhNodes;

@@ -384,6 +384,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
+    uint32_t nodeSteps = 0, triSteps = 0;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
@@ -491,6 +492,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
             }
             w.template advance<LDS_SCENE>(nodes, tris);
         }
+        nodeSteps += w.nodeSteps; triSteps += w.triSteps;
         __syncthreads();
         // ---- bin the chunk: order inside a material queue is wave, item, lane
         unsigned long long kinds = 0; // 4 bits per item
@@ -531,6 +533,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         __syncthreads(); // binCnt / binBase / kindOf / poolNext are rewritten by the next chunk
     }
     blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitClosest, binCnt);
+    waveFlushSteps(sc.visits, kVisitClosest, nodeSteps, triSteps);
 }
 
 // SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the table of the voxel that holds p
@@ -1149,6 +1152,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
+    uint32_t nodeSteps = 0, triSteps = 0;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
@@ -1190,9 +1194,11 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             }
             w.template advance<LDS_SCENE>(nodes, tris);
         }
+        nodeSteps += w.nodeSteps; triSteps += w.triSteps;
         __syncthreads(); // poolNext is rewritten by the next chunk
     }
     blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitShadow, red);
+    waveFlushSteps(sc.visits, kVisitShadow, nodeSteps, triSteps);
 }
 
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
