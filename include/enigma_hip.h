@@ -325,6 +325,11 @@ int enigma_comm_destroy(EnigmaCtx* h);
  * rgb = max(0, XYZToRGB(RGBToXYZ(sum)) / weight) * scale.  Host code, no device work. */
 int enigma_film_resolve(const float* rgbw, uint64_t n_pixels, float scale, float* rgb_out);
 
+/* The "eta" and "k" of a MetalMaterial that names neither (Enigma/Material.cpp:604-608): copper's measured index and
+ * extinction spectra turned into RGB by RGBSpectrum::FromSampled (Enigma/Spectrum.cpp:1489-1511) over the CIE 1931
+ * colour matching functions.  Host code; no handle, no device work. */
+int enigma_default_metal_spectra(float eta_rgb[3], float k_rgb[3]);
+
 int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out);
 
 /* ---- debug taps for bit-exact parity checks (run the device code paths) ---- */
@@ -354,6 +359,12 @@ int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int
 #define ENIGMA_NOALLOC_MAX_RAYS 131072u
 int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
                                    uint32_t* prim_id_out, float* t_out, float* bary_out);
+/* BSDF::f, BSDF::Pdf and BSDF::sample_f with BSDF_ALL (Enigma/BxDF.cpp:885-985) of the BSDF that
+ * Material::computeScatteringFunctions builds for `material` (constant parameters; allowMultipleLobes = true as under the
+ * PathIntegrator) at a surface whose geometric and shading normal are (0,0,1) and whose dpdu is (1,0,0).  For n triples
+ * (wo, wi, u): out12 = f.rgb, Pdf, sampled f.rgb, sampled pdf, sampled wi.xyz, sampled BxDFType as a float. */
+int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, uint32_t n, const float* wo3, const float* wi3,
+                      const float* u2, float* out12);
 /* FilmTile::AddSample footprint (Enigma/Film.cpp:269-292) for n film positions:
  * up to max_per (pixel x, pixel y) pairs and filter weights each, count in counts. */
 int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per,

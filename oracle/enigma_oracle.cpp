@@ -3095,6 +3095,75 @@ int oracle_debug_bsdf(const EnigmaMaterial* m, uint32_t n, const float* wo3, con
     return 0;
 }
 
+// ---- sampled spectra -> RGB (Enigma/Spectrum.cpp:15-31,297-309,1489-1511) and the default metal (Enigma/Material.cpp:604-605) ----
+} // extern "C"
+namespace spectral {
+#include "../raytrace_amd/csrc/spectral_data.inc" // the CIE and copper tables as data (pinned by tests/golden/spectral_digest.json)
+static const float CIE_Y_integral = 106.856895f; // Enigma/Spectrum.h:46
+static bool SpectrumSamplesSorted(const float* lambda, const float*, int n) {
+    for (int i = 0; i < n - 1; ++i)
+        if (lambda[i] > lambda[i + 1]) return false;
+    return true;
+}
+static void SortSpectrumSamples(float* lambda, float* vals, int n) {
+    std::vector<std::pair<float, float>> sortVec;
+    for (int i = 0; i < n; ++i) sortVec.push_back(std::make_pair(lambda[i], vals[i]));
+    std::sort(sortVec.begin(), sortVec.end());
+    for (int i = 0; i < n; ++i) { lambda[i] = sortVec[i].first; vals[i] = sortVec[i].second; }
+}
+template <class Pred> static int FindInterval(int size, const Pred& pred) { // Enigma/Misc.h:70-83
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (pred(middle)) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    return std::min(std::max(first - 1, 0), size - 2);
+}
+static float Lerp(float start, float end, float t) { // Enigma/MathCommon.h:31-39
+    if (t < 0.f) return start;
+    if (t > 1.f) return end;
+    const float diff = (end - start) * t;
+    return start + diff;
+}
+static float InterpolateSpectrumSamples(const float* lambda, const float* vals, int n, float l) {
+    if (l <= lambda[0]) return vals[0];
+    if (l >= lambda[n - 1]) return vals[n - 1];
+    int offset = FindInterval(n, [&](int index) { return lambda[index] <= l; });
+    float t = (l - lambda[offset]) / (lambda[offset + 1] - lambda[offset]);
+    return Lerp(vals[offset], vals[offset + 1], t);
+}
+static void FromSampled(const float* lambda, const float* v, int n, float rgb[3]) { // RGBSpectrum::FromSampled
+    if (!SpectrumSamplesSorted(lambda, v, n)) {
+        std::vector<float> slambda(&lambda[0], &lambda[n]);
+        std::vector<float> sv(&v[0], &v[n]);
+        SortSpectrumSamples(&slambda[0], &sv[0], n);
+        return FromSampled(&slambda[0], &sv[0], n, rgb);
+    }
+    float xyz[3] = {0, 0, 0};
+    for (int i = 0; i < kCieSamples; ++i) {
+        float val = InterpolateSpectrumSamples(lambda, v, n, kCieLambda[i]);
+        xyz[0] += val * kCieX[i];
+        xyz[1] += val * kCieY[i];
+        xyz[2] += val * kCieZ[i];
+    }
+    float scale = float(kCieLambda[kCieSamples - 1] - kCieLambda[0]) / float(CIE_Y_integral * kCieSamples);
+    xyz[0] *= scale; xyz[1] *= scale; xyz[2] *= scale;
+    XYZToRGB(xyz, rgb);
+}
+} // namespace spectral
+extern "C" {
+void oracle_rgb_from_sampled(const float* lambda, const float* v, int n, float* rgb) { spectral::FromSampled(lambda, v, n, rgb); }
+void oracle_default_metal(float* eta, float* k) { // the statics of CreateMetalMaterial
+    spectral::FromSampled(spectral::kCopperLambda, spectral::kCopperN, spectral::kCopperSamples, eta);
+    spectral::FromSampled(spectral::kCopperLambda, spectral::kCopperK, spectral::kCopperSamples, k);
+}
+void oracle_spectral_tables(float* cie4x471, float* copper3x56) { // lambda, X, Y, Z rows; lambda, n, k rows
+    memcpy(cie4x471, spectral::kCieLambda, 471 * 4); memcpy(cie4x471 + 471, spectral::kCieX, 471 * 4);
+    memcpy(cie4x471 + 942, spectral::kCieY, 471 * 4); memcpy(cie4x471 + 1413, spectral::kCieZ, 471 * 4);
+    memcpy(copper3x56, spectral::kCopperLambda, 56 * 4); memcpy(copper3x56 + 56, spectral::kCopperN, 56 * 4); memcpy(copper3x56 + 112, spectral::kCopperK, 56 * 4);
+}
+
 // scalar known-answer taps
 float oracle_gamma(int n) { return orc::gamma(n); }
 float oracle_next_float_up(float v) { return NextFloatUp(v); }

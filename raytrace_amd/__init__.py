@@ -20,7 +20,7 @@ SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
     "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
-    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc",
+    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_default_metal_spectra",
     "enigma_comm_unique_id", "enigma_comm_init", "enigma_comm_info", "enigma_film_reduce", "enigma_comm_destroy",
 ]
 
@@ -56,6 +56,7 @@ def load_library():
         L.enigma_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.enigma_debug_bsdf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_film_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -207,6 +208,15 @@ class Renderer:
         self._chk(self.L.enigma_debug_intersect_any(self.h, rays7.shape[0], abi.ptr(rays7), abi.ptr(out)))
         return out
 
+    def bsdf_eval(self, material, wo, wi, u):
+        """f, Pdf and sample_f of the material's BSDF at a +z surface for (wo, wi, u) triples: an (n, 12) array."""
+        wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+        wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((wo.shape[0], 12), dtype=np.float32)
+        self._chk(self.L.enigma_debug_bsdf(self.h, C.byref(material), wo.shape[0], abi.ptr(wo), abi.ptr(wi), abi.ptr(u), abi.ptr(out)))
+        return out
+
     def film_footprint(self, pfilm, max_per=64):
         pfilm = np.ascontiguousarray(pfilm, dtype=np.float32).reshape(-1, 2)
         n = pfilm.shape[0]
@@ -215,6 +225,16 @@ class Renderer:
         cnt = np.zeros(n, dtype=np.uint32)
         self._chk(self.L.enigma_debug_film_footprint(self.h, n, abi.ptr(pfilm), max_per, abi.ptr(pix), abi.ptr(w), abi.ptr(cnt)))
         return pix, w, cnt
+
+
+def default_metal_spectra():
+    """(eta rgb, k rgb) of a metal that names neither: the reference's copper (host code inside the library)."""
+    L = load_library()
+    eta, k = (C.c_float * 3)(), (C.c_float * 3)()
+    rc = L.enigma_default_metal_spectra(eta, k)
+    if rc != 0:
+        raise EnigmaError(rc, "enigma_default_metal_spectra")
+    return np.array(eta[:], dtype=np.float32), np.array(k[:], dtype=np.float32)
 
 
 def resolve(film_rgbw, scale=1.0):

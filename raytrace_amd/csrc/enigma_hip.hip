@@ -9,6 +9,7 @@
 #include "envmap_host.h"
 #include <memory>
 #include "sobol_host.h"
+#include "spectrum_host.h"
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -207,6 +208,59 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
 
 extern "C" const char* enigma_last_error(const EnigmaCtx* h) { return h ? h->error.c_str() : "null context"; }
 
+// Material::computeScatteringFunctions' parameter evaluation for constant parameters (Enigma/Material.cpp:76-255): kind,
+// clamped colours, roughness -> alpha.  Texture bindings and lobe presence are the caller's business.
+static bool convertMaterial(const EnigmaMaterial& m, DevMaterial& d) {
+    auto clamp01inf = [](float v) { return v < 0.f ? 0.f : v; }; // Spectrum::Clamp(0, inf)
+    auto remap = [](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
+    r = std::max(r, (float)1e-3);
+    float x = std::log(r);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+    };
+    float ur = m.uroughness, vr = m.vroughness;
+    float orenA = 0.f, orenB = 0.f;
+    bool specularGlass = false;
+    switch (m.type) {
+    case ENIGMA_MAT_MATTE:
+        d.kind = MK_MATTE;
+        for (int c = 0; c < 3; ++c) d.c0[c] = clamp01inf(m.kd[c]);
+        {   // sigma clamped to [0, 90] degrees; != 0 selects OrenNayer (Enigma/Material.cpp:86-91, Enigma/BxDF.cpp:744-753)
+            const float sig = std::min(std::max(m.sigma, 0.f), 90.f);
+            if (sig != 0.f) {
+                d.kind = MK_MATTE_ROUGH;
+                const float sigma = sig * (3.1415926535897932384f / 180.0f), sigma2 = sigma * sigma;
+                orenA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                orenB = (0.45f * sigma2) / (sigma2 + 0.09f);
+            }
+        }
+        break;
+    case ENIGMA_MAT_METAL:
+        d.kind = MK_METAL;
+        for (int c = 0; c < 3; ++c) { d.c0[c] = m.eta[c]; d.c1[c] = m.k[c]; }
+        if (m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
+        break;
+    case ENIGMA_MAT_GLASS:
+        specularGlass = (ur == 0.f && vr == 0.f);
+        d.kind = specularGlass ? MK_GLASS_SMOOTH : MK_GLASS_ROUGH;
+        for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kr[c]); d.c1[c] = clamp01inf(m.kt[c]); }
+        d.eta = m.index;
+        if (!specularGlass && m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
+        break;
+    case ENIGMA_MAT_PLASTIC:
+        d.kind = MK_PLASTIC;
+        for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kd[c]); d.c1[c] = clamp01inf(m.ks[c]); }
+        if (m.remap_roughness) ur = remap(ur);
+        vr = ur;
+        break;
+    default:
+        return false;
+    }
+    d.alphax = std::max(float(0.001), ur); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
+    d.alphay = std::max(float(0.001), vr);
+    if (d.kind == MK_MATTE_ROUGH) { d.alphax = orenA; d.alphay = orenB; } // the Oren-Nayar coefficients travel in the alpha slots
+    return true;
+}
+
 // An emissive triangle of a mesh with normals: the side of its plane that its vertex normals lie on, +1 for the side of
 // Cross(p1 - p0, p2 - p0), -1 for the other, 0 when they disagree or graze the plane.  Triangle::sample and
 // Triangle::intersect turn the geometric normal to face the interpolated one (Enigma/TriangleMesh.cpp:618-623,
@@ -308,12 +362,6 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     for (int k = 0; k < MK_COUNT; ++k) { h->kindPresent[k] = false; h->kindTextured[k] = false; }
     h->smoothGlass = false;
     h->glassBranches = h->glassSpecular = false;
-    auto clamp01inf = [](float v) { return v < 0.f ? 0.f : v; }; // Spectrum::Clamp(0, inf)
-    auto remap = [](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
-        r = std::max(r, (float)1e-3);
-        float x = std::log(r);
-        return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-    };
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         EnigmaMaterial m = s->materials[i];
         DevMaterial d;
@@ -330,47 +378,7 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             binds[b].value[0] = c.r; binds[b].value[1] = c.g; binds[b].value[2] = c.b;
             (binds[b].slot ? d.tex1 : d.tex0) = texDevice[binds[b].tex - 1];
         }
-        float ur = m.uroughness, vr = m.vroughness;
-        float orenA = 0.f, orenB = 0.f;
-        bool specularGlass = false;
-        switch (m.type) {
-        case ENIGMA_MAT_MATTE:
-            d.kind = MK_MATTE;
-            for (int c = 0; c < 3; ++c) d.c0[c] = clamp01inf(m.kd[c]);
-            {   // sigma clamped to [0, 90] degrees; != 0 selects OrenNayer (Enigma/Material.cpp:86-91, Enigma/BxDF.cpp:744-753)
-                const float sig = std::min(std::max(m.sigma, 0.f), 90.f);
-                if (sig != 0.f) {
-                    d.kind = MK_MATTE_ROUGH;
-                    const float sigma = sig * (3.1415926535897932384f / 180.0f), sigma2 = sigma * sigma;
-                    orenA = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
-                    orenB = (0.45f * sigma2) / (sigma2 + 0.09f);
-                }
-            }
-            break;
-        case ENIGMA_MAT_METAL:
-            d.kind = MK_METAL;
-            for (int c = 0; c < 3; ++c) { d.c0[c] = m.eta[c]; d.c1[c] = m.k[c]; }
-            if (m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
-            break;
-        case ENIGMA_MAT_GLASS:
-            specularGlass = (ur == 0.f && vr == 0.f);
-            d.kind = specularGlass ? MK_GLASS_SMOOTH : MK_GLASS_ROUGH;
-            for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kr[c]); d.c1[c] = clamp01inf(m.kt[c]); }
-            d.eta = m.index;
-            if (!specularGlass && m.remap_roughness) { ur = remap(ur); vr = remap(vr); }
-            break;
-        case ENIGMA_MAT_PLASTIC:
-            d.kind = MK_PLASTIC;
-            for (int c = 0; c < 3; ++c) { d.c0[c] = clamp01inf(m.kd[c]); d.c1[c] = clamp01inf(m.ks[c]); }
-            if (m.remap_roughness) ur = remap(ur);
-            vr = ur;
-            break;
-        default:
-            return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
-        }
-        d.alphax = std::max(float(0.001), ur); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
-        d.alphay = std::max(float(0.001), vr);
-        if (d.kind == MK_MATTE_ROUGH) { d.alphax = orenA; d.alphay = orenB; } // the Oren-Nayar coefficients travel in the alpha slots
+        if (!convertMaterial(m, d)) return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
         bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f;
         bool nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
         if (d.tex0) nb0 = true; // decided per hit
@@ -1414,6 +1422,12 @@ extern "C" int enigma_film_resolve(const float* rgbw, uint64_t n_pixels, float s
     return ENIGMA_OK;
 }
 
+extern "C" int enigma_default_metal_spectra(float eta_rgb[3], float k_rgb[3]) {
+    if (!eta_rgb || !k_rgb) return ENIGMA_E_INVALID;
+    enigma::default_metal_spectra(eta_rgb, k_rgb);
+    return ENIGMA_OK;
+}
+
 extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     if (!h || !out) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1613,6 +1627,42 @@ extern "C" int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float*
     return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     return debugIntersect(h, n, rays7, 1, hit_out, nullptr, nullptr, nullptr);
+    });
+}
+
+extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
+    if (!h || !material || !wo3 || !wi3 || !u2 || !out12) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n == 0) return ENIGMA_OK;
+    const EnigmaMaterial& m = *material;
+    if (m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k) return h->fail(ENIGMA_E_UNSUPPORTED, "the BSDF tap takes constant parameters only");
+    DevMaterial d;
+    memset(&d, 0, sizeof(d));
+    if (!convertMaterial(m, d)) return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
+    const bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f, nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
+    d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
+    DevBuf<float> dWo, dWi, dU, dOut;
+    hipError_t e = dWo.upload(std::vector<float>(wo3, wo3 + 3 * (size_t)n));
+    if (e == hipSuccess) e = dWi.upload(std::vector<float>(wi3, wi3 + 3 * (size_t)n));
+    if (e == hipSuccess) e = dU.upload(std::vector<float>(u2, u2 + 2 * (size_t)n));
+    if (e == hipSuccess) e = dOut.alloc((size_t)n * 12);
+    if (e == hipSuccess) {
+        const unsigned grid = (n + 255) / 256;
+        switch (d.kind) {
+        case MK_MATTE: k_debug_bsdf<MK_MATTE><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_MATTE_ROUGH: k_debug_bsdf<MK_MATTE_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_METAL: k_debug_bsdf<MK_METAL><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_GLASS_SMOOTH: k_debug_bsdf<MK_GLASS_SMOOTH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_GLASS_ROUGH: k_debug_bsdf<MK_GLASS_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        default: k_debug_bsdf<MK_PLASTIC><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        }
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(out12, dOut.p, (size_t)n * 12 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    dWo.release(); dWi.release(); dU.release(); dOut.release();
+    if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_bsdf: %s", hipGetErrorString(e));
+    return ENIGMA_OK;
     });
 }
 

@@ -670,10 +670,11 @@ private:
             m.sigma = p.FindOneFloat("sigma", 0.f);
         } else if (name == "metal") {
             m.type = ENIGMA_MAT_METAL;
-            // the reference's defaults are the sampled copper spectra (Material.cpp:604-605); their RGB needs the CIE tables
-            if ((!p.HasSpectrum("eta") && p.FindTexture("eta").empty()) || (!p.HasSpectrum("k") && p.FindTexture("k").empty())) throw std::runtime_error("metal: give \"rgb eta\" and \"rgb k\" explicitly (sampled-spectrum defaults are not supported)");
-            put(m.eta, p.FindOneSpectrum("eta", Spectrum(1.f))); bind("eta", m.eta, &m.tex_eta);
-            put(m.k, p.FindOneSpectrum("k", Spectrum(1.f))); bind("k", m.k, &m.tex_k);
+            // the reference's defaults are the sampled copper spectra (Material.cpp:604-608) as RGB
+            float cuEta[3], cuK[3];
+            if (enigma_default_metal_spectra(cuEta, cuK) != ENIGMA_OK) throw std::runtime_error("metal: default spectra unavailable");
+            put(m.eta, p.FindOneSpectrum("eta", Spectrum(cuEta[0], cuEta[1], cuEta[2]))); bind("eta", m.eta, &m.tex_eta);
+            put(m.k, p.FindOneSpectrum("k", Spectrum(cuK[0], cuK[1], cuK[2]))); bind("k", m.k, &m.tex_k);
             float rough = p.FindOneFloat("roughness", .5f);
             m.uroughness = p.FindOneFloat("uroughness", rough); // MetalMaterial: u/v fall back to roughness (Material.cpp:121-126)
             m.vroughness = p.FindOneFloat("vroughness", rough);

@@ -1378,6 +1378,24 @@ __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_
     tOut[i] = h.tri >= 0 ? h.t : EDEV_INF;
     baryOut[3 * (size_t)i] = h.b0; baryOut[3 * (size_t)i + 1] = h.b1; baryOut[3 * (size_t)i + 2] = h.b2;
 }
+// BSDF::f / Pdf / sample_f (Enigma/BxDF.cpp:885-985) of one material at a surface whose geometric and shading normal
+// are +z and whose dpdu is +x, for n (wo, wi, u) triples: out = f.rgb, Pdf, sampled f.rgb, sampled pdf, sampled wi.xyz, sampled type
+template <int MK>
+__global__ void k_debug_bsdf(DevMaterial m, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Bsdf b;
+    makeBsdf<MK>(m, F3(0.f, 0.f, 1.f), F3(0.f, 0.f, 1.f), F3(1.f, 0.f, 0.f), &b);
+    const F3 wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+    float* o = out12 + 12 * (size_t)i;
+    const F3 f = bsdfF<MK>(b, wo, wi, BSDF_ALL);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = bsdfPdf<MK>(b, wo, wi, BSDF_ALL);
+    F3 wis(0.f);
+    float pdf = 0.f;
+    int type = 0;
+    const F3 fs = bsdfSample<MK>(b, wo, &wis, u2[2 * i], u2[2 * i + 1], &pdf, BSDF_ALL, &type);
+    o[4] = fs.x; o[5] = fs.y; o[6] = fs.z; o[7] = pdf; o[8] = wis.x; o[9] = wis.y; o[10] = wis.z; o[11] = (float)type;
+}
 __global__ void k_debug_footprint(DevFilm F, uint32_t n, const float* pfilm, uint32_t maxPer, int32_t* pixOut, float* wOut, uint32_t* countOut) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -34,6 +34,9 @@ def lib(fast=False):
         L.oracle_fr_dielectric.argtypes = [C.c_float] * 3
         L.oracle_tr_D.argtypes = [C.c_float] * 5
         L.oracle_distribution1d.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_rgb_from_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_default_metal.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_spectral_tables.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_film_write_image.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_render.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
         L.oracle_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -41,6 +44,26 @@ def lib(fast=False):
         L.oracle_set_sobol_tables(abi.ptr(m32), abi.ptr(vdc), abi.ptr(vdci))
         _libs[name] = L
     return _libs[name]
+
+
+def rgb_from_sampled(lam, v):
+    """RGBSpectrum::FromSampled of the restatement."""
+    lam = np.ascontiguousarray(lam, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    lib().oracle_rgb_from_sampled(abi.ptr(lam), abi.ptr(v), C.c_int(lam.shape[0]), abi.ptr(out))
+    return out
+
+
+def default_metal():
+    eta, k = np.zeros(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+    lib().oracle_default_metal(abi.ptr(eta), abi.ptr(k))
+    return eta, k
+
+
+def spectral_tables():
+    cie, cu = np.zeros((4, 471), dtype=np.float32), np.zeros((3, 56), dtype=np.float32)
+    lib().oracle_spectral_tables(abi.ptr(cie), abi.ptr(cu))
+    return cie, cu
 
 
 class Oracle:

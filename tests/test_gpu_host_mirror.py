@@ -140,3 +140,39 @@ def test_scene_description_default_light_strategy_is_spatial(tmp_path):
     o.render(0, 8, threads=4)
     assert common.mean_relative_error(_read_pfm(out_file), o.image()) < 1e-3
     o.close()
+
+
+def test_scene_file_with_the_default_metal_renders_like_the_oracle_with_copper(tmp_path):
+    """Material "metal" that names neither eta nor k (CreateMetalMaterial's copper, roughness 0.5, remapped,
+    Enigma/Material.cpp:604-613): the scene file through enigma_render against the oracle given the oracle's own
+    RGBSpectrum::FromSampled of the copper tables."""
+    import math
+    import pbrt_writer
+    xres, yres, spp = 72, 48, 8
+    sc = scenes.cornell_box("microfacet")
+    eta, k = orc.default_metal()
+    idx = [i for i in range(sc.n_materials) if sc.materials[i].type == abi.MAT_METAL]
+    assert idx
+    for i in idx:
+        sc.materials[i] = abi.metal([float(v) for v in eta], [float(v) for v in k], roughness=0.5, remap=True)
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp)
+    lines = text.split("\n")
+    n_default = 0
+    for j, ln in enumerate(lines):
+        if '"metal"' in ln:    # drop every parameter: the front end must come up with the same material by itself
+            head = ln[:ln.index('"metal"') + len('"metal"')]
+            lines[j] = head
+            n_default += 1
+    assert n_default == len(idx)
+    scene_file, out_file = str(tmp_path / "copper.pbrt"), str(tmp_path / "out.pfm")
+    with open(scene_file, "w") as f:
+        f.write("\n".join(lines))
+    p = subprocess.run([EXE, scene_file, out_file], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    img = _read_pfm(out_file)
+    cam, film = scenes.cornell_camera(xres, yres), scenes.film_desc(xres, yres)
+    o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, spp))
+    o.render(0, spp, threads=4)
+    assert common.mean_relative_error(img, o.image()) < 1e-3
+    o.close()

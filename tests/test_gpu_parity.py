@@ -750,8 +750,43 @@ def test_full_size_film_invariants_1080p():
     img = ra.resolve(f)
     r.clear(); r.render(1020, 1022); r.render(1022, 1024)
     assert np.allclose(ra.resolve(r.film()), img, rtol=1e-4, atol=1e-5)
-    # a 270p slice of the same job agrees with the oracle
-    r.close()
+    # a 256 x 160 window of the same job (pixel bounds; full-size Sobol' indices, last sample numbers) against the oracle,
+    # pixel by pixel (min.x == min.y: the tile-row rule of test_pixel_bounds_and_crop_window)
+    integ_w = scenes.integrator_desc(film, 1024)
+    integ_w.pixel_bounds[:] = [500, 500, 756, 660]
+    r.set_integrator(integ_w)
+    r.clear(); r.render(1020, 1024)
+    o = orc.Oracle(sc, cam, film, integ_w)
+    o.render(1020, 1024, threads=16)
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])
+    win = (slice(500, 660), slice(500, 756))
+    a, b = r.image()[win], o.image()[win]
+    assert np.allclose(img[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)    # the window is a piece of the whole job
+    assert common.mean_relative_error(a, b) < 1e-4
+    r.close(); o.close()
+
+
+def test_cornell_512x512_16spp_against_the_oracle():
+    """BASELINE configs[0] at its own size: the diffuse Cornell box, 512 x 512, 16 spp, maxdepth 5, the whole image
+    against the CPU restatement (same sample numbers, same arithmetic up to libm and summation order).  Tolerances:
+    the north star's 1 % mean relative error and 3 sigma per pixel, and the much tighter agreement actually reached."""
+    setup = common.cornell_setup(res=512, spp=16, variant="diffuse")
+    r, o = pair(setup)
+    r.render(0, 16); o.render(0, 16, threads=16)
+    a, b = r.image(), o.image()
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])                                     # same pixels, same filter weights
+    mre = common.mean_relative_error(a, b)
+    assert mre < 0.01
+    assert mre < 1e-4
+    # 3 sigma of the Monte Carlo estimator per pixel: sigma from the spread of 16 one-sample images would need 16 more
+    # renders; the two images use the SAME samples, so their difference is far below any sampling noise: bound it directly
+    assert np.abs(a - b).max() < 0.05 * max(1.0, float(b.max()))
+    gs, os_ = r.stats(), o.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(gs[k]) - int(os_[k])) <= max(2, 1e-5 * os_[k]), k               # the same paths, ray for ray (exact-distance ties aside)
+    r.close(); o.close()
 
 
 def test_full_size_big_mesh_1080p():
@@ -790,6 +825,30 @@ def test_full_size_big_mesh_1080p():
     assert common.mean_relative_error(a, b) < 0.01
     assert np.median(np.abs(a - b) / np.maximum(b, 1e-3)) < 1e-5
     r.close(); o.close()
+
+
+def test_bsdf_point_evaluations_match_the_golden_fixture():
+    """BSDF::f, Pdf and sample_f (Enigma/BxDF.cpp:885-985) of the five material kinds at sixteen (wo, wi, u) triples each,
+    device against the fixture the oracle wrote (tools/make_golden.py) and against the oracle itself.  Values agree to a few
+    ulp (libm: sinf, cosf, tanf, atanf, sqrtf orders), sampled lobe types exactly."""
+    g = np.load(os.path.join(GOLD, "bsdf_points.npz"))
+    mats = {"matte": abi.matte((0.6, 0.5, 0.4)), "metal": abi.metal(scenes.COPPER_ETA, scenes.COPPER_K, 0.1),
+            "glass_rough": abi.glass(1.5, 0.05, 0.08), "glass_smooth": abi.glass(1.5, 0, 0), "plastic": abi.plastic((0.3, 0.3, 0.6), (0.4, 0.4, 0.4), 0.05)}
+    r = ra.Renderer(0)
+    wo, wi, u = g["wo"], g["wi"], g["u"]
+    for name, m in mats.items():
+        got, want = r.bsdf_eval(m, wo, wi, u), g[name]
+        assert np.array_equal(orc.bsdf_eval(m, wo, wi, u), want), name                 # the fixture is what the oracle says today
+        assert np.array_equal(got[:, 11], want[:, 11]), name                            # same lobe sampled
+        scale = np.maximum(np.abs(want[:, :11]), 1e-6)
+        assert (np.abs(got[:, :11] - want[:, :11]) / scale).max() < 2e-4, (name, (np.abs(got[:, :11] - want[:, :11]) / scale).max())
+    # a rough matte (Oren-Nayar) and anisotropic metal against the oracle directly
+    for m in (abi.matte((0.5, 0.6, 0.7), sigma=30.0), abi.metal(scenes.COPPER_ETA, scenes.COPPER_K, uroughness=0.05, vroughness=0.3)):
+        got, want = r.bsdf_eval(m, wo, wi, u), orc.bsdf_eval(m, wo, wi, u)
+        assert np.array_equal(got[:, 11], want[:, 11])
+        scale = np.maximum(np.abs(want[:, :11]), 1e-6)
+        assert (np.abs(got[:, :11] - want[:, :11]) / scale).max() < 2e-4
+    r.close()
 
 
 def test_error_conventions():

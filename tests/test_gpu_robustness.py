@@ -40,18 +40,20 @@ def test_failed_scene_upload_leaves_no_scene():
     r.close()
 
 
-def test_failed_integrator_config_leaves_no_integrator():
+def test_rejected_integrator_config_keeps_the_old_one():
+    """Arguments refused before anything is rewritten leave the configured integrator usable; the handle never
+    holds a half-rebuilt sampler (a failure after the rewrite has begun clears the integrator: haveInteg)."""
     r, sc, cam, film, integ = _renderer()
+    r.render(0, 1)
+    before = r.film()
     bad = copy.copy(integ)
     bad.samples_per_pixel = 0
     with pytest.raises(ra.EnigmaError) as e:
         r.set_integrator(bad)
     assert e.value.code == E_INVALID
-    with pytest.raises(ra.EnigmaError) as e:
-        r.render(0, 1)
-    assert e.value.code == E_STATE
-    r.set_integrator(integ)
-    r.render(0, 1)
+    r.clear()
+    r.render(0, 1)   # still the 4-spp integrator of the set-up
+    assert np.array_equal(r.film(), before)
     r.close()
 
 

@@ -102,3 +102,35 @@ def test_volpath_delta_lights_through_fog_and_sample_ranges_add_up():
     r.clear(); r.render(0, 5); r.render(5, 16)
     assert np.allclose(r.film(), whole, rtol=1e-5, atol=1e-5)
     r.close(); o.close()
+
+
+def test_volpath_full_size_1080p_invariants_and_window():
+    """The VolPathIntegrator at the BASELINE size (1920 x 1080 sampler and film): film invariants of one pass over the
+    fog scene, additivity of sample ranges, and a window of the same job against the oracle pixel by pixel."""
+    sc = scenes.cornell_fog("microfacet")
+    cam = scenes.cornell_camera(1920, 1080)
+    film = scenes.film_desc(1920, 1080)
+    integ = scenes.volpath_desc(film, 512)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(508, 512)
+    f = r.film()
+    st = r.stats()
+    assert st["camera_samples"] == 1920 * 1080 * 4
+    assert f[..., 3].min() >= 4 and f[..., 3].sum() - 4 * 1920 * 1080 < 0.01 * 4 * 1920 * 1080
+    assert np.isfinite(f).all() and f[..., :3].min() >= 0
+    whole = ra.resolve(f)
+    r.clear(); r.render(508, 510); r.render(510, 512)
+    assert np.allclose(ra.resolve(r.film()), whole, rtol=1e-4, atol=1e-5)
+    integ_w = scenes.volpath_desc(film, 512)
+    integ_w.pixel_bounds[:] = [700, 700, 892, 808]
+    r.set_integrator(integ_w)
+    r.clear(); r.render(508, 512)
+    o = orc.Oracle(sc, cam, film, integ_w)
+    o.render(508, 512, threads=16)
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])
+    win = (slice(700, 808), slice(700, 892))
+    a, b = r.image()[win], o.image()[win]
+    assert np.allclose(whole[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)
+    assert common.mean_relative_error(a, b) < 5e-3
+    r.close(); o.close()

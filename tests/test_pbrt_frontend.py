@@ -172,7 +172,6 @@ WorldEnd
     ('WorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd\n', "cylinder"),
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
-    ('WorldBegin\nMaterial "metal"\nWorldEnd\n', "eta"),
     ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),
     ('Sampler "halton"\nWorldBegin\nWorldEnd\n', "sobol"),
     ('Integrator "bdpt"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', "bdpt"),
@@ -186,6 +185,18 @@ WorldEnd
 def test_front_end_refuses_what_it_cannot_render(tmp_path, text, needle):
     err = dump(tmp_path, text, expect_fail=True)
     assert needle in err, err
+
+
+def test_metal_without_eta_and_k_is_the_reference_copper(tmp_path):
+    """CreateMetalMaterial's defaults (Enigma/Material.cpp:604-613): copper's spectra as RGB, roughness 0.5, remapped."""
+    import raytrace_amd as ra
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nMaterial "metal"\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\n'
+                       'Material "metal" "rgb k" [1 2 3]\nShape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1]\nWorldEnd\n')
+    eta, k = ra.default_metal_spectra()
+    m0, m1 = d["materials"][0], d["materials"][1]
+    assert m0["type"] == abi.MAT_METAL and m0["remap"] == 1 and m0["uroughness"] == 0.5 and m0["vroughness"] == 0.5
+    assert np.allclose(m0["eta"], eta, rtol=1e-6) and np.allclose(m0["k"], k, rtol=1e-6)
+    assert np.allclose(m1["eta"], eta, rtol=1e-6) and m1["k"] == [1, 2, 3]        # each default on its own
 
 
 def test_include_comments_and_named_materials(tmp_path):
