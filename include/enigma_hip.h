@@ -129,11 +129,10 @@ typedef struct EnigmaMedium {
 #define ENIGMA_NO_MATERIAL 0xffffffffu
 
 /* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or
- * partial (z range, phi sweep), any object-to-world transform.  Spheres are tested one by one beside the triangles'
- * BVH (at most ENIGMA_MAX_SPHERES of them).  A sphere may carry a DiffuseAreaLight
+ * partial (z range, phi sweep), any object-to-world transform.  Spheres are leaf entries of the BVH beside the
+ * triangles; triangles and spheres together number fewer than 2^28.  A sphere may carry a DiffuseAreaLight
  * (`light`); its sampling routines are the reference's: they cover the whole sphere whatever the z range and sweep,
  * and compare the object-space radius with world-space distances (Enigma/ShapeImp.cpp:210-310). */
-#define ENIGMA_MAX_SPHERES 256u
 typedef struct EnigmaSphere {
     float object_to_world[16]; /* Shape::m_objectToWorld->m_mat, row-major m[r][c] */
     float world_to_object[16]; /* Shape::m_worldToObject->m_mat */
@@ -253,6 +252,9 @@ typedef struct EnigmaStats {
     /* Wave-wide steps of the pooled traversal kernels: a step either fetches a node in every lane that is at one or
      * tests triangles in every lane that holds some.  nodes / (64 * node steps) = lanes busy in a node step. */
     uint64_t node_steps_closest, tri_steps_closest, node_steps_shadow, tri_steps_shadow;
+    /* Times a traversal found its per-lane stack full and dropped a subtree.  Always 0: the builder caps the tree at
+     * the 64 levels the stacks hold; anything else is a defect worth failing a test on. */
+    uint64_t stack_overflows;
 } EnigmaStats;
 
 typedef struct EnigmaCtx EnigmaCtx;
@@ -345,8 +347,10 @@ int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const
 int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy, const int64_t* sample_nums,
                              float* out_ray, float* out_pfilm);
 /* Scene::intersect / intersectP (Enigma/Scene.cpp:33-44) for n rays given as
- * o.xyz, d.xyz, tMax: closest-hit returns the triangle index (or -1), its
- * reference primitive id (0 on miss), t and barycentrics; any-hit returns 0/1. */
+ * o.xyz, d.xyz, tMax: closest-hit returns the triangle index (or -1; a sphere
+ * reports n_triangles + its index), its reference primitive id (0 on miss), t
+ * and barycentrics (for a sphere: the object-space hit point of
+ * Sphere::intersect, Enigma/ShapeImp.cpp:38-92); any-hit returns 0/1. */
 int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
                            uint32_t* prim_id_out, float* t_out, float* bary_out);
 int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out);

@@ -2839,7 +2839,6 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     // spheres: primitive index n_triangles + s in the per-primitive arrays
     sc.spheres.clear();
     BBox3 sphereBounds;
-    if (s->n_spheres > ENIGMA_MAX_SPHERES) { h->o.error = "too many spheres"; return -4; }
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const EnigmaSphere& e = s->spheres[i];
         if (e.material != ENIGMA_NO_MATERIAL && e.material >= s->n_materials) { h->o.error = "sphere material index out of range"; return -1; }

@@ -43,7 +43,6 @@ class EnigmaMedium(C.Structure):
     _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("reserved", C.c_uint32)]
 
 
-MAX_SPHERES = 256
 
 
 class EnigmaSphere(C.Structure):
@@ -97,7 +96,8 @@ class EnigmaStats(C.Structure):
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
                 ("nodes_mis", C.c_uint64), ("tris_mis", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
                 ("scene_in_lds", C.c_uint64), ("ms_shadow", C.c_double), ("shadow_launches", C.c_uint64),
-                ("node_steps_closest", C.c_uint64), ("tri_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64), ("tri_steps_shadow", C.c_uint64)]
+                ("node_steps_closest", C.c_uint64), ("tri_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64), ("tri_steps_shadow", C.c_uint64),
+                ("stack_overflows", C.c_uint64)]
 
 
 def ptr(a):

@@ -39,11 +39,15 @@ struct Builder {
     std::vector<TmpNode> nodes;
     uint32_t maxLeaf;
     static constexpr int kBins = 16;
+    // Below this depth the surface-area splits stop and ranges are halved by count, which ends within log2(count) more
+    // levels: a tree over up to 2^28 primitives is at most 64 levels deep whatever the geometry, the depth the traversal
+    // stacks are sized for.
+    static constexpr uint32_t kSahDepth = 36;
 
     Builder(const std::vector<Box>& tb, const std::vector<float>& c, std::vector<uint32_t>& o, uint32_t ml)
         : triBox(tb), centroid(c), order(o), maxLeaf(ml) {}
 
-    int build(uint32_t first, uint32_t count) {
+    int build(uint32_t first, uint32_t count, uint32_t depth = 0) {
         int id = (int)nodes.size();
         nodes.emplace_back();
         Box box, cbox;
@@ -62,6 +66,10 @@ struct Builder {
         if (ext[axis] <= 0.f) {
             if (count <= maxLeaf) return makeLeaf();
             // coincident centroids: split by count
+        } else if (depth >= kSahDepth) {
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t x, uint32_t y) {
+                return centroid[3 * (size_t)x + axis] < centroid[3 * (size_t)y + axis];
+            });
         } else {
             float bestCost = FLT_MAX;
             int bestAxis = -1, bestBin = -1;
@@ -112,8 +120,8 @@ struct Builder {
                 });
             }
         }
-        int l = build(first, mid - first);
-        int r = build(mid, first + count - mid);
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
         nodes[id].left = l;
         nodes[id].right = r;
         nodes[id].first = first; // an inner node's subtree covers one range of the order array too
@@ -122,95 +130,7 @@ struct Builder {
     }
 };
 
-void clearNode(Bvh4Node& n) {
-    memset(&n, 0, sizeof(n));
-    for (int c = 0; c < 4; ++c) {
-        n.lox[c] = n.loy[c] = n.loz[c] = FLT_MAX;
-        n.hix[c] = n.hiy[c] = n.hiz[c] = -FLT_MAX;
-        n.child[c] = kEmptyChild;
-    }
-}
-void setChildBox(Bvh4Node& n, int c, const Box& b) {
-    n.lox[c] = b.lo[0]; n.loy[c] = b.lo[1]; n.loz[c] = b.lo[2];
-    n.hix[c] = b.hi[0]; n.hiy[c] = b.hi[1]; n.hiz[c] = b.hi[2];
-}
-
 } // namespace
-
-void build_bvh(const float* vertices, const uint32_t* indices, uint32_t nTris, uint32_t maxLeaf, BvhResult* out) {
-    maxLeaf = std::max(1u, std::min(8u, maxLeaf));
-    std::vector<Box> triBox(nTris);
-    std::vector<float> centroid((size_t)nTris * 3);
-    for (uint32_t t = 0; t < nTris; ++t) {
-        for (int k = 0; k < 3; ++k) triBox[t].grow(&vertices[3 * (size_t)indices[3 * (size_t)t + k]]);
-        for (int a = 0; a < 3; ++a) centroid[3 * (size_t)t + a] = 0.5f * triBox[t].lo[a] + 0.5f * triBox[t].hi[a];
-    }
-    out->triOrder.resize(nTris);
-    for (uint32_t t = 0; t < nTris; ++t) out->triOrder[t] = t;
-    out->nodes.clear();
-    out->maxDepth = 1;
-    out->stackNeed = 3;
-    if (nTris == 0) {
-        Bvh4Node n;
-        clearNode(n);
-        out->nodes.push_back(n);
-        for (int a = 0; a < 3; ++a) { out->rootLo[a] = 0; out->rootHi[a] = 0; }
-        return;
-    }
-    Builder B(triBox, centroid, out->triOrder, maxLeaf);
-    B.nodes.reserve((size_t)nTris * 2);
-    int root = B.build(0, nTris);
-    for (int a = 0; a < 3; ++a) { out->rootLo[a] = B.nodes[root].box.lo[a]; out->rootHi[a] = B.nodes[root].box.hi[a]; }
-    auto leafRef = [](const TmpNode& n) -> int32_t { return ~(int32_t)((n.first << 3) | (n.count - 1)); };
-    if (B.nodes[root].left < 0) { // whole scene is one leaf
-        Bvh4Node n;
-        clearNode(n);
-        setChildBox(n, 0, B.nodes[root].box);
-        n.child[0] = leafRef(B.nodes[root]);
-        out->nodes.push_back(n);
-        return;
-    }
-    // Collapse to four children per node: start from the two children of a binary inner node and keep
-    // replacing the inner child with the largest box by its own two children.  Nodes are emitted in
-    // depth-first preorder (explicit stack; depth tracked for the traversal stack bound).
-    struct Item { int tmp; int outIndex; uint32_t depth; };
-    std::vector<Item> stack;
-    out->nodes.reserve(B.nodes.size() / 3 + 1);
-    out->nodes.emplace_back();
-    stack.push_back({root, 0, 1});
-    while (!stack.empty()) {
-        Item it = stack.back();
-        stack.pop_back();
-        out->maxDepth = std::max(out->maxDepth, it.depth);
-        int kids[4] = {B.nodes[it.tmp].left, B.nodes[it.tmp].right, -1, -1};
-        int nk = 2;
-        while (nk < 4) {
-            int best = -1;
-            float bestArea = -1.f;
-            for (int c = 0; c < nk; ++c) {
-                const TmpNode& k = B.nodes[kids[c]];
-                if (k.left >= 0 && k.box.area() > bestArea) { bestArea = k.box.area(); best = c; }
-            }
-            if (best < 0) break;
-            int opened = kids[best];
-            kids[best] = B.nodes[opened].left;
-            kids[nk++] = B.nodes[opened].right;
-        }
-        Bvh4Node n;
-        clearNode(n);
-        int slots[4] = {-1, -1, -1, -1};
-        for (int c = 0; c < nk; ++c) {
-            const TmpNode& k = B.nodes[kids[c]];
-            setChildBox(n, c, k.box);
-            if (k.left < 0) n.child[c] = leafRef(k);
-            else { n.child[c] = (int32_t)out->nodes.size(); slots[c] = n.child[c]; out->nodes.emplace_back(); }
-        }
-        out->nodes[it.outIndex] = n;
-        for (int c = nk - 1; c >= 0; --c) // first child's subtree is laid out next
-            if (slots[c] >= 0) stack.push_back({kids[c], slots[c], it.depth + 1});
-    }
-    out->stackNeed = 3 * out->maxDepth;
-}
 
 // ---------------------------------------------------------------- 8-wide compressed tree
 namespace {
@@ -228,11 +148,13 @@ uint8_t exponentFor(float extent) {
 
 } // namespace
 
-void build_bvh8(const float* vertices, const uint32_t* indices, uint32_t nTris, Bvh8Result* out) {
+void build_bvh8(const float* vertices, const uint32_t* indices, uint32_t nTriangles, const float* boxes, uint32_t nBoxes, Bvh8Result* out) {
+    const uint32_t nTris = nTriangles + nBoxes; // primitives of either kind from here on
     std::vector<Box> triBox(nTris);
     std::vector<float> centroid((size_t)nTris * 3);
     for (uint32_t t = 0; t < nTris; ++t) {
-        for (int k = 0; k < 3; ++k) triBox[t].grow(&vertices[3 * (size_t)indices[3 * (size_t)t + k]]);
+        if (t < nTriangles) for (int k = 0; k < 3; ++k) triBox[t].grow(&vertices[3 * (size_t)indices[3 * (size_t)t + k]]);
+        else { triBox[t].grow(&boxes[6 * (size_t)(t - nTriangles)]); triBox[t].grow(&boxes[6 * (size_t)(t - nTriangles) + 3]); }
         for (int a = 0; a < 3; ++a) centroid[3 * (size_t)t + a] = 0.5f * triBox[t].lo[a] + 0.5f * triBox[t].hi[a];
     }
     std::vector<uint32_t> order(nTris);

@@ -1,7 +1,7 @@
 // Sphere shapes (Enigma/ShapeImp.cpp:13-203): intersection with the reference's running-error arithmetic (Enigma/eFloat.h)
 // and error-carrying transforms (Enigma/Transform.h:212-330), and the surface interaction at a hit
-// (Enigma/Interaction.cpp:101-130, Enigma/Transform.cpp:322-356).  Spheres are not in the BVH: a ray that has finished its
-// walk through the triangles is tested against every sphere of the scene (a scene holds at most a few hundred).
+// (Enigma/Interaction.cpp:101-130, Enigma/Transform.cpp:322-356).  Spheres are leaf entries of the BVH beside the triangles
+// (dev_trace8.h).
 #pragma once
 #include "dev_common.h"
 #include "dev_types.h"
@@ -118,21 +118,6 @@ DEV bool sphereHit(const DevSphere& s, F3 wo_, F3 wd_, float tMaxRay, F3* pHitOu
     }
     *pHitOut = pHit; *dObjOut = d; *tOut = tShapeHit.v;
     return true;
-}
-
-// closest sphere hit closer than *t: updates (*prim, *t, *pHit); prim = nTris + sphere index
-DEV void sphereClosest(const DevScene& sc, F3 o, F3 d, int* prim, float* t, float* b0, float* b1, float* b2) {
-    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
-        F3 pHit, dObj; float th;
-        if (sphereHit(sc.spheres[i], o, d, *t, &pHit, &dObj, &th)) { *t = th; *prim = (int)(sc.nTris + i); *b0 = pHit.x; *b1 = pHit.y; *b2 = pHit.z; }
-    }
-}
-DEV bool sphereAny(const DevScene& sc, F3 o, F3 d, float tMax) {
-    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
-        F3 pHit, dObj; float th;
-        if (sphereHit(sc.spheres[i], o, d, tMax, &pHit, &dObj, &th)) return true;
-    }
-    return false;
 }
 
 // The SurfaceInteraction of a sphere hit in world space: p, pError, geometric normal, dpdu, and wo -- which the

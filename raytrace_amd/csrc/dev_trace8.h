@@ -17,8 +17,15 @@
 // a node form a bit mask whose bit order is the visiting order for this ray (slot ^ octant), and what is left of a
 // node's children waits on the stack as ONE entry (first child index + mask).  The stack is as deep as the tree, not
 // three entries per level.  Triangles of the hit leaves of a node form a 24-bit mask over the node's triangle range.
+//
+// Spheres are leaf entries like triangles (template flag SPH, the build for scenes that have any): a sphere owns a
+// slot of the triangle array whose first word pair says so (sign bit of v0.w set, sphere index below it), and the
+// triangle step of such a slot runs Sphere::intersect / intersectP (dev_sphere.h) instead.  A sphere hit is reported
+// as primitive sphereBase + sphere index, sphereBase = the number of slots of the triangle array, with the object-
+// space hit point in place of the barycentrics.
 #pragma once
 #include "dev_trace.h"
+#include "dev_sphere.h"
 
 namespace edev {
 
@@ -98,7 +105,8 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
 
 // Per-lane stack of node groups, two words an entry; the first LDSN levels in LDS (entry l of a lane at words
 // (2l) * STRIDE and (2l + 1) * STRIDE of its column: a lane always uses bank lane % 32), deeper levels in a private
-// array.  Behind the stack rows sit the lane's two visit tallies, as in LaneStack.
+// array.  Behind the stack rows sit the lane's two visit tallies
+// (nodes fetched, triangles tested since the block zeroed them: ds_add without return, no register lives across steps).
 template <int LDSN, int OVF, int STRIDE>
 struct GroupStack {
     static constexpr int kRows = 2 * LDSN;
@@ -112,7 +120,7 @@ struct GroupStack {
     DEV void push(uint32_t x, uint32_t y) {
         if (sp < LDSN) { lds[(2 * sp) * STRIDE] = x; lds[(2 * sp + 1) * STRIDE] = y; ++sp; }
         else if (OVF > 0 && sp < LDSN + OVF) { ov[2 * (sp - LDSN)] = x; ov[2 * (sp - LDSN) + 1] = y; ++sp; }
-        // deeper than LDSN + OVF cannot happen: the host refuses trees that deep
+        else atomicOr(&lds[(kRows + 1) * STRIDE], kStackFullFlag); // cannot happen (the host builds no tree this deep): reported, not silent
     }
     DEV bool pop(uint32_t* x, uint32_t* y) {
         if (sp == 0) return false;
@@ -184,12 +192,23 @@ DEV bool triangleAccepted(F3 p0, F3 p1, F3 p2) {
     return true;
 }
 
-template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4>
+// what the walkers of scenes with spheres know of them (uniform values)
+struct SphereRefs {
+    const DevSphere* table;
+    uint32_t base; // primitive number of sphere 0
+    DEV SphereRefs() : table(nullptr), base(0) {}
+    DEV SphereRefs(const DevScene& sc) : table(sc.spheres), base(sc.nTris) {}
+};
+DEV bool slotIsSphere(float4 v0) { return (__float_as_uint(v0.w) >> 31) != 0; }
+DEV uint32_t slotSphere(float4 v0) { return __float_as_uint(v0.w) & 0x7fffffffu; }
+
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false>
 struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
     static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
     Hit h;
-    DEV ClosestWalker8(uint32_t* column, uint32_t* spill) : Base(column, spill) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
+    SphereRefs spheres;
+    DEV ClosestWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs()) : Base(column, spill), spheres(sr) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
     DEV void start(F3 o, F3 d, float tMax) {
         Base::begin(o, d);
         h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
@@ -197,7 +216,15 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     DEV void testOne(const float4* tris) {
         const uint32_t tri = Base::takeTriangle();
         const float4* tp = tris + (size_t)tri * 3;
-        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        float4 v0 = tp[0];
+        if (SPH && slotIsSphere(v0)) { // Sphere::intersect
+            F3 pHit, dObj;
+            float th;
+            const uint32_t i = slotSphere(v0);
+            if (sphereHit(spheres.table[i], this->r.o, this->r.d, h.t, &pHit, &dObj, &th)) { h.t = th; h.tri = (int)(spheres.base + i); h.b0 = pHit.x; h.b1 = pHit.y; h.b2 = pHit.z; }
+            return;
+        }
+        float4 v1 = tp[1], v2 = tp[2];
         float t, b0, b1, b2;
         if (triangleTest(this->r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2) && triangleAccepted(xyz(v0), xyz(v1), xyz(v2))) {
             h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2;
@@ -227,13 +254,14 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
-template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4>
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false>
 struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
     static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
     float tMax;
     bool occluded;
-    DEV AnyWalker8(uint32_t* column, uint32_t* spill) : Base(column, spill), tMax(0.f), occluded(false) {}
+    SphereRefs spheres;
+    DEV AnyWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs()) : Base(column, spill), tMax(0.f), occluded(false), spheres(sr) {}
     DEV void start(F3 o, F3 d, float tMaxRay) {
         Base::begin(o, d);
         tMax = tMaxRay;
@@ -242,7 +270,14 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     DEV void testOne(const float4* tris) { // Triangle::intersectP
         const uint32_t tri = Base::takeTriangle();
         const float4* tp = tris + (size_t)tri * 3;
-        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        float4 v0 = tp[0];
+        if (SPH && slotIsSphere(v0)) { // Sphere::intersectP
+            F3 pHit, dObj;
+            float th;
+            if (sphereHit(spheres.table[slotSphere(v0)], this->r.o, this->r.d, tMax, &pHit, &dObj, &th)) { occluded = true; Base::finish(); }
+            return;
+        }
+        float4 v1 = tp[1], v2 = tp[2];
         float t, b0, b1, b2;
         if (triangleTest(this->r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) { occluded = true; Base::finish(); }
     }
@@ -268,38 +303,30 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
-// ---- which tree a kernel walks ----
-// W = 4: the 128-byte nodes with full-precision child boxes (dev_trace.h); W = 8: the compressed nodes above.
-// NS: 16-byte pieces between consecutive nodes (a copy of the scene in LDS staggers the wide nodes over the banks).
-template <int W> struct TreeLayout;
-template <> struct TreeLayout<4> { static constexpr int kNodeVec4 = 8, kLdsPitch = 9; };
-template <> struct TreeLayout<8> { static constexpr int kNodeVec4 = kNode8Vec4, kLdsPitch = kNode8Vec4; };
-template <int W, int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel;
-template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel<4, LDSN, OVF, STRIDE, LDS_SCENE> {
-    static constexpr int NS = LDS_SCENE ? TreeLayout<4>::kLdsPitch : TreeLayout<4>::kNodeVec4;
-    using Closest = ClosestWalker<LDSN, OVF, STRIDE, NS>;
-    using Any = AnyWalker<LDSN, OVF, STRIDE, NS>;
-};
-template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE> struct WalkerSel<8, LDSN, OVF, STRIDE, LDS_SCENE> {
-    static constexpr int NS = LDS_SCENE ? TreeLayout<8>::kLdsPitch : TreeLayout<8>::kNodeVec4;
-    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS>;
-    using Any = AnyWalker8<LDSN, OVF, STRIDE, NS>;
+// ---- the walkers of a kernel ----
+// NS: 16-byte pieces between consecutive nodes (the same in HBM and in a block's LDS copy of a small scene: five
+// pieces put consecutive nodes on different banks already).
+constexpr int kLdsNodePitch = kNode8Vec4;
+template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE, bool SPH = false> struct WalkerSel {
+    static constexpr int NS = LDS_SCENE ? kLdsNodePitch : kNode8Vec4;
+    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS, SPH>;
+    using Any = AnyWalker8<LDSN, OVF, STRIDE, NS, SPH>;
 };
 constexpr int spillWords(int ovf) { return 2 * (ovf > 0 ? ovf : 1); }
 
 // one ray per lane, start to finish (kernels that do not pool rays); column: the lane's LDS column of Closest::kWords rows
-template <int W, int LDSN, int OVF, int STRIDE, bool LDS_SCENE = false>
-DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE = false, bool SPH = false>
+DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column, SphereRefs sr = SphereRefs()) {
     uint32_t spill[spillWords(OVF)];
-    typename WalkerSel<W, LDSN, OVF, STRIDE, LDS_SCENE>::Closest w(column, spill);
+    typename WalkerSel<LDSN, OVF, STRIDE, LDS_SCENE, SPH>::Closest w(column, spill, sr);
     w.start(o, d, tMax);
     while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
     return w.h;
 }
-template <int W, int LDSN, int OVF, int STRIDE>
-DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column) {
+template <int LDSN, int OVF, int STRIDE, bool SPH = false>
+DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMax, uint32_t* column, SphereRefs sr = SphereRefs()) {
     uint32_t spill[spillWords(OVF)];
-    typename WalkerSel<W, LDSN, OVF, STRIDE, false>::Any w(column, spill);
+    typename WalkerSel<LDSN, OVF, STRIDE, false, SPH>::Any w(column, spill, sr);
     w.start(o, d, tMax);
     while (__ballot(!w.done()) != 0) w.step(nodes, tris);
     return w.occluded;

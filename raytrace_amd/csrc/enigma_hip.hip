@@ -87,7 +87,6 @@ struct EnigmaCtx {
     uint32_t refillIdle = 16;
     DevScene scene{};
     uint32_t bvhDepth = 0, bvhNodes = 0, bvhStack = 0;
-    int bvhWidth = 8; // 8: compressed 80-byte nodes (dev_trace8.h); 4: 128-byte nodes with full-precision boxes (scenes with spheres)
     double msBvhBuild = 0;
 
     // camera / film / integrator
@@ -391,74 +390,9 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         h->kindPresent[d.kind] = true;
         mats[i] = d;
     }
-    // BVH + triangle reorder.  Scenes with spheres keep the 4-wide tree: their kernels test the spheres beside it.
-    auto t0 = std::chrono::steady_clock::now();
-    int width = s->n_spheres ? 4 : 8;
-    if (const char* e = getenv("ENIGMA_BVH_WIDTH")) width = atoi(e) == 4 ? 4 : width; // measurement knob: the 4-wide tree for any scene
-    enigma::BvhResult bvh;
-    enigma::Bvh8Result bvh8;
-    if (width == 8) {
-        enigma::build_bvh8(s->vertices, s->indices, s->n_triangles, &bvh8);
-        bvh.triOrder = bvh8.triOrder;
-        bvh.maxDepth = bvh8.maxDepth;
-        bvh.stackNeed = bvh8.maxDepth; // one stack entry per level
-    } else {
-        uint32_t maxLeaf = 4;
-        if (const char* e = getenv("ENIGMA_BVH_MAX_LEAF")) maxLeaf = (uint32_t)atoi(e); // tuning knob, 1..8
-        enigma::build_bvh(s->vertices, s->indices, s->n_triangles, maxLeaf, &bvh);
-    }
-    h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (bvh.stackNeed > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH needs %u traversal stack entries (limit 64)", bvh.stackNeed);
-    h->bvhWidth = width;
-    h->bvhDepth = bvh.maxDepth;
-    h->bvhStack = bvh.stackNeed;
-    h->bvhNodes = (uint32_t)(width == 8 ? bvh8.nodes.size() : bvh.nodes.size());
-    std::vector<float4> triData((size_t)std::max(1u, s->n_triangles) * 3, make_float4(0, 0, 0, 0));
-    std::vector<uint32_t> newPos(s->n_triangles);
-    std::vector<float4> shadeData; // filled when some triangle has per-vertex normals or uvs
-    for (uint32_t k = 0; k < s->n_triangles; ++k) {
-        uint32_t t = bvh.triOrder[k];
-        newPos[t] = k;
-        const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
-        bool flip = (fl & ENIGMA_TRI_FLIP_NORMAL) != 0;
-        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0) // what FaceForward(n, shading.n) leaves, shading.n = -ns under ReverseOrientation;
-            flip = (emitterNormalSide(s, t) < 0) != ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) != 0); // the emission tests read it, the shading path turns n itself
-        const uint32_t bits = (flip ? 1u << 31 : 0u) | ((fl & ENIGMA_TRI_HAS_NORMALS) ? 1u << 27 : 0u) |
-                              ((fl & ENIGMA_TRI_HAS_UVS) ? 1u << 28 : 0u) | ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
-        const bool noMat = s->tri_material[t] == ENIGMA_NO_MATERIAL;
-        uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | bits : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | bits, (uint32_t)s->tri_light[t]};
-        if (fl & (ENIGMA_TRI_HAS_NORMALS | ENIGMA_TRI_HAS_UVS)) {
-            if (shadeData.empty()) shadeData.assign((size_t)s->n_triangles * 4, make_float4(0, 0, 0, 0));
-            float4* sd = &shadeData[(size_t)k * 4];
-            float uvw[6] = {0, 0, 0, 0, 0, 0};
-            for (int v = 0; v < 3; ++v) {
-                const size_t vi = s->indices[3 * (size_t)t + v];
-                if (fl & ENIGMA_TRI_HAS_UVS) { uvw[v] = s->uvs[2 * vi]; uvw[3 + v] = s->uvs[2 * vi + 1]; }
-                const float* n = (fl & ENIGMA_TRI_HAS_NORMALS) ? &s->normals[3 * vi] : nullptr;
-                sd[v] = make_float4(n ? n[0] : 0.f, n ? n[1] : 0.f, n ? n[2] : 0.f, uvw[v]);
-            }
-            sd[3] = make_float4(uvw[3], uvw[4], uvw[5], 0.f);
-        }
-        for (int v = 0; v < 3; ++v) {
-            const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
-            float wf;
-            memcpy(&wf, &w[v], 4);
-            triData[(size_t)k * 3 + v] = make_float4(p[0], p[1], p[2], wf);
-        }
-    }
-    std::vector<float4> nodeData;
-    if (width == 8) {
-        nodeData.resize(bvh8.nodes.size() * kNode8Vec4);
-        memcpy(nodeData.data(), bvh8.nodes.data(), bvh8.nodes.size() * sizeof(enigma::Bvh8Node));
-    } else {
-        nodeData.resize(bvh.nodes.size() * 8);
-        memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh4Node));
-    }
-    std::vector<uint32_t> prim(std::max(1u, s->n_triangles));
-    for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
-    // spheres (Enigma/ShapeImp.cpp:13-27): tested one by one beside the BVH, primitive index n_triangles + i
+    // spheres (Enigma/ShapeImp.cpp:13-27): leaf entries of the BVH beside the triangles
     std::vector<DevSphere> sphereTable;
-    if (s->n_spheres > ENIGMA_MAX_SPHERES) return h->fail(ENIGMA_E_UNSUPPORTED, "%u spheres (limit %u: spheres are not in the BVH)", s->n_spheres, ENIGMA_MAX_SPHERES);
+    if ((uint64_t)s->n_triangles + s->n_spheres >= (1u << 28)) return h->fail(ENIGMA_E_INVALID, "too many primitives");
     if (s->n_spheres && !s->spheres) return h->fail(ENIGMA_E_INVALID, "null sphere array");
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const EnigmaSphere& e = s->spheres[i];
@@ -485,6 +419,82 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         d.light = e.light;
         sphereTable.push_back(d);
     }
+    // Shape::worldBound: the eight corners of objectBound() through m_objectToWorld (Enigma/Transform.h:82-94, transformPoint :36-45)
+    auto sphereWorldBound = [](const DevSphere& sp, float* lo, float* hi) {
+        const float olo[3] = {-sp.radius, -sp.radius, sp.zMin}, ohi[3] = {sp.radius, sp.radius, sp.zMax};
+        for (int k = 0; k < 8; ++k) {
+            const float x = (k & 1) ? ohi[0] : olo[0], y = (k & 2) ? ohi[1] : olo[1], z = (k & 4) ? ohi[2] : olo[2];
+            for (int c = 0; c < 3; ++c) {
+                const float* m = &sp.o2w[4 * c];
+                const float q = m[0] * x + m[1] * y + m[2] * z + m[3];
+                lo[c] = std::min(lo[c], q); hi[c] = std::max(hi[c], q);
+            }
+        }
+    };
+    // BVH + reorder of the primitives.  A sphere enters the tree with its world bound, widened by a few ulps of its size
+    // and distance from the origin: the hit points that Sphere::intersect accepts carry rounding errors of that order.
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> sphereBoxes((size_t)s->n_spheres * 6);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        sphereWorldBound(sphereTable[i], lo, hi);
+        for (int c = 0; c < 3; ++c) {
+            const float pad = 1e-5f * ((hi[c] - lo[c]) + std::max(std::fabs(lo[c]), std::fabs(hi[c])));
+            sphereBoxes[6 * (size_t)i + c] = lo[c] - pad; sphereBoxes[6 * (size_t)i + 3 + c] = hi[c] + pad;
+        }
+    }
+    enigma::Bvh8Result bvh;
+    enigma::build_bvh8(s->vertices, s->indices, s->n_triangles, sphereBoxes.data(), s->n_spheres, &bvh);
+    h->msBvhBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bvh.maxDepth > 64) return h->fail(ENIGMA_E_UNSUPPORTED, "BVH of %u levels (the traversal stacks hold 64)", bvh.maxDepth);
+    h->bvhDepth = bvh.maxDepth;
+    h->bvhStack = bvh.maxDepth; // one stack entry per level
+    h->bvhNodes = (uint32_t)bvh.nodes.size();
+    // the triangle array in tree order: three float4 per slot; a sphere's slot holds its index (sign bit of the first word set)
+    const uint32_t nSlots = s->n_triangles + s->n_spheres;
+    std::vector<float4> triData((size_t)std::max(1u, nSlots) * 3, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> newPos(s->n_triangles);
+    std::vector<float4> shadeData; // filled when some triangle has per-vertex normals or uvs
+    for (uint32_t k = 0; k < nSlots; ++k) {
+        uint32_t t = bvh.triOrder[k];
+        if (t >= s->n_triangles) {
+            const uint32_t w[3] = {0x80000000u | (t - s->n_triangles), sphereTable[t - s->n_triangles].mw, 0xffffffffu};
+            for (int v = 0; v < 3; ++v) { float wf; memcpy(&wf, &w[v], 4); triData[(size_t)k * 3 + v] = make_float4(0.f, 0.f, 0.f, wf); }
+            continue;
+        }
+        newPos[t] = k;
+        const uint32_t fl = s->tri_flags ? s->tri_flags[t] : 0u;
+        bool flip = (fl & ENIGMA_TRI_FLIP_NORMAL) != 0;
+        if ((fl & ENIGMA_TRI_HAS_NORMALS) && s->tri_light[t] >= 0) // what FaceForward(n, shading.n) leaves, shading.n = -ns under ReverseOrientation;
+            flip = (emitterNormalSide(s, t) < 0) != ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) != 0); // the emission tests read it, the shading path turns n itself
+        const uint32_t bits = (flip ? 1u << 31 : 0u) | ((fl & ENIGMA_TRI_HAS_NORMALS) ? 1u << 27 : 0u) |
+                              ((fl & ENIGMA_TRI_HAS_UVS) ? 1u << 28 : 0u) | ((fl & ENIGMA_TRI_REVERSE_ORIENTATION) ? 1u << 29 : 0u);
+        const bool noMat = s->tri_material[t] == ENIGMA_NO_MATERIAL;
+        uint32_t w[3] = {t, noMat ? ((uint32_t)MK_NONE << 24) | bits : s->tri_material[t] | (mats[s->tri_material[t]].kind << 24) | bits, (uint32_t)s->tri_light[t]};
+        if (fl & (ENIGMA_TRI_HAS_NORMALS | ENIGMA_TRI_HAS_UVS)) {
+            if (shadeData.empty()) shadeData.assign((size_t)nSlots * 4, make_float4(0, 0, 0, 0));
+            float4* sd = &shadeData[(size_t)k * 4];
+            float uvw[6] = {0, 0, 0, 0, 0, 0};
+            for (int v = 0; v < 3; ++v) {
+                const size_t vi = s->indices[3 * (size_t)t + v];
+                if (fl & ENIGMA_TRI_HAS_UVS) { uvw[v] = s->uvs[2 * vi]; uvw[3 + v] = s->uvs[2 * vi + 1]; }
+                const float* n = (fl & ENIGMA_TRI_HAS_NORMALS) ? &s->normals[3 * vi] : nullptr;
+                sd[v] = make_float4(n ? n[0] : 0.f, n ? n[1] : 0.f, n ? n[2] : 0.f, uvw[v]);
+            }
+            sd[3] = make_float4(uvw[3], uvw[4], uvw[5], 0.f);
+        }
+        for (int v = 0; v < 3; ++v) {
+            const float* p = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + v]];
+            float wf;
+            memcpy(&wf, &w[v], 4);
+            triData[(size_t)k * 3 + v] = make_float4(p[0], p[1], p[2], wf);
+        }
+    }
+    std::vector<float4> nodeData(bvh.nodes.size() * kNode8Vec4);
+    memcpy(nodeData.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(enigma::Bvh8Node));
+    std::vector<uint32_t> prim(std::max(1u, nSlots)); // by the caller's primitive number: triangles, then spheres
+    for (uint32_t t = 0; t < s->n_triangles; ++t) prim[t] = s->tri_prim_id ? s->tri_prim_id[t] : t + 1;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) prim[s->n_triangles + i] = s->spheres[i].prim_id ? s->spheres[i].prim_id : s->n_triangles + i + 1;
     // lights (Enigma/Lights.cpp:89-129,560-651); Power().y() feeds the light distribution
     h->hostLights.assign(s->n_lights, DevLight());
     h->haveAreaLights = false;
@@ -499,17 +509,7 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             const float* p = &s->vertices[3 * (size_t)s->indices[k]];
             for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], p[c]); hi[c] = std::max(hi[c], p[c]); }
         }
-        for (const DevSphere& sp : sphereTable) { // Shape::worldBound: the eight corners of objectBound() through m_objectToWorld (Enigma/Transform.h:82-94)
-            const float olo[3] = {-sp.radius, -sp.radius, sp.zMin}, ohi[3] = {sp.radius, sp.radius, sp.zMax};
-            for (int k = 0; k < 8; ++k) {
-                const float x = (k & 1) ? ohi[0] : olo[0], y = (k & 2) ? ohi[1] : olo[1], z = (k & 4) ? ohi[2] : olo[2];
-                for (int c = 0; c < 3; ++c) { // Transform::transformPoint, Enigma/Transform.h:36-45
-                    const float* m = &sp.o2w[4 * c];
-                    const float q = m[0] * x + m[1] * y + m[2] * z + m[3];
-                    lo[c] = std::min(lo[c], q); hi[c] = std::max(hi[c], q);
-                }
-            }
-        }
+        for (const DevSphere& sp : sphereTable) sphereWorldBound(sp, lo, hi);
         for (int c = 0; c < 3; ++c) { h->worldLo[c] = lo[c]; h->worldHi[c] = hi[c]; }
         float ctr[3], d2 = 0.f;
         bool inside = true;
@@ -620,15 +620,16 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             for (int c = 0; c < 3; ++c) { md[i].sigmaT[c] = m.sigma_s[c] + m.sigma_a[c]; md[i].sigmaS[c] = m.sigma_s[c]; }
             md[i].g = m.g; md[i].pad = 0.f;
         }
-        std::vector<uint32_t> tm(haveMedia ? std::max(1u, s->n_triangles) + s->n_spheres : 0, 0u);
+        std::vector<uint32_t> tm(haveMedia ? std::max(1u, nSlots) + s->n_spheres : 0, 0u); // by primitive number on the device: slots, then spheres
         for (uint32_t i = 0; haveMedia && i < s->n_spheres; ++i) { // spheres follow the triangles; their ABI fields already hold index + 1
             const EnigmaSphere& e = s->spheres[i];
             if (e.medium_inside < 0 || e.medium_inside > (int32_t)s->n_media || e.medium_outside < 0 || e.medium_outside > (int32_t)s->n_media)
                 return h->fail(ENIGMA_E_INVALID, "sphere %u: medium index out of range", i);
-            tm[std::max(1u, s->n_triangles) + i] = (uint32_t)e.medium_inside | ((uint32_t)e.medium_outside << 16);
+            tm[std::max(1u, nSlots) + i] = (uint32_t)e.medium_inside | ((uint32_t)e.medium_outside << 16);
         }
-        for (uint32_t k = 0; k < ((haveMedia && triMedia) ? s->n_triangles : 0u); ++k) { // tm is sized by haveMedia
+        for (uint32_t k = 0; k < ((haveMedia && triMedia) ? nSlots : 0u); ++k) { // tm is sized by haveMedia
             uint32_t t = bvh.triOrder[k];
+            if (t >= s->n_triangles) continue;
             tm[k] = (uint32_t)(s->tri_medium_inside[t] + 1) | ((uint32_t)(s->tri_medium_outside[t] + 1) << 16);
         }
         HIPCHK(h, h->media.upload(md));
@@ -663,7 +664,7 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->scene.lights = h->lights.p;
     h->scene.primId = h->primId.p;
     h->scene.nLights = (int)s->n_lights;
-    h->scene.nTris = std::max(1u, s->n_triangles);
+    h->scene.nTris = std::max(1u, nSlots);
     h->scene.nNodes = h->bvhNodes;
     h->scene.nMaterials = s->n_materials;
     h->lightDistDirty = true;
@@ -982,8 +983,7 @@ static int ensureCapacity(EnigmaCtx* h, size_t n, size_t raysPerPath, size_t pen
 // Scenes up to this many bytes of nodes + triangles are traversed out of LDS (see stageSceneToLds).
 static constexpr size_t kLdsSceneBytes = 32 * 1024;
 static size_t sceneLdsBytes(const EnigmaCtx* h) {
-    const size_t pitch = h->bvhWidth == 8 ? TreeLayout<8>::kLdsPitch : TreeLayout<4>::kLdsPitch;
-    return ((size_t)h->scene.nNodes * pitch + (size_t)h->scene.nTris * 3) * sizeof(float4);
+    return ((size_t)h->scene.nNodes * kLdsNodePitch + (size_t)h->scene.nTris * 3) * sizeof(float4);
 }
 
 // triangles + materials + lights + light distribution, as k_shade stages them
@@ -1019,7 +1019,7 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
         if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
 }
 
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -1031,7 +1031,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(ev.c1, s);
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1045,16 +1045,16 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One iteration of VolPathIntegrator::Li's loop for every path in flight (Enigma/VolPathIntegrator.cpp:63-174):
 // trace + medium sampling, then the surface, medium and boundary branches, then the shadow and MIS rays.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int iter, int gridTrace,
                             int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -1066,7 +1066,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                               h->refillIdle, nullptr);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1082,17 +1082,17 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
 // One step of the depth-first walk of DirectLightingIntegrator::Li's recursion for every path in flight:
 // trace the current rays, shade the hits (direct lighting + the specular children), resume pending branches
 // of the paths that missed, then the shadow and MIS rays of this step.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths,
                              int step, int gridTrace, int gridShadow, int gridShade, const StepEvents& ev) {
     DevCounters* ctr = h->counters.p;
@@ -1104,7 +1104,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
                                                                                                                  h->refillIdle, D.pendCount);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
@@ -1120,10 +1120,10 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH, W><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
-        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH, W><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
+        if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
 }
 
@@ -1152,7 +1152,8 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
-    // traversal flavour: scene in LDS (shallow tree) | all stack levels in LDS | 12 levels in LDS + scratch spill
+    // traversal flavour: scene in LDS (small scene, shallow tree) | all stack levels in LDS | 11 levels in LDS + a private spill array;
+    // scenes with spheres: the last one, with the sphere test compiled in
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
     const bool ldsScene = h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
     h->stats.scene_in_lds = ldsScene ? 1 : 0;
@@ -1202,14 +1203,9 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             for (int step = 0; direct; ++step) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
-                if (h->scene.nSpheres) launchDirectStep<12, 52, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhWidth == 8) {
-                    if (ldsScene) launchDirectStep<12, 0, true, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                    else if (h->bvhStack <= 11) launchDirectStep<11, 0, false, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                    else launchDirectStep<11, 53, false, false, 8>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                }
+                if (h->scene.nSpheres) launchDirectStep<11, 53, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhStack <= 12) launchDirectStep<12, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 11) launchDirectStep<11, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 else launchDirectStep<11, 53, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
                 uint32_t alive = 0;
@@ -1223,14 +1219,9 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             for (int iter = 0; vol; ++iter) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
-                if (h->scene.nSpheres) launchVolBounce<12, 52, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhWidth == 8) {
-                    if (ldsScene) launchVolBounce<12, 0, true, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                    else if (h->bvhStack <= 11) launchVolBounce<11, 0, false, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                    else launchVolBounce<11, 53, false, false, 8>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                }
+                if (h->scene.nSpheres) launchVolBounce<11, 53, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhStack <= 12) launchVolBounce<12, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 11) launchVolBounce<11, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 else launchVolBounce<11, 53, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
                 uint32_t alive = 0;
@@ -1242,14 +1233,9 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             for (int b = 0; !direct && !vol && b <= h->integ.maxDepth; ++b) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
-                if (h->scene.nSpheres) launchBounce<12, 52, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhWidth == 8) {
-                    if (ldsScene) launchBounce<12, 0, true, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                    else if (h->bvhStack <= 11) launchBounce<11, 0, false, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                    else launchBounce<11, 53, false, false, 8>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                }
+                if (h->scene.nSpheres) launchBounce<11, 53, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                else if (h->bvhStack <= 12) launchBounce<12, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else if (h->bvhStack <= 11) launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
             }
@@ -1440,19 +1426,20 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     {   // traversal tallies: one slot per block of a launch, summed here
         std::vector<unsigned long long> v(h->visits.n);
         HIPCHK(h, hipMemcpy(v.data(), h->visits.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        uint64_t dummy[2];
-        uint64_t* outs[kVisitKinds * kVisitTallies] = {&h->stats.nodes_closest, &h->stats.tris_closest, &h->stats.node_steps_closest, &h->stats.tri_steps_closest,
-                                                       &h->stats.nodes_shadow, &h->stats.tris_shadow, &h->stats.node_steps_shadow, &h->stats.tri_steps_shadow,
-                                                       &h->stats.nodes_mis, &h->stats.tris_mis, &dummy[0], &dummy[1]};
+        uint64_t unused[2], full[kVisitKinds];
+        uint64_t* outs[kVisitKinds * kVisitTallies] = {&h->stats.nodes_closest, &h->stats.tris_closest, &h->stats.node_steps_closest, &h->stats.tri_steps_closest, &full[0],
+                                                       &h->stats.nodes_shadow, &h->stats.tris_shadow, &h->stats.node_steps_shadow, &h->stats.tri_steps_shadow, &full[1],
+                                                       &h->stats.nodes_mis, &h->stats.tris_mis, &unused[0], &unused[1], &full[2]};
         for (uint32_t k = 0; k < kVisitKinds * kVisitTallies; ++k) {
             uint64_t sum = 0;
             for (uint32_t i = 0; i < kVisitSlots; ++i) sum += v[(size_t)k * kVisitSlots + i];
             *outs[k] = sum;
         }
+        h->stats.stack_overflows = full[0] + full[1] + full[2];
     }
     h->stats.bvh_nodes = h->bvhNodes;
     h->stats.bvh_depth = h->bvhDepth;
-    h->stats.bvh_node_bytes = h->bvhWidth == 8 ? sizeof(enigma::Bvh8Node) : sizeof(enigma::Bvh4Node);
+    h->stats.bvh_node_bytes = sizeof(enigma::Bvh8Node);
     h->stats.ms_bvh_build = h->msBvhBuild;
     *out = h->stats;
     return ENIGMA_OK;
@@ -1529,20 +1516,21 @@ extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t*
     });
 }
 
+template <bool SPH>
+static void launchDebugIntersect(EnigmaCtx* h, int grid, uint32_t n, const float* dRays, int anyHit, int32_t* dTri, uint32_t* dPrim, float* dT, float* dB) {
+    // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the private spill array hard
+    if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    else if (h->bvhStack <= 12) k_debug_intersect<12, 0, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    else k_debug_intersect<12, 52, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+}
+
 // Launches the intersection tap over rays already on the device and brings the results back; the staging buffers
 // are the caller's (device memory of the call, or the fixed scratch array of the entry point that allocates nothing).
 static hipError_t debugIntersectRun(EnigmaCtx* h, uint32_t n, const float* dRays, int anyHit, int32_t* dTri, uint32_t* dPrim, float* dT, float* dB,
                                     int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
     int grid = (int)((n + kBlock - 1) / kBlock);
-    // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the scratch spill path hard
-    if (h->bvhWidth == 8) {
-        if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
-        else if (h->bvhStack <= 12) k_debug_intersect<12, 0, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
-        else k_debug_intersect<12, 52, 8><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
-    }
-    else if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
-    else if (h->bvhStack <= 12) k_debug_intersect<12, 0><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
-    else k_debug_intersect<12, 52><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    if (h->scene.nSpheres) launchDebugIntersect<true>(h, grid, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    else launchDebugIntersect<false>(h, grid, n, dRays, anyHit, dTri, dPrim, dT, dB);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(triOut, dTri, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && !anyHit) {
@@ -1556,7 +1544,6 @@ static hipError_t debugIntersectRun(EnigmaCtx* h, uint32_t n, const float* dRays
 
 static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyHit, int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
     if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
-    if (h->scene.nSpheres) return h->fail(ENIGMA_E_UNSUPPORTED, "the intersection taps cover triangles only; the scene has spheres");
     if (n == 0) return ENIGMA_OK;
     DevBuf<float> dRays, dT, dB; DevBuf<int32_t> dTri; DevBuf<uint32_t> dPrim;
     std::vector<float> r(rays7, rays7 + 7 * (size_t)n);
@@ -1596,7 +1583,6 @@ extern "C" int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const fl
     if (!h || !rays7 || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
-    if (h->scene.nSpheres) return h->fail(ENIGMA_E_UNSUPPORTED, "the intersection taps cover triangles only; the scene has spheres");
     if (n > ENIGMA_NOALLOC_MAX_RAYS) return h->fail(ENIGMA_E_INVALID, "%u rays exceed the %u the fixed staging array holds", n, (unsigned)ENIGMA_NOALLOC_MAX_RAYS);
     if (n == 0) return ENIGMA_OK;
     uint32_t* base = (h->device >= 0 && h->device < kMaxDevices) ? g_scratchPtr[h->device] : nullptr;

@@ -157,15 +157,12 @@ static_assert(kWavesPerBlock == 4, "blockReserve3 lays its counts out for four w
 // Scenes whose BVH nodes + triangles fit a few tens of KB (the Cornell-box configurations) are copied
 // into LDS by every traversal block before it starts: node and triangle fetches become ds_read_b128
 // instead of 64 divergent 16-byte requests per wave-instruction through the texture-address path,
-// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 9 float4 apart][tris: 3 float4 each].
-// Nodes sit 9 float4 apart in LDS (144 bytes = 36 banks): lanes at different nodes then read from
-// different banks, where a 128-byte pitch would put every other node on the same ones.
-template <int W>
+// which is what bounds traversal of a cache-resident scene.  Layout: [nodes: 5 float4 each][tris: 3 float4 each]
+// (80-byte nodes start 20 banks apart: lanes at neighbouring nodes read from different banks).
 DEV void stageSceneToLds(const DevScene& sc, float4* lds) {
-    constexpr uint32_t kVec = TreeLayout<W>::kNodeVec4, kPitch = TreeLayout<W>::kLdsPitch;
-    const uint32_t nN = sc.nNodes * kVec, nT = sc.nTris * 3u;
-    for (uint32_t i = threadIdx.x; i < nN; i += kBlock) lds[(i / kVec) * kPitch + (i % kVec)] = sc.nodes[i];
-    for (uint32_t i = threadIdx.x; i < nT; i += kBlock) lds[sc.nNodes * kPitch + i] = sc.tris[i];
+    const uint32_t n = sc.nNodes * kLdsNodePitch + sc.nTris * 3u;
+    const uint32_t nN = sc.nNodes * kLdsNodePitch;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) lds[i] = i < nN ? sc.nodes[i] : sc.tris[i - nN];
     __syncthreads();
 }
 
@@ -274,13 +271,9 @@ __global__ void __launch_bounds__(kBlock) k_sphere_surface(DevScene sc, DevPaths
     }
 }
 
-// A ray that has finished its walk through the triangles' BVH still has the scene's spheres to meet.  The traversal
-// kernels exist in two builds (template flag SPH): scenes without spheres run code that knows nothing of them -- with the
-// sphere test inlined, its registers cost the BVH walk a third of its speed.
-template <bool SPH>
-DEV void finishClosest(const DevScene& sc, const RaySetup& r, Hit* h) {
-    if (SPH) sphereClosest(sc, r.o, r.d, &h->tri, &h->t, &h->b0, &h->b1, &h->b2);
-}
+// The traversal kernels exist in two builds (template flag SPH): scenes without spheres run code that knows nothing of
+// them -- with the sphere test inlined, its registers cost the BVH walk a third of its speed.  A sphere's primitive
+// number is sc.nTris + its index (sc.nTris counts the slots of the triangle array, the spheres' own included).
 template <bool SPH>
 DEV bool isSpherePrim(const DevScene& sc, int prim) { return SPH && prim >= (int)sc.nTris; }
 // the second triangle word of a primitive of either kind
@@ -364,13 +357,13 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
 // MODE 2: the head of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:63-111): a ray that travels in a medium
 // samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
 // medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
-template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     constexpr int NK = MODE == 0 ? MK_COUNT : (MODE == 1 ? MK_COUNT + 1 : kQueueKinds);
-    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];
     __shared__ uint32_t binBase[kQueueKinds];
@@ -382,7 +375,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nodeSteps = 0, triSteps = 0;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -391,7 +384,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        Walker w(stack + threadIdx.x, spill);
+        Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
         uint32_t pos = kNoRay, p = 0, state = 0;
         bool exhausted = false;
         for (;;) {
@@ -402,7 +395,6 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
                     uint32_t kind = 0;
                     Hit h = w.h;
-                    finishClosest<SPH>(sc, w.r, &h);
                     bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
                     if (VOL && stMedium(state) != 0) {
                         const DevMedium md = sc.media[stMedium(state) - 1u];
@@ -1138,9 +1130,9 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
-    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Any;
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Any;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t poolNext;
     __shared__ uint32_t red[2 * kWavesPerBlock];
@@ -1150,14 +1142,14 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
     if (blockIdx.x * kTraceChunk >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nodeSteps = 0, triSteps = 0;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
         const uint32_t chunkCount = min(kTraceChunk, count - chunk);
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
-        Walker w(stack + threadIdx.x, spill);
+        Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
         uint32_t p = kNoRay;
         F3 contrib(0.f); // fetched with the ray: no dependent load when the ray is through
         bool exhausted = false;
@@ -1167,7 +1159,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
             uint32_t nIdle = __popcll(idleMask);
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && p != kNoRay) {
-                    if (!w.occluded && !(SPH && sphereAny(sc, w.r.o, w.r.d, w.tMax))) {
+                    if (!w.occluded) {
                         if (shq.perPath == 1) { // the path's only ray in this kernel: nobody else touches its L
                             float4 L = P.L[p];
                             P.L[p] = make_float4(L.x + contrib.x, L.y + contrib.y, L.z + contrib.z, 0.f);
@@ -1204,9 +1196,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevR
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
 // the sampled light's triangle.  Few rays per bounce (only those that hit the light's own triangle
 // are queued), one per lane.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
@@ -1214,14 +1206,13 @@ __global__ void __launch_bounds__(kBlock) k_mis(DevScene sc, DevPaths P, DevRayQ
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
         uint32_t p = misq.idx[i];
         float4 o = misq.o[p], d = misq.d[p];
-        Hit h = traceClosest<W, LDSN, OVF, kBlock, LDS_SCENE>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x);
-        if (SPH) {
-            sphereClosest(sc, xyz(o), xyz(d), &h.tri, &h.t, &h.b0, &h.b1, &h.b2);
+        Hit h = traceClosest<LDSN, OVF, kBlock, LDS_SCENE, SPH>(nodes, tris, xyz(o), xyz(d), EDEV_INF, stack + threadIdx.x, SphereRefs(sc));
+        {
             if (isSpherePrim<SPH>(sc, h.tri)) { // lightIsect.Le(-wi) of an emissive sphere, if it is the sampled light
                 const DevSphere& sp = sc.spheres[h.tri - (int)sc.nTris];
                 if ((int)sp.light - 1 != __float_as_int(d.w)) continue;
@@ -1358,21 +1349,22 @@ __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int3
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
     outPfilm[2 * (size_t)i] = fx; outPfilm[2 * (size_t)i + 1] = fy;
 }
-template <int LDSN, int OVF, int W = 4>
+template <int LDSN, int OVF, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_t n, const float* rays7, int anyHit, int32_t* triOut,
                                                             uint32_t* primOut, float* tOut, float* baryOut) {
-    __shared__ uint32_t stack[WalkerSel<W, LDSN, OVF, kBlock, false>::Closest::kWords * kBlock]; // the walkers tally into the last two rows
+    __shared__ uint32_t stack[WalkerSel<LDSN, OVF, kBlock, false, SPH>::Closest::kWords * kBlock]; // the walkers tally into the last two rows
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
     F3 o(r[0], r[1], r[2]), d(r[3], r[4], r[5]);
     if (anyHit) {
-        triOut[i] = traceAny<W, LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x) ? 1 : 0;
+        triOut[i] = traceAny<LDSN, OVF, kBlock, SPH>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x, SphereRefs(sc)) ? 1 : 0;
         return;
     }
-    Hit h = traceClosest<W, LDSN, OVF, kBlock>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x);
-    int orig = -1;
-    if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
+    Hit h = traceClosest<LDSN, OVF, kBlock, false, SPH>(sc.nodes, sc.tris, o, d, r[6], stack + threadIdx.x, SphereRefs(sc));
+    int orig = -1; // the primitive's number in the caller's arrays: triangles first, then spheres
+    if (isSpherePrim<SPH>(sc, h.tri)) orig = h.tri - (int)sc.nTris + (int)(sc.nTris - sc.nSpheres);
+    else if (h.tri >= 0) orig = __float_as_int(sc.tris[(size_t)h.tri * 3].w);
     triOut[i] = orig;
     primOut[i] = orig >= 0 ? sc.primId[orig] : 0u;
     tOut[i] = h.tri >= 0 ? h.t : EDEV_INF;

@@ -198,9 +198,9 @@ DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, 
 // end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
 // without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
 // far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
-    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
@@ -209,13 +209,13 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;
-        Walker w(stack + threadIdx.x, spill);
+        Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
         uint32_t p = 0, med = 0;
         F3 o(0.f), d(0.f), contrib(0.f), Tr(1.f), lp(0.f), lpErr(0.f), ln(0.f);
         if (active) {
@@ -231,7 +231,6 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
         while (__ballot(active) != 0) {
             if (active && w.done()) {
                 Hit h = w.h;
-                finishClosest<SPH>(sc, w.r, &h);
                 bool hit = h.tri >= 0;
                 uint32_t kind = MK_NONE;
                 if (hit) kind = triKind(primWord<SPH>(sc, tris, h.tri));
@@ -267,9 +266,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
 // Scene::intersectTr for the MIS rays of one bounce: closest-hit queries through material-less surfaces
 // (isect.SpawnRay(ray.m_dir)), attenuated by the media on the way; the first surface with a material must be
 // the sampled light's triangle.  Every query counts as a MIS ray.
-template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false, int W = 4>
+template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevRayQueue misq, DevCounters* ctr) {
-    using Walker = typename WalkerSel<W, LDSN, OVF, kBlock, LDS_SCENE>::Closest;
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
@@ -278,13 +277,13 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
     if (blockIdx.x * kBlock >= count) return;
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
-    if (LDS_SCENE) { stageSceneToLds<W>(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * TreeLayout<W>::kLdsPitch; }
+    if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nQueries = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;
-        Walker w(stack + threadIdx.x, spill);
+        Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
         uint32_t p = 0, med = 0;
         int wantLight = -1;
         F3 o(0.f), d(0.f), Tr(1.f);
@@ -298,7 +297,6 @@ __global__ void __launch_bounds__(kBlock) k_mis_tr(DevScene sc, DevPaths P, DevR
         while (__ballot(active) != 0) {
             if (active && w.done()) {
                 Hit h = w.h;
-                finishClosest<SPH>(sc, w.r, &h);
                 bool hit = h.tri >= 0;
                 if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : EDEV_INF);
                 if (!hit) {

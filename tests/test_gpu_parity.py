@@ -543,8 +543,8 @@ def test_image_parity_spheres_without_material():
 
 
 def test_spheres_alone_and_refusals():
-    """A scene without a single triangle; more spheres than the limit, a sphere with a trilinear texture and the
-    intersection taps on a scene with spheres are refused."""
+    """A scene without a single triangle, through the image and the intersection taps; a sphere whose medium index is
+    out of range is refused."""
     b = scenes.MeshBuilder()
     b.add_sphere(b.add_material(abi.matte((0.5, 0.5, 0.5))), radius=5.0)
     b.add_sphere(b.add_material(abi.glass(1.5, 0.0, 0.0)), radius=2.0, object_to_world=scenes._translation(0, 9, 0))
@@ -558,17 +558,14 @@ def test_spheres_alone_and_refusals():
     r.render(0, 8); o.render(0, 8, threads=4)
     assert r.image().max() > 0
     assert common.mean_relative_error(r.image(), o.image()) < 1e-3
-    with pytest.raises(ra.EnigmaError) as e:
-        r.intersect(np.array([[0, 40, 0, 0, -1, 0, 1e30]], np.float32))
-    assert e.value.code == -4
+    rays = np.array([[0, 40, 0, 0, -1, 0, 1e30], [0, 40, 0, 0, 1, 0, 1e30], [0.5, 40, 0.5, 0, -1, 0, 25.0]], np.float32)
+    hit = r.intersect(rays)
+    ref = o.intersect(rays, ambiguous=False)
+    assert hit["tri"].tolist() == [1, -1, -1] == ref["tri"].tolist()      # the glass ball above the matte one; away; tMax short of it
+    assert np.array_equal(hit["t"], ref["t"]) and hit["prim_id"].tolist() == [2, 0, 0]
+    assert r.intersect_any(rays).tolist() == o.intersect_any(rays).tolist() == [1, 0, 0]
+    assert r.stats()["stack_overflows"] == 0
     r.close(); o.close()
-    many = scenes.MeshBuilder()
-    m = many.add_material(abi.matte((0.5, 0.5, 0.5)))
-    for i in range(abi.MAX_SPHERES + 1):
-        many.add_sphere(m, radius=1.0, object_to_world=scenes._translation(3.0 * i, 0, 0))
-    with pytest.raises(ra.EnigmaError) as e:
-        ra.Renderer(0).configure(many.arrays(), cam, film, integ)
-    assert e.value.code == -4
     one = scenes.MeshBuilder()
     one.add_sphere(one.add_material(abi.matte((0.5, 0.5, 0.5))), radius=1.0)
     one.add_medium(abi.homogeneous_medium((0.1, 0.1, 0.1), (0.1, 0.1, 0.1), 0.0))
@@ -577,6 +574,67 @@ def test_spheres_alone_and_refusals():
     with pytest.raises(ra.EnigmaError) as e:
         ra.Renderer(0).configure(one.arrays(), cam, film, integ)
     assert e.value.code == -1
+
+
+def _sphere_cloud(n, seed=11, with_floor=True):
+    """n small spheres (some partial, some scaled and turned) over a floor of two triangles, lit by a point light and
+    an emissive sphere."""
+    rng = np.random.default_rng(seed)
+    b = scenes.MeshBuilder()
+    mats = [b.add_material(abi.matte((0.6, 0.5, 0.4))), b.add_material(abi.glass(1.5, 0.0, 0.0)), b.add_material(abi.matte((0.2, 0.6, 0.7)))]
+    if with_floor:
+        b.add_quad([(-60, 0, -60), (60, 0, -60), (60, 0, 60), (-60, 0, 60)], mats[0])
+    for i in range(n):
+        c = rng.uniform((-50, 1, -50), (50, 30, 50))
+        m = np.eye(4)
+        m[:3, :3] = np.diag(rng.uniform(0.6, 1.6, 3)) if i % 5 == 0 else np.eye(3)
+        if i % 7 == 0:
+            a = rng.uniform(0, np.pi)
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            m[:3, :3] = rot @ m[:3, :3]
+        m[:3, 3] = c
+        kw = dict(z_min=-0.5, z_max=0.8, phi_max=270.0) if i % 11 == 0 else {}
+        b.add_sphere(mats[i % 3], radius=float(rng.uniform(0.4, 1.5)), object_to_world=m, **kw)
+    b.add_point_light((0, 80, 0), (40000.0, 40000.0, 40000.0))
+    return b
+
+
+def test_thousands_of_spheres_in_the_tree():
+    """Spheres are leaf entries of the device tree like triangles (BVHAccel holds any Primitive, Enigma/BVH.cpp:148-199):
+    5000 of them, full and partial, under rotations and non-uniform scales, through the two intersection taps against
+    the oracle's one-by-one tests, and 700 of them through an image."""
+    b = _sphere_cloud(5000)
+    sc = b.arrays()
+    cam, film = scenes.camera_desc((0, 60, -120), (0, 10, 0), (0, 1, 0), 45.0, 64, 64), scenes.film_desc(64, 64)
+    integ = scenes.integrator_desc(film, 4, light_strategy=abi.LIGHTS_UNIFORM)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    rng = np.random.default_rng(3)
+    n = 6000
+    org = rng.uniform((-55, 0.5, -55), (55, 35, 55), (n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d, np.where(rng.random(n) < 0.3, rng.uniform(1, 40, n), np.inf)[:, None]], axis=1).astype(np.float32)
+    got, ref = r.intersect(rays), o.intersect(rays, ambiguous=False)
+    assert (ref["tri"] >= 2).sum() > n // 4 and (ref["tri"] < 0).sum() > 50      # many sphere hits, some misses
+    assert np.array_equal(got["tri"], ref["tri"]) and np.array_equal(got["t"], ref["t"])
+    assert np.array_equal(got["prim_id"], ref["prim_id"])
+    on_tri = (ref["tri"] >= 0) & (ref["tri"] < 2)
+    assert np.array_equal(got["bary"][on_tri], ref["bary"][on_tri])
+    assert np.array_equal(r.intersect_any(rays), o.intersect_any(rays))
+    assert r.stats()["stack_overflows"] == 0
+    r.close(); o.close()
+    sc = _sphere_cloud(700, seed=5).arrays()
+    for make in (scenes.integrator_desc, scenes.volpath_desc):
+        integ = make(film, 4, light_strategy=abi.LIGHTS_UNIFORM)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 4); o.render(0, 4, threads=16)
+        assert o.image().max() > 0
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for key in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[key] - so[key]) <= max(4, 1e-4 * so[key]), (key, st[key], so[key])
+        r.close(); o.close()
 
 
 def test_image_parity_oren_nayar():

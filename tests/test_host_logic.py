@@ -117,24 +117,60 @@ def test_pixel_table_factorisation_is_exact(hostcheck, m):
 def test_bvh_builder_invariants(hostcheck, builder, kw):
     sc = {"cornell": scenes.cornell_box, "many": scenes.many_lights, "big": scenes.big_mesh}[builder](**kw)
     nT = sc.indices.shape[0]
-    order = np.zeros(nT, dtype=np.uint32)
+    rng = np.random.default_rng(5)
+    lo = rng.uniform(-100, 600, (17, 3)).astype(np.float32)
+    boxes = np.concatenate([lo, lo + rng.uniform(0, 80, (17, 3)).astype(np.float32)], axis=1)   # primitives that are not triangles
+    for nB in (0, 17):
+        order = np.zeros(nT + nB, dtype=np.uint32)
+        checks = np.zeros(5, dtype=np.uint32)
+        nodes = hostcheck.hc_bvh(abi.ptr(sc.vertices), abi.ptr(sc.indices), nT, abi.ptr(boxes), nB, abi.ptr(order), abi.ptr(checks))
+        assert sorted(order.tolist()) == list(range(nT + nB))       # a permutation
+        assert checks[1] == nT + nB and checks[4] == 0              # every primitive in exactly one leaf
+        assert checks[2] == 0 and checks[3] == 0                    # stored boxes hold what is below them; encoding consistent
+        assert 1 <= checks[0] <= 64 and nodes >= 1
+
+
+def _bvh_checks(hostcheck, v, idx, boxes=None):
+    nT = idx.shape[0]
+    nB = 0 if boxes is None else boxes.shape[0]
+    order = np.zeros(max(1, nT + nB), dtype=np.uint32)
     checks = np.zeros(5, dtype=np.uint32)
-    nodes = hostcheck.hc_bvh(abi.ptr(sc.vertices), abi.ptr(sc.indices), nT, 4, abi.ptr(order), abi.ptr(checks))
-    assert sorted(order.tolist()) == list(range(nT))           # a permutation
-    assert checks[1] == nT and checks[4] == 0                   # every triangle in exactly one leaf
-    assert checks[2] == 0 and checks[3] == 0                    # leaf boxes contain their triangles; refs valid
-    assert 1 <= checks[0] <= 64 and nodes >= 1
+    b = boxes if nB else np.zeros((1, 6), dtype=np.float32)
+    hostcheck.hc_bvh(abi.ptr(v), abi.ptr(idx), nT, abi.ptr(b), nB, abi.ptr(order), abi.ptr(checks))
+    return checks
 
 
 def test_bvh_builder_degenerate_inputs(hostcheck):
-    # all triangles identical (coincident centroids) and a single triangle
+    # all triangles identical (coincident centroids), a single triangle, none at all
     v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
-    for nT in (1, 2, 37):
-        idx = np.tile(np.array([0, 1, 2], dtype=np.uint32), (nT, 1))
-        order = np.zeros(nT, dtype=np.uint32)
-        checks = np.zeros(5, dtype=np.uint32)
-        hostcheck.hc_bvh(abi.ptr(v), abi.ptr(idx), nT, 4, abi.ptr(order), abi.ptr(checks))
+    for nT in (0, 1, 2, 37):
+        idx = np.tile(np.array([0, 1, 2], dtype=np.uint32), (max(nT, 1), 1))[:nT].reshape(nT, 3)
+        checks = _bvh_checks(hostcheck, v, idx)
         assert checks[1] == nT and checks[2] == 0 and checks[3] == 0 and checks[4] == 0
+    # boxes only; a grid of coplanar quads (flat nodes on one axis)
+    boxes = np.array([[0, 0, 0, 1, 1, 1], [5, 5, 5, 6, 7, 8]], dtype=np.float32)
+    checks = _bvh_checks(hostcheck, v, np.zeros((0, 3), dtype=np.uint32), boxes)
+    assert checks[1] == 2 and checks[2] == 0 and checks[3] == 0
+    g = 24
+    xs, zs = np.meshgrid(np.arange(g + 1, dtype=np.float32), np.arange(g + 1, dtype=np.float32))
+    vv = np.stack([xs.ravel(), np.full(xs.size, 5, dtype=np.float32), zs.ravel()], axis=1)
+    q = np.array([[i * (g + 1) + j, i * (g + 1) + j + 1, (i + 1) * (g + 1) + j] for i in range(g) for j in range(g)], dtype=np.uint32)
+    checks = _bvh_checks(hostcheck, vv, q)
+    assert checks[1] == g * g and checks[2] == 0 and checks[3] == 0 and checks[4] == 0
+
+
+def test_bvh_depth_is_bounded_for_adversarial_geometry(hostcheck):
+    """Triangles whose sizes grow geometrically around one corner make surface-area splits peel one triangle per level;
+    the builder stops splitting by area at a fixed depth and halves by count, so the tree stays within the 64 levels the
+    traversal stacks hold."""
+    n = 400
+    s = (1.07 ** np.arange(n)).astype(np.float32)
+    v = np.zeros((3 * n, 3), dtype=np.float32)
+    v[1::3, 0] = s; v[2::3, 1] = s; v[0::3, 2] = s * 1e-3
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    checks = _bvh_checks(hostcheck, v, idx)
+    assert checks[1] == n and checks[2] == 0 and checks[3] == 0 and checks[4] == 0
+    assert checks[0] <= 64
 
 
 def test_scene_builders():
