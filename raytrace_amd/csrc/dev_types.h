@@ -81,14 +81,21 @@ struct DevSphere {          // 128 bytes: a Sphere shape and its primitive
     uint32_t light;         // index + 1 of its DiffuseAreaLight (DevLight type 5), 0 = not emissive
 };
 
+constexpr uint32_t kSpatialEmpty = 0xffffffffu, kSpatialClaimed = 0xfffffffeu;
+
 struct DevScene {
-    const float4* nodes;        // 4-wide BVH nodes, 8 float4 each
-    const float4* tris;         // triangles in BVH order, 3 float4 each
+    const float4* nodes;        // 8-wide BVH nodes, 5 float4 each
+    const float4* tris;         // triangles in BVH order, 3 float4 each (a sphere owns a slot too, see dev_trace8.h)
     const DevMaterial* materials;
     const DevLight* lights;
-    // SpatialLightDistribution (Enigma/LightDist.cpp:80-267), every voxel filled: per voxel nLights func values, nLights + 1
-    // cdf values and funcInt; nullptr = one table for the whole scene (lightCdf / lightFunc below)
-    const float* spatialTable;
+    // SpatialLightDistribution (Enigma/LightDist.cpp:80-267): per filled voxel nLights func values, nLights + 1 cdf values
+    // and funcInt; nullptr = one table for the whole scene (lightCdf / lightFunc below).  As in the reference a voxel's
+    // table is made when a path first lands in the voxel: spatialSlot[voxel] = its row of the table, or kSpatialEmpty.
+    float* spatialTable;
+    uint32_t* spatialSlot;
+    uint32_t* spatialCtl;       // [0] rows in use, [1] rows claimed since the last fill, [2] voxels that found the table full
+    uint32_t* spatialNew;       // the voxels claimed since the last fill
+    uint32_t spatialCapacity;   // rows of the table
     int nVoxels[3];
     float boundMin[3], boundMax[3]; // Scene::worldBound()
     const float* lightCdf;      // Distribution1D::cdf, nLights + 1

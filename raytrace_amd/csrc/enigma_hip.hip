@@ -73,6 +73,7 @@ struct EnigmaCtx {
     DevBuf<float4> triShade;
     DevBuf<DevSphere> spheres;
     DevBuf<float> spatialTable, halton;
+    DevBuf<uint32_t> spatialSlot, spatialCtl, spatialNew; // see DevScene
     float worldLo[3] = {0, 0, 0}, worldHi[3] = {0, 0, 0}; // Scene::worldBound(): the union of the primitives' bounds
     DevBuf<float4> sphereGeom;
     DevBuf<float4> texTexels, texColors;
@@ -191,7 +192,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     DevBuf<float4>* f4[] = {&h->nodes, &h->tris, &h->filmPixels, &h->pathRec, &h->L, &h->shO, &h->shD, &h->miRec};
     for (auto* b : f4) b->release();
     h->shWz.release(); h->shRec.release();
-    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release(); h->spheres.release(); h->sphereGeom.release(); h->spatialTable.release(); h->halton.release();
+    h->media.release(); h->triMedium.release(); h->triShade.release(); h->texTexels.release(); h->texColors.release(); h->textures.release(); h->spheres.release(); h->sphereGeom.release(); h->spatialTable.release(); h->halton.release(); h->spatialSlot.release(); h->spatialCtl.release(); h->spatialNew.release();
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
@@ -905,8 +906,9 @@ static int buildLightDistribution(EnigmaCtx* h) {
     h->scene.lightFunc = h->lightFunc.p;
     h->scene.spatialTable = nullptr;
     if (h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && n > 1) { // one light: uniform (Enigma/LightDist.cpp:22)
-        // SpatialLightDistribution's constructor (Enigma/LightDist.cpp:80-103); the reference fills a voxel's table when a
-        // path first lands in it, here every voxel is filled now -- the table of a voxel does not depend on when it is made
+        // SpatialLightDistribution's constructor (Enigma/LightDist.cpp:80-103).  As in the reference a voxel's table is made
+        // when a path first lands in the voxel (launchSpatialFill); here the rows those tables will take are set aside:
+        // one per voxel, or as many as fit the memory allowed for them
         float diag[3], bmax = 0.f;
         for (int c = 0; c < 3; ++c) { diag[c] = h->worldHi[c] - h->worldLo[c]; }
         const int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2); // BBox3::maximumExtent
@@ -918,8 +920,9 @@ static int buildLightDistribution(EnigmaCtx* h) {
             total *= (size_t)h->scene.nVoxels[c];
         }
         const size_t stride = 2 * (size_t)n + 2;
-        if (total * stride * sizeof(float) > ((size_t)32 << 30))
-            return h->fail(ENIGMA_E_UNSUPPORTED, "the spatial light distribution of %d lights over %zu voxels needs more than 32 GB; use the power strategy", n, total);
+        size_t budget = (size_t)32 << 30; // a scene whose paths reach more voxels than this holds fails its render with a message
+        if (const char* e = getenv("ENIGMA_SPATIAL_TABLE_BYTES")) budget = (size_t)atoll(e);
+        const size_t capacity = std::max<size_t>(1, std::min(total, budget / (stride * sizeof(float))));
         std::vector<float> hal(5 * 128);
         auto radical = [](int base, uint64_t a) { // RadicalInverseSpecialized, Enigma/SamplerInclude.h:49-62
             const float invBase = (float)1 / (float)base;
@@ -935,11 +938,17 @@ static int buildLightDistribution(EnigmaCtx* h) {
             hal[128 + i] = radical(3, i); hal[256 + i] = radical(5, i); hal[384 + i] = radical(7, i); hal[512 + i] = radical(11, i);
         }
         HIPCHK(h, h->halton.upload(hal));
-        HIPCHK(h, h->spatialTable.alloc(total * stride));
-        const size_t work = total * (size_t)n;
-        k_spatial_contrib<<<(unsigned)((work + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(h->scene, h->halton.p, h->spatialTable.p, (uint32_t)total);
-        k_spatial_finish<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, h->stream>>>(h->spatialTable.p, (uint32_t)n, (uint32_t)total);
+        HIPCHK(h, h->spatialTable.alloc(capacity * stride));
+        HIPCHK(h, h->spatialSlot.alloc(total));
+        HIPCHK(h, h->spatialNew.alloc(capacity));
+        HIPCHK(h, h->spatialCtl.alloc(4));
+        HIPCHK(h, hipMemsetAsync(h->spatialSlot.p, 0xff, total * sizeof(uint32_t), h->stream)); // kSpatialEmpty
+        HIPCHK(h, hipMemsetAsync(h->spatialCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->scene.spatialSlot = h->spatialSlot.p;
+        h->scene.spatialNew = h->spatialNew.p;
+        h->scene.spatialCtl = h->spatialCtl.p;
+        h->scene.spatialCapacity = (uint32_t)capacity;
         h->scene.spatialTable = h->spatialTable.p;
     }
     h->lightDistDirty = false;
@@ -1019,6 +1028,18 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
         if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
 }
 
+// The light-distribution tables of the voxels that this bounce's interactions lie in and that have none yet
+// (kernels_tex.h); lastKind: the last queue whose interactions ask for a table.
+static void launchSpatialFill(EnigmaCtx* h, const DevPaths& P, int grid, int lastKind) {
+    if (!h->scene.spatialTable) return;
+    MatQueues mq;
+    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
+    k_spatial_mark<<<grid, kBlock, 0, h->stream>>>(h->scene, P, mq, 0, lastKind, h->counters.p);
+    k_spatial_contrib<<<grid, kBlock, 0, h->stream>>>(h->scene, h->halton.p);
+    k_spatial_finish<<<grid, kBlock, 0, h->stream>>>(h->scene);
+    k_spatial_filled<<<1, 1, 0, h->stream>>>(h->scene);
+}
+
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, const StepEvents& ev) {
@@ -1036,6 +1057,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     launchTextures(h, P, gridShade);
+    launchSpatialFill(h, P, gridShade, MK_COUNT - 1);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -1072,6 +1094,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     launchTextures(h, P, gridShade);
+    launchSpatialFill(h, P, gridShade, kQueueMedium);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -1245,6 +1268,15 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
         HIPCHK(h, hipStreamSynchronize(h->stream)); // the constant table is re-uploaded per chunk
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->scene.spatialTable) {
+        uint32_t ctl[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpy(ctl, h->spatialCtl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+        if (ctl[2]) {
+            h->lightDistDirty = true; // the next render starts from an empty table
+            return h->fail(ENIGMA_E_UNSUPPORTED, "the paths reached %u voxels of the spatial light distribution, the table holds %u (%d lights; ENIGMA_SPATIAL_TABLE_BYTES raises the limit): the film holds samples lit from a wrong table -- use the power strategy",
+                           ctl[0], h->scene.spatialCapacity, h->scene.nLights);
+        }
+    }
     for (uint64_t i = 0; i < h->stats.intersect_launches; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->evPool[i * 4], h->evPool[i * 4 + 1]) == hipSuccess) h->stats.ms_intersect += ms;

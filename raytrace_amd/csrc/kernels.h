@@ -528,8 +528,8 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
     waveFlushSteps(sc.visits, kVisitClosest, nodeSteps, triSteps);
 }
 
-// SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the table of the voxel that holds p
-DEV const float* spatialLookup(const DevScene& sc, F3 p) {
+// SpatialLightDistribution::Lookup (Enigma/LightDist.cpp:116-131): the voxel that holds p
+DEV uint32_t spatialVoxel(const DevScene& sc, F3 p) {
     F3 o = p - F3(sc.boundMin[0], sc.boundMin[1], sc.boundMin[2]); // BBox3::offset, Enigma/BBox.h:235-241
     if (sc.boundMax[0] > sc.boundMin[0]) o.x /= sc.boundMax[0] - sc.boundMin[0];
     if (sc.boundMax[1] > sc.boundMin[1]) o.y /= sc.boundMax[1] - sc.boundMin[1];
@@ -537,8 +537,12 @@ DEV const float* spatialLookup(const DevScene& sc, F3 p) {
     int px = min(max((int)(o.x * sc.nVoxels[0]), 0), sc.nVoxels[0] - 1);
     int py = min(max((int)(o.y * sc.nVoxels[1]), 0), sc.nVoxels[1] - 1);
     int pz = min(max((int)(o.z * sc.nVoxels[2]), 0), sc.nVoxels[2] - 1);
-    size_t voxel = ((size_t)px * sc.nVoxels[1] + py) * sc.nVoxels[2] + pz;
-    return sc.spatialTable + voxel * (2 * (size_t)sc.nLights + 2);
+    return ((uint32_t)px * (uint32_t)sc.nVoxels[1] + (uint32_t)py) * (uint32_t)sc.nVoxels[2] + (uint32_t)pz;
+}
+// ... and its table, filled before the kernel that asks started (k_spatial_mark saw the same point)
+DEV const float* spatialLookup(const DevScene& sc, F3 p) {
+    const uint32_t row = min(sc.spatialSlot[spatialVoxel(sc, p)], sc.spatialCapacity - 1u); // a full table fails the render; stay inside it meanwhile
+    return sc.spatialTable + (size_t)row * (2 * (size_t)sc.nLights + 2);
 }
 
 // Distribution1D::SampleDiscrete, Enigma/MonteCarlo.h:61-69 (std::upper_bound on the cdf)

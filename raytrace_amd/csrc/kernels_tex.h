@@ -176,49 +176,78 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
     }
 }
 
-// ---------------------------------------------------------------- SpatialLightDistribution, every voxel (Enigma/LightDist.cpp:210-266)
-// halton: RadicalInverse(b, i) for b = 0..4 and i = 0..127, [b * 128 + i]
-__global__ void __launch_bounds__(kBlock) k_spatial_contrib(DevScene sc, const float* halton, float* table, uint32_t nVoxelsTotal) {
-    const size_t id = (size_t)blockIdx.x * kBlock + threadIdx.x;
+// ---------------------------------------------------------------- SpatialLightDistribution (Enigma/LightDist.cpp:116-266)
+// The reference computes a voxel's table when a path first asks for it.  Here, between the closest-hit kernel of a
+// bounce and the kernels that shade its hits: k_spatial_mark claims a row of the table for every voxel that one of
+// the queued interactions lies in and that has none yet, k_spatial_contrib and k_spatial_finish fill the rows
+// claimed.  A voxel's table depends on the voxel only, not on when it is made.
+// Claims the voxels of the interactions in queues [firstKind, lastKind]: surface hits, and the medium interactions of
+// the VolPathIntegrator's queue kQueueMedium.
+__global__ void __launch_bounds__(kBlock) k_spatial_mark(DevScene sc, DevPaths P, MatQueues mq, int firstKind, int lastKind, const DevCounters* ctr) {
+    for (int k = firstKind; k <= lastKind; ++k) {
+        if (k == MK_NONE) continue; // material-less surfaces are passed through, never lit
+        const uint32_t count = ctr->matCount[k].v;
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+            const uint32_t p = mq.q[k][i];
+            const float4 rdv = P.rayD[p], hv = P.hit[p];
+            F3 at;
+            if (k == kQueueMedium) at = xyz(P.rayO[p]) + xyz(rdv) * hv.y; // as k_shade_medium places it
+            else at = hitGeometry(sc, sc.tris, __float_as_int(hv.x), hv.y, hv.z, hv.w, xyz(rdv), p).p;
+            const uint32_t voxel = spatialVoxel(sc, at);
+            if (sc.spatialSlot[voxel] != kSpatialEmpty) continue;
+            if (atomicCAS(&sc.spatialSlot[voxel], kSpatialEmpty, kSpatialClaimed) != kSpatialEmpty) continue;
+            const uint32_t row = atomicAdd(&sc.spatialCtl[0], 1u);
+            if (row < sc.spatialCapacity) { sc.spatialNew[atomicAdd(&sc.spatialCtl[1], 1u)] = voxel; sc.spatialSlot[voxel] = row; }
+            else atomicAdd(&sc.spatialCtl[2], 1u); // the voxel stays claimed; the render reports the full table when it ends
+        }
+    }
+}
+// halton: RadicalInverse(b, i) for b = 0..4 and i = 0..127, [b * 128 + i]; one (claimed voxel, light) pair per thread and turn
+__global__ void __launch_bounds__(kBlock) k_spatial_contrib(DevScene sc, const float* halton) {
     const uint32_t nl = (uint32_t)sc.nLights;
-    if (id >= (size_t)nVoxelsTotal * nl) return;
-    const uint32_t voxel = (uint32_t)(id / nl), j = (uint32_t)(id % nl);
-    const int pz = (int)(voxel % (uint32_t)sc.nVoxels[2]), py = (int)((voxel / (uint32_t)sc.nVoxels[2]) % (uint32_t)sc.nVoxels[1]),
-              px = (int)(voxel / ((uint32_t)sc.nVoxels[2] * (uint32_t)sc.nVoxels[1]));
+    const size_t work = (size_t)sc.spatialCtl[1] * nl;
     auto lerp1 = [](float a, float b, float t) { if (t < 0.f) return a; if (t > 1.f) return b; const float diff = (b - a) * t; return a + diff; }; // Enigma/MathCommon.h:31-39
-    float lo[3], hi[3];
-    const int pi[3] = {px, py, pz};
-    for (int c = 0; c < 3; ++c) {
-        float a = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c]) / float(sc.nVoxels[c]));
-        float b = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c] + 1) / float(sc.nVoxels[c]));
-        lo[c] = smin(a, b); hi[c] = smax(a, b);
+    for (size_t id = (size_t)blockIdx.x * kBlock + threadIdx.x; id < work; id += (size_t)gridDim.x * kBlock) {
+        const uint32_t voxel = sc.spatialNew[id / nl], j = (uint32_t)(id % nl);
+        const int pz = (int)(voxel % (uint32_t)sc.nVoxels[2]), py = (int)((voxel / (uint32_t)sc.nVoxels[2]) % (uint32_t)sc.nVoxels[1]),
+                  px = (int)(voxel / ((uint32_t)sc.nVoxels[2] * (uint32_t)sc.nVoxels[1]));
+        float lo[3], hi[3];
+        const int pi[3] = {px, py, pz};
+        for (int c = 0; c < 3; ++c) {
+            float a = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c]) / float(sc.nVoxels[c]));
+            float b = lerp1(sc.boundMin[c], sc.boundMax[c], float(pi[c] + 1) / float(sc.nVoxels[c]));
+            lo[c] = smin(a, b); hi[c] = smax(a, b);
+        }
+        const DevLight& lt = sc.lights[j];
+        float contrib = 0.f;
+        for (int i = 0; i < 128; ++i) {
+            F3 po(lerp1(lo[0], hi[0], halton[i]), lerp1(lo[1], hi[1], halton[128 + i]), lerp1(lo[2], hi[2], halton[256 + i]));
+            LightSample s = sampleLight<true>(sc, lt, sc.tris, po, halton[384 + i], halton[512 + i]);
+            if (s.pdf > 0) contrib += (0.212671f * s.Li.x + 0.715160f * s.Li.y + 0.072169f * s.Li.z) / s.pdf;
+        }
+        sc.spatialTable[(size_t)sc.spatialSlot[voxel] * (2 * (size_t)nl + 2) + j] = contrib;
     }
-    const DevLight& lt = sc.lights[j];
-    float contrib = 0.f;
-    for (int i = 0; i < 128; ++i) {
-        F3 po(lerp1(lo[0], hi[0], halton[i]), lerp1(lo[1], hi[1], halton[128 + i]), lerp1(lo[2], hi[2], halton[256 + i]));
-        LightSample s = sampleLight<true>(sc, lt, sc.tris, po, halton[384 + i], halton[512 + i]);
-        if (s.pdf > 0) contrib += (0.212671f * s.Li.x + 0.715160f * s.Li.y + 0.072169f * s.Li.z) / s.pdf;
+}
+// one claimed voxel per thread: the sums run in the reference's order
+__global__ void __launch_bounds__(kBlock) k_spatial_finish(DevScene sc) {
+    const uint32_t nl = (uint32_t)sc.nLights, nNew = sc.spatialCtl[1];
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nNew; v += gridDim.x * kBlock) {
+        float* func = sc.spatialTable + (size_t)sc.spatialSlot[sc.spatialNew[v]] * (2 * (size_t)nl + 2);
+        float* cdf = func + nl;
+        float sumContrib = 0.f;
+        for (uint32_t i = 0; i < nl; ++i) sumContrib += func[i];
+        const float avgContrib = sumContrib / (float)(128u * nl); // the reference divides by a size_t product
+        const float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
+        for (uint32_t i = 0; i < nl; ++i) func[i] = smax(func[i], minContrib);
+        // Distribution1D (Enigma/MonteCarlo.h:17-38)
+        cdf[0] = 0.f;
+        for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)nl;
+        const float funcInt = cdf[nl];
+        if (funcInt == 0.f) for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = float(i) / float(nl);
+        else for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] /= funcInt;
+        cdf[nl + 1] = funcInt;
     }
-    table[(size_t)voxel * (2 * (size_t)nl + 2) + j] = contrib;
 }
-__global__ void __launch_bounds__(kBlock) k_spatial_finish(float* table, uint32_t nl, uint32_t nVoxelsTotal) {
-    const uint32_t voxel = blockIdx.x * kBlock + threadIdx.x;
-    if (voxel >= nVoxelsTotal) return;
-    float* func = table + (size_t)voxel * (2 * (size_t)nl + 2);
-    float* cdf = func + nl;
-    float sumContrib = 0.f;
-    for (uint32_t i = 0; i < nl; ++i) sumContrib += func[i];
-    const float avgContrib = sumContrib / (float)(128u * nl); // the reference divides by a size_t product
-    const float minContrib = (avgContrib > 0) ? (float)(.001 * (double)avgContrib) : 1.f;
-    for (uint32_t i = 0; i < nl; ++i) func[i] = smax(func[i], minContrib);
-    // Distribution1D (Enigma/MonteCarlo.h:17-38)
-    cdf[0] = 0.f;
-    for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)nl;
-    const float funcInt = cdf[nl];
-    if (funcInt == 0.f) for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] = float(i) / float(nl);
-    else for (uint32_t i = 1; i < nl + 1; ++i) cdf[i] /= funcInt;
-    cdf[nl + 1] = funcInt;
-}
+__global__ void k_spatial_filled(DevScene sc) { sc.spatialCtl[1] = 0u; }
 
 } // namespace edev

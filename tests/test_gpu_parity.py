@@ -665,8 +665,8 @@ def test_image_parity_oren_nayar():
 
 def test_image_parity_spatial_light_distribution():
     """lightsamplestrategy "spatial", the reference's default (Enigma/LightDist.cpp:80-267): one table per voxel from 128 Halton
-    points x every light's Sample_Li.  The library fills every voxel at configuration time, the oracle when a path first lands
-    in it; the tables are the same either way.  Two lights (Cornell), many lights with the path and the VolPath integrator."""
+    points x every light's Sample_Li, made when a path first lands in the voxel (between the closest-hit kernel of a bounce and
+    its shading kernels here).  Two lights (Cornell), many lights with the path and the VolPath integrator."""
     cases = [(scenes.cornell_box("microfacet"), "path"), (scenes.many_lights(n_quads=24, n_points=8), "path"), (scenes.cornell_fog("diffuse"), "volpath"),
              (scenes.cornell_box("diffuse", delta_lights=True), "path")]
     cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
@@ -691,6 +691,32 @@ def test_image_parity_spatial_light_distribution():
         r.close()
     assert not np.allclose(imgs[0], imgs[1], rtol=1e-3)
     assert abs(imgs[0].mean() - imgs[1].mean()) < 0.03 * imgs[0].mean()
+
+
+def test_spatial_tables_are_made_on_demand_within_a_memory_limit(monkeypatch):
+    """Only the voxels that paths reach get a table, so a scene whose table over every voxel would not fit still renders
+    (an emitter of many triangles, each a light of its own: Enigma/Api.cpp makes one DiffuseAreaLight per triangle); a limit
+    below what the paths need fails the render with a message instead of lighting from a wrong table."""
+    sc = scenes.many_lights(n_quads=256, n_points=64)          # 576 lights: 4.6 KB per voxel, 1.2 GB over every voxel
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    integ = scenes.integrator_desc(film, 8, light_strategy=abi.LIGHTS_SPATIAL)
+    o = orc.Oracle(sc, cam, film, integ)
+    o.render(0, 8, threads=16)
+    monkeypatch.setenv("ENIGMA_SPATIAL_TABLE_BYTES", str(128 << 20))  # about 29,000 voxels of 262,144; the paths reach some 17,000
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(0, 4); r.render(4, 8)                              # the second call finds its voxels filled
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+    r.close()
+    monkeypatch.setenv("ENIGMA_SPATIAL_TABLE_BYTES", str(1 << 20))    # 227 voxels: not enough
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    with pytest.raises(ra.EnigmaError) as e:
+        r.render(0, 8)
+    assert e.value.code == -4 and "voxels" in str(e.value)
+    r.set_integrator(scenes.integrator_desc(film, 8))           # the power strategy, as the message says
+    r.clear()
+    r.render(0, 8)
+    assert np.isfinite(r.image()).all() and r.image().max() > 0
+    r.close(); o.close()
 
 
 def test_uv_quarter_turn_equals_swapped_roughness_on_the_gpu():
