@@ -31,12 +31,9 @@ namespace edev {
 
 constexpr int kNode8Vec4 = 5;      // 16-byte pieces per node in global memory
 constexpr uint32_t kNodeHits = 0xff000000u;
-// The middle sixteen bits of a node group's second word hold a lower bound of the entry distances of its children: the
-// upper half of the float (positive, so cutting the mantissa rounds down).  A group that comes off the stack after the
-// ray has found a nearer hit is dropped unfetched, the decision the reference takes when it visits such a node
-// (tMin < ray.m_maxT, Enigma/BBox.h:294).
-constexpr uint32_t kGroupBound = 0x00ffff00u;
-DEV float groupBound(uint32_t gy) { return __uint_as_float((gy << 8) & 0xffff0000u); }
+// (A lower bound of the children's entry distances kept with a stacked group, to drop the group unfetched once the ray
+// has a nearer hit, was measured and bought nothing: the bound includes the child taken first, whose subtree is what
+// found the hit.)
 
 struct Ray8 { float ox, oy, oz, ix, iy, iz; uint32_t oct4; bool nx, ny, nz; };
 
@@ -54,10 +51,12 @@ DEV Ray8 makeRay8(const RaySetup& r) {
 }
 
 DEV float ubyteToFloat(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); } // v_cvt_f32_ubyte<b>
+typedef float Pair __attribute__((ext_vector_type(2)));
+DEV Pair pairFma(Pair a, Pair b, Pair c) { return __builtin_elementwise_fma(a, b, c); } // each half rounded once, like fmaf
 
 // One node against the ray: the node group (first inner child, hit bits in visiting order | inner mask) and the
 // triangle group (first triangle, one bit per triangle of the hit leaves).
-template <int NS, bool BOUND>
+template <int NS>
 DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, float tMax, uint32_t* gx, uint32_t* gy, uint32_t* tx, uint32_t* ty) {
     const uint4* np = reinterpret_cast<const uint4*>(nodes + (size_t)index * NS);
     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
@@ -70,15 +69,17 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
     const float Bz = (__uint_as_float(n0.z) - r.oz) * r.iz;
     const float kSlack = 0x1p-21f;
     const float sx = __builtin_fmaf(256.f, fabsf(Ax), fabsf(Bx)), sy = __builtin_fmaf(256.f, fabsf(Ay), fabsf(By)), sz = __builtin_fmaf(256.f, fabsf(Az), fabsf(Bz));
-    const float Bnx = __builtin_fmaf(-kSlack, sx, Bx), Bny = __builtin_fmaf(-kSlack, sy, By), Bnz = __builtin_fmaf(-kSlack, sz, Bz);
-    const float Bfx = __builtin_fmaf(kSlack, sx, Bx), Bfy = __builtin_fmaf(kSlack, sy, By), Bfz = __builtin_fmaf(kSlack, sz, Bz);
+    // entry and exit plane of an axis side by side: one packed multiply-add (v_pk_fma_f32) gives both distances
+    const Pair Bx2 = {__builtin_fmaf(-kSlack, sx, Bx), __builtin_fmaf(kSlack, sx, Bx)};
+    const Pair By2 = {__builtin_fmaf(-kSlack, sy, By), __builtin_fmaf(kSlack, sy, By)};
+    const Pair Bz2 = {__builtin_fmaf(-kSlack, sz, Bz), __builtin_fmaf(kSlack, sz, Bz)};
+    const Pair Ax2 = {Ax, Ax}, Ay2 = {Ay, Ay}, Az2 = {Az, Az};
     // the plane a ray enters a slab through is the low one unless it travels in the negative direction
     const uint32_t nxw[2] = {r.nx ? n3.z : n2.x, r.nx ? n3.w : n2.y}, fxw[2] = {r.nx ? n2.x : n3.z, r.nx ? n2.y : n3.w};
     const uint32_t nyw[2] = {r.ny ? n4.x : n2.z, r.ny ? n4.y : n2.w}, fyw[2] = {r.ny ? n2.z : n4.x, r.ny ? n2.w : n4.y};
     const uint32_t nzw[2] = {r.nz ? n4.z : n3.x, r.nz ? n4.w : n3.y}, fzw[2] = {r.nz ? n3.x : n4.z, r.nz ? n3.y : n4.w};
     const uint32_t metaw[2] = {n1.z, n1.w};
     uint32_t hitmask = 0;
-    float tLow = EDEV_INF; // smallest entry distance among the hit children
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const uint32_t meta4 = metaw[half];
@@ -88,18 +89,16 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
         const uint32_t childBits4 = (meta4 >> 5) & 0x07070707u;                 // inner: 1; leaf: one bit per triangle
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const float tnx = __builtin_fmaf(ubyteToFloat(nxw[half], b), Ax, Bnx), tfx = __builtin_fmaf(ubyteToFloat(fxw[half], b), Ax, Bfx);
-            const float tny = __builtin_fmaf(ubyteToFloat(nyw[half], b), Ay, Bny), tfy = __builtin_fmaf(ubyteToFloat(fyw[half], b), Ay, Bfy);
-            const float tnz = __builtin_fmaf(ubyteToFloat(nzw[half], b), Az, Bnz), tfz = __builtin_fmaf(ubyteToFloat(fzw[half], b), Az, Bfz);
-            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
-            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tMax));
-            if (tn <= tf) {
-                hitmask |= ((childBits4 >> (8 * b)) & 0xffu) << ((bitIndex4 >> (8 * b)) & 0xffu);
-                if (BOUND) tLow = fminf(tLow, tn);
-            }
+            const Pair tx = pairFma(Pair{ubyteToFloat(nxw[half], b), ubyteToFloat(fxw[half], b)}, Ax2, Bx2);
+            const Pair ty = pairFma(Pair{ubyteToFloat(nyw[half], b), ubyteToFloat(fyw[half], b)}, Ay2, By2);
+            const Pair tz = pairFma(Pair{ubyteToFloat(nzw[half], b), ubyteToFloat(fzw[half], b)}, Az2, Bz2);
+            const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.f));
+            const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tMax));
+            const uint32_t bits = ((childBits4 >> (8 * b)) & 0xffu) << ((bitIndex4 >> (8 * b)) & 0xffu);
+            hitmask |= tn <= tf ? bits : 0u; // a select, not a branch: the wave would skip it only when no lane hits
         }
     }
-    *gx = n1.x; *gy = (hitmask & kNodeHits) | (BOUND ? (__float_as_uint(tLow) >> 8) & kGroupBound : 0u) | (ew >> 24);
+    *gx = n1.x; *gy = (hitmask & kNodeHits) | (ew >> 24);
     *tx = n1.y; *ty = hitmask & ~kNodeHits;
 }
 
@@ -147,7 +146,7 @@ struct Walker8Base {
         r = setupRayWith(o, d, F3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)));
         q = makeRay8(r);
         st.sp = 0;
-        gx = 0; gy = 0x80000000u; // the root as the only child of a group without siblings (bound 0, inner mask 0)
+        gx = 0; gy = 0x80000000u; // the root as the only child of a group without siblings (inner mask 0)
         tx = 0; ty = 0;
     }
     DEV void finish() { gy = 0; ty = 0; st.sp = 0; }
@@ -155,7 +154,6 @@ struct Walker8Base {
     DEV bool atTriangles() const { return ty != 0; }
     DEV bool atNode() const { return ty == 0 && (gy & kNodeHits) != 0; }
     // takes the nearest unvisited child of G, leaves the rest of G on the stack, and intersects the child's node
-    template <bool BOUND>
     DEV void nodeStep(const float4* nodes, float tMax) {
         st.countNode();
         const uint32_t hits = gy & kNodeHits;
@@ -164,17 +162,11 @@ struct Walker8Base {
         const uint32_t slot = (bit - 24u) ^ (q.oct4 & 7u);
         const uint32_t child = gx + __popc(rest & 0xffu & ((1u << slot) - 1u)); // inner slots below it
         if (rest & kNodeHits) st.push(gx, rest);
-        intersectNode8<NS, BOUND>(nodes, child, q, tMax, &gx, &gy, &tx, &ty);
+        intersectNode8<NS>(nodes, child, q, tMax, &gx, &gy, &tx, &ty);
     }
-    // when G and T are both empty: the next group from the stack whose children can still lie before tMax, if any
-    template <bool BOUND>
-    DEV void refill(float tMax) {
-        if (ty == 0 && (gy & kNodeHits) == 0) {
-            for (;;) {
-                if (!st.pop(&gx, &gy)) { gy = 0; break; }
-                if (!BOUND || groupBound(gy) <= tMax) break;
-            }
-        }
+    // when G and T are both empty: the next group from the stack, if any
+    DEV void refill() {
+        if (ty == 0 && (gy & kNodeHits) == 0 && !st.pop(&gx, &gy)) gy = 0;
     }
     DEV uint32_t takeTriangle() { // lowest set bit of T
         const uint32_t b = (uint32_t)__ffs((int)ty) - 1u;
@@ -236,20 +228,20 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
         if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
             ++this->nodeSteps;
             if (!n) return;
-            Base::template nodeStep<true>(nodes, h.t);
+            Base::nodeStep(nodes, h.t);
         } else {
             ++this->triSteps;
             if (!t) return;
             testOne(tris);
             if (this->ty != 0) testOne(tris);
         }
-        Base::template refill<true>(h.t);
+        Base::refill();
     }
     // descend until the lane holds triangles (or is through), then test them all
     DEV void round(const float4* nodes, const float4* tris) {
-        while (Base::atNode()) { Base::template nodeStep<true>(nodes, h.t); Base::template refill<true>(h.t); }
+        while (Base::atNode()) { Base::nodeStep(nodes, h.t); Base::refill(); }
         while (this->ty != 0) testOne(tris);
-        Base::template refill<true>(h.t);
+        Base::refill();
     }
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
@@ -286,19 +278,19 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
         if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
             ++this->nodeSteps;
             if (!n) return;
-            Base::template nodeStep<false>(nodes, tMax);
+            Base::nodeStep(nodes, tMax);
         } else {
             ++this->triSteps;
             if (!t) return;
             testOne(tris);
             if (this->ty != 0) testOne(tris);
         }
-        Base::template refill<false>(tMax);
+        Base::refill();
     }
     DEV void round(const float4* nodes, const float4* tris) {
-        while (Base::atNode()) { Base::template nodeStep<false>(nodes, tMax); Base::template refill<false>(tMax); }
+        while (Base::atNode()) { Base::nodeStep(nodes, tMax); Base::refill(); }
         while (this->ty != 0) testOne(tris);
-        Base::template refill<false>(tMax);
+        Base::refill();
     }
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };

@@ -816,8 +816,12 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
 // sampled for every BSDF (no test for non-specular lobes), and every ray leaving the surface takes the medium on
 // its side of the surface (Interaction::GetMedium, Enigma/Interaction.cpp:72-75).
 // SPH: the build for scenes with spheres, the only one that can sample a light on a sphere
+// Waves per SIMD asked of the compiler: four for the Lambertian and smooth-glass builds (128 registers, some thirty
+// spilled), three for the microfacet ones (168).  The kernels wait on memory more than they compute; measured against
+// the unconstrained builds (165 to 199 registers): Cornell 3 % faster per step, BigMesh 1 %; one wave more each
+// (96 / 128 registers, a hundred spilled) is 15 % slower.
 template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false>
-__global__ void __launch_bounds__(kBlock) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
+__global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUGH || MK == MK_GLASS_SMOOTH) ? 4 : 3) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
     extern __shared__ float4 sceneLds[];
@@ -1135,7 +1139,7 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
-__global__ void __launch_bounds__(kBlock) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
+__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
     using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Any;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t poolNext;
