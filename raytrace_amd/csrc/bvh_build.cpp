@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -38,7 +39,8 @@ struct Builder {
     std::vector<uint32_t>& order;
     std::vector<TmpNode> nodes;
     uint32_t maxLeaf;
-    static constexpr int kBins = 16;
+    static constexpr int kMaxBins = 64;
+    int kBins = 16;
     // Below this depth the surface-area splits stop and ranges are halved by count, which ends within log2(count) more
     // levels: a tree over up to 2^28 primitives is at most 64 levels deep whatever the geometry, the depth the traversal
     // stacks are sized for.
@@ -75,8 +77,8 @@ struct Builder {
             int bestAxis = -1, bestBin = -1;
             for (int a = 0; a < 3; ++a) {
                 if (ext[a] <= 0.f) continue;
-                Box bb[kBins];
-                uint32_t bc[kBins] = {0};
+                Box bb[kMaxBins];
+                uint32_t bc[kMaxBins] = {0};
                 float scale = kBins / ext[a];
                 for (uint32_t i = first; i < first + count; ++i) {
                     uint32_t t = order[i];
@@ -84,8 +86,8 @@ struct Builder {
                     bb[b].grow(triBox[t]);
                     bc[b]++;
                 }
-                float rightArea[kBins];
-                uint32_t rightCount[kBins];
+                float rightArea[kMaxBins];
+                uint32_t rightCount[kMaxBins];
                 Box acc;
                 uint32_t cnt = 0;
                 for (int b = kBins - 1; b > 0; --b) {
@@ -167,6 +169,7 @@ void build_bvh8(const float* vertices, const uint32_t* indices, uint32_t nTriang
     auto emptyNode = [] { Bvh8Node n; memset(&n, 0, sizeof(n)); n.e[0] = n.e[1] = n.e[2] = 1; return n; };
     if (nTris == 0) { out->nodes.push_back(emptyNode()); return; }
     Builder B(triBox, centroid, order, 1); // down to single triangles: the collapse below decides what a leaf is
+    if (const char* e = getenv("ENIGMA_BVH_BINS")) B.kBins = std::max(4, std::min(64, atoi(e)));
     B.nodes.reserve((size_t)nTris * 2);
     const int root = B.build(0, nTris);
     for (int a = 0; a < 3; ++a) { out->rootLo[a] = B.nodes[root].box.lo[a]; out->rootHi[a] = B.nodes[root].box.hi[a]; }
@@ -178,7 +181,9 @@ void build_bvh8(const float* vertices, const uint32_t* indices, uint32_t nTriang
     //                                       wide node = area * cNode + distribute(n, 8)
     //   cost[n][i] = min(distribute(n, i), cost[n][i - 1]),  distribute(n, j) = min over k of cost[left][k] + cost[right][j - k]
     // Binary nodes are numbered parent before children, so one backward sweep sees children first.
-    constexpr float cNode = 1.0f, cPrim = 0.6f; // a node visit against one triangle test, by their instruction counts
+    const float cNode = 1.0f;
+    float cPrim = 0.6f; // a node visit against one triangle test, by their instruction counts
+    if (const char* e = getenv("ENIGMA_BVH_CPRIM")) cPrim = (float)atof(e);
     const size_t nb = B.nodes.size();
     std::vector<float> cost(nb * 8, 0.f);        // [n][i], i = 1..7 (slot 0 unused)
     std::vector<uint8_t> splitK(nb * 9, 0);      // [n][j], j = 2..8: the k of distribute(n, j)
