@@ -307,8 +307,10 @@ DEV float lobePdf(const Bsdf& b, F3 wo, F3 wi) {
     return 0.f;
 }
 // BxDF::sample_f of one lobe.  Returns f; *pdf stays 0 when the lobe fails to sample.
+// whShared: the microfacet normal when the caller has sampled it already (the two lobes of rough glass draw the same
+// wh from the same numbers; sampled before the lanes split over the lobes, it is computed once for the wave)
 template <int KIND>
-DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
+DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType, const F3* whShared = nullptr) {
     if (KIND == LOBE_LAMBERT || KIND == LOBE_OREN_NAYAR) { // BxDF.cpp:529-536
         *wi = cosineSampleHemisphere(u0, u1);
         if (wo.z < 0.f) wi->z *= -1.f;
@@ -316,7 +318,7 @@ DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, floa
         return lobeF<KIND>(b, col, wo, *wi);
     } else if (KIND == LOBE_MICRO_REFL_CONDUCTOR || KIND == LOBE_MICRO_REFL_DIELECTRIC) { // BxDF.cpp:1102-1114
         if (wo.z == 0) return F3(0.f);
-        F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
+        F3 wh = whShared ? *whShared : trSampleWh(b.ax, b.ay, wo, u0, u1);
         if (dot(wo, wh) < 0) return F3(0.f);
         *wi = reflect(wo, wh);
         if (!sameHemisphere(wo, *wi)) return F3(0.f);
@@ -324,7 +326,7 @@ DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, floa
         return microReflF<KIND>(b, col, wo, *wi);
     } else if (KIND == LOBE_MICRO_TRANS) { // BxDF.cpp:1045-1056
         if (wo.z == 0) return F3(0.f);
-        F3 wh = trSampleWh(b.ax, b.ay, wo, u0, u1);
+        F3 wh = whShared ? *whShared : trSampleWh(b.ax, b.ay, wo, u0, u1);
         if (dot(wo, wh) < 0) return F3(0.f);
         float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
         if (!refract(wo, wh, eta, wi)) return F3(0.f);
@@ -410,14 +412,19 @@ DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf
     if (wo.z == 0) return F3(0.f);
     F3 f;
     bool specular;
+    constexpr bool micro0 = K0 == LOBE_MICRO_REFL_CONDUCTOR || K0 == LOBE_MICRO_REFL_DIELECTRIC || K0 == LOBE_MICRO_TRANS;
+    constexpr bool micro1 = K1 == LOBE_MICRO_REFL_CONDUCTOR || K1 == LOBE_MICRO_REFL_DIELECTRIC || K1 == LOBE_MICRO_TRANS;
+    F3 whBoth(0.f);
+    if (micro0 && micro1) whBoth = trSampleWh(b.ax, b.ay, wo, ur0, u1); // one distribution, the same numbers: either lobe would draw this wh
+    const F3* whShared = (micro0 && micro1) ? &whBoth : nullptr;
     if (pick1) {
         *sampledType = lobeType(K1 < 0 ? 0 : K1);
         specular = (lobeType(K1 < 0 ? 0 : K1) & BSDF_SPECULAR) != 0;
-        f = lobeSample<K1>(b, b.col1, wo, ur0, u1, &wi, pdf, sampledType);
+        f = lobeSample<K1>(b, b.col1, wo, ur0, u1, &wi, pdf, sampledType, whShared);
     } else {
         *sampledType = lobeType(K0);
         specular = (lobeType(K0) & BSDF_SPECULAR) != 0;
-        f = lobeSample<K0>(b, b.col0, wo, ur0, u1, &wi, pdf, sampledType);
+        f = lobeSample<K0>(b, b.col0, wo, ur0, u1, &wi, pdf, sampledType, whShared);
     }
     if (*pdf == 0) { *sampledType = 0; return F3(0.f); }
     *wiW = toWorld(b, wi);

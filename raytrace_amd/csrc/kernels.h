@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                 }
                 if (__ballot(!w.done()) == 0) break;
             }
-            w.template advance<LDS_SCENE>(nodes, tris);
+            w.template advance<false>(nodes, tris); // voted steps, also for a scene in LDS (2 % faster than whole rounds for closest hits)
         }
         nodeSteps += w.nodeSteps; triSteps += w.triSteps;
         __syncthreads();
@@ -1192,7 +1192,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_shadow(DevScene s
                 }
                 if (__ballot(!w.done()) == 0) break;
             }
-            w.template advance<LDS_SCENE>(nodes, tris);
+            w.template advance<LDS_SCENE>(nodes, tris); // any-hit rays of a scene in LDS: whole rounds (9 % faster than voted steps there)
         }
         nodeSteps += w.nodeSteps; triSteps += w.triSteps;
         __syncthreads(); // poolNext is rewritten by the next chunk
