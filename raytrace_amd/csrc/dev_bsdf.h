@@ -367,6 +367,49 @@ DEV F3 lobeSample(const Bsdf& b, F3 col, F3 wo, float u0, float u1, F3* wi, floa
     return F3(0.f);
 }
 
+// ---- rough glass: MicrofacetReflection + MicrofacetTransmission over one distribution, evaluated together ----
+// For a pair of directions at most one of the two lobes is non-zero (reflection when both lie on one side of the
+// surface, transmission otherwise), and both lobes are built from the same pieces: D and G of the distribution at a
+// half vector, one dielectric Fresnel term, trPdf at a half vector.  The lanes of a wave differ in which lobe applies;
+// with the half vector and the Fresnel argument picked per lane, the shared pieces run once for the whole wave instead
+// of once per side.  Each lane's values come from the same operations on the same operands as in microReflF /
+// microTransF / microReflPdf / microTransPdf above (x * 1 and x + 0 are exact).
+DEV F3 roughGlassF(const Bsdf& b, F3 wo, F3 wi, bool refl, bool on0, bool on1) {
+    bool live = (refl ? on0 : on1) && wi.z != 0 && wo.z != 0;
+    if (!refl && sameHemisphere(wo, wi)) live = false;
+    const float eta = cosTheta(wo) > 0 ? (b.dEtaT / b.dEtaI) : (b.dEtaI / b.dEtaT);
+    const F3 whRaw = refl ? wi + wo : wo + wi * eta;
+    if (refl && whRaw.x == 0 && whRaw.y == 0 && whRaw.z == 0) live = false;
+    F3 wh = normalize(whRaw);
+    if (!refl && wh.z < 0) wh = -wh;
+    const float dO = dot(wo, wh), dI = dot(wi, wh);
+    if (!refl && dO * dI > 0) live = false;
+    const float D = trD(b.ax, b.ay, wh), G = trG(b.ax, b.ay, wo, wi);
+    const float F = frDielectric(refl ? dot(wi, faceForward(wh, F3(0, 0, 1))) : dO, b.dEtaI, b.dEtaT);
+    if (!live) return F3(0.f);
+    if (refl) return b.col0 * D * G * F3(F) / (4 * absCosTheta(wi) * absCosTheta(wo));
+    const float cosThetaO = cosTheta(wo), cosThetaI = cosTheta(wi);
+    const float sqrtDenom = dO + eta * dI;
+    const float factor = 1 / eta;
+    const float sv = fabsf(D * G * eta * eta * fabsf(dI) * fabsf(dO) * factor * factor / (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    return (F3(1.f) - F3(F)) * b.col1 * sv;
+}
+// whSampled: the half vector MicrofacetReflection::sample_f has in hand (it does not rebuild it from wo + wi); nullptr when
+// evaluating a given pair of directions
+DEV float roughGlassPdf(const Bsdf& b, F3 wo, F3 wi, bool on0, bool on1, const F3* whSampled = nullptr) {
+    const bool same = sameHemisphere(wo, wi);
+    const float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
+    F3 wh = normalize(same ? wo + wi : wo + wi * eta);
+    if (whSampled && same) wh = *whSampled;
+    const float dO = dot(wo, wh), dI = dot(wi, wh);
+    const bool live = (same ? on0 : on1) && (same || !(dO * dI > 0));
+    const float tp = trPdf(b.ax, b.ay, wo, wh);
+    if (!live) return 0.f;
+    if (same) return tp / (4 * dO);
+    const float sqrtDenom = dO + eta * dI;
+    return tp * fabsf((eta * eta * dI) / (sqrtDenom * sqrtDenom));
+}
+
 // sum of lobe f over the slots matching flags on the side (reflection / transmission) of the pair
 template <int MK, int I>
 DEV F3 sideF(const Bsdf& b, F3 wo, F3 wi, int flags, bool refl) {
@@ -382,6 +425,7 @@ DEV F3 bsdfF(const Bsdf& b, F3 woW, F3 wiW, int flags) {
     F3 wi = toLocal(b, wiW), wo = toLocal(b, woW);
     if (wo.z == 0) return F3(0.f);
     bool refl = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    if (MK == MK_GLASS_ROUGH) return roughGlassF(b, wo, wi, refl, lobeOn<MK, 0>(b, flags), lobeOn<MK, 1>(b, flags));
     F3 f(0.f);
     f += sideF<MK, 0>(b, wo, wi, flags, refl);
     f += sideF<MK, 1>(b, wo, wi, flags, refl);
@@ -392,6 +436,11 @@ template <int MK>
 DEV float bsdfPdf(const Bsdf& b, F3 woW, F3 wiW, int flags) {
     if (!b.has0 && !b.has1) return 0.f;
     F3 wo = toLocal(b, woW), wi = toLocal(b, wiW);
+    if (MK == MK_GLASS_ROUGH) {
+        const bool on0 = lobeOn<MK, 0>(b, flags), on1 = lobeOn<MK, 1>(b, flags);
+        const int n = (on0 ? 1 : 0) + (on1 ? 1 : 0);
+        return n > 0 ? roughGlassPdf(b, wo, wi, on0, on1) / n : 0.f;
+    }
     float pdf = 0.f; int matching = 0;
     if (lobeOn<MK, 0>(b, flags)) { ++matching; pdf += lobePdf<LobeOf<MK, 0>::kind>(b, wo, wi); }
     if (lobeOn<MK, 1>(b, flags)) { ++matching; pdf += lobePdf<LobeOf<MK, 1>::kind>(b, wo, wi); }
@@ -410,6 +459,26 @@ DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf
     float ur0 = smin(u0 * matching - comp, kOneMinusEpsilon);
     F3 wo = toLocal(b, woW), wi(0.f);
     if (wo.z == 0) return F3(0.f);
+    if (MK == MK_GLASS_ROUGH) { // MicrofacetReflection::sample_f / MicrofacetTransmission::sample_f (BxDF.cpp:1102-1114,1045-1056), then BSDF::sample_f's sums
+        *sampledType = pick1 ? lobeType(LOBE_MICRO_TRANS) : lobeType(LOBE_MICRO_REFL_DIELECTRIC);
+        const F3 wh = trSampleWh(b.ax, b.ay, wo, ur0, u1); // either lobe draws this wh
+        bool ok = !(dot(wo, wh) < 0);
+        const float eta = cosTheta(wo) > 0 ? (b.dEtaI / b.dEtaT) : (b.dEtaT / b.dEtaI);
+        F3 wt(0.f);
+        const bool refracted = refract(wo, wh, eta, &wt);
+        wi = pick1 ? wt : reflect(wo, wh);
+        if (pick1 ? !refracted : !sameHemisphere(wo, wi)) ok = false;
+        // the sampled lobe's pdf; the other lobe's is zero on this side of the surface, which roughGlassPdf decides by itself
+        const bool same = sameHemisphere(wo, wi);
+        if (pick1 ? same : !same) ok = false; // microTransPdf: 0 on the reflection side (the reflection side was checked above)
+        const float own = roughGlassPdf(b, wo, wi, !pick1, pick1, &wh);
+        if (!ok || own == 0) { *pdf = 0; *sampledType = 0; return F3(0.f); }
+        *pdf = own;
+        *wiW = toWorld(b, wi);
+        if (matching > 1) *pdf /= matching; // + the other lobe's pdf: exactly 0 here
+        const bool refl = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+        return roughGlassF(b, wo, wi, refl, on0, on1);
+    }
     F3 f;
     bool specular;
     constexpr bool micro0 = K0 == LOBE_MICRO_REFL_CONDUCTOR || K0 == LOBE_MICRO_REFL_DIELECTRIC || K0 == LOBE_MICRO_TRANS;
