@@ -125,7 +125,9 @@ typedef struct EnigmaMedium {
 } EnigmaMedium;
 
 /* tri_material value of a GeometricPrimitive without a material (MakeMaterial "" / "none", Enigma/Api.cpp:135):
- * a medium boundary the VolPathIntegrator passes through (Enigma/VolPathIntegrator.cpp:105-111). */
+ * a medium boundary that the VolPathIntegrator and the PathIntegrator pass through without counting a bounce
+ * (Enigma/VolPathIntegrator.cpp:105-111, Enigma/PathIntegrator.cpp:87-93); the DirectLightingIntegrator's recursion
+ * through such surfaces is not built: enigma_render returns ENIGMA_E_UNSUPPORTED for it. */
 #define ENIGMA_NO_MATERIAL 0xffffffffu
 
 /* A Sphere shape with its GeometricPrimitive (Enigma/ShapeImp.cpp:13-203, Enigma/Primitive.cpp:146-162): full or

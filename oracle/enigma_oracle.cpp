@@ -2299,6 +2299,11 @@ struct PathIntegrator {
                 else for (const Light& light : scene.lights) if (light.flags & 8) L += beta * light.LeRay(ray); // scene.m_infiniteLights
             }
             if (!foundIntersection || bounces >= maxDepth) break;
+            if (scene.triMaterial[isect.primIndex] == ENIGMA_NO_MATERIAL) { // no BSDF: skip over the medium boundary, PathIntegrator.cpp:87-93
+                ray = isect.SpawnRay(ray.d);
+                bounces--;
+                continue;
+            }
             std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
             const Distribution1D* distrib = Lookup(isect.p); // PathIntegrator.cpp:95
             if (bsdf->numComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
@@ -2950,9 +2955,9 @@ int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_
         BBox2i sb = h->o.film->GetSampleBounds();
         if (sb.mn.x < sb.mn.y) { h->o.error = "sample bounds with min.x < min.y: reference result undefined"; return -4; }
     }
-    if (!h->o.useVolPath)
+    if (h->o.useDirect)
         for (uint32_t m : h->o.scene.triMaterial)
-            if (m == ENIGMA_NO_MATERIAL) { h->o.error = "surfaces without a material are restated for the VolPathIntegrator only"; return -4; }
+            if (m == ENIGMA_NO_MATERIAL) { h->o.error = "surfaces without a material are not restated for the DirectLightingIntegrator"; return -4; }
     if (h->o.useDirect) { // SpecularReflect / SpecularTransmit carry ray differentials on (Integrator.cpp:329-444): not restated
         bool trilinear = false, smoothGlass = false;
         for (const ImageTex& t : h->o.scene.textures.tex) trilinear = trilinear || t.mip.doTrilinear;

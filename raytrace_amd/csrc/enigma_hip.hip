@@ -1054,7 +1054,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     (void)hipEventRecord(ev.c0, s);
     k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
     (void)hipEventRecord(ev.c1, s);
-    if (bounce >= h->integ.maxDepth) return; // nothing survives the depth test: no shading, no shadow rays
+    if (bounce >= h->integ.maxDepth && !h->haveNoMaterial) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     launchTextures(h, P, gridShade);
     launchSpatialFill(h, P, gridShade, MK_COUNT - 1);
@@ -1064,6 +1064,8 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    // surfaces without a material: the ray goes on behind them and the vertex does not count as a bounce (Enigma/PathIntegrator.cpp:87-93)
+    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
@@ -1166,7 +1168,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (direct && h->haveTrilinear && h->smoothGlass)
         return h->fail(ENIGMA_E_UNSUPPORTED, "trilinear textures with a smooth glass under the DirectLightingIntegrator: its specular rays carry ray differentials on "
                                              "(Enigma/Integrator.cpp:329-444), which is not supported");
-    if (h->haveNoMaterial && !vol) return h->fail(ENIGMA_E_UNSUPPORTED, "the scene has surfaces without a material (medium boundaries): only the VolPathIntegrator renders them");
+    if (h->haveNoMaterial && direct) return h->fail(ENIGMA_E_UNSUPPORTED, "the scene has surfaces without a material (medium boundaries): the DirectLightingIntegrator's recursion through them (Enigma/DirectLightingIntegrator.cpp:41-55) is not supported; the PathIntegrator and the VolPathIntegrator render them");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
     size_t basePaths = (size_t)32 << 20; // ~11 GB of path state at 330 B per path; larger launches run closer to the hardware's rates
@@ -1253,7 +1255,9 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 if (alive == 0) break;
                 if (iter > 4096) return h->fail(ENIGMA_E_DEVICE, "VolPathIntegrator: paths still alive after 4096 iterations");
             }
-            for (int b = 0; !direct && !vol && b <= h->integ.maxDepth; ++b) {
+            // PathIntegrator: one launch set per bounce.  With surfaces without a material in the scene a pass through one of
+            // them is an iteration that is no bounce, so the iterations go on until no path is left (the host reads the count)
+            for (int b = 0; !direct && !vol && (h->haveNoMaterial || b <= h->integ.maxDepth); ++b) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchBounce<11, 53, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
@@ -1261,6 +1265,13 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 else if (h->bvhStack <= 11) launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
+                if (h->haveNoMaterial) {
+                    uint32_t alive = 0;
+                    HIPCHK(h, hipMemcpyAsync(&alive, &h->counters.p->extCount[(b & 1) ^ 1].v, sizeof(alive), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    if (alive == 0) break;
+                    if (b > 4096) return h->fail(ENIGMA_E_DEVICE, "PathIntegrator: paths still alive after 4096 iterations");
+                }
             }
             k_film_splat<<<(nPixels + kBlock - 1) / kBlock, kBlock, 0, h->stream>>>(P, h->film, h->integ, nPixels, ks);
             HIPCHK(h, hipGetLastError());

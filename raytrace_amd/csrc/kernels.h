@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
-    constexpr int NK = MODE == 0 ? MK_COUNT : (MODE == 1 ? MK_COUNT + 1 : kQueueKinds);
+    constexpr int NK = MODE == 2 ? kQueueKinds : MK_COUNT + 1; // queue MK_COUNT: surfaces without a material / (MODE 1) paths that resume a branch
     using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];

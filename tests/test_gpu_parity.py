@@ -535,11 +535,61 @@ def test_image_parity_spheres_without_material():
             for key in ("rays_closest", "rays_shadow", "rays_mis"):
                 assert abs(st[key] - so[key]) <= max(8, 1e-3 * so[key]), (key, st[key], so[key])
             r.close(); o.close()
-    r = ra.Renderer(0).configure(sc, cam, film, scenes.integrator_desc(film, 4))
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.direct_lighting_desc(film, 4))
     with pytest.raises(ra.EnigmaError) as e:       # refused when a render is asked for, as for triangles without a material
         r.render(0, 4)
     assert e.value.code == -4
     r.close()
+
+
+def test_path_integrator_passes_through_surfaces_without_a_material():
+    """PathIntegrator::Li skips an intersection without a BSDF: the ray goes on behind it and the vertex is no bounce
+    (Enigma/PathIntegrator.cpp:87-93); shadow rays and the BSDF-sampled light rays stop at such surfaces like at any other
+    (Scene::intersectP / intersect).  A ball and a box of material-less surfaces in the Cornell box, the ball in front of
+    the camera: same image and the same rays as the oracle, and not the image of the scene without them (their shadows)."""
+    from test_oracle_kat import _fog_ball_scene
+    cam, film = scenes.camera_desc((0, 5, -40), (0, 2, 0), (0, 1, 0), 40.0, 48, 48), scenes.film_desc(48, 48)
+    sc = _fog_ball_scene((0.02, 0.03, 0.05), (0.15, 0.15, 0.12), g=0.3, lamp=True)
+    for strategy in (abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL):
+        integ = scenes.integrator_desc(film, 16, max_depth=3, light_strategy=strategy)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16); o.render(0, 16, threads=8)
+        assert o.image().max() > 0.5
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for key in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[key] - so[key]) <= max(4, 1e-4 * so[key]), (key, st[key], so[key])
+        assert so["rays_closest"] > 1.2 * so["samples"]          # crossings of the ball are rays of their own
+        r.close(); o.close()
+    base = scenes.cornell_box("diffuse")
+    # triangles without a material: a closed box around the short block of the Cornell box
+    v = base.vertices.copy()
+    lo, hi = np.array([100.0, 0.5, 100.0]), np.array([300.0, 250.0, 300.0])
+    corners = np.array([[lo[0] if i & 1 == 0 else hi[0], lo[1] if i & 2 == 0 else hi[1], lo[2] if i & 4 == 0 else hi[2]] for i in range(8)], dtype=np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = np.array([[q[0], q[1], q[2]] for q in quads] + [[q[0], q[2], q[3]] for q in quads], dtype=np.uint32) + v.shape[0]
+    boxed = abi.SceneArrays(np.concatenate([v, corners]), np.concatenate([base.indices, tris]),
+                            np.concatenate([base.tri_material, np.full(12, abi.NO_MATERIAL, dtype=np.uint32)]),
+                            np.concatenate([base.tri_light, np.full(12, -1, dtype=np.int32)]),
+                            list(base.materials)[:base.n_materials], list(base.lights)[:base.n_lights])
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    integ = scenes.integrator_desc(film, 16)
+    imgs = []
+    for scene in (boxed, base):
+        r = ra.Renderer(0).configure(scene, cam, film, integ)
+        r.render(0, 16)
+        imgs.append(r.image())
+        if scene is boxed:
+            o = orc.Oracle(scene, cam, film, integ)
+            o.render(0, 16, threads=8)
+            assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+            so, st = o.stats(), r.stats()
+            for key in ("rays_closest", "rays_shadow", "rays_mis"):
+                assert abs(st[key] - so[key]) <= max(4, 1e-4 * so[key]), (key, st[key], so[key])
+            o.close()
+        r.close()
+    assert common.mean_relative_error(imgs[0], imgs[1]) > 0.02   # the box is invisible to camera rays but shadows what is inside
 
 
 def test_spheres_alone_and_refusals():

@@ -79,8 +79,15 @@ def test_volpath_absorbing_slab_beer_lambert_on_the_gpu():
     r.render(0, 1024)
     want = np.array([1.0, 2.0, 3.0]) * np.exp(-sigma * d)
     assert np.allclose(r.image().astype(np.float64).mean(axis=(0, 1)), want, rtol=0.01)
-    # the other integrators refuse material-less surfaces
-    r.set_integrator(scenes.integrator_desc(film, 4))
+    # the PathIntegrator skips the slab's faces and knows nothing of its medium: the wall arrives unattenuated, three rays a
+    # sample (face, face, wall; the black wall ends the path); the DirectLightingIntegrator refuses material-less surfaces
+    r.set_integrator(scenes.integrator_desc(film, 4, max_depth=3))
+    r.clear()
+    before = r.stats()["rays_closest"]
+    r.render(0, 4)
+    assert np.allclose(r.image().astype(np.float64).mean(axis=(0, 1)), [1.0, 2.0, 3.0], rtol=1e-5)
+    assert r.stats()["rays_closest"] - before == 3 * 4 * 64
+    r.set_integrator(scenes.direct_lighting_desc(film, 4))
     with pytest.raises(ra.EnigmaError) as e:
         r.render(0, 4)
     assert e.value.code == -4

@@ -394,11 +394,17 @@ def test_volpath_absorbing_slab_follows_beer_lambert():
     want = np.array([1.0, 2.0, 3.0]) * math.exp(-sigma * d)
     assert np.allclose(img.mean(axis=(0, 1)), want, rtol=0.01)
     assert s["rays_closest"] >= 3 * s["samples"] * 0.3            # boundary in, boundary out, wall: for the survivors
-    # a path integrator must refuse the scene: material-less surfaces are medium boundaries
-    p = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 4))
-    with pytest.raises(Exception):
-        p.render(0, 4, threads=1)
+    # PathIntegrator::Li skips surfaces without a BSDF and knows nothing of media (Enigma/PathIntegrator.cpp:87-93): it sees
+    # the wall unattenuated through the slab's faces; DirectLightingIntegrator's recursion through them is not restated
+    p = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 4, max_depth=3))
+    p.render(0, 4, threads=1)
+    assert np.allclose(p.image().astype(np.float64).mean(axis=(0, 1)), [1.0, 2.0, 3.0], rtol=1e-5)
+    assert p.stats()["rays_closest"] == 3 * p.stats()["samples"]     # face, face, wall: crossings are no bounces, the wall ends the path
     p.close()
+    q = orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 4))
+    with pytest.raises(Exception):
+        q.render(0, 4, threads=1)
+    q.close()
 
 
 def test_volpath_scattering_slab_conserves_energy_inside_a_furnace():
@@ -942,7 +948,7 @@ def test_sphere_without_material_bounds_its_medium():
     """A GeometricPrimitive without a material is passed through and switches the ray's medium
     (Enigma/VolPathIntegrator.cpp:105-111, Enigma/Interaction.cpp:72-75); for a Sphere the crossing points come from
     Sphere::intersect.  Through the centre of an absorbing ball of radius r the wall behind it keeps exp(-sigma_a 2r)
-    of its radiance, beside the ball all of it; the other integrators refuse such a scene."""
+    of its radiance, beside the ball all of it; the DirectLightingIntegrator refuses such a scene."""
     L = np.array([2.0, 1.0, 0.5])
     sa = np.array([0.05, 0.1, 0.2])
     sc = _fog_ball_scene(tuple(sa), (0.0, 0.0, 0.0))
@@ -956,4 +962,4 @@ def test_sphere_without_material_bounds_its_medium():
     assert np.allclose(img[22, 22], L * np.exp(-sa * 10.0), rtol=0.02), img[22, 22]
     assert np.allclose(img[22, 0], L, rtol=1e-5) and np.allclose(img[5, 44], L, rtol=1e-5)
     with pytest.raises(RuntimeError):
-        orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 16)).render(0, 1, threads=1)
+        orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16)).render(0, 1, threads=1)
