@@ -13,9 +13,13 @@
 // reference's Transform composition transposes on construction (Enigma/Transform.cpp:295-314) and gives
 // wrong matrices for chained operations; that defect is not reproduced.
 //
-// Outside the subset (textures other than constants, shapes other than trianglemesh, shading normals,
-// spectra other than rgb, object instancing, media, other samplers / cameras / lights / integrators) the
-// front end throws std::runtime_error naming the directive; it never renders something else silently.
+// Inside the subset: trianglemesh (with N, uv / st) and sphere shapes; matte, metal (default spectra: the reference's
+// copper), glass, plastic and "none" materials; constant and imagemap (PFM) textures; point, spot, distant, infinite
+// and diffuse area lights; homogeneous named media and medium interfaces; the path, directlighting and volpath
+// integrators; the sobol sampler, the perspective camera, the image film with its five filters.  Outside it (other
+// shapes and texture classes, spectra other than rgb, object instancing, heterogeneous media, other samplers / cameras /
+// lights / integrators) the front end throws std::runtime_error naming the directive; it never renders something
+// else silently.
 #pragma once
 #include "enigma_host.h"
 
