@@ -143,13 +143,33 @@ def run_workload(args, variant, steps, ctx):
         integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
         integ_label = "DirectLightingIntegrator maxdepth 5 strategy %s, Sobol, box filter" % ("all" if strat == abi.DL_SAMPLE_ALL else "one")
     r = ra.Renderer(ctx["local_rank"]).configure(scene, camera, film, integ)
+    torch_reduce = None
     if world > 1:  # the library's own communicator: rank 0 makes the id, torch's process group only carries the 128 bytes
-        ident = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            ident.copy_(torch.frombuffer(bytearray(ra.Renderer.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(ident, 0)
-        r.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            ident = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(ra.Renderer.comm_unique_id()), dtype=torch.uint8))
+        except ra.EnigmaError as e:  # RCCL could not be loaded by the library on this host
+            sys.stderr.write("rank %d: %s\n" % (rank, e))
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()):
+            dist.broadcast(ident, 0)
+            try:
+                r.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+            except ra.EnigmaError as e:
+                sys.stderr.write("rank %d: %s\n" % (rank, e))
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                r.comm_destroy()
+        if not int(ok.item()):  # every rank falls back together: the film as a torch view, reduced by torch's own RCCL communicator
+            from raytrace_amd import distributed
+            film_view = distributed.film_tensor(r, dev)
+            torch_reduce = lambda: dist.reduce(film_view, dst=0, op=dist.ReduceOp.SUM)
     rccl_rank, rccl_world = r.comm_info()
+    reduce_film = torch_reduce if torch_reduce is not None else (lambda: r.film_reduce(0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,7 +180,7 @@ def run_workload(args, variant, steps, ctx):
     # warm-up: the last sample numbers of the range (and one reduce, which sets the communicator's channels up), then a clean film
     for _ in range(W):
         r.render(total_spp - SPP_PER_STEP, total_spp)
-    r.film_reduce(0)
+    reduce_film()
     r.clear()
     s_before = r.stats()
 
@@ -174,7 +194,7 @@ def run_workload(args, variant, steps, ctx):
         st = r.stats()
         ms_closest += st["ms_intersect"]; n_closest += st["intersect_launches"]
         ms_shadow += st["ms_shadow"]; n_shadow += st["shadow_launches"]
-    r.film_reduce(0)
+    reduce_film()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -203,7 +223,7 @@ def run_workload(args, variant, steps, ctx):
         "job_1024spp_seconds": elapsed / K * (1024.0 / SPP_PER_STEP) / N,
         "config": {"workload": "%s 1920x1080, %s; %d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
                    "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP,
-                   "parallelism": "spp-shard x%d + one ncclReduce of the film" % N},
+                   "parallelism": "spp-shard x%d + one %s of the film" % (N, "ncclReduce inside the library" if torch_reduce is None else "torch.distributed reduce (the library could not load RCCL)")},
         "rccl_ranks": rccl_world,
         "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
     }

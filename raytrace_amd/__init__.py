@@ -157,6 +157,9 @@ class Renderer:
     def film_reduce(self, root=0):
         self._chk(self.L.enigma_film_reduce(self.h, root))
 
+    def comm_destroy(self):
+        self._chk(self.L.enigma_comm_destroy(self.h))
+
     def film_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.L.enigma_film_device_ptr(self.h, C.byref(p), C.byref(n)))
