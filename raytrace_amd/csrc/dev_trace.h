@@ -95,6 +95,17 @@ enum VisitKind : uint32_t { kVisitClosest = 0, kVisitShadow = 1, kVisitMis = 2, 
 DEV void blockZeroVisits(uint32_t* column, int rows, int stride) { column[rows * stride] = 0u; column[(rows + 1) * stride] = 0u; }
 // every thread of the block calls it once, after its last traversal step; red: 2 * (block size / 64) words of LDS
 constexpr uint32_t kVisitTallies = 5;
+// where a walker without per-lane tallies reports a push that found its stack full
+DEV unsigned long long* stackFullCounter(unsigned long long* visits, uint32_t kind) {
+    return visits ? &visits[((size_t)kind * kVisitTallies + 4) * kVisitSlots + blockIdx.x % kVisitSlots] : nullptr;
+}
+// a wave's own counts of nodes fetched and triangles tested (walkers without per-lane tallies; uniform values: one lane adds them)
+DEV void waveFlushVisits(unsigned long long* visits, uint32_t kind, uint32_t nodeVisits, uint32_t triVisits) {
+    if (!visits || (threadIdx.x & 63u) != 0) return;
+    const uint32_t slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kVisitSlots;
+    atomicAdd(&visits[((size_t)kind * kVisitTallies + 0) * kVisitSlots + slot], (unsigned long long)nodeVisits);
+    atomicAdd(&visits[((size_t)kind * kVisitTallies + 1) * kVisitSlots + slot], (unsigned long long)triVisits);
+}
 // a wave's step counts (uniform values: one lane adds them)
 DEV void waveFlushSteps(unsigned long long* visits, uint32_t kind, uint32_t nodeSteps, uint32_t triSteps) {
     if (!visits || (threadIdx.x & 63u) != 0) return;

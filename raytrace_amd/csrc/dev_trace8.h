@@ -106,20 +106,25 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
 // (2l) * STRIDE and (2l + 1) * STRIDE of its column: a lane always uses bank lane % 32), deeper levels in a private
 // array.  Behind the stack rows sit the lane's two visit tallies
 // (nodes fetched, triangles tested since the block zeroed them: ds_add without return, no register lives across steps).
-template <int LDSN, int OVF, int STRIDE>
+// LANE_TALLY = false: no tally rows; the walkers then count per wave (their voted steps know how many lanes take part),
+// and a full stack is reported through `full`, a counter in global memory.
+template <int LDSN, int OVF, int STRIDE, bool LANE_TALLY = true>
 struct GroupStack {
     static constexpr int kRows = 2 * LDSN;
-    static constexpr int kWords = kRows + 2;
+    static constexpr int kWords = kRows + (LANE_TALLY ? 2 : 0);
     uint32_t* lds;
     uint32_t* ov; // [2 * OVF], caller's frame
+    unsigned long long* full;
     int sp;
-    DEV GroupStack(uint32_t* column, uint32_t* spill) : lds(column), ov(spill), sp(0) {}
-    DEV void countNode() { atomicAdd(&lds[kRows * STRIDE], 1u); }
-    DEV void countTriangle() { atomicAdd(&lds[(kRows + 1) * STRIDE], 1u); }
+    DEV GroupStack(uint32_t* column, uint32_t* spill, unsigned long long* fullCounter = nullptr) : lds(column), ov(spill), full(fullCounter), sp(0) {}
+    DEV void countNode() { if (LANE_TALLY) atomicAdd(&lds[kRows * STRIDE], 1u); }
+    DEV void countTriangle() { if (LANE_TALLY) atomicAdd(&lds[(kRows + 1) * STRIDE], 1u); }
     DEV void push(uint32_t x, uint32_t y) {
         if (sp < LDSN) { lds[(2 * sp) * STRIDE] = x; lds[(2 * sp + 1) * STRIDE] = y; ++sp; }
         else if (OVF > 0 && sp < LDSN + OVF) { ov[2 * (sp - LDSN)] = x; ov[2 * (sp - LDSN) + 1] = y; ++sp; }
-        else atomicOr(&lds[(kRows + 1) * STRIDE], kStackFullFlag); // cannot happen (the host builds no tree this deep): reported, not silent
+        // cannot happen (the host builds no tree this deep): reported, not silent
+        else if (LANE_TALLY) atomicOr(&lds[(kRows + 1) * STRIDE], kStackFullFlag);
+        else if (full) atomicAdd(full, 1ull);
     }
     DEV bool pop(uint32_t* x, uint32_t* y) {
         if (sp == 0) return false;
@@ -132,14 +137,16 @@ struct GroupStack {
 
 // Common state machine of the two walkers.  A lane holds a node group G (children still to visit) and a triangle
 // group T (triangles still to test); T is emptied before the lane takes its next node.  done: both empty, stack empty.
-template <int LDSN, int OVF, int STRIDE, int NS>
+template <int LDSN, int OVF, int STRIDE, int NS, bool LANE_TALLY = true>
 struct Walker8Base {
     RaySetup r;
     Ray8 q;
     uint32_t gx, gy, tx, ty;
-    uint32_t nodeSteps, triSteps; // wave steps of either kind this walker has made (the same in every lane of the wave)
-    GroupStack<LDSN, OVF, STRIDE> st;
-    DEV Walker8Base(uint32_t* column, uint32_t* spill) : gx(0), gy(0), tx(0), ty(0), nodeSteps(0), triSteps(0), st(column, spill) {}
+    uint32_t nodeSteps, triSteps;   // wave steps of either kind this walker has made (the same in every lane of the wave)
+    uint32_t nodeVisits, triVisits; // LANE_TALLY = false: nodes fetched / triangles tested by the lanes of the wave in those steps
+    GroupStack<LDSN, OVF, STRIDE, LANE_TALLY> st;
+    DEV Walker8Base(uint32_t* column, uint32_t* spill, unsigned long long* fullCounter = nullptr)
+        : gx(0), gy(0), tx(0), ty(0), nodeSteps(0), triSteps(0), nodeVisits(0), triVisits(0), st(column, spill, fullCounter) {}
     DEV void begin(F3 o, F3 d) {
         // the hardware reciprocal (one ulp) is enough for the box distances: their slack covers it; the shear constants
         // of the triangle test stay correctly rounded quotients
@@ -194,13 +201,14 @@ struct SphereRefs {
 DEV bool slotIsSphere(float4 v0) { return (__float_as_uint(v0.w) >> 31) != 0; }
 DEV uint32_t slotSphere(float4 v0) { return __float_as_uint(v0.w) & 0x7fffffffu; }
 
-template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false>
-struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
-    using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
-    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false, bool LANE_TALLY = true>
+struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
+    using Base = Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY>;
+    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kRows;
     Hit h;
     SphereRefs spheres;
-    DEV ClosestWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs()) : Base(column, spill), spheres(sr) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
+    DEV ClosestWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs(), unsigned long long* fullCounter = nullptr)
+        : Base(column, spill, fullCounter), spheres(sr) { h.tri = -1; h.t = 0.f; h.b0 = h.b1 = h.b2 = 0.f; }
     DEV void start(F3 o, F3 d, float tMax) {
         Base::begin(o, d);
         h.tri = -1; h.t = tMax; h.b0 = h.b1 = h.b2 = 0.f;
@@ -225,15 +233,19 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     // one kind of work per wave step, whichever has more lanes waiting (see ClosestWalker::step)
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
-        if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+        const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
+        if (cn >= ct) {
             ++this->nodeSteps;
+            this->nodeVisits += cn;
             if (!n) return;
             Base::nodeStep(nodes, h.t);
         } else {
             ++this->triSteps;
-            if (!t) return;
+            if (t) testOne(tris);
+            const bool second = t && this->ty != 0;
+            this->triVisits += ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second))); // the vote below is for the count only
+            if (!second) { if (t) Base::refill(); return; }
             testOne(tris);
-            if (this->ty != 0) testOne(tris);
         }
         Base::refill();
     }
@@ -246,14 +258,15 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     template <bool ROUNDS> DEV void advance(const float4* nodes, const float4* tris) { if (ROUNDS) round(nodes, tris); else step(nodes, tris); }
 };
 
-template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false>
-struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
-    using Base = Walker8Base<LDSN, OVF, STRIDE, NS>;
-    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE>::kRows;
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false, bool LANE_TALLY = true>
+struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
+    using Base = Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY>;
+    static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kRows;
     float tMax;
     bool occluded;
     SphereRefs spheres;
-    DEV AnyWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs()) : Base(column, spill), tMax(0.f), occluded(false), spheres(sr) {}
+    DEV AnyWalker8(uint32_t* column, uint32_t* spill, SphereRefs sr = SphereRefs(), unsigned long long* fullCounter = nullptr)
+        : Base(column, spill, fullCounter), tMax(0.f), occluded(false), spheres(sr) {}
     DEV void start(F3 o, F3 d, float tMaxRay) {
         Base::begin(o, d);
         tMax = tMaxRay;
@@ -275,15 +288,19 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
     }
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
-        if (__popcll(__ballot(n)) >= __popcll(__ballot(t))) {
+        const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
+        if (cn >= ct) {
             ++this->nodeSteps;
+            this->nodeVisits += cn;
             if (!n) return;
             Base::nodeStep(nodes, tMax);
         } else {
             ++this->triSteps;
-            if (!t) return;
+            if (t) testOne(tris);
+            const bool second = t && this->ty != 0;
+            this->triVisits += ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second)));
+            if (!second) { if (t) Base::refill(); return; }
             testOne(tris);
-            if (this->ty != 0) testOne(tris);
         }
         Base::refill();
     }
@@ -299,10 +316,10 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS> {
 // NS: 16-byte pieces between consecutive nodes (the same in HBM and in a block's LDS copy of a small scene: five
 // pieces put consecutive nodes on different banks already).
 constexpr int kLdsNodePitch = kNode8Vec4;
-template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE, bool SPH = false> struct WalkerSel {
+template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE, bool SPH = false, bool LANE_TALLY = true> struct WalkerSel {
     static constexpr int NS = LDS_SCENE ? kLdsNodePitch : kNode8Vec4;
-    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS, SPH>;
-    using Any = AnyWalker8<LDSN, OVF, STRIDE, NS, SPH>;
+    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS, SPH, LANE_TALLY>;
+    using Any = AnyWalker8<LDSN, OVF, STRIDE, NS, SPH, LANE_TALLY>;
 };
 constexpr int spillWords(int ovf) { return 2 * (ovf > 0 ? ovf : 1); }
 

@@ -226,6 +226,7 @@ struct DevCounters {
     DevTail extCount[2];        // extension-ray queue sizes (current, next)
     DevTail matCount[kQueueKinds];
     DevTail shadowCount, misCount;
+    DevTail shadowCursor;       // next unreserved position of the shadow queue while k_shadow_stream runs (its waves reserve runs of it)
     unsigned long long raysClosest, raysShadow, raysMis, samples;
 };
 

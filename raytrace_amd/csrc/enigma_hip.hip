@@ -86,6 +86,7 @@ struct EnigmaCtx {
     bool kindPresent[MK_COUNT] = {};
     bool haveAreaLights = false;
     uint32_t refillIdle = 16;
+    int residentTraceBlocks = 256 * 6; // blocks of a traversal kernel the chip holds at once: its waves stream rays until the queue is empty
     DevScene scene{};
     uint32_t bvhDepth = 0, bvhNodes = 0, bvhStack = 0;
     double msBvhBuild = 0;
@@ -1069,7 +1070,8 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if constexpr (LDS_SCENE) k_shadow<LDSN, OVF, true, SPH><<<gridTrace, kBlock, sceneLdsBytes(h), s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        else k_shadow_stream<LDSN, OVF, SPH><<<std::min(gridTrace, h->residentTraceBlocks), kBlock, 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
@@ -1145,7 +1147,8 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow<LDSN, OVF, LDS_SCENE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        if constexpr (LDS_SCENE) k_shadow<LDSN, OVF, true, SPH><<<gridTrace, kBlock, sceneLdsBytes(h), s>>>(h->scene, P, shq, ctr, h->refillIdle);
+        else k_shadow_stream<LDSN, OVF, SPH><<<std::min(gridTrace, h->residentTraceBlocks), kBlock, 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
@@ -1185,6 +1188,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
+    h->residentTraceBlocks = cus * 6;
     for (int64_t c0 = 0; c0 < nSamples; c0 += chunkMax) {
         int64_t cn = std::min(chunkMax, nSamples - c0);
         std::vector<uint32_t> consts((size_t)cn * h->nDims + 16, 0u);

@@ -326,6 +326,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
 // Scene::intersect for queue[0..count) (queue == nullptr: identity) + the head of the Li loop.
 struct MatQueues { uint32_t* q[kQueueKinds]; };
 
+// The closest-hit kernel keeps the chunk as its unit although the shadow kernel of scenes in HBM streams (k_shadow_stream):
+// a streaming build of this kernel -- waves reserving runs of 512 rays, finished paths handed to the material queues either
+// from a list of the wave (queues lose their pixel order: shading and the next bounce 10-19 % slower) or run by run in
+// position order (more state, 31 instead of 17 spilled registers: the kernel itself 17 % slower) -- lost either way on
+// the 1.18 M-triangle scene (5.9 -> 7.4 / 8.4 ms per launch), while coherent camera rays gained nothing from it.
 // Chunks go to blocks in plain order (chunk c -> block c mod gridDim), i.e. round-robin over the eight XCDs and their L2s.
 // Measured alternatives on the 1.18 M-triangle scene: runs of 8 consecutive chunks per XCD inside groups of 64 blocks:
 // no change (68.9 vs 68.7 ms per step); runs of 32: 1 % slower; one contiguous eighth of every sweep per XCD: 40 %
@@ -355,6 +360,89 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
     base = __shfl(base, leader);
     *baseOut = base;
     return base + __popcll(idleMask & ((1ull << lane) - 1ull));
+}
+
+// The head of the Li loop for a ray that has finished its walk (Enigma/PathIntegrator.cpp:62-87; MODE 1: the
+// DirectLightingIntegrator's, MODE 2: the VolPathIntegrator's with its medium sampling): emitted radiance, the depth
+// test, the hit record.  Returns the queue the path goes to + 1 (its material kind, the boundary / resume queue, the
+// medium queue), 0 when the path has ended.
+template <int MODE, bool SPH, class Walker>
+DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevIntegrator& I, const DevSampler& S, const float4* tris, const Walker& w,
+                           uint32_t p, uint32_t state, const uint32_t* pendCount) {
+    constexpr bool DL = MODE == 1, VOL = MODE == 2;
+    uint32_t kind = 0;
+    Hit h = w.h;
+    bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
+    if (VOL && stMedium(state) != 0) {
+        const DevMedium md = sc.media[stMedium(state) - 1u];
+        uint32_t px, py, slot;
+        pathPixel(I, S, p, &px, &py, &slot);
+        uint32_t dim = stDim(state);
+        float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
+        state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state)) | (state & kStNoDifferentials);
+        reinterpret_cast<float*>(&P.rayD[p])[3] = __uint_as_float(state);
+        int channel = min((int)(uc * 3), 3 - 1);
+        float dist = -logf(1 - ud) / md.sigmaT[channel];
+        float len = length(w.r.d);
+        float tHit = h.tri >= 0 ? h.t : EDEV_INF;
+        float t = smin(dist / len, tHit);
+        bool sampledMedium = t < tHit;
+        float tt = smin(t, EDEV_MAXF);
+        F3 Tr(expf(-md.sigmaT[0] * tt * len), expf(-md.sigmaT[1] * tt * len), expf(-md.sigmaT[2] * tt * len));
+        F3 sigT(md.sigmaT[0], md.sigmaT[1], md.sigmaT[2]);
+        F3 density = sampledMedium ? sigT * Tr : Tr;
+        float pdf = 0;
+        pdf += density.x; pdf += density.y; pdf += density.z;
+        pdf *= 1 / (float)3;
+        if (pdf == 0) pdf = 1;
+        F3 wgt = sampledMedium ? Tr * F3(md.sigmaS[0], md.sigmaS[1], md.sigmaS[2]) / pdf : Tr / pdf;
+        float4 be = P.beta[p];
+        F3 beta = xyz(be) * wgt;
+        P.beta[p] = mk4(beta, be.w);
+        if (isBlack(beta)) proceed = false;
+        else if (sampledMedium) {
+            proceed = false;
+            if ((int)stBounces(state) < I.maxDepth) {
+                kind = (uint32_t)kQueueMedium + 1u;
+                P.hit[p] = make_float4(__int_as_float(-1), t, 0.f, 0.f);
+            }
+        }
+    }
+    if (proceed && h.tri >= 0) {
+        uint32_t st = state;
+        uint32_t bounces = stBounces(st);
+        const bool sphere = isSpherePrim<SPH>(sc, h.tri); // nothing to fetch from the triangle array
+        const float4* tp = tris + (size_t)(sphere ? 0 : h.tri) * 3;
+        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+        int lightIdx = sphere ? (int)sc.spheres[h.tri - (int)sc.nTris].light - 1 : __float_as_int(v2.w);
+        uint32_t mw = sphere ? sc.spheres[h.tri - (int)sc.nTris].mw : __float_as_uint(v1.w);
+        if ((DL || bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
+            const DevLight& lt = sc.lights[lightIdx];
+            F3 n;
+            if (SPH && sphere) {
+                F3 ps, pe, dpdu, wo;
+                sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), w.r.d, &ps, &pe, &n, &dpdu, &wo);
+            } else n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
+            if (lt.twoSided || dot(n, -w.r.d) > 0) {
+                float4 L = P.L[p], be = P.beta[p];
+                F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
+                P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+            }
+        }
+        if (DL || (int)bounces < I.maxDepth) {
+            kind = triKind(mw) + 1u;
+            P.hit[p] = make_float4(__int_as_float(h.tri), h.b0, h.b1, h.b2);
+        }
+    } else {
+        if (proceed && sc.nInfinite > 0 && (DL || stBounces(state) == 0 || stSpec(state))) { // L += beta * light->Le(ray) over the infinite lights
+            float4 L = P.L[p];
+            F3 be = xyz(P.beta[p]), acc = xyz(L);
+            for (int k = 0; k < sc.nInfinite; ++k) acc += be * infiniteLe(sc, sc.lights[sc.infiniteLights[k]], w.r.d);
+            P.L[p] = mk4(acc, 0.f);
+        }
+        if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
+    }
+    return kind;
 }
 
 // DL: the head of DirectLightingIntegrator::Li instead (Enigma/DirectLightingIntegrator.cpp:41-55): emitted
@@ -398,78 +486,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
             uint32_t nIdle = __popcll(idleMask);
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
-                    uint32_t kind = 0;
-                    Hit h = w.h;
-                    bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
-                    if (VOL && stMedium(state) != 0) {
-                        const DevMedium md = sc.media[stMedium(state) - 1u];
-                        uint32_t px, py, slot;
-                        pathPixel(I, S, p, &px, &py, &slot);
-                        uint32_t dim = stDim(state);
-                        float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
-                        state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state)) | (state & kStNoDifferentials);
-                        reinterpret_cast<float*>(&P.rayD[p])[3] = __uint_as_float(state);
-                        int channel = min((int)(uc * 3), 3 - 1);
-                        float dist = -logf(1 - ud) / md.sigmaT[channel];
-                        float len = length(w.r.d);
-                        float tHit = h.tri >= 0 ? h.t : EDEV_INF;
-                        float t = smin(dist / len, tHit);
-                        bool sampledMedium = t < tHit;
-                        float tt = smin(t, EDEV_MAXF);
-                        F3 Tr(expf(-md.sigmaT[0] * tt * len), expf(-md.sigmaT[1] * tt * len), expf(-md.sigmaT[2] * tt * len));
-                        F3 sigT(md.sigmaT[0], md.sigmaT[1], md.sigmaT[2]);
-                        F3 density = sampledMedium ? sigT * Tr : Tr;
-                        float pdf = 0;
-                        pdf += density.x; pdf += density.y; pdf += density.z;
-                        pdf *= 1 / (float)3;
-                        if (pdf == 0) pdf = 1;
-                        F3 wgt = sampledMedium ? Tr * F3(md.sigmaS[0], md.sigmaS[1], md.sigmaS[2]) / pdf : Tr / pdf;
-                        float4 be = P.beta[p];
-                        F3 beta = xyz(be) * wgt;
-                        P.beta[p] = mk4(beta, be.w);
-                        if (isBlack(beta)) proceed = false;
-                        else if (sampledMedium) {
-                            proceed = false;
-                            if ((int)stBounces(state) < I.maxDepth) {
-                                kind = (uint32_t)kQueueMedium + 1u;
-                                P.hit[p] = make_float4(__int_as_float(-1), t, 0.f, 0.f);
-                            }
-                        }
-                    }
-                    if (proceed && h.tri >= 0) {
-                        uint32_t st = state;
-                        uint32_t bounces = stBounces(st);
-                        const bool sphere = isSpherePrim<SPH>(sc, h.tri); // nothing to fetch from the triangle array
-                        const float4* tp = tris + (size_t)(sphere ? 0 : h.tri) * 3;
-                        float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                        int lightIdx = sphere ? (int)sc.spheres[h.tri - (int)sc.nTris].light - 1 : __float_as_int(v2.w);
-                        uint32_t mw = sphere ? sc.spheres[h.tri - (int)sc.nTris].mw : __float_as_uint(v1.w);
-                        if ((DL || bounces == 0 || stSpec(st)) && lightIdx >= 0) { // L += beta * isect.Le(-ray.d)
-                            const DevLight& lt = sc.lights[lightIdx];
-                            F3 n;
-                            if (SPH && sphere) {
-                                F3 ps, pe, dpdu, wo;
-                                sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), w.r.d, &ps, &pe, &n, &dpdu, &wo);
-                            } else n = triNormal(xyz(v0), xyz(v1), xyz(v2), triFlip(mw));
-                            if (lt.twoSided || dot(n, -w.r.d) > 0) {
-                                float4 L = P.L[p], be = P.beta[p];
-                                F3 add = xyz(be) * F3(lt.L[0], lt.L[1], lt.L[2]);
-                                P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
-                            }
-                        }
-                        if (DL || (int)bounces < I.maxDepth) {
-                            kind = triKind(mw) + 1u;
-                            P.hit[p] = make_float4(__int_as_float(h.tri), h.b0, h.b1, h.b2);
-                        }
-                    } else {
-                        if (proceed && sc.nInfinite > 0 && (DL || stBounces(state) == 0 || stSpec(state))) { // L += beta * light->Le(ray) over the infinite lights
-                            float4 L = P.L[p];
-                            F3 be = xyz(P.beta[p]), acc = xyz(L);
-                            for (int k = 0; k < sc.nInfinite; ++k) acc += be * infiniteLe(sc, sc.lights[sc.infiniteLights[k]], w.r.d);
-                            P.L[p] = mk4(acc, 0.f);
-                        }
-                        if (DL && pendCount[p] != 0) kind = MK_COUNT + 1u;
-                    }
+                    const uint32_t kind = finishPathRay<MODE, SPH>(sc, P, I, S, tris, w, p, state, pendCount);
                     kindOf[pos] = (uint8_t)kind;
                     pos = kNoRay;
                 }
@@ -1206,6 +1223,74 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_shadow(DevScene s
     waveFlushSteps(sc.visits, kVisitShadow, nodeSteps, triSteps);
 }
 
+// Rays a wave reserves from the shadow queue at a time.
+constexpr uint32_t kShadowRun = 512;
+template <int LDSN, int OVF, bool SPH = false>
+__global__ void __launch_bounds__(kBlock, 6) k_shadow_stream(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
+    using Walker = typename WalkerSel<LDSN, OVF, kBlock, false, SPH, false>::Any;
+    __shared__ uint32_t stack[Walker::kWords * kBlock];
+    uint32_t spill[spillWords(OVF)];
+    const uint32_t count = ctr->shadowCount.v;
+    if (blockIdx.x * kBlock >= count) return; // more blocks than rays
+    const float4* nodes = sc.nodes;
+    const float4* tris = sc.tris;
+    // Every wave streams on its own: it reserves runs of kShadowRun queue positions from the queue's cursor and hands them
+    // to its lanes as they fall idle, until the cursor has passed the end of the queue.  No wave waits for another, and
+    // lanes run dry only once, at the end of the launch.
+    const uint32_t lane = threadIdx.x & 63u;
+    Walker w(stack + threadIdx.x, spill, SphereRefs(sc), stackFullCounter(sc.visits, kVisitShadow));
+    uint32_t p = kNoRay;
+    F3 contrib(0.f); // fetched with the ray: no dependent load when the ray is through
+    uint32_t runLo = 0, runHi = 0;
+    bool exhausted = false;
+    for (;;) {
+        bool idle = w.done();
+        unsigned long long idleMask = __ballot(idle);
+        uint32_t nIdle = __popcll(idleMask);
+        if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
+            if (idle && p != kNoRay) {
+                if (!w.occluded) {
+                    if (shq.perPath == 1) { // the path's only ray in this kernel: nobody else touches its L
+                        float4 L = P.L[p];
+                        P.L[p] = make_float4(L.x + contrib.x, L.y + contrib.y, L.z + contrib.z, 0.f);
+                    } else {
+                        float* L = reinterpret_cast<float*>(P.L + p / shq.perPath);
+                        atomicAdd(L + 0, contrib.x); atomicAdd(L + 1, contrib.y); atomicAdd(L + 2, contrib.z);
+                    }
+                }
+                p = kNoRay;
+            }
+            if (!exhausted && runLo == runHi) {
+                uint32_t r = 0;
+                if (lane == 0) r = atomicAdd(&ctr->shadowCursor.v, kShadowRun);
+                r = __shfl(r, 0);
+                if (r >= count) exhausted = true;
+                else { runLo = r; runHi = min(r + kShadowRun, count); }
+            }
+            if (!exhausted) {
+                const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                const uint32_t take = min(nIdle, runHi - runLo);
+                if (idle && rank < take) {
+                    const uint32_t at = runLo + rank;
+                    p = shq.idx[at];
+                    const size_t rec = shq.dense ? (size_t)at : (size_t)p;
+                    float4 a = shq.o[rec], b = shq.d[rec];
+                    contrib = F3(b.z, b.w, shq.wz[rec]);
+                    w.start(F3(a.x, a.y, a.z), F3(a.w, b.x, b.y), 1 - kShadowEpsilon);
+                }
+                runLo += take;
+            }
+            if (__ballot(!w.done()) == 0) {
+                if (exhausted) break;
+                continue; // the run ended exactly here: reserve the next one
+            }
+        }
+        w.step(nodes, tris);
+    }
+    waveFlushVisits(sc.visits, kVisitShadow, w.nodeVisits, w.triVisits);
+    waveFlushSteps(sc.visits, kVisitShadow, w.nodeSteps, w.triSteps);
+}
+
 // The BSDF-sampled MIS rays of EstimateDirect (Enigma/Integrator.cpp:168-196): the closest hit must be
 // the sampled light's triangle.  Few rays per bounce (only those that hit the light's own triangle
 // are queued), one per lane.
@@ -1337,6 +1422,7 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
     } else if (phase == 1) {
         ctr->raysShadow += ctr->shadowCount.v;
         ctr->raysMis += ctr->misCount.v;
+        ctr->shadowCursor.v = 0;
     }
 }
 
