@@ -508,11 +508,11 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
         }
         nodeSteps += w.nodeSteps; triSteps += w.triSteps;
         __syncthreads();
-        // ---- bin the chunk: order inside a material queue is wave, item, lane
+        // ---- bin the chunk: order inside a material queue is wave, item, lane = the order of the positions in the chunk
         unsigned long long kinds = 0; // 4 bits per item
 #pragma unroll
         for (int it = 0; it < kTraceItems; ++it) {
-            uint32_t j = it * kBlock + threadIdx.x;
+            uint32_t j = wid * (kTraceChunk / kWavesPerBlock) + it * 64u + lane; // a wave bins one contiguous quarter of the chunk
             kinds |= (unsigned long long)(j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
         }
 #pragma unroll
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                 bool mine = (uint32_t)((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u;
                 unsigned long long mask = __ballot(mine);
                 if (mine) {
-                    uint32_t i = chunk + it * kBlock + threadIdx.x;
+                    uint32_t i = chunk + wid * (kTraceChunk / kWavesPerBlock) + it * 64u + lane;
                     mq.q[k][off + __popcll(mask & lanesBelow)] = queue ? queue[i] : i;
                 }
                 off += __popcll(mask);
