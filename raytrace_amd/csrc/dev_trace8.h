@@ -50,6 +50,9 @@ DEV Ray8 makeRay8(const RaySetup& r) {
     return q;
 }
 
+// a + b for counters that are the same in every lane of the wave: says so to the compiler, which then keeps them in
+// scalar registers
+DEV uint32_t uniformAdd(uint32_t a, uint32_t b) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(a + b)); }
 DEV float ubyteToFloat(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); } // v_cvt_f32_ubyte<b>
 typedef float Pair __attribute__((ext_vector_type(2)));
 DEV Pair pairFma(Pair a, Pair b, Pair c) { return __builtin_elementwise_fma(a, b, c); } // each half rounded once, like fmaf
@@ -235,15 +238,15 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         const bool n = Base::atNode(), t = Base::atTriangles();
         const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
         if (cn >= ct) {
-            ++this->nodeSteps;
-            this->nodeVisits += cn;
+            this->nodeSteps = uniformAdd(this->nodeSteps, 1u);
+            this->nodeVisits = uniformAdd(this->nodeVisits, cn);
             if (!n) return;
             Base::nodeStep(nodes, h.t);
         } else {
-            ++this->triSteps;
+            this->triSteps = uniformAdd(this->triSteps, 1u);
             if (t) testOne(tris);
             const bool second = t && this->ty != 0;
-            this->triVisits += ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second))); // the vote below is for the count only
+            this->triVisits = uniformAdd(this->triVisits, ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second)))); // that vote is for the count only
             if (!second) { if (t) Base::refill(); return; }
             testOne(tris);
         }
@@ -290,15 +293,15 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         const bool n = Base::atNode(), t = Base::atTriangles();
         const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
         if (cn >= ct) {
-            ++this->nodeSteps;
-            this->nodeVisits += cn;
+            this->nodeSteps = uniformAdd(this->nodeSteps, 1u);
+            this->nodeVisits = uniformAdd(this->nodeVisits, cn);
             if (!n) return;
             Base::nodeStep(nodes, tMax);
         } else {
-            ++this->triSteps;
+            this->triSteps = uniformAdd(this->triSteps, 1u);
             if (t) testOne(tris);
             const bool second = t && this->ty != 0;
-            this->triVisits += ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second)));
+            this->triVisits = uniformAdd(this->triVisits, ct + (LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(second))));
             if (!second) { if (t) Base::refill(); return; }
             testOne(tris);
         }
