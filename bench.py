@@ -262,6 +262,11 @@ def run_workload(args, variant, steps, ctx):
                 % (RAY_IO_BYTES, "" if not in_lds else "; tree and triangles are staged into LDS once per block and cost no HBM bytes per visit"
                    ) + ("" if in_lds else " + node_bytes x nodes fetched + 48 B x triangles tested"),
     }
+    if pmc and "valu_issue_share" in pmc and "valu_lane_use" in pmc:
+        # the other roof of this kernel: share of the chip's VALU issue slots that did lane work (issue share x lanes
+        # active per instruction, from the committed PMC pass of this workload); the binding one for a scene held in LDS
+        out["roofline"]["valu_frac"] = pmc["valu_issue_share"] * pmc["valu_lane_use"]
+        out["roofline"]["binding_roof"] = "valu issue" if (in_lds or pmc["valu_issue_share"] > achieved / HBM_PEAK_GBS) else "hbm"
     if n_shadow:
         nps, tps = nodes_s / max(1.0, rs), tris_s / max(1.0, rs)
         b_sh = 36 + 4 + 16 + (0.0 if in_lds else node_bytes * nps + TRIANGLE_BYTES * tps)  # ray + queue word read, radiance read-modify-write

@@ -1345,11 +1345,14 @@ RcclApi* rccl() {
     static RcclApi api;
     if (api.lib || !api.error.empty()) return &api;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
     for (const char* n : names) {
         api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (api.lib) break;
+        const char* e = dlerror(); // one call: it hands the message out once and then forgets it
+        why += std::string(why.empty() ? "" : "; ") + (e ? e : n);
     }
-    if (!api.lib) { api.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"); return &api; }
+    if (!api.lib) { api.error = "cannot load librccl: " + why; return &api; }
     struct { const char* name; void** slot; } syms[] = {
         {"ncclGetUniqueId", (void**)&api.getUniqueId}, {"ncclCommInitRank", (void**)&api.commInitRank}, {"ncclCommDestroy", (void**)&api.commDestroy},
         {"ncclCommCount", (void**)&api.commCount}, {"ncclCommUserRank", (void**)&api.commUserRank}, {"ncclReduce", (void**)&api.reduce},
