@@ -15,13 +15,14 @@
 //
 // Inside the subset: trianglemesh (with N, uv / st) and sphere shapes; matte, metal (default spectra: the reference's
 // copper), glass, plastic and "none" materials; constant and imagemap (PFM) textures; point, spot, distant, infinite
-// and diffuse area lights; homogeneous named media and medium interfaces; the path, directlighting and volpath
+// and diffuse area lights; homogeneous named media (with the measured presets) and medium interfaces; the path, directlighting and volpath
 // integrators; the sobol sampler, the perspective camera, the image film with its five filters.  Outside it (other
 // shapes and texture classes, spectra other than rgb, object instancing, heterogeneous media, other samplers / cameras /
 // lights / integrators) the front end throws std::runtime_error naming the directive; it never renders something
 // else silently.
 #pragma once
 #include "enigma_host.h"
+#include "medium_presets.inc"
 
 #include <cctype>
 #include <cstdlib>
@@ -311,9 +312,20 @@ public:
         if (type.empty()) throw std::runtime_error("No parameter string \"type\" found in MakeNamedMedium");
         if (type == "heterogeneous") throw std::runtime_error("MakeNamedMedium \"heterogeneous\": the reference's GridDensityMedium is a stub (Tr and Sample return black); only \"homogeneous\" media are supported");
         if (type != "homogeneous") throw std::runtime_error("Medium \"" + type + "\" unknown.");
-        if (!p.FindOneString("preset", "").empty()) throw std::runtime_error("MakeNamedMedium: \"preset\" (measured scattering tables) is not supported; give sigma_a and sigma_s");
+        Spectrum sigA(.0011f, .0024f, .014f), sigS(2.55f, 3.21f, 3.77f);
+        // GetMediumScatteringProperties (Enigma/MediumInterface.cpp:184-194): a measured medium by name; an unknown name keeps the defaults
+        const std::string preset = p.FindOneString("preset", "");
+        bool found = false;
+        for (const MediumPreset& mp : kMediumPresets)
+            if (preset == mp.name) {
+                sigA = Spectrum(mp.sigma_a[0], mp.sigma_a[1], mp.sigma_a[2]);
+                sigS = Spectrum(mp.sigma_prime_s[0], mp.sigma_prime_s[1], mp.sigma_prime_s[2]);
+                found = true;
+                break;
+            }
+        if (!preset.empty() && !found) Warn("Material preset \"" + preset + "\" not found.  Using defaults.");
         float scale = p.FindOneFloat("scale", 1.f);
-        Spectrum sa = p.FindOneSpectrum("sigma_a", Spectrum(.0011f, .0024f, .014f)), ss = p.FindOneSpectrum("sigma_s", Spectrum(2.55f, 3.21f, 3.77f));
+        Spectrum sa = p.FindOneSpectrum("sigma_a", sigA), ss = p.FindOneSpectrum("sigma_s", sigS);
         EnigmaMedium m{};
         for (int c = 0; c < 3; ++c) { m.sigma_a[c] = sa[c] * scale; m.sigma_s[c] = ss[c] * scale; }
         m.g = p.FindOneFloat("g", 0.0f);

@@ -286,15 +286,52 @@ def test_media_medium_interfaces_and_the_volpath_integrator(tmp_path):
         tri_mat += [m["material"]] * n; tri_in += [m["medium_inside"]] * n; tri_out += [m["medium_outside"]] * n
     assert tri_in == list(sc.tri_medium_inside) and tri_out == list(sc.tri_medium_outside)
     assert [(-1 if int(x) == abi.NO_MATERIAL else int(x)) for x in sc.tri_material] == tri_mat
-    # a medium named before it is made, a heterogeneous medium, a preset: reported, not guessed
+    # a medium named before it is made, a heterogeneous medium: reported, not guessed
     head = 'Camera "perspective"\nFilm "image" "integer xresolution" 4 "integer yresolution" 4\nSampler "sobol"\nWorldBegin\n'
     for body, msg in (('MediumInterface "fog" ""\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "undefined"),
-                      ('MakeNamedMedium "a" "string type" "heterogeneous" "float density" [1]\nWorldEnd\n', "stub"),
-                      ('MakeNamedMedium "a" "string type" "homogeneous" "string preset" "Skin1"\nWorldEnd\n', "preset")):
+                      ('MakeNamedMedium "a" "string type" "heterogeneous" "float density" [1]\nWorldEnd\n', "stub")):
         f = tmp_path / "bad.pbrt"
         f.write_text(head + body)
         p = subprocess.run([EXE, "--dump", str(f), str(tmp_path / "bad.json")], capture_output=True, text=True)
         assert p.returncode != 0 and msg in p.stderr
+
+
+def _presets():
+    rows = [l.rstrip("\n").split(" | ") for l in open(os.path.join(ROOT, "raytrace_amd", "data", "medium_presets.txt")) if not l.startswith("#")]
+    return [r[0] for r in rows], np.array([[float(t) for t in (r[1] + " " + r[2]).split()] for r in rows], dtype="<f4")
+
+
+def test_measured_medium_presets_are_the_reference_table(tmp_path):
+    """MakeNamedMedium's "preset" (Enigma/Api.cpp:285-298, GetMediumScatteringProperties, Enigma/MediumInterface.cpp:184-194):
+    the table of measured media is pinned to the reference's by digest (tests/golden/medium_presets_digest.json, written
+    by tools/derive_medium_presets.py from the reference's text); a preset sets sigma_a and sigma'_s, explicit spectra
+    override it, "scale" multiplies either, and an unknown name warns and keeps the defaults (those of "Wholemilk")."""
+    import hashlib
+    names, coeff = _presets()
+    digest = json.load(open(os.path.join(ROOT, "tests", "golden", "medium_presets_digest.json")))
+    assert len(names) == digest["count"] == 47
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == digest["names"]
+    assert hashlib.sha256(coeff.tobytes()).hexdigest() == digest["coefficients"]
+    head = 'Camera "perspective"\nFilm "image" "integer xresolution" 4 "integer yresolution" 4\nSampler "sobol"\nWorldBegin\n'
+    body = "".join('MakeNamedMedium "m%d" "string type" "homogeneous" "string preset" "%s"\n' % (i, n) for i, n in enumerate(names))
+    body += 'MakeNamedMedium "scaled" "string type" "homogeneous" "string preset" "Skin1" "float scale" 4 "float g" 0.5\n'
+    body += 'MakeNamedMedium "mixed" "string type" "homogeneous" "string preset" "Ketchup" "rgb sigma_s" [1 2 3]\n'
+    body += 'MakeNamedMedium "unknown" "string type" "homogeneous" "string preset" "Unobtainium"\n'
+    body += 'MakeNamedMedium "plain" "string type" "homogeneous"\n'
+    d = dump(tmp_path, head + body + 'Shape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
+    media = d["media"]
+    assert len(media) == len(names) + 4
+    for i in range(len(names)):  # the compiled table (what the driver was built with) against the data file, value for value
+        assert np.array_equal(np.float32(media[i]["sigma_s"]), coeff[i, :3]) and np.array_equal(np.float32(media[i]["sigma_a"]), coeff[i, 3:]), names[i]
+        assert media[i]["g"][0] == 0.0
+    skin, ketchup, milk = names.index("Skin1"), names.index("Ketchup"), names.index("Wholemilk")
+    scaled, mixed, unknown, plain = media[len(names):]
+    assert np.array_equal(np.float32(scaled["sigma_a"]), coeff[skin, 3:] * np.float32(4)) and np.array_equal(np.float32(scaled["sigma_s"]), coeff[skin, :3] * np.float32(4))
+    assert scaled["g"][0] == 0.5
+    assert np.array_equal(np.float32(mixed["sigma_a"]), coeff[ketchup, 3:]) and np.array_equal(np.float32(mixed["sigma_s"]), np.float32([1, 2, 3]))
+    for m in (unknown, plain):
+        assert np.array_equal(np.float32(m["sigma_a"]), coeff[milk, 3:]) and np.array_equal(np.float32(m["sigma_s"]), coeff[milk, :3])
+    assert any("Unobtainium" in w for w in d["warnings"])
 
 
 def test_shading_normals_and_uvs_reach_the_mesh(tmp_path):
