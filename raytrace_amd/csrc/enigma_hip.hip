@@ -266,18 +266,22 @@ static bool convertMaterial(const EnigmaMaterial& m, DevMaterial& d) {
 // Cross(p1 - p0, p2 - p0), -1 for the other, 0 when they disagree or graze the plane.  Triangle::sample and
 // Triangle::intersect turn the geometric normal to face the interpolated one (Enigma/TriangleMesh.cpp:618-623,
 // Enigma/Interaction.cpp:139-141); with all three on one side that is the same turn at every point of the triangle.
+// The cross product is the single-precision one the sampling code itself forms (same operations, same order): for a
+// sliver whose exact normal drowns in the cancellation, the turn must follow the normal that code sees, not the exact one.
 static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
     const float* p[3]; const float* n[3];
     for (int k = 0; k < 3; ++k) { p[k] = &s->vertices[3 * (size_t)s->indices[3 * (size_t)t + k]]; n[k] = &s->normals[3 * (size_t)s->indices[3 * (size_t)t + k]]; }
-    const double e1[3] = {(double)p[1][0] - p[0][0], (double)p[1][1] - p[0][1], (double)p[1][2] - p[0][2]};
-    const double e2[3] = {(double)p[2][0] - p[0][0], (double)p[2][1] - p[0][1], (double)p[2][2] - p[0][2]};
-    const double g[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+    const float e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+    const float gx = e1[1] * e2[2] - e2[1] * e1[2], gy = e1[2] * e2[0] - e2[2] * e1[0], gz = e1[0] * e2[1] - e2[0] * e1[1];
+    const double g[3] = {(double)gx, (double)gy, (double)gz};
     const double gl = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    if (gl == 0) return 1; // no area: never hit, and its sampled normal is NaN whichever way it is turned (the pdf test drops the sample)
     int pos = 0, neg = 0;
     for (int k = 0; k < 3; ++k) {
         const double nl = std::sqrt((double)n[k][0] * n[k][0] + (double)n[k][1] * n[k][1] + (double)n[k][2] * n[k][2]);
         const double c = (g[0] * n[k][0] + g[1] * n[k][1] + g[2] * n[k][2]) / (gl * nl);
-        if (c > 1e-3) ++pos; else if (c < -1e-3) ++neg; // NaN (a zero normal or a degenerate triangle) counts for neither
+        if (c > 1e-3) ++pos; else if (c < -1e-3) ++neg; // NaN (a zero normal) counts for neither
     }
     return pos == 3 ? 1 : neg == 3 ? -1 : 0;
 }

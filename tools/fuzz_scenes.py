@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the GPU library against the CPU oracle on random small scenes (needs a GPU).
+
+    python tools/fuzz_scenes.py <first seed> <count> [out.json]
+
+A seed fixes everything: a soup of random triangles (some degenerate, some tiny, some huge, some with per-vertex
+normals / uvs), random materials of every kind, emissive triangles, delta lights, optionally spheres, media and an
+environment light, a random camera, integrator (path / direct lighting / volpath), depth, Russian-roulette threshold,
+light strategy and pixel filter; a second stream of choices adds image textures, a dense bumpy sheet (a deep tree),
+surfaces without a material and a crop window.  Per seed the script compares ray counts and images and prints one
+line; failures (an error code on one side only, other than the documented refusals; counts apart by more than 1 %;
+mean relative error above 1 %) end in a non-zero exit status.  tests/test_gpu_random_scenes.py runs a fixed handful of seeds through random_case().
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from raytrace_amd import abi, scenes  # noqa: E402
+
+
+DOCUMENTED_REFUSALS = ("reads past the sample arrays", "vertex normals lie on both sides", "trilinear textures", "without a material")
+
+
+def _unit(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def _colour(rng, lo=0.05, hi=0.95):
+    return tuple(float(x) for x in rng.uniform(lo, hi, 3))
+
+
+def random_material(rng):
+    k = rng.randint(0, 7)
+    if k == 0:
+        return abi.matte(_colour(rng))
+    if k == 1:
+        return abi.matte(_colour(rng), sigma=float(rng.uniform(5, 80)))
+    if k == 2:
+        if rng.rand() < 0.5:
+            return abi.metal(_colour(rng, 0.1, 2.0), _colour(rng, 1.0, 5.0), roughness=float(10 ** rng.uniform(-3, -0.3)), remap=bool(rng.randint(2)))
+        return abi.metal(_colour(rng, 0.1, 2.0), _colour(rng, 1.0, 5.0), uroughness=float(10 ** rng.uniform(-2.5, -0.5)), vroughness=float(10 ** rng.uniform(-2.5, -0.5)), remap=bool(rng.randint(2)))
+    if k == 3:
+        return abi.glass(float(rng.uniform(1.05, 2.2)), 0.0, 0.0, kr=_colour(rng), kt=_colour(rng))
+    if k == 4:
+        return abi.glass(float(rng.uniform(1.05, 2.2)), float(10 ** rng.uniform(-2.5, -0.5)), float(10 ** rng.uniform(-2.5, -0.5)), kr=_colour(rng), kt=_colour(rng), remap=bool(rng.randint(2)))
+    if k == 5:
+        return abi.plastic(_colour(rng), _colour(rng), roughness=float(10 ** rng.uniform(-2.5, -0.3)), remap=bool(rng.randint(2)))
+    return abi.glass(1.5, 0.0, 0.0, kr=(1, 1, 1), kt=(0, 0, 0))  # a mirror-like glass: reflection only
+
+
+def random_case(seed, res=24, spp=4):
+    """(scene arrays, camera, film, integrator description, label) of one seed."""
+    rng = np.random.RandomState(seed)
+    b = scenes.MeshBuilder()
+    mats = [b.add_material(random_material(rng)) for _ in range(rng.randint(1, 7))]
+    extent = 10.0
+    integ_kind = rng.choice(["path", "path", "path", "direct-one", "direct-all", "volpath"])
+    use_media = integ_kind == "volpath" and rng.rand() < 0.8
+    med = -1
+    if use_media:
+        med = b.add_medium(abi.homogeneous_medium(_colour(rng, 0.0, 0.05), _colour(rng, 0.0, 0.15), g=float(rng.uniform(-0.7, 0.7))))
+    # a closed room (sometimes), so that most paths keep bouncing
+    if rng.rand() < 0.6:
+        lo, hi = -2.0, extent + 2.0
+        c = [(lo, lo, lo), (hi, lo, lo), (hi, hi, lo), (lo, hi, lo), (lo, lo, hi), (hi, lo, hi), (hi, hi, hi), (lo, hi, hi)]
+        centre = ((lo + hi) / 2,) * 3
+        for f in ((0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 3, 7, 4)):
+            b.add_quad([c[i] for i in f], mats[rng.randint(len(mats))], toward=centre)
+    n_tris = rng.randint(4, 60)
+    n_emit = 0
+    for i in range(n_tris):
+        centre = rng.uniform(0, extent, 3)
+        size = 10 ** rng.uniform(-1.0, 0.9)
+        p = [centre + rng.normal(size=3) * size for _ in range(3)]
+        kind = rng.rand()
+        if kind < 0.04:
+            p[2] = p[1].copy()                      # two equal vertices
+        elif kind < 0.08:
+            p[2] = p[0] + 2.5 * (p[1] - p[0])       # collinear
+        elif kind < 0.12:
+            p = [centre + rng.normal(size=3) * 1e-4 for _ in range(3)]  # tiny
+        mat = mats[rng.randint(len(mats))]
+        emit = None
+        if rng.rand() < 0.12 or (i == n_tris - 1 and n_emit == 0 and rng.rand() < 0.7):
+            emit = tuple(float(x) for x in rng.uniform(2, 30, 3))
+            n_emit += 1
+        normals = uvs = None
+        if rng.rand() < 0.25:
+            g = np.cross(p[0] - p[2], p[1] - p[2])
+            gl = np.linalg.norm(g)
+            g = g / gl if gl > 0 else np.array([0.0, 0.0, 1.0])
+            if rng.rand() < 0.5:
+                g = -g
+            normals = [g + rng.normal(size=3) * 0.3 for _ in range(3)]
+        if rng.rand() < 0.25:
+            uvs = [rng.uniform(0, 1, 2) for _ in range(3)]
+            if rng.rand() < 0.15:
+                uvs[2] = uvs[1]                     # degenerate uvs
+        if use_media and rng.rand() < 0.2:
+            b.medium_interface(med if rng.rand() < 0.5 else -1, med if rng.rand() < 0.7 else -1)
+        else:
+            b.medium_interface(med if use_media and rng.rand() < 0.3 else -1, med if use_media and rng.rand() < 0.3 else -1) if use_media else b.medium_interface(-1, -1)
+        b.add_tri(p[0], p[1], p[2], mat, emit=emit, two_sided=bool(rng.randint(2)), normals=normals, uvs=uvs,
+                  reverse_orientation=bool(rng.rand() < 0.2))
+    b.medium_interface(-1, -1)
+    if integ_kind != "direct-all" and rng.rand() < 0.3:
+        for _ in range(rng.randint(1, 4)):
+            m = np.eye(4)
+            m[:3, 3] = rng.uniform(0, extent, 3)
+            if rng.rand() < 0.5:
+                m[:3, :3] = scenes._rotation(_unit(rng), float(rng.uniform(0, 360)))[:3, :3]
+            kw = {}
+            if rng.rand() < 0.3:
+                kw = dict(z_min=float(-rng.uniform(0.2, 1.0)), z_max=float(rng.uniform(0.2, 1.0)), phi_max=float(rng.uniform(90, 360)))
+            emit = tuple(float(x) for x in rng.uniform(2, 20, 3)) if rng.rand() < 0.3 else None
+            r = float(rng.uniform(0.3, 2.0))
+            if kw:
+                kw["z_min"] *= r; kw["z_max"] *= r
+            b.add_sphere(mats[rng.randint(len(mats))], r, m, emit=emit, two_sided=bool(rng.randint(2)), reverse_orientation=bool(rng.rand() < 0.2), **kw)
+    if rng.rand() < 0.35:
+        b.add_point_light(tuple(rng.uniform(0, extent, 3)), tuple(float(x) for x in rng.uniform(20, 200, 3)))
+    if rng.rand() < 0.25:
+        b.add_spot_light(tuple(rng.uniform(0, extent, 3)), tuple(rng.uniform(0, extent, 3)), tuple(float(x) for x in rng.uniform(50, 400, 3)),
+                         coneangle=float(rng.uniform(10, 80)), conedeltaangle=float(rng.uniform(1, 9)))
+    if rng.rand() < 0.2:
+        b.add_distant_light(tuple(rng.uniform(-1, 1, 3) * 2), (0, 0, 0), tuple(float(x) for x in rng.uniform(0.5, 3, 3)))
+    if rng.rand() < 0.2:
+        b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if rng.rand() < 0.5 else None))
+    # ---- a second stream of choices (textures, a dense piece of mesh, boundary surfaces, a crop window): drawn apart from
+    # the first so that a seed's basic scene stays what it was when a choice is added here
+    xr = np.random.RandomState((seed * 2654435761 + 0x5EED) & 0x7fffffff)
+    if xr.rand() < 0.3:
+        for _ in range(xr.randint(1, 4)):
+            img = scenes.test_pattern(int(xr.choice([2, 5, 16, 32])), int(xr.choice([2, 7, 16, 64])), seed=int(xr.randint(1 << 30)))
+            t = b.add_texture(abi.image_texture(img * float(xr.uniform(0.3, 1.0)), trilinear=bool(xr.rand() < 0.7), gamma=bool(xr.rand() < 0.8),
+                                                scale=float(xr.uniform(0.5, 1.0)), wrap=int(xr.randint(3)), su=float(xr.uniform(0.3, 4)), sv=float(xr.uniform(0.3, 4)),
+                                                du=float(xr.uniform(-1, 1)), dv=float(xr.uniform(-1, 1))))
+            m = b.materials[xr.randint(len(b.materials))]
+            field = {abi.MAT_MATTE: ["tex_kd"], abi.MAT_METAL: ["tex_eta", "tex_k"], abi.MAT_GLASS: ["tex_kr", "tex_kt"], abi.MAT_PLASTIC: ["tex_kd", "tex_ks"]}[m.type]
+            setattr(m, field[xr.randint(len(field))], t)
+    if xr.rand() < 0.25:  # a bumpy sheet of many small triangles: a deep tree under a shallow one
+        n = int(xr.choice([8, 24, 48]))
+        org, ax, ay = xr.uniform(1, 6, 3), _unit(xr) * xr.uniform(2, 6), _unit(xr) * xr.uniform(2, 6)
+        up = np.cross(ax, ay); up = up / max(np.linalg.norm(up), 1e-9)
+        hgt = xr.uniform(-0.15, 0.15, (n + 1, n + 1))
+        P = lambda i, j: org + ax * (i / n) + ay * (j / n) + up * hgt[i, j]
+        mat = mats[xr.randint(len(mats))]
+        smooth = xr.rand() < 0.5
+        for i in range(n):
+            for j in range(n):
+                q = [P(i, j), P(i + 1, j), P(i + 1, j + 1), P(i, j + 1)]
+                uv = [(i / n, j / n), ((i + 1) / n, j / n), ((i + 1) / n, (j + 1) / n), (i / n, (j + 1) / n)]
+                nrm = [up + xr.normal(size=3) * 0.05 for _ in range(4)] if smooth else None
+                b.add_tri(q[0], q[1], q[2], mat, uvs=(uv[0], uv[1], uv[2]), normals=None if nrm is None else (nrm[0], nrm[1], nrm[2]))
+                b.add_tri(q[0], q[2], q[3], mat, uvs=(uv[0], uv[2], uv[3]), normals=None if nrm is None else (nrm[0], nrm[2], nrm[3]))
+    if integ_kind in ("path", "volpath") and xr.rand() < 0.2:  # surfaces without a material: passed through
+        for _ in range(xr.randint(1, 4)):
+            centre = xr.uniform(0, extent, 3)
+            if use_media:
+                b.medium_interface(med if xr.rand() < 0.7 else -1, med if xr.rand() < 0.3 else -1)
+            p = [centre + xr.normal(size=3) * 3 for _ in range(3)]
+            b.add_tri(p[0], p[1], p[2], abi.NO_MATERIAL)
+        b.medium_interface(-1, -1)
+    crop = (0.0, 1.0, 0.0, 1.0)
+    if xr.rand() < 0.2:
+        x0, y0 = xr.uniform(0, 0.5, 2)
+        crop = (float(x0), float(x0 + xr.uniform(0.2, 0.5)), float(y0), float(y0 + xr.uniform(0.2, 0.5)))
+    sc = b.arrays(weld=bool(rng.randint(2)))
+    eye = rng.uniform(0, extent, 3)
+    look = rng.uniform(2, extent - 2, 3)
+    if np.linalg.norm(look - eye) < 1e-2:
+        look = eye + np.array([0, 0, 1.0])
+    up = _unit(rng)
+    if abs(np.dot(up, (look - eye) / np.linalg.norm(look - eye))) > 0.95:
+        up = np.cross(up, look - eye); up /= np.linalg.norm(up)
+    lens = float(rng.uniform(0.01, 0.2)) if rng.rand() < 0.2 else 0.0
+    xres, yres = res + rng.randint(0, 9), res + rng.randint(0, 9)
+    cam = scenes.camera_desc(tuple(eye), tuple(look), tuple(up), float(rng.uniform(25, 100)), xres, yres, lens_radius=lens, focal_distance=float(rng.uniform(2, 12)) if lens else 1e30)
+    fk = rng.choice(["box", "box", "triangle", "gaussian", "mitchell", "sinc"])
+    film = scenes.film_desc(xres, yres, fk, crop=crop)
+    depth = int(rng.randint(1, 9))
+    strategy = [abi.LIGHTS_UNIFORM, abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL][rng.randint(3)]
+    rr = float(rng.choice([1.0, 1.0, 0.2, 0.0, 5.0]))
+    if integ_kind == "path":
+        integ = scenes.integrator_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy)
+    elif integ_kind == "volpath":
+        integ = scenes.volpath_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy)
+    else:
+        integ = scenes.direct_lighting_desc(film, spp, max_depth=min(depth, 4), strategy=abi.DL_SAMPLE_ALL if integ_kind == "direct-all" else abi.DL_SAMPLE_ONE)
+    label = "%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
+        integ_kind, depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), " crop" if crop != (0.0, 1.0, 0.0, 1.0) else "")
+    return sc, cam, film, integ, label
+
+
+def compare(seed, res=24, spp=4):
+    """{"status": "ok" | "both-refuse" | "mismatch", ...} for one seed."""
+    import orc
+    import raytrace_amd as ra
+    import common
+    sc, cam, film, integ, label = random_case(seed, res, spp)
+    out = {"seed": seed, "label": label}
+    r = o = None
+    try:
+        gerr = oerr = None
+        try:
+            r = ra.Renderer(0).configure(sc, cam, film, integ)
+            r.render(0, spp)
+        except ra.EnigmaError as e:
+            gerr = str(e)
+        try:
+            o = orc.Oracle(sc, cam, film, integ)
+            o.render(0, spp, threads=8)
+        except Exception as e:  # the oracle wrapper raises RuntimeError with its message
+            oerr = str(e)
+        if gerr and not oerr and o.read_past_arrays():
+            oerr = "the render read past the integrator's sample arrays (undefined in the reference)"
+        if gerr or oerr:
+            status = "both-refuse" if (gerr and oerr) else "mismatch"
+            # what the library refuses from the scene alone, before a path could run into it (both documented): strategy "all"
+            # next to a branching smooth glass (undefined in the reference once a path meets it), an emissive triangle
+            # whose vertex normals disagree about its side
+            if gerr and not oerr and any(t in gerr for t in DOCUMENTED_REFUSALS):
+                status = "gpu-refuses"
+            # the one combination the oracle does not restate and the library renders: untested here, not a disagreement
+            if oerr and not gerr and "are not restated" in oerr:
+                status = "oracle-refuses"
+            out.update(status=status, gpu_error=gerr, oracle_error=oerr)
+            return out
+        a, bimg = r.image(), o.image()
+        sg, so = r.stats(), o.stats()
+        counts = {k: (int(sg[k]), int(so[k])) for k in ("rays_closest", "rays_shadow", "rays_mis")}
+        out["counts"] = counts
+        out["finite"] = bool(np.isfinite(a).all())
+        out["mre"] = float(common.mean_relative_error(a, bimg))
+        out["median_rel"] = float(np.median(np.abs(a - bimg) / np.maximum(bimg, 1e-3)))
+        out["stack_overflows"] = int(sg.get("stack_overflows", 0))
+        apart = max(abs(g - c) / max(200, c) for g, c in counts.values())  # a ray or two of a few dozen is no percentage
+        out["counts_apart"] = apart
+        # A path whose throughput has run up to 1e12 and beyond (a mirror-sharp lobe met off its peak, bounce after bounce)
+        # sits at the edge of the float range: one more factor overflows or not depending on the last bits of the libm
+        # each side uses, and an overflowed sample is scrubbed to zero (Enigma/Integrator.cpp:284-292).  Such images are
+        # compared by their ray counts and their median pixel only.
+        out["extreme"] = bool(max(float(np.nanmax(np.abs(a))), float(np.nanmax(np.abs(bimg)))) > 1e12)
+        ok = out["finite"] and (out["extreme"] or out["mre"] < 0.01) and out["median_rel"] < 1e-3 and apart <= 0.01 and out["stack_overflows"] == 0
+        out["status"] = "ok" if ok else "mismatch"
+        return out
+    finally:
+        if r is not None:
+            r.close()
+        if o is not None:
+            o.close()
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    results, bad = [], 0
+    for seed in range(first, first + count):
+        res = compare(seed)
+        results.append(res)
+        if res["status"] == "mismatch":
+            bad += 1
+        print(json.dumps(res), flush=True)
+    if len(sys.argv) > 3:
+        json.dump(results, open(sys.argv[3], "w"), indent=1)
+    print("seeds %d..%d: %d ok, %d both refuse, %d refused by the library alone (documented), %d not restated by the oracle, %d mismatch" % (
+        first, first + count - 1, sum(r["status"] == "ok" for r in results), sum(r["status"] == "both-refuse" for r in results),
+        sum(r["status"] == "gpu-refuses" for r in results), sum(r["status"] == "oracle-refuses" for r in results), bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
