@@ -31,11 +31,13 @@ def look_at(pos, look, up):
 def perspective_raster_to_camera(fov_deg, xres, yres, n=1e-2, f=1000.0):
     """rasterToCamera = Inverse(cameraToScreen) * Inverse(screenToRaster)
     (Enigma/Camera.cpp:90-97,421-430) evaluated in float64."""
-    frame = xres / yres
-    if frame > 1.0:
-        screen = (-frame, frame, -1.0, 1.0)
+    # the screen window is a single-precision quantity (CreatePerspectiveCamera, Enigma/Camera.cpp:385-432: float frame,
+    # Bounds2f screen); everything after it is evaluated in float64 and rounded once
+    frame = F32(xres) / F32(yres)
+    if frame > F32(1.0):
+        screen = (float(-frame), float(frame), -1.0, 1.0)
     else:
-        screen = (-1.0, 1.0, -1.0 / frame, 1.0 / frame)
+        screen = (-1.0, 1.0, float(F32(-1.0) / frame), float(F32(1.0) / frame))
     persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], dtype=np.float64)
     inv_tan = 1.0 / math.tan(math.radians(fov_deg) / 2)
     cam_to_screen = np.diag([inv_tan, inv_tan, 1, 1]) @ persp

@@ -54,8 +54,10 @@ def random_material(rng):
     return abi.glass(1.5, 0.0, 0.0, kr=(1, 1, 1), kt=(0, 0, 0))  # a mirror-like glass: reflection only
 
 
-def random_case(seed, res=24, spp=4):
-    """(scene arrays, camera, film, integrator description, label) of one seed."""
+def random_case(seed, res=24, spp=4, for_file=False, details=None):
+    """(scene arrays, camera, film, integrator description, label) of one seed.
+    for_file: the variant tests/pbrt_writer.py can write down (lights on spheres last, a constant environment);
+    details: a dictionary that receives what the scene file's header needs (camera, filter, integrator, crop)."""
     rng = np.random.RandomState(seed)
     b = scenes.MeshBuilder()
     mats = [b.add_material(random_material(rng)) for _ in range(rng.randint(1, 7))]
@@ -109,20 +111,23 @@ def random_case(seed, res=24, spp=4):
         b.add_tri(p[0], p[1], p[2], mat, emit=emit, two_sided=bool(rng.randint(2)), normals=normals, uvs=uvs,
                   reverse_orientation=bool(rng.rand() < 0.2))
     b.medium_interface(-1, -1)
-    if integ_kind != "direct-all" and rng.rand() < 0.3:
+    def add_spheres():
         for _ in range(rng.randint(1, 4)):
-            m = np.eye(4)
-            m[:3, 3] = rng.uniform(0, extent, 3)
-            if rng.rand() < 0.5:
-                m[:3, :3] = scenes._rotation(_unit(rng), float(rng.uniform(0, 360)))[:3, :3]
-            kw = {}
-            if rng.rand() < 0.3:
-                kw = dict(z_min=float(-rng.uniform(0.2, 1.0)), z_max=float(rng.uniform(0.2, 1.0)), phi_max=float(rng.uniform(90, 360)))
-            emit = tuple(float(x) for x in rng.uniform(2, 20, 3)) if rng.rand() < 0.3 else None
-            r = float(rng.uniform(0.3, 2.0))
-            if kw:
-                kw["z_min"] *= r; kw["z_max"] *= r
-            b.add_sphere(mats[rng.randint(len(mats))], r, m, emit=emit, two_sided=bool(rng.randint(2)), reverse_orientation=bool(rng.rand() < 0.2), **kw)
+                m = np.eye(4)
+                m[:3, 3] = rng.uniform(0, extent, 3)
+                if rng.rand() < 0.5:
+                    m[:3, :3] = scenes._rotation(_unit(rng), float(rng.uniform(0, 360)))[:3, :3]
+                kw = {}
+                if rng.rand() < 0.3:
+                    kw = dict(z_min=float(-rng.uniform(0.2, 1.0)), z_max=float(rng.uniform(0.2, 1.0)), phi_max=float(rng.uniform(90, 360)))
+                emit = tuple(float(x) for x in rng.uniform(2, 20, 3)) if rng.rand() < 0.3 else None
+                r = float(rng.uniform(0.3, 2.0))
+                if kw:
+                    kw["z_min"] *= r; kw["z_max"] *= r
+                b.add_sphere(mats[rng.randint(len(mats))], r, m, emit=emit, two_sided=bool(rng.randint(2)), reverse_orientation=bool(rng.rand() < 0.2), **kw)
+    want_spheres = integ_kind != "direct-all" and rng.rand() < 0.3
+    if want_spheres and not for_file:
+        add_spheres()
     if rng.rand() < 0.35:
         b.add_point_light(tuple(rng.uniform(0, extent, 3)), tuple(float(x) for x in rng.uniform(20, 200, 3)))
     if rng.rand() < 0.25:
@@ -131,7 +136,9 @@ def random_case(seed, res=24, spp=4):
     if rng.rand() < 0.2:
         b.add_distant_light(tuple(rng.uniform(-1, 1, 3) * 2), (0, 0, 0), tuple(float(x) for x in rng.uniform(0.5, 3, 3)))
     if rng.rand() < 0.2:
-        b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if rng.rand() < 0.5 else None))
+        b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if (rng.rand() < 0.5 and not for_file) else None))
+    if want_spheres and for_file:
+        add_spheres()
     # ---- a second stream of choices (textures, a dense piece of mesh, boundary surfaces, a crop window): drawn apart from
     # the first so that a seed's basic scene stays what it was when a choice is added here
     xr = np.random.RandomState((seed * 2654435761 + 0x5EED) & 0x7fffffff)
@@ -180,8 +187,15 @@ def random_case(seed, res=24, spp=4):
     if abs(np.dot(up, (look - eye) / np.linalg.norm(look - eye))) > 0.95:
         up = np.cross(up, look - eye); up /= np.linalg.norm(up)
     lens = float(rng.uniform(0.01, 0.2)) if rng.rand() < 0.2 else 0.0
+    f32 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)  # what a scene file can carry: single-precision parameters
+    if for_file:
+        eye, look, up, lens = f32(eye), f32(look), f32(up), float(f32(lens))
     xres, yres = res + rng.randint(0, 9), res + rng.randint(0, 9)
-    cam = scenes.camera_desc(tuple(eye), tuple(look), tuple(up), float(rng.uniform(25, 100)), xres, yres, lens_radius=lens, focal_distance=float(rng.uniform(2, 12)) if lens else 1e30)
+    fov, focal = float(rng.uniform(25, 100)), float(rng.uniform(2, 12))
+    if for_file:
+        fov, focal = float(f32(fov)), float(f32(focal))
+        crop = tuple(float(f32(c)) for c in crop)
+    cam = scenes.camera_desc(tuple(eye), tuple(look), tuple(up), fov, xres, yres, lens_radius=lens, focal_distance=focal if lens else 1e30)
     fk = rng.choice(["box", "box", "triangle", "gaussian", "mitchell", "sinc"])
     film = scenes.film_desc(xres, yres, fk, crop=crop)
     depth = int(rng.randint(1, 9))
@@ -193,6 +207,9 @@ def random_case(seed, res=24, spp=4):
         integ = scenes.volpath_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy)
     else:
         integ = scenes.direct_lighting_desc(film, spp, max_depth=min(depth, 4), strategy=abi.DL_SAMPLE_ALL if integ_kind == "direct-all" else abi.DL_SAMPLE_ONE)
+    if details is not None:
+        details.update(eye=tuple(float(v) for v in eye), look=tuple(float(v) for v in look), up=tuple(float(v) for v in up), fov=fov, xres=int(xres), yres=int(yres),
+                       lens=lens, focal=float(cam.focal_distance), filter=str(fk), crop=crop, integ_kind=str(integ_kind), depth=depth, rr=rr, strategy=strategy)
     label = "%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
         integ_kind, depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), " crop" if crop != (0.0, 1.0, 0.0, 1.0) else "")
     return sc, cam, film, integ, label
@@ -257,7 +274,93 @@ def compare(seed, res=24, spp=4):
             o.close()
 
 
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        assert float(f.readline()) < 0
+        img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    return img[::-1]
+
+
+def compare_file(seed, directory, res=24, spp=4):
+    """The same comparison through the scene-description front end: the seed's scene written as pbrt-format text
+    (tests/pbrt_writer.py), rendered by raytrace_amd/enigma_render (front end, host mirror classes, C ABI, GPU), against
+    the oracle rendering the scene built in Python."""
+    import subprocess
+    import orc
+    import common
+    import pbrt_writer
+    d = {}
+    sc, cam, film, integ, label = random_case(seed, res, spp, for_file=True, details=d)
+    out = {"seed": seed, "label": label}
+    strategy = {abi.LIGHTS_UNIFORM: "uniform", abi.LIGHTS_POWER: "power", abi.LIGHTS_SPATIAL: "spatial"}[d["strategy"]]
+    if d["integ_kind"] == "path":
+        itext = 'Integrator "path" "integer maxdepth" %d "float rrthreshold" %.9g "string lightsamplestrategy" "%s"' % (d["depth"], d["rr"], strategy)
+    elif d["integ_kind"] == "volpath":
+        itext = 'Integrator "volpath" "integer maxdepth" %d "float rrthreshold" %.9g "string lightsamplestrategy" "%s"' % (d["depth"], d["rr"], strategy)
+    else:
+        itext = 'Integrator "directlighting" "integer maxdepth" %d "string strategy" "%s"' % (min(d["depth"], 4), "all" if d["integ_kind"] == "direct-all" else "one")
+    crop = d["crop"]
+    film_extra = "" if crop == (0.0, 1.0, 0.0, 1.0) else '"float cropwindow" [%.9g %.9g %.9g %.9g]' % crop
+    lens = '"float lensradius" %.9g "float focaldistance" %.9g' % (d["lens"], d["focal"]) if d["lens"] else ""
+    text = pbrt_writer.scene_text(sc, d["eye"], d["look"], d["up"], d["fov"], d["xres"], d["yres"], spp, integrator=itext,
+                                  pixel_filter='PixelFilter "%s"' % d["filter"], film_extra=film_extra, lens=lens, texture_dir=directory)
+    scene_file, out_file = os.path.join(directory, "s%d.pbrt" % seed), os.path.join(directory, "s%d.pfm" % seed)
+    with open(scene_file, "w") as f:
+        f.write(text)
+    p = subprocess.run([os.path.join(ROOT, "raytrace_amd", "enigma_render"), scene_file, out_file], capture_output=True, text=True, timeout=300)
+    gerr = None if p.returncode == 0 else (p.stderr.strip().splitlines() or ["exit status %d" % p.returncode])[-1]
+    if p.returncode < 0 or p.returncode > 2:
+        out.update(status="mismatch", gpu_error="enigma_render died: %s" % gerr)
+        return out
+    o = oerr = None
+    try:
+        o = orc.Oracle(sc, cam, film, integ)
+        o.render(0, spp, threads=8)
+    except Exception as e:
+        oerr = str(e)
+    try:
+        if gerr and not oerr and o.read_past_arrays():
+            oerr = "the render read past the integrator's sample arrays (undefined in the reference)"
+        if gerr or oerr:
+            status = "both-refuse" if (gerr and oerr) else "mismatch"
+            if gerr and not oerr and any(t in gerr for t in DOCUMENTED_REFUSALS):
+                status = "gpu-refuses"
+            if oerr and not gerr and "are not restated" in oerr:
+                status = "oracle-refuses"
+            out.update(status=status, gpu_error=gerr, oracle_error=oerr)
+            return out
+        a, bimg = read_pfm(out_file), o.image()
+        if a.shape != bimg.shape:
+            out.update(status="mismatch", gpu_error="image %s against %s" % (a.shape, bimg.shape))
+            return out
+        out["finite"] = bool(np.isfinite(a).all())
+        out["mre"] = float(common.mean_relative_error(a, bimg))
+        out["median_rel"] = float(np.median(np.abs(a - bimg) / np.maximum(bimg, 1e-3)))
+        out["extreme"] = bool(max(float(np.nanmax(np.abs(a))), float(np.nanmax(np.abs(bimg)))) > 1e12)
+        ok = out["finite"] and (out["extreme"] or out["mre"] < 0.01) and out["median_rel"] < 1e-3
+        out["status"] = "ok" if ok else "mismatch"
+        return out
+    finally:
+        if o is not None:
+            o.close()
+        for f in (scene_file, out_file):
+            if os.path.exists(f) and out.get("status") != "mismatch":
+                os.remove(f)
+
+
 def main():
+    if sys.argv[1] == "--files":   # python tools/fuzz_scenes.py --files <first seed> <count> <directory>
+        first, count, directory = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+        os.makedirs(directory, exist_ok=True)
+        results = [compare_file(seed, directory) for seed in range(first, first + count)]
+        for r in results:
+            if r["status"] != "ok":
+                print(json.dumps(r), flush=True)
+        import collections
+        print("scene files, seeds %d..%d: %s" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results))))
+        sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     first, count = int(sys.argv[1]), int(sys.argv[2])
     results, bad = [], 0
     for seed in range(first, first + count):
