@@ -20,12 +20,16 @@ struct Box {
     void grow(const Box& b) {
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
     }
-    float area() const {
-        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-        if (dx < 0) return 0.f;
-        return 2.f * (dx * dy + dx * dz + dy * dz);
+    // in double: the extents of a scene that reaches out to 2^60 square to 2^122, and the cost sums below add many of those
+    double area() const {
+        double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        if (dx < 0) return 0.0;
+        return 2.0 * (dx * dy + dx * dz + dy * dz);
     }
 };
+
+// the bin of a centroid at offset * scale along an axis: in range whatever the product is (NaN and negatives go to bin 0)
+inline int binOf(float offsetTimesScale, int bins) { return offsetTimesScale >= 0.f ? (offsetTimesScale < (float)bins ? (int)offsetTimesScale : bins - 1) : 0; }
 
 struct TmpNode {
     Box box;
@@ -73,7 +77,7 @@ struct Builder {
                 return centroid[3 * (size_t)x + axis] < centroid[3 * (size_t)y + axis];
             });
         } else {
-            float bestCost = FLT_MAX;
+            double bestCost = HUGE_VAL;
             int bestAxis = -1, bestBin = -1;
             for (int a = 0; a < 3; ++a) {
                 if (ext[a] <= 0.f) continue;
@@ -82,11 +86,11 @@ struct Builder {
                 float scale = kBins / ext[a];
                 for (uint32_t i = first; i < first + count; ++i) {
                     uint32_t t = order[i];
-                    int b = std::min(kBins - 1, (int)((centroid[3 * (size_t)t + a] - cbox.lo[a]) * scale));
+                    int b = binOf((centroid[3 * (size_t)t + a] - cbox.lo[a]) * scale, kBins);
                     bb[b].grow(triBox[t]);
                     bc[b]++;
                 }
-                float rightArea[kMaxBins];
+                double rightArea[kMaxBins];
                 uint32_t rightCount[kMaxBins];
                 Box acc;
                 uint32_t cnt = 0;
@@ -99,18 +103,18 @@ struct Builder {
                 for (int b = 0; b < kBins - 1; ++b) {
                     accL.grow(bb[b]); cntL += bc[b];
                     if (cntL == 0 || rightCount[b + 1] == 0) continue;
-                    float cost = accL.area() * cntL + rightArea[b + 1] * rightCount[b + 1];
+                    double cost = accL.area() * cntL + rightArea[b + 1] * rightCount[b + 1];
                     if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = b; }
                 }
             }
-            float parentArea = std::max(box.area(), 1e-30f);
-            float splitCost = 1.0f + bestCost / parentArea;
-            if (count <= maxLeaf && (bestAxis < 0 || (float)count <= splitCost)) return makeLeaf();
+            double parentArea = std::max(box.area(), 1e-30);
+            double splitCost = 1.0 + bestCost / parentArea;
+            if (count <= maxLeaf && (bestAxis < 0 || (double)count <= splitCost)) return makeLeaf();
             if (bestAxis >= 0) {
                 float scale = kBins / ext[bestAxis];
                 float lo = cbox.lo[bestAxis];
                 auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-                    int b = std::min(kBins - 1, (int)((centroid[3 * (size_t)t + bestAxis] - lo) * scale));
+                    int b = binOf((centroid[3 * (size_t)t + bestAxis] - lo) * scale, kBins);
                     return b <= bestBin;
                 });
                 mid = (uint32_t)(it - order.begin());
@@ -181,37 +185,37 @@ void build_bvh8(const float* vertices, const uint32_t* indices, uint32_t nTriang
     //                                       wide node = area * cNode + distribute(n, 8)
     //   cost[n][i] = min(distribute(n, i), cost[n][i - 1]),  distribute(n, j) = min over k of cost[left][k] + cost[right][j - k]
     // Binary nodes are numbered parent before children, so one backward sweep sees children first.
-    const float cNode = 1.0f;
-    float cPrim = 0.6f; // a node visit against one triangle test, by their instruction counts
-    if (const char* e = getenv("ENIGMA_BVH_CPRIM")) cPrim = (float)atof(e);
+    const double cNode = 1.0;
+    double cPrim = 0.6; // a node visit against one triangle test, by their instruction counts
+    if (const char* e = getenv("ENIGMA_BVH_CPRIM")) cPrim = atof(e);
     const size_t nb = B.nodes.size();
-    std::vector<float> cost(nb * 8, 0.f);        // [n][i], i = 1..7 (slot 0 unused)
+    std::vector<double> cost(nb * 8, 0.0);       // [n][i], i = 1..7 (slot 0 unused)
     std::vector<uint8_t> splitK(nb * 9, 0);      // [n][j], j = 2..8: the k of distribute(n, j)
     std::vector<uint8_t> takesDist(nb * 8, 0);   // [n][i], i = 2..7: cost[n][i] is distribute(n, i), not cost[n][i - 1]
     std::vector<uint8_t> asLeaf(nb, 0);
     for (size_t ni = nb; ni-- > 0;) {
         const TmpNode& n = B.nodes[ni];
-        const float area = n.box.area();
-        const float leafCost = n.count <= 3 ? area * (float)n.count * cPrim : FLT_MAX;
+        const double area = n.box.area();
+        const double leafCost = n.count <= 3 ? area * (double)n.count * cPrim : HUGE_VAL;
         if (n.left < 0) { // a single triangle
             for (int i = 1; i <= 7; ++i) cost[ni * 8 + i] = leafCost;
             asLeaf[ni] = 1;
             continue;
         }
-        const float* cl = &cost[(size_t)n.left * 8];
-        const float* cr = &cost[(size_t)n.right * 8];
-        float dist[9];
+        const double* cl = &cost[(size_t)n.left * 8];
+        const double* cr = &cost[(size_t)n.right * 8];
+        double dist[9];
         for (int j = 2; j <= 8; ++j) {
-            float best = FLT_MAX;
+            double best = HUGE_VAL;
             int bk = 1;
             for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); ++k) {
-                const float c = cl[k] + cr[j - k];
+                const double c = cl[k] + cr[j - k];
                 if (c < best) { best = c; bk = k; }
             }
             dist[j] = best;
             splitK[ni * 9 + j] = (uint8_t)bk;
         }
-        const float wideCost = area * cNode + dist[8];
+        const double wideCost = area * cNode + dist[8];
         asLeaf[ni] = leafCost <= wideCost;
         cost[ni * 8 + 1] = std::min(leafCost, wideCost);
         for (int i = 2; i <= 7; ++i) {

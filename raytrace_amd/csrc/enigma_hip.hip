@@ -298,6 +298,13 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     if (s->n_materials >= (1u << 24)) return h->fail(ENIGMA_E_UNSUPPORTED, "more than 2^24 materials");
     for (size_t i = 0; i < (size_t)s->n_triangles * 3; ++i)
         if (s->indices[i] >= s->n_vertices) return h->fail(ENIGMA_E_INVALID, "vertex index %u out of range", s->indices[i]);
+    // Coordinates must be finite and at most 2^60 in size: products of two of them (surface areas in the tree builder, the
+    // edge functions of the triangle test) then stay finite in single precision.  Beyond that the reference's own
+    // arithmetic overflows too, and nothing is ever hit.
+    if (s->n_triangles)
+        for (size_t i = 0; i < (size_t)s->n_vertices * 3; ++i)
+            if (!(std::fabs(s->vertices[i]) <= 0x1p60f))
+                return h->fail(ENIGMA_E_INVALID, "vertex %zu: coordinate %g is not finite or larger than 2^60", i / 3, (double)s->vertices[i]);
     // a scene has media when it lists any; triangles without the per-triangle arrays have no interface (-1 on both sides),
     // the spheres carry their own fields
     const bool haveMedia = s->n_media > 0;
@@ -445,6 +452,8 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         sphereWorldBound(sphereTable[i], lo, hi);
         for (int c = 0; c < 3; ++c) {
+            if (!(std::fabs(lo[c]) <= 0x1p60f) || !(std::fabs(hi[c]) <= 0x1p60f)) // a NaN / infinite radius or matrix entry, or a sphere out of the range vertices may have
+                return h->fail(ENIGMA_E_INVALID, "sphere %u: its world bound is not finite or reaches beyond 2^60", i);
             const float pad = 1e-5f * ((hi[c] - lo[c]) + std::max(std::fabs(lo[c]), std::fabs(hi[c])));
             sphereBoxes[6 * (size_t)i + c] = lo[c] - pad; sphereBoxes[6 * (size_t)i + 3 + c] = hi[c] + pad;
         }

@@ -68,6 +68,30 @@ def test_bogus_sample_bounds_are_an_error_code(bounds):
     r.close()
 
 
+@pytest.mark.parametrize("value", [float("nan"), float("inf"), -float("inf"), 3.0e38, -2.0e19])
+def test_coordinates_that_are_not_finite_or_out_of_range_are_an_error_code(value):
+    """A NaN, an infinity or a coordinate beyond 2^60 would reach the tree builder (bins, surface areas) and the traversal
+    arithmetic: the upload refuses it, a valid upload afterwards works, 2^60 itself is accepted."""
+    import numpy as np
+    sc = scenes.cornell_box("diffuse")
+    good = sc.vertices.copy()
+    r = ra.Renderer(0)
+    sc.vertices[7, 1] = value
+    with pytest.raises(ra.EnigmaError) as e:
+        r.upload_scene(sc)
+    assert e.value.code == E_INVALID and "vertex 7" in str(e.value)
+    sc.vertices[:] = good
+    sc.vertices[7, 1] = np.float32(2.0 ** 60)
+    r.upload_scene(sc)
+    # a sphere whose radius or transform is not finite
+    sp = scenes.cornell_spheres()
+    sp.spheres[0].object_to_world[3] = value
+    with pytest.raises(ra.EnigmaError) as e:
+        r.upload_scene(sp)
+    assert e.value.code == E_INVALID and "sphere 0" in str(e.value)
+    r.close()
+
+
 def test_sample_count_beyond_the_sobol_index_width_is_refused():
     # resolution 4096 leaves 52 - 24 = 28 bits for the sample number (Enigma/SamplerInclude.h:2600-2637)
     sc = scenes.cornell_box("diffuse")

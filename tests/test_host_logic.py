@@ -173,6 +173,24 @@ def test_bvh_depth_is_bounded_for_adversarial_geometry(hostcheck):
     assert checks[0] <= 64
 
 
+def test_bvh_builder_extreme_coordinates(hostcheck):
+    """Coordinates out to 1e18 (the library accepts up to 2^60): surface areas reach 1e37 and their sums over a tree
+    leave single precision, so the cost model runs in double; every triangle must still be found in a leaf and every
+    stored box must hold what lies below it.  Denormal coordinates likewise.  Non-finite input, which the library
+    refuses before it gets here, must at least not take the process down (bins are clamped)."""
+    rng = np.random.RandomState(69)
+    for scale, n in ((1e14, 2000), (1e17, 300), (1e-40, 300)):
+        v = (rng.normal(size=(3 * n, 3)) * 10 ** rng.uniform(-3, 3) * scale).astype(np.float32)
+        v = np.clip(v, -1.1e18, 1.1e18)
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        checks = _bvh_checks(hostcheck, v, idx)
+        assert checks[1] == n and checks[2] == 0 and checks[3] == 0 and checks[4] == 0 and checks[0] <= 64, (scale, checks)
+    for bad in (np.nan, np.inf, -np.inf):
+        v = rng.normal(size=(150, 3)).astype(np.float32)
+        v[rng.randint(150, size=5), rng.randint(3, size=5)] = bad
+        _bvh_checks(hostcheck, v, np.arange(150, dtype=np.uint32).reshape(50, 3))
+
+
 def test_scene_builders():
     c = scenes.cornell_box("diffuse")
     assert c.indices.shape[0] == 32 and c.n_lights == 2
