@@ -407,6 +407,10 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
                 P.hit[p] = make_float4(__int_as_float(-1), t, 0.f, 0.f);
             }
         }
+    } else if (VOL) {
+        // the loop's test of the throughput (Enigma/VolPathIntegrator.cpp:71) sits outside its medium branch: a path whose
+        // colour filters have multiplied to black (a red reflection, then a blue transmission) ends here, after the walk
+        if (isBlack(xyz(P.beta[p]))) proceed = false;
     }
     if (proceed && h.tri >= 0) {
         uint32_t st = state;

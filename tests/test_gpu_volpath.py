@@ -46,6 +46,34 @@ def test_volpath_without_media_matches_the_path_integrator_on_the_gpu():
     r.close()
 
 
+def test_volpath_ends_paths_whose_throughput_is_black():
+    """VolPathIntegrator::Li tests beta.IsBlack() after every walk, in a medium or not (Enigma/VolPathIntegrator.cpp:71),
+    the PathIntegrator never does: between walls of pure red, green and blue (and a glass that reflects red and transmits
+    blue) a path's throughput multiplies to black, and from there on the two integrators trace different numbers of rays for the same picture.  Counts must
+    match the oracle's for both."""
+    sc = scenes.cornell_box("specular")
+    pure = [[0.8, 0.0, 0.0], [0.0, 0.0, 0.8], [0.0, 0.8, 0.0]]           # walls and floor red, the side walls blue and green
+    for i in range(sc.n_materials):
+        m = sc.materials[i]
+        if m.type == abi.MAT_GLASS:
+            m.kr[:] = [1.0, 0.0, 0.0]
+            m.kt[:] = [0.0, 0.0, 1.0]
+        elif m.type == abi.MAT_MATTE:
+            m.kd[:] = pure[i % 3]
+    cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    counts = {}
+    for name, desc in (("volpath", scenes.volpath_desc(film, 8, max_depth=6)), ("path", scenes.integrator_desc(film, 8, max_depth=6))):
+        r, o = _pair(sc, cam, film, desc)
+        r.render(0, 8); o.render(0, 8, threads=4)
+        sg, so = r.stats(), o.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(sg[k] - so[k]) <= max(2, so[k] // 10000), (name, k, sg[k], so[k])   # a libm-level flip or two; the rule itself is worth 5 %
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+        counts[name] = sg["rays_closest"]
+        r.close(); o.close()
+    assert counts["volpath"] < 0.97 * counts["path"]      # the test of the throughput is what ends those paths early
+
+
 @pytest.mark.parametrize("variant", ["diffuse", "microfacet", "specular"])
 def test_volpath_fog_cornell(variant):
     """Fog slab (scattering, g = 0.3) in front of the blocks, absorbing medium inside the tall block: medium sampling,
