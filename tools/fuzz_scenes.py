@@ -236,21 +236,45 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
         crop = tuple(float(f32(c)) for c in crop)
     cam = scenes.camera_desc(tuple(eye), tuple(look), tuple(up), fov, xres, yres, lens_radius=lens, focal_distance=focal if lens else 1e30)
     fk = rng.choice(["box", "box", "triangle", "gaussian", "mitchell", "sinc"])
-    film = scenes.film_desc(xres, yres, fk, crop=crop)
+    # ---- a fourth stream: film and integrator options (filter radii, a luminance clamp, pixel bounds, samples per light,
+    # more samples per pixel rendered in several calls)
+    orr = np.random.RandomState((seed * 69069 + 0x0F17) & 0x7fffffff)
+    film_kw = {}
+    pixel_bounds = None
+    splits = None
+    if not for_file and orr.rand() < 0.4:
+        if orr.rand() < 0.4:
+            film_kw["radius"] = (float(orr.uniform(0.5, 3.5)), float(orr.uniform(0.5, 3.5)))
+        if orr.rand() < 0.25:
+            film_kw["max_sample_luminance"] = float(10 ** orr.uniform(-1, 2))
+        if orr.rand() < 0.3:
+            x0, y0 = int(orr.randint(0, xres // 2)), int(orr.randint(0, yres // 2))
+            x0 = max(x0, y0)   # rows start at min.x in the reference's tile loop: min.x < min.y is undefined there
+            pixel_bounds = [x0, y0, int(orr.randint(x0 + 1, xres + 1)), int(orr.randint(y0 + 1, yres + 1))]
+        if orr.rand() < 0.3:
+            for l in b.lights:
+                l.n_samples = int(orr.choice([1, 2, 3, 4, 8]))
+            sc = b.arrays(weld=bool(orr.randint(2)))
+        if orr.rand() < 0.3:
+            spp = int(orr.choice([1, 2, 8, 16]))
+            cuts = sorted(set(int(c) for c in orr.randint(0, spp + 1, size=2)))
+            splits = [0] + cuts + [spp]
+    film = scenes.film_desc(xres, yres, fk, crop=crop, **film_kw)
     depth = int(rng.randint(1, 9))
     strategy = [abi.LIGHTS_UNIFORM, abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL][rng.randint(3)]
     rr = float(rng.choice([1.0, 1.0, 0.2, 0.0, 5.0]))
     if integ_kind == "path":
-        integ = scenes.integrator_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy)
+        integ = scenes.integrator_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy, pixel_bounds=pixel_bounds)
     elif integ_kind == "volpath":
-        integ = scenes.volpath_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy)
+        integ = scenes.volpath_desc(film, spp, max_depth=depth, rr_threshold=rr, light_strategy=strategy, pixel_bounds=pixel_bounds)
     else:
-        integ = scenes.direct_lighting_desc(film, spp, max_depth=min(depth, 4), strategy=abi.DL_SAMPLE_ALL if integ_kind == "direct-all" else abi.DL_SAMPLE_ONE)
+        integ = scenes.direct_lighting_desc(film, spp, max_depth=min(depth, 4), strategy=abi.DL_SAMPLE_ALL if integ_kind == "direct-all" else abi.DL_SAMPLE_ONE,
+                                            pixel_bounds=pixel_bounds)
     if details is not None:
-        details.update(eye=tuple(float(v) for v in eye), look=tuple(float(v) for v in look), up=tuple(float(v) for v in up), fov=fov, xres=int(xres), yres=int(yres),
+        details.update(spp=spp, splits=splits, eye=tuple(float(v) for v in eye), look=tuple(float(v) for v in look), up=tuple(float(v) for v in up), fov=fov, xres=int(xres), yres=int(yres),
                        lens=lens, focal=float(cam.focal_distance), filter=str(fk), crop=crop, integ_kind=str(integ_kind), depth=depth, rr=rr, strategy=strategy)
     label = "%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
-        integ_kind, depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), " crop" if crop != (0.0, 1.0, 0.0, 1.0) else "")
+        integ_kind, depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), (" crop" if crop != (0.0, 1.0, 0.0, 1.0) else "") + (" options %s%s%s" % (sorted(film_kw), pixel_bounds or "", splits or "") if (film_kw or pixel_bounds or splits) else ""))
     return sc, cam, film, integ, label
 
 
@@ -259,14 +283,18 @@ def compare(seed, res=24, spp=4):
     import orc
     import raytrace_amd as ra
     import common
-    sc, cam, film, integ, label = random_case(seed, res, spp)
+    d = {}
+    sc, cam, film, integ, label = random_case(seed, res, spp, details=d)
+    spp = d["spp"]
     out = {"seed": seed, "label": label}
     r = o = None
     try:
         gerr = oerr = None
         try:
             r = ra.Renderer(0).configure(sc, cam, film, integ)
-            r.render(0, spp)
+            cuts = d["splits"] or [0, spp]
+            for a_, b_ in zip(cuts[:-1], cuts[1:]):   # the library in several calls, the oracle in one
+                r.render(a_, b_)
         except ra.EnigmaError as e:
             gerr = str(e)
         try:
