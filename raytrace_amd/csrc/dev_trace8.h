@@ -186,20 +186,36 @@ struct Walker8Base {
     }
 };
 
-// degenerate triangles report no hit (Enigma/TriangleMesh.cpp:249-256)
-DEV bool triangleAccepted(F3 p0, F3 p1, F3 p2) {
-    F3 dpdu = (p1 - p2) - (p0 - p2);
-    F3 dpdv = -(p1 - p2);
-    if (lengthSqr(cross(dpdu, dpdv)) == 0) return lengthSqr(cross(p2 - p0, p1 - p0)) != 0;
-    return true;
+// Degenerate triangles report no hit (Enigma/TriangleMesh.cpp:238-256): Triangle::intersect gives up when its dpdu x dpdv
+// vanishes (or its uvs are degenerate) AND the geometric normal Cross(p2 - p0, p1 - p0) vanishes too.  A triangle with a
+// normal is therefore never refused, and only one without needs dpdu and dpdv -- from the mesh's own uvs where it has
+// them (shade: four float4 per triangle, the uvs in the .w of the first three and in the fourth; mw: the triangle's
+// material word, bit 28 = the mesh has uvs), else from the default uvs (0,0), (1,0), (1,1).  A collinear sliver can pass
+// the hit test; whether it is reported then hangs on the last bits of these products, so they are the reference's.
+DEV bool triangleAccepted(F3 p0, F3 p1, F3 p2, uint32_t mw, const float4* shade, uint32_t tri) {
+    if (lengthSqr(cross(p2 - p0, p1 - p0)) != 0) return true;
+    F3 dp02 = p0 - p2, dp12 = p1 - p2;
+    F3 dpdu = dp12 - dp02, dpdv = -dp12;
+    if (shade && ((mw >> 28) & 1u)) {
+        const float4* sp = shade + (size_t)tri * 4;
+        const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], vv = sp[3];
+        float du02 = s0.w - s2.w, dv02 = vv.x - vv.z, du12 = s1.w - s2.w, dv12 = vv.y - vv.z;
+        float determinant = du02 * dv12 - dv02 * du12;
+        if (fabsf(determinant) < 1e-8) return false;
+        float invdet = 1 / determinant;
+        dpdu = (dv12 * dp02 - dv02 * dp12) * invdet;
+        dpdv = (-du12 * dp02 + du02 * dp12) * invdet;
+    }
+    return lengthSqr(cross(dpdu, dpdv)) != 0;
 }
 
 // what the walkers of scenes with spheres know of them (uniform values)
 struct SphereRefs {
     const DevSphere* table;
     uint32_t base; // primitive number of sphere 0
-    DEV SphereRefs() : table(nullptr), base(0) {}
-    DEV SphereRefs(const DevScene& sc) : table(sc.spheres), base(sc.nTris) {}
+    const float4* shade; // per-triangle normals and uvs of meshes that have them (triangleAccepted), nullptr if none has
+    DEV SphereRefs() : table(nullptr), base(0), shade(nullptr) {}
+    DEV SphereRefs(const DevScene& sc) : table(sc.spheres), base(sc.nTris), shade(sc.triShade) {}
 };
 DEV bool slotIsSphere(float4 v0) { return (__float_as_uint(v0.w) >> 31) != 0; }
 DEV uint32_t slotSphere(float4 v0) { return __float_as_uint(v0.w) & 0x7fffffffu; }
@@ -229,7 +245,7 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         }
         float4 v1 = tp[1], v2 = tp[2];
         float t, b0, b1, b2;
-        if (triangleTest(this->r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2) && triangleAccepted(xyz(v0), xyz(v1), xyz(v2))) {
+        if (triangleTest(this->r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2) && triangleAccepted(xyz(v0), xyz(v1), xyz(v2), __float_as_uint(v1.w), spheres.shade, tri)) {
             h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2;
         }
     }

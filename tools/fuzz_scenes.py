@@ -341,6 +341,92 @@ def compare(seed, res=24, spp=4):
             o.close()
 
 
+def adversarial_rays(sc, rng, n=3000):
+    """[n, 7] rays (o, d, tMax): uniform ones, and ones built to sit on the decisions of the tests -- aimed exactly at
+    vertices, at points on edges and inside triangles, starting on surfaces, along the axes, with zero components, with
+    short and enormous tMax."""
+    v = sc.vertices.astype(np.float64)
+    t = sc.indices
+    lo, hi = (v.min(axis=0) - 2, v.max(axis=0) + 2) if len(v) else (np.zeros(3) - 5, np.zeros(3) + 15)
+    o = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    tmax = np.full(n, np.inf)
+    if len(t):
+        k = rng.randint(0, len(t), n)
+        tri = v[t[k]]                                    # [n, 3, 3]
+        mode = rng.randint(0, 10, n)
+        w = rng.dirichlet((1, 1, 1), n)
+        inside = (tri * w[:, :, None]).sum(axis=1)
+        edge_w = np.stack([rng.rand(n), 1 - rng.rand(n) * 0, np.zeros(n)], axis=1)
+        u = rng.rand(n)
+        on_edge = tri[:, 0] * u[:, None] + tri[:, 1] * (1 - u)[:, None]
+        target = np.where((mode == 0)[:, None], tri[:, 0], np.where((mode == 1)[:, None], on_edge, inside))
+        aimed = mode <= 4
+        d[aimed] = (target - o)[aimed]
+        start_on = mode == 5                              # a ray that starts on a surface
+        o[start_on] = inside[start_on]
+        ax = mode == 6                                    # axis-aligned, two components exactly zero
+        axis = rng.randint(0, 3, n)
+        dd = np.zeros((n, 3)); dd[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+        d[ax] = dd[ax]
+        zc = mode == 7                                    # one component exactly zero
+        d[zc, rng.randint(0, 3)] = 0.0
+        short = mode == 8                                 # tMax right at the hit distance
+        dist = np.linalg.norm(inside - o, axis=1) / np.maximum(np.linalg.norm(d, axis=1), 1e-30)
+        d[short] = (inside - o)[short]
+        tmax[short] = rng.choice([1.0, 0.999999, 1.000001, 0.5, 1e-6], int(short.sum()))
+        big = mode == 9
+        tmax[big] = 3e38
+    d[np.abs(d).sum(axis=1) == 0] = (0, 0, 1)
+    scale = 10 ** rng.uniform(-3, 3, n)                   # directions are not unit vectors in the reference either
+    d = d * scale[:, None]
+    tmax = np.where(np.isfinite(tmax) & (tmax < 1e30), tmax / 1.0, tmax)
+    return np.concatenate([o, d, tmax[:, None]], axis=1).astype(np.float32)
+
+
+def compare_rays(seed, n=3000):
+    """Closest hits and any-hit decisions of adversarial rays against the seed's scene: primitive, t and barycentrics bit
+    for bit (rays the oracle flags as exact ties between two primitives: the same distance)."""
+    import orc
+    import raytrace_amd as ra
+    sc, cam, film, integ, label = random_case(seed)
+    out = {"seed": seed, "label": label}
+    rng = np.random.RandomState(seed + 77)
+    rays = adversarial_rays(sc, rng, n)
+    r = o = None
+    try:
+        try:
+            r = ra.Renderer(0)
+            r.upload_scene(sc)
+        except ra.EnigmaError as e:
+            out.update(status="gpu-refuses" if any(t in str(e) for t in DOCUMENTED_REFUSALS) else "mismatch", gpu_error=str(e))
+            return out
+        o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 4))
+        ho, hg = o.intersect(rays), r.intersect(rays)
+        ok = ho["ambiguous"] == 0
+        u32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+        on_triangle = ho["tri"] < sc.indices.shape[0]    # for a sphere the taps carry different things in place of barycentrics
+        bad = (ho["prim_id"] != hg["prim_id"]) | (ho["tri"] != hg["tri"]) | (u32(ho["t"]) != u32(hg["t"])) | ((u32(ho["bary"]) != u32(hg["bary"])).any(axis=1) & on_triangle)
+        bad &= ok
+        amb_bad = (~ok) & ~np.isclose(ho["t"], hg["t"], rtol=2e-6)
+        any_o, any_g = o.intersect_any(rays), r.intersect_any(rays)
+        any_bad = (any_o != any_g) & ok
+        out.update(rays=int(n), hits=int((ho["tri"] >= 0).sum()), ambiguous=int((~ok).sum()), closest_bad=int(bad.sum()), tie_bad=int(amb_bad.sum()), any_bad=int(any_bad.sum()))
+        if bad.any():
+            i = int(np.nonzero(bad)[0][0])
+            out["first_bad"] = {"ray": rays[i].tolist(), "oracle": [int(ho["tri"][i]), float(ho["t"][i])] + ho["bary"][i].tolist(), "gpu": [int(hg["tri"][i]), float(hg["t"][i])] + hg["bary"][i].tolist()}
+        if any_bad.any():
+            i = int(np.nonzero(any_bad)[0][0])
+            out["first_any_bad"] = {"ray": rays[i].tolist(), "oracle": int(any_o[i]), "gpu": int(any_g[i])}
+        out["status"] = "ok" if not (bad.any() or amb_bad.any() or any_bad.any()) else "mismatch"
+        return out
+    finally:
+        if r is not None:
+            r.close()
+        if o is not None:
+            o.close()
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
@@ -418,6 +504,16 @@ def compare_file(seed, directory, res=24, spp=4):
 
 
 def main():
+    if sys.argv[1] == "--rays":    # python tools/fuzz_scenes.py --rays <first seed> <count>
+        first, count = int(sys.argv[2]), int(sys.argv[3])
+        results = [compare_rays(seed) for seed in range(first, first + count)]
+        for r in results:
+            if r["status"] == "mismatch":
+                print(json.dumps(r), flush=True)
+        import collections
+        print("rays, seeds %d..%d: %s; %d rays, %d hits, %d exact ties" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results)),
+              sum(r.get("rays", 0) for r in results), sum(r.get("hits", 0) for r in results), sum(r.get("ambiguous", 0) for r in results)))
+        sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     if sys.argv[1] == "--files":   # python tools/fuzz_scenes.py --files <first seed> <count> <directory>
         first, count, directory = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
         os.makedirs(directory, exist_ok=True)
