@@ -92,6 +92,22 @@ def test_adversarial_rays_hit_bit_for_bit():
 
 
 @pytest.mark.gpu
+def test_bit_exact_tiers_at_random_films():
+    """Sobol' sample values, pinhole camera rays and film footprints (pixel indices, filter weights) at random films:
+    resolutions from 1 x 1 to 4096 x 4096, crop windows, the five pixel filters with random radii, up to 2^16 samples per
+    pixel; pixels out to the corners of the sample bounds, film positions on the half-pixel lattice where ceil and floor
+    decide.  Everything bit for bit (400 films ran; a slice here).  What the library refuses here it refuses by design:
+    sample bounds with min.x < min.y (undefined in the reference), a resolution whose Log2Int the reference computes
+    inexactly (8192 and up), an empty crop window."""
+    ok = 0
+    for seed in range(0, 60):
+        res = fuzz_scenes.compare_taps(seed)
+        assert res["status"] != "mismatch", res
+        ok += res["status"] == "ok"
+    assert ok >= 25
+
+
+@pytest.mark.gpu
 def test_bsdf_point_evaluations_of_random_materials():
     """BSDF::f, Pdf and sample_f (Enigma/BxDF.cpp:885-985) of random materials of every kind, their parameters at the
     edges of their ranges among them, at 4000 adversarial (wo, wi, u) each (grazing, in the surface, along the normal,

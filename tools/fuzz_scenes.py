@@ -501,6 +501,83 @@ def compare_bsdf(seed, n=4000):
     return out
 
 
+def compare_taps(seed):
+    """The bit-exact tiers at a random film: Sobol' sample values and camera rays (pinhole) of random pixels and sample
+    numbers, film footprints (pixel indices and filter weights) of random and lattice-aligned film positions -- for a
+    random resolution up to 4096, crop window, pixel filter and radii, samples per pixel up to 2^16."""
+    import orc
+    import raytrace_amd as ra
+    rng = np.random.RandomState(seed)
+    xres, yres = int(rng.choice([1, 2, 3, 17, 64, 100, 257, 640, 1000, 1920, 4096])), int(rng.choice([1, 2, 5, 31, 64, 99, 256, 480, 1080, 2160, 4096]))
+    fk = str(rng.choice(["box", "triangle", "gaussian", "mitchell", "sinc"]))
+    kw = {}
+    if rng.rand() < 0.5:
+        kw["radius"] = (float(rng.uniform(0.3, 4.5)), float(rng.uniform(0.3, 4.5)))
+    crop = (0.0, 1.0, 0.0, 1.0)
+    if rng.rand() < 0.4:
+        x0, y0 = rng.uniform(0, 0.6, 2)
+        crop = (float(x0), float(min(1.0, x0 + rng.uniform(0.1, 0.6))), float(y0), float(min(1.0, y0 + rng.uniform(0.1, 0.6))))
+    film = scenes.film_desc(xres, yres, fk, crop=crop, **kw)
+    spp = int(2 ** rng.randint(0, 17))
+    integ = scenes.integrator_desc(film, spp, max_depth=int(rng.randint(1, 9)))
+    eye, look = rng.uniform(-5, 5, 3), rng.uniform(-5, 5, 3)
+    if np.linalg.norm(look - eye) < 1e-2:
+        look = eye + (0, 0, 1)
+    cam = scenes.camera_desc(tuple(eye), tuple(look), (0.1, 1.0, 0.05), float(rng.uniform(10, 140)), xres, yres)
+    sc = scenes.cornell_box("diffuse")
+    out = {"seed": seed, "label": "%dx%d crop %s filter %s %s spp %d" % (xres, yres, crop, fk, kw.get("radius"), spp)}
+    r = o = None
+    try:
+        gerr = oerr = None
+        try:
+            r = ra.Renderer(0).configure(sc, cam, film, integ)
+        except ra.EnigmaError as e:
+            gerr = str(e)
+        try:
+            o = orc.Oracle(sc, cam, film, integ)
+            sb = scenes.sample_bounds(film)
+            if sb[0] < sb[1]:
+                oerr = "sample bounds with min.x < min.y: reference result undefined"
+        except Exception as e:
+            oerr = str(e)
+        if gerr or oerr:
+            out.update(status="both-refuse" if (gerr and oerr) else ("gpu-refuses" if gerr and ("min.x < min.y" in gerr or "Log2Int" in gerr or "empty sample bounds" in gerr) else "mismatch"), gpu_error=gerr, oracle_error=oerr)
+            # (the library looks at the sample bounds when the sampler is configured, the oracle when it renders)
+            if not gerr and oerr and "min.x < min.y" in oerr:
+                out["status"] = "both-refuse"
+            return out
+        sb = scenes.sample_bounds(film)
+        n = 2000
+        P = np.stack([rng.randint(sb[0], max(sb[0] + 1, sb[2]), n), rng.randint(sb[1], max(sb[1] + 1, sb[3]), n)], axis=1).astype(np.int32)
+        P[:4] = [(sb[0], sb[1]), (sb[2] - 1, sb[3] - 1), (sb[2] - 1, sb[1]), (sb[0], sb[3] - 1)]
+        S = rng.randint(0, spp, n).astype(np.int64)
+        S[:3] = [0, spp - 1, spp // 2]
+        u32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+        nd = 5 + 8 * int(integ.max_depth)                            # the dimensions a path of this depth can consume are tabulated
+        io, do = o.sobol(P, S, nd)
+        ig, dg = r.sobol(P, S, nd)
+        ro, po = o.camera_rays(P, S)
+        rg, pg = r.camera_rays(P, S)
+        b = film.cropped_pixel_bounds
+        pf = np.stack([rng.uniform(b[0] - 5, b[2] + 5, n), rng.uniform(b[1] - 5, b[3] + 5, n)], axis=1).astype(np.float32)
+        lat = rng.rand(n) < 0.3                                      # positions on the half-pixel lattice, where ceil / floor decide
+        pf[lat] = np.round(pf[lat] * 2) / 2
+        fo, fg = o.film_footprint(pf, 100), r.film_footprint(pf, 100)
+        used = np.arange(100)[None, :] < np.minimum(fo[2], 100)[:, None]      # entries past a position's count are not written
+        fo = (np.where(used[:, :, None], fo[0], 0), np.where(used, fo[1], 0), fo[2])
+        fg = (np.where(used[:, :, None], fg[0], 0), np.where(used, fg[1], 0), fg[2])
+        out.update(sobol_index=int((io != ig).sum()), sobol_bits=int((u32(do) != u32(dg)).sum()), ray_bits=int((u32(ro) != u32(rg)).sum()), pfilm_bits=int((u32(po) != u32(pg)).sum()),
+                   footprint_counts=int((fo[2] != fg[2]).sum()), footprint_pixels=int((fo[0] != fg[0]).sum()), footprint_weights=int((u32(fo[1]) != u32(fg[1])).sum()))
+        bad = sum(out[k] for k in ("sobol_index", "sobol_bits", "ray_bits", "pfilm_bits", "footprint_counts", "footprint_pixels", "footprint_weights"))
+        out["status"] = "ok" if bad == 0 else "mismatch"
+        return out
+    finally:
+        if r is not None:
+            r.close()
+        if o is not None:
+            o.close()
+
+
 def read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
@@ -578,22 +655,40 @@ def compare_file(seed, directory, res=24, spp=4):
 
 
 def main():
+    if sys.argv[1] == "--taps":    # python tools/fuzz_scenes.py --taps <first seed> <count>
+        first, count = int(sys.argv[2]), int(sys.argv[3])
+        results = []
+        for seed in range(first, first + count):
+            results.append(compare_taps(seed))
+            if results[-1]["status"] == "mismatch":
+                print(json.dumps(results[-1]), flush=True)
+            elif seed % 20 == 0:
+                print("seed %d %s" % (seed, results[-1]["status"]), flush=True)
+        import collections
+        print("taps, seeds %d..%d: %s" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results))))
+        sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     if sys.argv[1] == "--bsdf":    # python tools/fuzz_scenes.py --bsdf <first seed> <count>
         first, count = int(sys.argv[2]), int(sys.argv[3])
-        results = [compare_bsdf(seed) for seed in range(first, first + count)]
-        for r in results:
-            if r["status"] == "mismatch":
-                print(json.dumps(r), flush=True)
+        results = []
+        for seed in range(first, first + count):
+            results.append(compare_bsdf(seed))
+            if results[-1]["status"] == "mismatch":
+                print(json.dumps(results[-1]), flush=True)
+            elif seed % 50 == 0:
+                print("seed %d %s" % (seed, results[-1]["status"]), flush=True)
         print("bsdf, seeds %d..%d: %d ok, %d mismatch; largest relative difference among the ok ones %.3g" % (
             first, first + count - 1, sum(r["status"] == "ok" for r in results), sum(r["status"] == "mismatch" for r in results),
             max([r["max_err"] for r in results if r["status"] == "ok"] or [0])))
         sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     if sys.argv[1] == "--rays":    # python tools/fuzz_scenes.py --rays <first seed> <count>
         first, count = int(sys.argv[2]), int(sys.argv[3])
-        results = [compare_rays(seed) for seed in range(first, first + count)]
-        for r in results:
-            if r["status"] == "mismatch":
-                print(json.dumps(r), flush=True)
+        results = []
+        for seed in range(first, first + count):
+            results.append(compare_rays(seed))
+            if results[-1]["status"] == "mismatch":
+                print(json.dumps(results[-1]), flush=True)
+            elif seed % 50 == 0:
+                print("seed %d %s" % (seed, results[-1]["status"]), flush=True)
         import collections
         print("rays, seeds %d..%d: %s; %d rays, %d hits, %d exact ties" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results)),
               sum(r.get("rays", 0) for r in results), sum(r.get("hits", 0) for r in results), sum(r.get("ambiguous", 0) for r in results)))
