@@ -714,9 +714,10 @@ def main():
         print("scene files, seeds %d..%d: %s" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results))))
         sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     first, count = int(sys.argv[1]), int(sys.argv[2])
+    res_px = int(os.environ.get("FUZZ_RES", "24"))   # FUZZ_RES=256: films of 256 to 264 pixels a side (many chunks and blocks per launch)
     results, bad = [], 0
     for seed in range(first, first + count):
-        res = compare(seed)
+        res = compare(seed, res=res_px)
         results.append(res)
         if res["status"] == "mismatch":
             bad += 1
