@@ -71,7 +71,18 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
+    # a rank that dies (no such GPU, a failed import) would leave the others waiting in the rendezvous for minutes: watch
+    # them all, and end the rest as soon as one has failed (rank 0 prints one short line, so its pipe cannot fill up)
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    if any(c not in (None, 0) for c in codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read().decode()
     codes = [p.wait() for p in procs]
     sys.stdout.write(out)
     sys.stdout.flush()
