@@ -278,8 +278,10 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
     return sc, cam, film, integ, label
 
 
-def compare(seed, res=24, spp=4):
-    """{"status": "ok" | "both-refuse" | "mismatch", ...} for one seed."""
+def compare(seed, res=24, spp=4, shared=None):
+    """{"status": "ok" | "both-refuse" | "mismatch", ...} for one seed.
+    shared: a one-element list holding a Renderer that is kept from seed to seed (scenes, films and integrators of every
+    kind configured one after the other on one handle, refusals in between), instead of a fresh handle per seed."""
     import orc
     import raytrace_amd as ra
     import common
@@ -290,8 +292,17 @@ def compare(seed, res=24, spp=4):
     r = o = None
     try:
         gerr = oerr = None
+        before = None
         try:
-            r = ra.Renderer(0).configure(sc, cam, film, integ)
+            if shared is not None:
+                if shared[0] is None:
+                    shared[0] = ra.Renderer(0)
+                r = shared[0]
+                r.configure(sc, cam, film, integ)
+                r.clear()
+                before = r.stats()
+            else:
+                r = ra.Renderer(0).configure(sc, cam, film, integ)
             cuts = d["splits"] or [0, spp]
             for a_, b_ in zip(cuts[:-1], cuts[1:]):   # the library in several calls, the oracle in one
                 r.render(a_, b_)
@@ -318,6 +329,8 @@ def compare(seed, res=24, spp=4):
             return out
         a, bimg = r.image(), o.image()
         sg, so = r.stats(), o.stats()
+        if before is not None:   # the counters of a handle run on across renders
+            sg = dict(sg, **{k: sg[k] - before[k] for k in ("rays_closest", "rays_shadow", "rays_mis")})
         counts = {k: (int(sg[k]), int(so[k])) for k in ("rays_closest", "rays_shadow", "rays_mis")}
         out["counts"] = counts
         out["finite"] = bool(np.isfinite(a).all())
@@ -334,15 +347,16 @@ def compare(seed, res=24, spp=4):
         # Below that edge the same thing happens on a smaller scale: a path through mirror-sharp lobes (alpha 0.001) carries
         # weights of 1e5 and more, a branch flipped by the last bit of a sine moves one pixel by orders of magnitude and the
         # mean with it.  Such a firefly is a pixel or two; what a defect moves is many (the defects found moved a sixth of
-        # the image, or the ray counts).  So: the mean, or else at most 1 % of the pixels off by more than 1 %.
+        # the image, or the ray counts).  So: the mean, or else at most 8 % of the pixels off by more than 1 % (a firefly
+        # under the widest filter, 8 x 8 pixels of a film of 30 x 30).
         rel = np.abs(a - bimg).max(axis=2) / np.maximum(np.abs(bimg).max(axis=2), 1e-3)
         out["pixels_off"] = float((rel > 0.01).mean())
-        ok = (out["finite"] and (out["extreme"] or out["mre"] < 0.01 or out["pixels_off"] <= 0.01) and out["median_rel"] < 1e-3 and apart <= 0.01
+        ok = (out["finite"] and (out["extreme"] or out["mre"] < 0.01 or out["pixels_off"] <= 0.08) and out["median_rel"] < 1e-3 and apart <= 0.01
               and out["stack_overflows"] == 0)
         out["status"] = "ok" if ok else "mismatch"
         return out
     finally:
-        if r is not None:
+        if r is not None and shared is None:
             r.close()
         if o is not None:
             o.close()
@@ -653,7 +667,7 @@ def compare_file(seed, directory, res=24, spp=4):
         out["extreme"] = bool(max(float(np.nanmax(np.abs(a))), float(np.nanmax(np.abs(bimg)))) > 1e9)
         rel = np.abs(a - bimg).max(axis=2) / np.maximum(np.abs(bimg).max(axis=2), 1e-3)
         out["pixels_off"] = float((rel > 0.01).mean())
-        ok = out["finite"] and (out["extreme"] or out["mre"] < 0.01 or out["pixels_off"] <= 0.01) and out["median_rel"] < 1e-3
+        ok = out["finite"] and (out["extreme"] or out["mre"] < 0.01 or out["pixels_off"] <= 0.08) and out["median_rel"] < 1e-3
         out["status"] = "ok" if ok else "mismatch"
         return out
     finally:
@@ -714,10 +728,11 @@ def main():
         print("scene files, seeds %d..%d: %s" % (first, first + count - 1, dict(collections.Counter(r["status"] for r in results))))
         sys.exit(1 if any(r["status"] == "mismatch" for r in results) else 0)
     first, count = int(sys.argv[1]), int(sys.argv[2])
+    shared = [None] if os.environ.get("FUZZ_REUSE") else None   # FUZZ_REUSE=1: one handle for all the seeds
     res_px = int(os.environ.get("FUZZ_RES", "24"))   # FUZZ_RES=256: films of 256 to 264 pixels a side (many chunks and blocks per launch)
     results, bad = [], 0
     for seed in range(first, first + count):
-        res = compare(seed, res=res_px)
+        res = compare(seed, res=res_px, shared=shared)
         results.append(res)
         if res["status"] == "mismatch":
             bad += 1
