@@ -234,7 +234,7 @@ def run_workload(args, variant, steps, ctx):
         "job_1024spp_seconds": elapsed / K * (1024.0 / SPP_PER_STEP) / N,
         "config": {"workload": "%s 1920x1080, %s; %d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
                    "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP,
-                   "parallelism": "spp-shard x%d + one %s of the film" % (N, "ncclReduce inside the library" if torch_reduce is None else "torch.distributed reduce (the library could not load RCCL)")},
+                   "parallelism": "spp-shard x%d + one %s of the film" % (N, "ncclReduce inside the library" if torch_reduce is None else "torch.distributed reduce (the library's own RCCL communicator did not come up; the reason is on stderr)")},
         "rccl_ranks": rccl_world,
         "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
     }
@@ -339,10 +339,19 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Rehearsal knobs for a box with fewer GPUs than ranks (the control flow of N ranks, not a measurement):
+    # ENIGMA_BENCH_ONE_GPU=1 puts every rank on device 0, ENIGMA_BENCH_BACKEND=gloo carries torch's collectives without
+    # RCCL (which refuses two ranks on one device, as the library's own communicator then does: the fallback path runs).
+    if os.environ.get("ENIGMA_BENCH_ONE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("ENIGMA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev}
 
     first = "microfacet" if args.variant == "default" else args.variant
