@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
                     help="lightsamplestrategy of the path / volpath integrators (the headline configuration names power)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-spp", type=int, default=0, help="sample numbers per pixel the CPU baseline renders (0 = 8 for Cornell scenes, 1 for bigmesh)")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="sample numbers per pixel the CPU baseline renders (0 = two per thread for Cornell scenes, one per eight threads for bigmesh: about 10 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every CPU this process may run on)")
     return ap.parse_args()
 
@@ -294,7 +294,8 @@ def run_workload(args, variant, steps, ctx):
         import orc
         avail, quota = host_cpus()
         cores = args.cpu_threads or avail
-        cpu_spp = args.cpu_spp or (1 if variant == "bigmesh" else 8)
+        # about 10 s of wall time on the threads in use (measured: 0.33 s per Cornell spp and 6 s per BigMesh spp on 16 threads)
+        cpu_spp = args.cpu_spp or (max(1, cores // 8) if variant == "bigmesh" else max(8, 2 * cores))
         o = orc.Oracle(scene, camera, film, integ, fast=True)
         o.render(0, cpu_spp, threads=cores)
         sc = o.stats()
