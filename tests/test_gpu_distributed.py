@@ -95,3 +95,29 @@ def test_two_rank_native_reduce_matches_single_render(tmp_path):
     for p in procs:
         assert p.wait(timeout=240) == 0
     assert result.read_text() == "ok"
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The N-rank control flow of bench.py on a box with one GPU: it spawns its two ranks, both on device 0, with gloo
+    under torch.distributed.  RCCL refuses two ranks of one device, so the library's communicator fails on every rank,
+    the ranks agree on the fallback and torch reduces the film.  Checks the line's accounting, not a speed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENIGMA_BENCH_ONE_GPU="1", ENIGMA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--variant", "microfacet"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["spp_rendered"] == 2 * 2 * 16  # ranks x steps x 16 spp
+    assert "torch.distributed reduce" in line["config"]["parallelism"] and line["rccl_ranks"] == 1
+    per_sample = line["rays"]["per_sample"]
+    assert 3.5 < per_sample < 4.0  # the Cornell box's rays per camera sample: both ranks' work is in the totals
+    samples = 1920 * 1080 * line["config"]["spp_rendered"]
+    assert abs(line["msamples_per_s"] * 1e6 * line["ms_per_step"] * 1e-3 * line["steps"] / samples - 1.0) < 1e-6
