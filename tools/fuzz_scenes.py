@@ -322,7 +322,9 @@ def compare(seed, res=24, spp=4, shared=None):
             # whose vertex normals disagree about its side
             if gerr and not oerr and any(t in gerr for t in DOCUMENTED_REFUSALS):
                 status = "gpu-refuses"
-            # the one combination the oracle does not restate and the library renders: untested here, not a disagreement
+            # what the oracle does not restate and refuses before looking at the film, on a film whose tile loop visits no pixel
+            # (rows start at the sample bounds' min.x, Integrator.cpp:254: none when that is past max.y), where the library
+            # returns the empty render before its own refusal of the same combination: untested here, not a disagreement
             if oerr and not gerr and "are not restated" in oerr:
                 status = "oracle-refuses"
             out.update(status=status, gpu_error=gerr, oracle_error=oerr)
