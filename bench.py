@@ -29,6 +29,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SPP_PER_STEP = 16
 XRES, YRES = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: lane operations per second, in 1e12
+JOB_SPP = {"bigmesh_fog": 512}  # samples per pixel of the configuration's whole job (1024 unless named here)
 # bytes the closest-hit kernel moves per ray besides the tree: the 64-byte path record read, the 16-byte hit record
 # written, the queue word read and the material-queue word written
 RAY_IO_BYTES = 64 + 16 + 8
@@ -42,7 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--variant", default="default",
                     help="default = the Cornell microfacet line with the bigmesh object inside it; one workload only: microfacet | diffuse | specular | "
-                         "bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3]) | fog (Cornell with a fog slab, for --integrator volpath)")
+                         "bigmesh (configs[2], 1.18 M triangles) | manylights (configs[3]) | fog (Cornell with a fog slab, for --integrator volpath) | "
+                         "bigmesh_fog (the defined part of configs[4]: the textured 1.18 M-triangle mesh in a homogeneous medium, for --integrator volpath)")
     ap.add_argument("--integrator", default="path", choices=["path", "direct-all", "direct-one", "volpath"],
                     help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
     ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
@@ -63,22 +66,28 @@ def free_port():
 
 
 def spawn_ranks(n):
-    """One child process per GPU, started before this process has touched torch or the GPU; rank 0's line is relayed."""
+    """One child process per GPU, started before this process has touched torch or the GPU; rank 0's line is relayed.
+    The communicator set-up and the film reduce are collectives without a timeout, so a rank that dies, or one that never
+    arrives, would leave the others waiting for good: the first bad exit, or ENIGMA_BENCH_DEADLINE_S seconds (default 1500),
+    ends every rank and this process exits non-zero."""
     port = free_port()
+    deadline = time.monotonic() + float(os.environ.get("ENIGMA_BENCH_DEADLINE_S", "1500"))
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    # a rank that dies (no such GPU, a failed import) would leave the others waiting in the rendezvous for minutes: watch
-    # them all, and end the rest as soon as one has failed (rank 0 prints one short line, so its pipe cannot fill up)
-    while True:
+    timed_out = False
+    while True:  # rank 0 prints one short line, so its pipe cannot fill up while nobody reads it
         codes = [p.poll() for p in procs]
         if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes):
             break
+        if time.monotonic() > deadline:
+            timed_out = True
+            break
         time.sleep(0.2)
-    if any(c not in (None, 0) for c in codes):
+    if timed_out or any(c not in (None, 0) for c in codes):
         for p in procs:
             if p.poll() is None:
                 p.kill()
@@ -86,8 +95,26 @@ def spawn_ranks(n):
     codes = [p.wait() for p in procs]
     sys.stdout.write(out)
     sys.stdout.flush()
+    if timed_out:
+        raise SystemExit("ranks did not finish before the deadline (ENIGMA_BENCH_DEADLINE_S); all were ended: %s" % codes)
     if any(codes):
         raise SystemExit("ranks exited with %s" % codes)
+
+
+def arm_watchdog():
+    """Under a launcher that is not ours (torch.distributed.run) nobody ends a rank whose peers have died inside a collective:
+    every rank ends itself, loudly, when the whole run has taken longer than ENIGMA_BENCH_DEADLINE_S seconds."""
+    import threading
+    limit = float(os.environ.get("ENIGMA_BENCH_DEADLINE_S", "1500"))
+
+    def fire():
+        sys.stderr.write("bench.py: rank %s still running after %.0f s (a peer lost inside a collective?); giving up\n" % (os.environ.get("RANK", "0"), limit))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 # ---------------------------------------------------------------- host description
@@ -134,6 +161,8 @@ def run_workload(args, variant, steps, ctx):
     K, W, N = steps, args.warmup, world
     if variant == "bigmesh":
         scene, camera, label = scenes.big_mesh(), scenes.big_mesh_camera(XRES, YRES), "BigMesh (terrain + spheres, 1.18 M triangles, conductor/dielectric microfacet)"
+    elif variant == "bigmesh_fog":
+        scene, camera, label = scenes.big_mesh_fog(), scenes.big_mesh_camera(XRES, YRES), "BigMesh in fog (1.18 M triangles with uvs, trilinear image textures, a homogeneous medium around them)"
     elif variant == "manylights":
         scene, camera, label = scenes.many_lights(), scenes.cornell_camera(XRES, YRES), "ManyLights (512 emissive triangles + 64 point lights)"
     elif variant == "fog":
@@ -157,11 +186,14 @@ def run_workload(args, variant, steps, ctx):
     torch_reduce = None
     if world > 1:  # the library's own communicator: rank 0 makes the id, torch's process group only carries the 128 bytes
         ok = torch.ones(1, dtype=torch.int32, device=dev)
+        ident = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         try:
-            ident = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            # EVERY rank asks for an id: the call loads RCCL into the library, so a rank that cannot load it says so here,
+            # before anybody enters the collective ncclCommInitRank (which has no timeout); rank 0's id is the one used
+            mine = ra.Renderer.comm_unique_id()
             if rank == 0:
-                ident.copy_(torch.frombuffer(bytearray(ra.Renderer.comm_unique_id()), dtype=torch.uint8))
-        except ra.EnigmaError as e:  # RCCL could not be loaded by the library on this host
+                ident.copy_(torch.frombuffer(bytearray(mine), dtype=torch.uint8))
+        except ra.EnigmaError as e:
             sys.stderr.write("rank %d: %s\n" % (rank, e))
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -169,18 +201,32 @@ def run_workload(args, variant, steps, ctx):
             dist.broadcast(ident, 0)
             try:
                 r.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+                if r.comm_info() != (rank, world):
+                    raise ra.EnigmaError(-3, "the communicator reports rank %d of %d, expected %d of %d" % (r.comm_info() + (rank, world)))
             except ra.EnigmaError as e:
                 sys.stderr.write("rank %d: %s\n" % (rank, e))
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if not int(ok.item()):
                 r.comm_destroy()
-        if not int(ok.item()):  # every rank falls back together: the film as a torch view, reduced by torch's own RCCL communicator
+        if not int(ok.item()):
+            # The library's communicator did not come up on some rank.  A scaling run must not credit torch's reduce to the
+            # library: every rank stops here unless the caller asked for the fallback by name (rehearsals on one GPU do).
+            if os.environ.get("ENIGMA_BENCH_ALLOW_FALLBACK") != "1":
+                if rank == 0:
+                    print(json.dumps({"metric": "Mrays/s", "value": None, "n_gpus": world, "reduce": "torch-fallback",
+                                      "error": "the library's RCCL communicator did not come up (reason on stderr); set ENIGMA_BENCH_ALLOW_FALLBACK=1 to "
+                                               "measure with torch.distributed's reduce instead"}))
+                    sys.stdout.flush()
+                r.close()
+                dist.barrier()
+                raise SystemExit(4)
             from raytrace_amd import distributed
             film_view = distributed.film_tensor(r, dev)
             torch_reduce = lambda: dist.reduce(film_view, dst=0, op=dist.ReduceOp.SUM)
     rccl_rank, rccl_world = r.comm_info()
     reduce_film = torch_reduce if torch_reduce is not None else (lambda: r.film_reduce(0))
+    reduce_kind = "none (one rank)" if world == 1 else ("torch-fallback" if torch_reduce is not None else "rccl-native")
 
     def barrier():
         torch.cuda.synchronize()
@@ -197,97 +243,127 @@ def run_workload(args, variant, steps, ctx):
 
     barrier()
     t0 = time.perf_counter()
-    ms_closest = ms_shadow = 0.0
-    n_closest = n_shadow = 0
+    ms_closest = ms_shadow = ms_shade = 0.0
+    n_closest = n_shadow = n_shade = 0
     for i in range(K):
         s0 = (i * N + rank) * SPP_PER_STEP
         r.render(s0, s0 + SPP_PER_STEP)
         st = r.stats()
         ms_closest += st["ms_intersect"]; n_closest += st["intersect_launches"]
         ms_shadow += st["ms_shadow"]; n_shadow += st["shadow_launches"]
+        ms_shade += st["ms_shade"]; n_shade += st["shade_launches"]
     reduce_film()
     barrier()
     elapsed = time.perf_counter() - t0
 
     s_after = r.stats()
     keys = ("camera_samples", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow",
-            "node_steps_closest", "tri_steps_closest", "node_steps_shadow", "tri_steps_shadow")
+            "node_steps_closest", "tri_steps_closest", "node_steps_shadow", "tri_steps_shadow", "shaded_vertices")
     counts = torch.tensor([s_after[k] - s_before[k] for k in keys], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    samples, rc, rs, rm, nodes_c, tris_c, nodes_s, tris_s, nsteps_c, tsteps_c, nsteps_s, tsteps_s = [float(v) for v in counts.tolist()]
+    samples, rc, rs, rm, nodes_c, tris_c, nodes_s, tris_s, nsteps_c, tsteps_c, nsteps_s, tsteps_s, shaded = [float(v) for v in counts.tolist()]
     rays = rc + rs + rm
     if rank != 0:
         r.close()
         return None
 
+    job_spp = JOB_SPP.get(variant, 1024)
     out = {
         "value": rays / elapsed / 1e6,
         "unit": "Mrays/s",
         "msamples_per_s": samples / elapsed / 1e6,
         "steps": K,
         "ms_per_step": elapsed / K * 1e3,
-        # the 1024-spp job of the config on these N GPUs (strong scaling): 64 / N steps per rank
-        "job_1024spp_seconds": elapsed / K * (1024.0 / SPP_PER_STEP) / N,
-        "config": {"workload": "%s 1920x1080, %s; %d spp per step and GPU (the 1024-spp job = 64 steps)" % (label, integ_label, SPP_PER_STEP),
+        # the whole job of the config on these N GPUs (strong scaling): job_spp / 16 / N steps per rank and one film reduce.
+        # Measured when exactly that was rendered (job_measured), else the step time scaled to it.
+        "job_spp": job_spp,
+        "job_seconds": elapsed if K * N * SPP_PER_STEP == job_spp else elapsed / K * (float(job_spp) / SPP_PER_STEP) / N,
+        "job_measured": K * N * SPP_PER_STEP == job_spp,
+        "config": {"workload": "%s 1920x1080, %s; %d spp per step and GPU (the %d-spp job = %d steps)" % (label, integ_label, SPP_PER_STEP, job_spp, job_spp // SPP_PER_STEP),
                    "triangles": int(scene.indices.shape[0]), "spp_rendered": K * N * SPP_PER_STEP,
                    "parallelism": "spp-shard x%d + one %s of the film" % (N, "ncclReduce inside the library" if torch_reduce is None else "torch.distributed reduce (the library's own RCCL communicator did not come up; the reason is on stderr)")},
         "rccl_ranks": rccl_world,
+        "reduce": reduce_kind,
+        "ms_bvh_build": s_after["ms_bvh_build"],
         "rays": {"closest": rc, "shadow": rs, "mis": rm, "per_sample": rays / samples},
     }
+    out["job_1024spp_seconds"] = out["job_seconds"] * 1024.0 / job_spp
 
-    # ---- roofline of the dominant kernel (k_intersect_closest): the bytes ITS OWN traversal needs, from the device tallies
+    # ---- rooflines.  Live in this run: launch durations (HIP events on the library's stream), rays, and the bytes THIS
+    # build's traversal needs for them (visit counts tallied on the device).  Recorded: what only a counter pass can tell --
+    # HBM bytes, L2 hit rate, VALU issue share and lane use per kernel -- read from profiles/traffic.json, which names the
+    # commit the passes were taken at; everything under "recorded" is of that commit, not of this run.
     node_bytes = float(s_after["bvh_node_bytes"])
     in_lds = bool(s_after["scene_in_lds"])
+    wl_key = "%s_%s_%s" % (variant, args.integrator, args.light_strategy)
+    recorded_all = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            recorded_all = json.load(open(tpath)).get(wl_key) or {}
+        except Exception:
+            recorded_all = {}
+
+    def roofline(kernel_family, kernel_label, ms_total, launches, units_per_launch, bytes_per_unit, extra):
+        """One kernel's entry: the roof that binds it (`bound`, `frac`) and the HBM view beside it."""
+        avg_ms = ms_total / max(1, launches)
+        algorithmic = bytes_per_unit * units_per_launch                     # bytes per launch
+        hbm_alg = algorithmic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        rec = (recorded_all.get("kernels") or {}).get(kernel_family)
+        e = {"kernel": kernel_label, "avg_launch_ms": avg_ms, "launches": launches, "units_per_launch": units_per_launch, "bytes_per_unit": bytes_per_unit,
+             "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS}, "traffic": None}
+        valu = None
+        if rec:
+            e["recorded"] = dict(rec, commit=recorded_all.get("commit"), source=recorded_all.get("source"))
+            if rec.get("bytes_per_launch") is not None:
+                e["traffic"] = rec["bytes_per_launch"]
+                # HBM bytes of the counter pass over THIS run's launch time; what of the algorithmic bytes the caches served
+                e["hbm_frac_counter"] = rec["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else None
+                e["l2_served"] = 1.0 - rec["bytes_per_launch"] / algorithmic if algorithmic > 0 else None
+            if rec.get("valu_issue_share") is not None and rec.get("valu_lane_use") is not None:
+                valu = rec["valu_issue_share"] * rec["valu_lane_use"]
+        hbm_frac = e.get("hbm_frac_counter") or e["hbm_algorithmic"]["frac"]
+        if valu is not None and rec["valu_issue_share"] >= hbm_frac:
+            # VALU issue binds: the fraction of the chip's lane slots (CUs x 4 SIMDs x 16 lanes x clock) that did work
+            e.update({"bound": "valu", "frac": valu, "achieved": valu * VALU_PEAK_TLANEOPS, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                      "frac_is": "recorded VALU issue share x lanes active per instruction"})
+        else:
+            e.update({"bound": "hbm", "frac": hbm_frac, "achieved": hbm_frac * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac_is": "recorded HBM bytes per launch / live launch time" if e.get("hbm_frac_counter") else "algorithmic bytes per launch / live launch time (no counter pass recorded for this workload)"})
+        e.update(extra)
+        return e
+
     npr, tpr = nodes_c / max(1.0, rc), tris_c / max(1.0, rc)
     # a scene staged into LDS is read from HBM once per block, not once per visit: only the ray records stream
     b_ray = RAY_IO_BYTES + (0.0 if in_lds else node_bytes * npr + TRIANGLE_BYTES * tpr)
-    rays_per_launch = rc / N / max(1, n_closest)  # this rank's launches; ranks are symmetric
-    avg_ms = ms_closest / max(1, n_closest)
-    achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, pmc = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    wl_key = "%s_%s_%s" % (variant, args.integrator, args.light_strategy)
-    if os.path.exists(tpath):
-        try:
-            entry = json.load(open(tpath)).get(wl_key)
-            if entry:
-                traffic = entry.get("k_intersect_closest_bytes_per_launch")
-                pmc = {k: entry[k] for k in ("valu_issue_share", "valu_lane_use", "l2_hit", "source") if k in entry}
-        except Exception:
-            pass
-    out["roofline"] = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "kernel": "k_intersect_closest", "avg_launch_ms": avg_ms, "launches": n_closest, "rays_per_launch": rays_per_launch,
-        "bytes_per_ray": b_ray, "nodes_per_ray": npr, "triangles_per_ray": tpr, "node_bytes": node_bytes, "scene_in_lds": in_lds,
-        "pmc": pmc,
-        # lanes of a wave that had work in a step (from the device's own step tallies; 0 where the kernel does not step wave-wide)
+    out["roofline"] = roofline("closest", "k_intersect_closest", ms_closest, n_closest, rc / N / max(1, n_closest), b_ray, {
+        "nodes_per_ray": npr, "triangles_per_ray": tpr, "node_bytes": node_bytes, "scene_in_lds": in_lds,
+        # lanes of a wave that had work in a step (from the device's own step tallies)
         "lanes_busy_node_step": nodes_c / (64.0 * nsteps_c) if nsteps_c else None,
         "triangles_per_tri_step": tris_c / tsteps_c if tsteps_c else None,
         "wave_steps_per_ray": (nsteps_c + tsteps_c) * 64.0 / max(1.0, rc),
-        "note": "achieved = algorithmic bytes of this build's own traversal per launch (per ray: %d B of path record, hit record and queue words%s; "
-                "visit counts tallied on the device) / the launch's duration from HIP events on the library's stream"
-                % (RAY_IO_BYTES, "" if not in_lds else "; tree and triangles are staged into LDS once per block and cost no HBM bytes per visit"
-                   ) + ("" if in_lds else " + node_bytes x nodes fetched + 48 B x triangles tested"),
-    }
-    if pmc and "valu_issue_share" in pmc and "valu_lane_use" in pmc:
-        # the other roof of this kernel: share of the chip's VALU issue slots that did lane work (issue share x lanes
-        # active per instruction, from the committed PMC pass of this workload); the binding one for a scene held in LDS
-        out["roofline"]["valu_frac"] = pmc["valu_issue_share"] * pmc["valu_lane_use"]
-        out["roofline"]["binding_roof"] = "valu issue" if (in_lds or pmc["valu_issue_share"] > achieved / HBM_PEAK_GBS) else "hbm"
+        "note": "bytes_per_unit = per ray %d B of path record, hit record and queue words%s" % (
+            RAY_IO_BYTES, "; tree and triangles are staged into LDS once per block and cost no HBM bytes per visit" if in_lds
+            else " + node_bytes x nodes fetched + 48 B x triangles tested (this build's own traversal, tallied on the device)")})
     if n_shadow:
         nps, tps = nodes_s / max(1.0, rs), tris_s / max(1.0, rs)
         b_sh = 36 + 4 + 16 + (0.0 if in_lds else node_bytes * nps + TRIANGLE_BYTES * tps)  # ray + queue word read, radiance read-modify-write
-        avg_sh = ms_shadow / n_shadow
-        ach_sh = b_sh * (rs / N / n_shadow) / (avg_sh * 1e-3) / 1e9
-        out["roofline_shadow"] = {"bound": "hbm", "kernel": "k_shadow", "achieved": ach_sh, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_sh / HBM_PEAK_GBS,
-                                  "avg_launch_ms": avg_sh, "launches": n_shadow, "bytes_per_ray": b_sh, "nodes_per_ray": nps, "triangles_per_ray": tps,
-                                  "lanes_busy_node_step": nodes_s / (64.0 * nsteps_s) if nsteps_s else None,
-                                  "triangles_per_tri_step": tris_s / tsteps_s if tsteps_s else None,
-                                  "wave_steps_per_ray": (nsteps_s + tsteps_s) * 64.0 / max(1.0, rs)}
+        stream = (not in_lds) and args.integrator != "volpath"
+        out["roofline_shadow"] = roofline("shadow", "k_shadow_tr" if args.integrator == "volpath" else ("k_shadow_stream" if stream else "k_shadow"),
+                                          ms_shadow, n_shadow, rs / N / n_shadow, b_sh, dict(
+            {"nodes_per_ray": nps, "triangles_per_ray": tps},
+            **({"lanes_busy_node_step": nodes_s / (64.0 * nsteps_s), "triangles_per_tri_step": tris_s / tsteps_s if tsteps_s else None,
+                "wave_steps_per_ray": (nsteps_s + tsteps_s) * 64.0 / max(1.0, rs)} if nsteps_s else {})))
+    if n_shade:
+        # the shading kernels of a step together (one per material kind present, + texture / medium / boundary kernels):
+        # per shaded path the 64-byte record and queue word read, 48 B of ray, throughput and state written back, the
+        # 36-byte shadow ray and two queue words written
+        out["roofline_shade"] = roofline("shade", "k_shade<kind> (all kinds of a step)", ms_shade, n_shade, shaded / N / n_shade, 64 + 4 + 48 + 36 + 8,
+                                         {"note": "units = path vertices handed to the shading kernels per step (the material queues' sizes, counted on the device)"})
 
     # ---- CPU baseline: the restated reference renderer on the host cores, a bounded sample of the same workload
     if N == 1 and not args.no_cpu:

@@ -205,7 +205,8 @@ typedef struct EnigmaFilmDesc {
 
 enum { ENIGMA_LIGHTS_UNIFORM = 0, ENIGMA_LIGHTS_POWER = 1,
        ENIGMA_LIGHTS_SPATIAL = 2 /* SpatialLightDistribution (Enigma/LightDist.cpp:80-267), the reference's default: one table per voxel
-                                    of a grid over the scene bounds; the library fills every voxel when the integrator is configured */ };
+                                    of a grid over the scene bounds; as in the reference a voxel's table is made when a path first
+                                    lands in the voxel (between the closest-hit kernel of a bounce and its shading kernels) */ };
 
 /* PathIntegrator + SobolSampler parameters (Enigma/PathIntegrator.cpp:30-44,
  * 182-201; Enigma/Sampler.cpp:211-222). */
@@ -257,6 +258,11 @@ typedef struct EnigmaStats {
     /* Times a traversal found its per-lane stack full and dropped a subtree.  Always 0: the builder caps the tree at
      * the 64 levels the stacks hold; anything else is a defect worth failing a test on. */
     uint64_t stack_overflows;
+    /* Device time of the shading kernels of the last call (texture evaluation, light-table fills, one shade kernel per
+     * material kind present, medium interactions, boundary crossings) and the number of steps that ran them. */
+    double ms_shade;
+    uint64_t shade_launches;
+    uint64_t shaded_vertices; /* path vertices the shading kernels have worked on since the handle was created */
 } EnigmaStats;
 
 typedef struct EnigmaCtx EnigmaCtx;
@@ -315,7 +321,10 @@ int enigma_film_device_ptr(EnigmaCtx* h, void** dev_ptr, uint64_t* n_floats);
  *   rank 0:  enigma_comm_unique_id(id)  -> the caller ships the 128 bytes to every rank (file, socket, MPI, ...)
  *   all:     enigma_comm_init(h, rank, world, id); enigma_render(h, my_begin, my_end); enigma_film_reduce(h, 0);
  *   rank 0:  enigma_film_read(h, ...)
- * RCCL is loaded when the first of these calls is made; without it they return ENIGMA_E_DEVICE. */
+ * RCCL is loaded when the first of these calls is made; without it they return ENIGMA_E_DEVICE.
+ * enigma_comm_init and enigma_film_reduce are collectives WITHOUT a timeout: every rank of the communicator must reach
+ * them, and a rank that fails before it does leaves its peers blocked inside RCCL.  A launcher must therefore watch its
+ * ranks and end all of them when one dies (enigma_render --gpus N and bench.py --gpus N do). */
 #define ENIGMA_COMM_ID_BYTES 128
 int enigma_comm_unique_id(void* id_out /* ENIGMA_COMM_ID_BYTES */);
 int enigma_comm_init(EnigmaCtx* h, int rank, int world, const void* unique_id);
@@ -356,6 +365,16 @@ int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t* pixels_xy,
 int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
                            uint32_t* prim_id_out, float* t_out, float* bary_out);
 int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* hit_out);
+/* Scene::intersect for the camera rays of ONE sample number of every pixel the tile loop visits
+ * (Enigma/Integrator.cpp:262-283: GetCameraSample, GenerateRayDifferential, the first scene.intersect of Li,
+ * Enigma/PathIntegrator.cpp:62-66; Enigma/BVH.cpp:639-680, Enigma/TriangleMesh.cpp:491-602), out of the kernels that
+ * render: the call launches the ray-generation kernel and then the closest-hit kernel of a pass exactly as enigma_render
+ * does for bounce 0 (same instantiation for the configured integrator and scene, same grid, ray pool and LDS staging) and
+ * reads back the hit records it left in the path state.  Arrays are row-major over the render region (sample bounds
+ * clipped to the integrator's pixel bounds, n_pixels = its width x height); values as enigma_debug_intersect reports
+ * them.  The rays it traces are counted in EnigmaStats like any others; the film is not touched.  max_depth >= 1. */
+int enigma_debug_primary_hits(EnigmaCtx* h, int64_t sample_num, uint64_t n_pixels, int32_t* tri_out,
+                              uint32_t* prim_id_out, float* t_out, float* bary_out);
 /* enigma_debug_intersect for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the rays
  * and results are staged in a fixed array inside the library (13 words per ray, ENIGMA_NOALLOC_MAX_RAYS rays, 6.5 MiB

@@ -994,6 +994,40 @@ struct BVHAccel {
         }
         return hit;
     }
+    // Not in the reference (a checker's helper): the number of triangles other than `winner` that the ray hits at a distance
+    // within tol of tWin.  Walks every leaf whose box the ray meets up to tWin + 2 tol, never shrinking the ray: the same
+    // count as testing every triangle of the scene, without the O(scene) cost per ray.
+    uint32_t countHitsNear(const Vec3& o, const Vec3& d, float tWin, float tol, int winner) const {
+        if (nodes.empty()) return 0;
+        Ray ray(o, d, tWin + 2 * tol);
+        Vec3 invDir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+        int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
+        int nodesToVisit[64];
+        int toVisitOffset = 0, currentNodeIndex = 0;
+        uint32_t count = 0;
+        while (true) {
+            const LinearBVHNode* node = &nodes[currentNodeIndex];
+            if (node->bounds.intersectP(ray, invDir, dirIsNeg)) {
+                if (node->nPrimitives > 0) {
+                    for (int i = 0; i < node->nPrimitives; ++i) {
+                        const int prim = primitives[node->primitivesOffset + i];
+                        if (prim == winner) continue;
+                        float t2; Vec3 b2;
+                        if ((*tris)[prim].intersects(ray, &t2, &b2) && std::abs(t2 - tWin) <= tol) ++count;
+                    }
+                    if (toVisitOffset == 0) break;
+                    currentNodeIndex = nodesToVisit[--toVisitOffset];
+                } else {
+                    nodesToVisit[toVisitOffset++] = node->secondChildOffset;
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            } else {
+                if (toVisitOffset == 0) break;
+                currentNodeIndex = nodesToVisit[--toVisitOffset];
+            }
+        }
+        return count;
+    }
     // BVH.cpp:682-722
     bool intersectP(const Ray& ray) const {
         if (nodes.empty()) return false;
@@ -3043,6 +3077,9 @@ int oracle_debug_intersect(OracleCtx* h, uint32_t n, const float* rays7, int32_t
             uint32_t amb = 0;
             if (hit) {
                 float tol = ray.tMax * 1e-6f;
+                static const bool brute = getenv("ORACLE_BRUTE_FORCE_TIES") != nullptr; // for the test that compares the two counts
+                if (!brute && sc.tris.size() > 4096 && ray.tMax + 2 * tol <= r[6]) amb = sc.accel->countHitsNear(ray.o, ray.d, ray.tMax, tol, isect.primIndex);
+                else
                 for (size_t k = 0; k < sc.tris.size(); ++k) {
                     if ((int)k == isect.primIndex) continue;
                     Ray r2(ray.o, ray.d, r[6]);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
     "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
-    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_default_metal_spectra",
+    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_primary_hits", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_default_metal_spectra",
     "enigma_comm_unique_id", "enigma_comm_init", "enigma_comm_info", "enigma_film_reduce", "enigma_comm_destroy",
 ]
 
@@ -56,6 +56,7 @@ def load_library():
         L.enigma_debug_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_intersect_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.enigma_debug_primary_hits.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_bsdf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_film_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -204,6 +205,18 @@ class Renderer:
         fn = self.L.enigma_debug_intersect_noalloc if noalloc else self.L.enigma_debug_intersect
         self._chk(fn(self.h, n, abi.ptr(rays7), abi.ptr(tri), abi.ptr(pid), abi.ptr(t), abi.ptr(bary)))
         return dict(tri=tri, prim_id=pid, t=t, bary=bary)
+
+    def primary_hits(self, sample_num, region_wh):
+        """The hit records the production closest-hit kernel leaves for the camera rays of one sample number, as (h, w)
+        arrays over the render region (region_wh = its width and height)."""
+        w, hgt = region_wh
+        n = w * hgt
+        tri = np.zeros(n, dtype=np.int32)
+        pid = np.zeros(n, dtype=np.uint32)
+        t = np.zeros(n, dtype=np.float32)
+        bary = np.zeros((n, 3), dtype=np.float32)
+        self._chk(self.L.enigma_debug_primary_hits(self.h, sample_num, n, abi.ptr(tri), abi.ptr(pid), abi.ptr(t), abi.ptr(bary)))
+        return dict(tri=tri.reshape(hgt, w), prim_id=pid.reshape(hgt, w), t=t.reshape(hgt, w), bary=bary.reshape(hgt, w, 3))
 
     def intersect_any(self, rays7):
         rays7 = np.ascontiguousarray(rays7, dtype=np.float32).reshape(-1, 7)

@@ -97,7 +97,7 @@ class EnigmaStats(C.Structure):
                 ("nodes_mis", C.c_uint64), ("tris_mis", C.c_uint64), ("bvh_node_bytes", C.c_uint64),
                 ("scene_in_lds", C.c_uint64), ("ms_shadow", C.c_double), ("shadow_launches", C.c_uint64),
                 ("node_steps_closest", C.c_uint64), ("tri_steps_closest", C.c_uint64), ("node_steps_shadow", C.c_uint64), ("tri_steps_shadow", C.c_uint64),
-                ("stack_overflows", C.c_uint64)]
+                ("stack_overflows", C.c_uint64), ("ms_shade", C.c_double), ("shade_launches", C.c_uint64), ("shaded_vertices", C.c_uint64)]
 
 
 def ptr(a):

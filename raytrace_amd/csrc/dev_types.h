@@ -114,6 +114,8 @@ struct DevScene {
     const DevTexture* textures; // trilinear image textures; nullptr = none
     float4* texColors;          // two float4 per path: the textured colours k_texture evaluated at the path's hit
     unsigned long long* visits; // tallies of nodes fetched / triangles tested per kind of ray query (dev_trace.h), nullptr = not kept
+    float* hitT;                // debug tap (enigma_debug_primary_hits): when set, the closest-hit kernel leaves the distance of every
+                                // ray that finishes its walk at the path's index (+inf for a miss); nullptr in every render
     const uint32_t* triMedium;  // per triangle (device order): (inside medium + 1) | (outside medium + 1) << 16, 0 = none; nullptr = no media
     float lightFuncInt;
     int nLights;
@@ -228,6 +230,7 @@ struct DevCounters {
     DevTail shadowCount, misCount;
     DevTail shadowCursor;       // next unreserved position of the shadow queue while k_shadow_stream runs (its waves reserve runs of it)
     unsigned long long raysClosest, raysShadow, raysMis, samples;
+    unsigned long long shaded;  // path vertices handed to the shading kernels (the material queues' sizes, summed when they are reset)
 };
 
 DEV uint32_t packState(uint32_t medium, uint32_t dim, uint32_t bounces, uint32_t spec) {

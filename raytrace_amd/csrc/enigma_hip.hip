@@ -133,8 +133,9 @@ struct EnigmaCtx {
 
     // stats
     EnigmaStats stats{};
-    std::vector<hipEvent_t> evPool;      // four per traversal step of a render call: closest-hit kernel begin / end, shadow kernel begin / end
+    std::vector<hipEvent_t> evPool;      // kEventsPerStep per traversal step of a render call
     std::vector<uint8_t> shadowTimed;   // per step: the shadow kernel was launched (its two events were recorded)
+    std::vector<uint8_t> shadeTimed;    // per step: the shading kernels were launched
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -1015,17 +1016,19 @@ static size_t shadeLdsBytes(const EnigmaCtx* h) {
 }
 
 // Events that bracket the two traversal kernels of a step, on the library's stream.
-struct StepEvents { hipEvent_t c0, c1, s0, s1; uint8_t* shadowTimed; };
+struct StepEvents { hipEvent_t c0, c1, s0, s1, h0, h1; uint8_t* shadowTimed; uint8_t* shadeTimed; };
+constexpr size_t kEventsPerStep = 6; // closest-hit kernel, shadow kernel, the shading kernels of the step: begin / end each
 static int acquireStepEvents(EnigmaCtx* h, StepEvents* ev) {
     const size_t i = h->stats.intersect_launches;
-    while (h->evPool.size() < (i + 1) * 4) {
+    while (h->evPool.size() < (i + 1) * kEventsPerStep) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreate(&e));
         h->evPool.push_back(e);
     }
-    if (h->shadowTimed.size() < i + 1) h->shadowTimed.resize(i + 1);
-    h->shadowTimed[i] = 0;
-    *ev = StepEvents{h->evPool[4 * i], h->evPool[4 * i + 1], h->evPool[4 * i + 2], h->evPool[4 * i + 3], &h->shadowTimed[i]};
+    if (h->shadowTimed.size() < i + 1) { h->shadowTimed.resize(i + 1); h->shadeTimed.resize(i + 1); }
+    h->shadowTimed[i] = 0; h->shadeTimed[i] = 0;
+    hipEvent_t* e = &h->evPool[kEventsPerStep * i];
+    *ev = StepEvents{e[0], e[1], e[2], e[3], e[4], e[5], &h->shadowTimed[i], &h->shadeTimed[i]};
     return ENIGMA_OK;
 }
 
@@ -1054,6 +1057,20 @@ static void launchSpatialFill(EnigmaCtx* h, const DevPaths& P, int grid, int las
     k_spatial_filled<<<1, 1, 0, h->stream>>>(h->scene);
 }
 
+// The one launch site of the closest-hit kernel: the three integrators' steps and the primary-hit tap all go through it,
+// so the tap runs the very instantiation and launch shape that renders.
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH>
+static void launchClosest(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int iter, int gridTrace, const uint32_t* pendCount) {
+    DevCounters* ctr = h->counters.p;
+    const uint32_t cur = (uint32_t)iter & 1u;
+    MatQueues mq;
+    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
+    const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
+    const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
+    k_intersect_closest<LDSN, OVF, LDS_SCENE, MODE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, h->stream>>>(
+        h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount);
+}
+
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
 static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t nPaths, int bounce, int gridTrace,
                          int gridShadow, int gridShade, const StepEvents& ev) {
@@ -1061,15 +1078,12 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     uint32_t cur = (uint32_t)bounce & 1u;
     hipStream_t s = h->stream;
     k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, bounce == 0 ? 1 : 0);
-    MatQueues mq;
-    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
-    const uint32_t* queue = bounce == 0 ? nullptr : h->extQ[cur].p;
-    const uint32_t* countPtr = bounce == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 0, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, nullptr);
+    launchClosest<LDSN, OVF, LDS_SCENE, 0, SPH>(h, P, nPaths, bounce, gridTrace, nullptr);
     (void)hipEventRecord(ev.c1, s);
     if (bounce >= h->integ.maxDepth && !h->haveNoMaterial) return; // nothing survives the depth test: no shading, no shadow rays
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
+    (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade);
     launchSpatialFill(h, P, gridShade, MK_COUNT - 1);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
@@ -1080,6 +1094,8 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     // surfaces without a material: the ray goes on behind them and the vertex does not count as a bounce (Enigma/PathIntegrator.cpp:87-93)
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
+    (void)hipEventRecord(ev.h1, s);
+    *ev.shadeTimed = 1;
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
@@ -1100,16 +1116,12 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     uint32_t cur = (uint32_t)iter & 1u;
     hipStream_t s = h->stream;
     k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, iter == 0 ? 1 : 0);
-    MatQueues mq;
-    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
-    const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
-    const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 2, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
-                                                                                                              h->refillIdle, nullptr);
+    launchClosest<LDSN, OVF, LDS_SCENE, 2, SPH>(h, P, nPaths, iter, gridTrace, nullptr);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade);
     launchSpatialFill(h, P, gridShade, kQueueMedium);
     if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
@@ -1120,6 +1132,8 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
+    (void)hipEventRecord(ev.h1, s);
+    *ev.shadeTimed = 1;
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
         k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
@@ -1139,16 +1153,12 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     uint32_t cur = (uint32_t)step & 1u;
     hipStream_t s = h->stream;
     k_stage<<<1, 1, 0, s>>>(ctr, 0, cur, nPaths, step == 0 ? 1 : 0);
-    MatQueues mq;
-    for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
-    const uint32_t* queue = step == 0 ? nullptr : h->extQ[cur].p;
-    const uint32_t* countPtr = step == 0 ? nullptr : &ctr->extCount[cur].v;
     (void)hipEventRecord(ev.c0, s);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, 1, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr,
-                                                                                                                 h->refillIdle, D.pendCount);
+    launchClosest<LDSN, OVF, LDS_SCENE, 1, SPH>(h, P, nPaths, step, gridTrace, D.pendCount);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
+    (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade);
     if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
@@ -1157,6 +1167,8 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
+    (void)hipEventRecord(ev.h1, s);
+    *ev.shadeTimed = 1;
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
@@ -1166,6 +1178,19 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
         *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
     }
+}
+
+// traversal flavour: scene in LDS (small scene, shallow tree) | all stack levels in LDS | 11 levels in LDS + a private spill array;
+// scenes with spheres: the last one, with the sphere test compiled in
+static bool sceneRunsFromLds(const EnigmaCtx* h) {
+    return h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 &&
+           sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+}
+// Paths per chunk of the traversal kernels' grids
+static int traceGrid(uint32_t nPaths, int cus) { return std::min((int)((nPaths + kTraceChunk - 1) / kTraceChunk), cus * 32); }
+static int deviceCus(const EnigmaCtx* h) {
+    hipDeviceProp_t prop;
+    return hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;
 }
 
 static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
@@ -1178,6 +1203,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
     h->stats.ms_render = 0; h->stats.ms_intersect = 0; h->stats.intersect_launches = 0;
     h->stats.ms_shadow = 0; h->stats.shadow_launches = 0;
+    h->stats.ms_shade = 0; h->stats.shade_launches = 0;
     if (nPixels == 0 || sample_begin == sample_end) return ENIGMA_OK;
     // passes of k sample numbers over all pixels, ~32M paths in flight (capped by the 12-bit sample slot)
     const bool direct = h->useDirect, vol = h->useVolPath && !h->useDirect;
@@ -1193,14 +1219,10 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     uint32_t k = (uint32_t)std::max<size_t>(1, std::min<size_t>(targetPaths / nPixels, 64));
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
-    // traversal flavour: scene in LDS (small scene, shallow tree) | all stack levels in LDS | 11 levels in LDS + a private spill array;
-    // scenes with spheres: the last one, with the sphere test compiled in
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
-    const bool ldsScene = h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 && sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
+    const bool ldsScene = sceneRunsFromLds(h);
     h->stats.scene_in_lds = ldsScene ? 1 : 0;
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) cus = prop.multiProcessorCount;
+    const int cus = deviceCus(h);
     h->residentTraceBlocks = cus * 6;
     for (int64_t c0 = 0; c0 < nSamples; c0 += chunkMax) {
         int64_t cn = std::min(chunkMax, nSamples - c0);
@@ -1235,7 +1257,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             int gridAll = (int)((nPaths + kBlock - 1) / kBlock);
             // traversal grids: enough blocks that the hardware dispatcher balances rays of very different cost,
             // few enough that launches late in a pass (short queues) do not drown in empty blocks
-            int gridTrace = std::min((int)((nPaths + kTraceChunk - 1) / kTraceChunk), cus * 32);
+            int gridTrace = traceGrid(nPaths, cus);
             int gridShadow = std::min(gridAll, cus * 4); // MIS rays: few per bounce
             int gridShade = std::min(gridAll, cus * 8);
             k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
@@ -1307,8 +1329,10 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     }
     for (uint64_t i = 0; i < h->stats.intersect_launches; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->evPool[i * 4], h->evPool[i * 4 + 1]) == hipSuccess) h->stats.ms_intersect += ms;
-        if (h->shadowTimed[i] && hipEventElapsedTime(&ms, h->evPool[i * 4 + 2], h->evPool[i * 4 + 3]) == hipSuccess) { h->stats.ms_shadow += ms; h->stats.shadow_launches++; }
+        hipEvent_t* e = &h->evPool[i * kEventsPerStep];
+        if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) h->stats.ms_intersect += ms;
+        if (h->shadowTimed[i] && hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) { h->stats.ms_shadow += ms; h->stats.shadow_launches++; }
+        if (h->shadeTimed[i] && hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) { h->stats.ms_shade += ms; h->stats.shade_launches++; }
     }
     h->stats.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return ENIGMA_OK;
@@ -1486,6 +1510,8 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
     h->stats.rays_closest = c.raysClosest;
     h->stats.rays_shadow = c.raysShadow;
     h->stats.rays_mis = c.raysMis;
+    h->stats.shaded_vertices = c.shaded;
+    for (int k = 0; k < kQueueKinds; ++k) h->stats.shaded_vertices += c.matCount[k].v; // the last step's queues are summed in when the next step resets them
     {   // traversal tallies: one slot per block of a launch, summed here
         std::vector<unsigned long long> v(h->visits.n);
         HIPCHK(h, hipMemcpy(v.data(), h->visits.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1619,6 +1645,82 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
     dRays.release(); dT.release(); dB.release(); dTri.release(); dPrim.release();
     if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_intersect: %s", hipGetErrorString(e));
     return ENIGMA_OK;
+}
+
+// ---- primary hits out of the production kernel ----
+template <int MODE>
+static void launchClosestFlavour(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int gridTrace, const uint32_t* pendCount) {
+    if (h->scene.nSpheres) launchClosest<11, 53, false, MODE, true>(h, P, nPaths, 0, gridTrace, pendCount);
+    else if (sceneRunsFromLds(h)) launchClosest<12, 0, true, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    else if (h->bvhStack <= 11) launchClosest<11, 0, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    else launchClosest<11, 53, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+}
+
+// The first two kernels of a real pass for ONE sample number of every pixel of the render region: k_generate, then the
+// closest-hit kernel exactly as enigma_render launches it for bounce 0 (ray pool, voted steps, the scene staged into LDS
+// when it is small, the material binning).  The hit records it leaves in the path state are what the shade kernels would
+// consume; they are read back instead.
+static int primaryHitsImpl(EnigmaCtx* h, int64_t sample_num, int32_t* triOut, uint32_t* primOut, float* tOut, float* baryOut) {
+    if (!h->haveScene || !h->haveCamera || !h->haveFilm || !h->haveInteg) return h->fail(ENIGMA_E_STATE, "scene, camera, film and integrator must be configured before the primary-hit tap");
+    if (sample_num < 0 || sample_num >= h->spp) return h->fail(ENIGMA_E_INVALID, "sample number %lld outside [0, %lld)", (long long)sample_num, (long long)h->spp);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->useDirect && h->directDirty) { int rc = finishDirectLighting(h); if (rc) return rc; }
+    const bool direct = h->useDirect, vol = h->useVolPath && !h->useDirect;
+    if (!direct && h->integ.maxDepth < 1) return h->fail(ENIGMA_E_INVALID, "the primary-hit tap needs max_depth >= 1 (at depth 0 the kernel writes no hit record)");
+    const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
+    if (nPixels == 0) return ENIGMA_OK;
+    std::vector<uint32_t> consts((size_t)h->nDims + 16, 0u);
+    enigma::sample_constants(h->log2Res, (uint64_t)sample_num, h->nDims, consts.data());
+    HIPCHK(h, h->sampleConst.upload(consts));
+    h->sampler.sampleConst = h->sampleConst.p;
+    h->sampler.sampleBase = (unsigned long long)sample_num;
+    const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
+    { int rc = ensureCapacity(h, nPixels, raysPerPath, pendingLevels); if (rc) return rc; }
+    DevPaths P{{h->pathRec.p}, {h->pathRec.p + 1}, h->L.p, {h->pathRec.p + 2}, {h->pathRec.p + 3}, h->pfilm.p};
+    DevDirect D{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (direct) D = DevDirect{h->arrayOff.p, h->pendCount.p, h->pendO.p, h->pendD.p, h->pendB.p};
+    h->integ.nPixels = nPixels;
+    h->integ.slotBase = 0;
+    DevBuf<float> dT, dB; DevBuf<int32_t> dTri; DevBuf<uint32_t> dPrim;
+    hipError_t e = dT.alloc(nPixels);
+    if (e == hipSuccess) e = dB.alloc((size_t)nPixels * 3);
+    if (e == hipSuccess) e = dTri.alloc(nPixels);
+    if (e == hipSuccess) e = dPrim.alloc(nPixels);
+    DevBuf<float> hitT;
+    if (e == hipSuccess) e = hitT.alloc(nPixels);
+    if (e == hipSuccess) {
+        const int cus = deviceCus(h);
+        const int gridAll = (int)((nPixels + kBlock - 1) / kBlock);
+        if (const char* env = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(env);
+        h->scene.hitT = hitT.p;
+        k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPixels, nPixels, 0u, h->counters.p, direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
+        k_stage<<<1, 1, 0, h->stream>>>(h->counters.p, 0, 0u, nPixels, 1);
+        const int gridTrace = traceGrid(nPixels, cus);
+        if (direct) launchClosestFlavour<1>(h, P, nPixels, gridTrace, D.pendCount);
+        else if (vol) launchClosestFlavour<2>(h, P, nPixels, gridTrace, nullptr);
+        else launchClosestFlavour<0>(h, P, nPixels, gridTrace, nullptr);
+        k_debug_gather_primary<<<gridAll, kBlock, 0, h->stream>>>(h->scene, P, h->integ, nPixels, dTri.p, dPrim.p, dT.p, dB.p);
+        h->scene.hitT = nullptr;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(triOut, dTri.p, (size_t)nPixels * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(primOut, dPrim.p, (size_t)nPixels * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(tOut, dT.p, (size_t)nPixels * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(baryOut, dB.p, (size_t)nPixels * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    h->scene.hitT = nullptr;
+    dT.release(); dB.release(); dTri.release(); dPrim.release(); hitT.release();
+    if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_primary_hits: %s", hipGetErrorString(e));
+    return ENIGMA_OK;
+}
+
+extern "C" int enigma_debug_primary_hits(EnigmaCtx* h, int64_t sample_num, uint64_t n_pixels, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
+    if (!h || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
+        const uint64_t want = (uint64_t)std::max(0, h->integ.rw) * (uint64_t)std::max(0, h->integ.rh);
+        if (h->haveInteg && n_pixels != want) return h->fail(ENIGMA_E_INVALID, "the render region has %llu pixels, the caller's arrays hold %llu", (unsigned long long)want, (unsigned long long)n_pixels);
+        return primaryHitsImpl(h, sample_num, tri_out, prim_id_out, t_out, bary_out);
+    });
 }
 
 // ---- the entry point that allocates nothing ----

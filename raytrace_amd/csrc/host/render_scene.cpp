@@ -16,7 +16,9 @@
 #include "enigma_host.h"
 #include "pbrt_frontend.h"
 
+#include <algorithm>
 #include <chrono>
+#include <csignal>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -123,7 +125,7 @@ static Ranks g_ranks;
 
 static bool exchangeCommId(const std::string& path, Ranks* r) {
     if (r->rank == 0) {
-        if (enigma_comm_unique_id(r->id) != ENIGMA_OK) { std::cerr << "enigma_comm_unique_id failed (RCCL not loadable)\n"; return false; }
+        if (enigma_comm_unique_id(r->id) != ENIGMA_OK) { std::cerr << "enigma_comm_unique_id failed (RCCL not loadable, or no GPU visible to it)\n"; return false; }
         const std::string tmp = path + ".part";
         { std::ofstream o(tmp, std::ios::binary); o.write(reinterpret_cast<const char*>(r->id), sizeof(r->id)); if (!o) return false; }
         return rename(tmp.c_str(), path.c_str()) == 0; // appears whole or not at all
@@ -137,14 +139,24 @@ static bool exchangeCommId(const std::string& path, Ranks* r) {
     return false;
 }
 
-// returns -1 in a child (which goes on to render as g_ranks.rank), else the parent's exit code
+// returns -1 in a child (which goes on to render as g_ranks.rank), else the parent's exit code.
+// The film reduce and the communicator set-up are collectives without a timeout: a rank that dies (no such GPU, a scene it
+// cannot load, an error of the library) would leave its peers waiting inside RCCL for good.  The parent therefore watches
+// all ranks at once: the first one that ends badly -- or a deadline, ENIGMA_RENDER_DEADLINE_S seconds, default none -- ends
+// the others (SIGKILL: a rank blocked inside a collective handles nothing else), every child is reaped, and the exit code
+// says that the job failed.
 static int forkRanks(int world, const std::string& out) {
     const std::string idFile = out + ".commid";
     unlink(idFile.c_str());
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
         pid_t pid = fork();
-        if (pid < 0) { std::cerr << "fork failed\n"; return 1; }
+        if (pid < 0) {
+            std::cerr << "fork failed\n";
+            for (pid_t k : kids) kill(k, SIGKILL);
+            for (pid_t k : kids) waitpid(k, nullptr, 0);
+            return 1;
+        }
         if (pid == 0) {
             g_ranks.rank = r; g_ranks.world = world;
             if (!exchangeCommId(idFile, &g_ranks)) _exit(3);
@@ -152,10 +164,35 @@ static int forkRanks(int world, const std::string& out) {
         }
         kids.push_back(pid);
     }
+    double deadline = 0;
+    if (const char* e = getenv("ENIGMA_RENDER_DEADLINE_S")) deadline = atof(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t left = kids.size();
     int rc = 0;
-    for (pid_t k : kids) {
+    while (left > 0) {
         int st = 0;
-        if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        const pid_t done = waitpid(-1, &st, WNOHANG);
+        if (done > 0) {
+            --left;
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                if (rc == 0) {
+                    const size_t rank = std::find(kids.begin(), kids.end(), done) - kids.begin();
+                    std::cerr << "enigma_render: rank " << rank << " failed (" << (WIFEXITED(st) ? "exit code " : "signal ") << (WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st))
+                              << "); ending the other ranks\n";
+                    for (pid_t k : kids) if (k != done) kill(k, SIGKILL); // already reaped ones are gone: ESRCH is harmless
+                }
+                rc = 1;
+            }
+            continue;
+        }
+        if (done < 0) { rc = 1; break; } // no children left to wait for although some were expected
+        if (deadline > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline) {
+            if (rc == 0) std::cerr << "enigma_render: the ranks did not finish within " << deadline << " s; ending them\n";
+            rc = 1;
+            deadline = 0;
+            for (pid_t k : kids) kill(k, SIGKILL);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
     unlink(idFile.c_str());
     return rc;

@@ -372,6 +372,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     uint32_t kind = 0;
     Hit h = w.h;
+    if (sc.hitT) sc.hitT[p] = h.tri >= 0 ? h.t : EDEV_INF; // the primary-hit tap reads the walk's own distance; no render sets the pointer
     bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
     if (VOL && stMedium(state) != 0) {
         const DevMedium md = sc.media[stMedium(state) - 1u];
@@ -1420,7 +1421,7 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (phase == 0) {
         ctr->raysClosest += useImm ? countImm : ctr->extCount[curIdx].v;
-        for (int k = 0; k < kQueueKinds; ++k) ctr->matCount[k].v = 0;
+        for (int k = 0; k < kQueueKinds; ++k) { ctr->shaded += ctr->matCount[k].v; ctr->matCount[k].v = 0; } // what the step before this one shaded
         ctr->extCount[curIdx ^ 1u].v = 0;
         ctr->shadowCount.v = 0; ctr->misCount.v = 0;
     } else if (phase == 1) {
@@ -1472,6 +1473,30 @@ __global__ void __launch_bounds__(kBlock) k_debug_intersect(DevScene sc, uint32_
     primOut[i] = orig >= 0 ? sc.primId[orig] : 0u;
     tOut[i] = h.tri >= 0 ? h.t : EDEV_INF;
     baryOut[3 * (size_t)i] = h.b0; baryOut[3 * (size_t)i + 1] = h.b1; baryOut[3 * (size_t)i + 2] = h.b2;
+}
+// The hit records that the closest-hit kernel of a pass left for the camera rays of one sample number (path index =
+// pixel number), brought into row-major pixel order over the render region and into the caller's primitive numbering.
+__global__ void __launch_bounds__(kBlock) k_debug_gather_primary(DevScene sc, DevPaths P, DevIntegrator I, uint32_t nPixels, int32_t* triOut,
+                                                                 uint32_t* primOut, float* tOut, float* baryOut) {
+    const uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= nPixels) return;
+    uint32_t x, y;
+    pixelOfIndex(I, pix, &x, &y);
+    const size_t o = (size_t)y * (uint32_t)I.rw + x;
+    const float t = sc.hitT[pix];
+    int orig = -1;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (t != EDEV_INF) { // a miss leaves the hit record of the path unwritten
+        const float4 hv = P.hit[pix];
+        const int tri = __float_as_int(hv.x);
+        b0 = hv.y; b1 = hv.z; b2 = hv.w;
+        if (sc.nSpheres && tri >= (int)sc.nTris) orig = tri - (int)sc.nTris + (int)(sc.nTris - sc.nSpheres);
+        else orig = __float_as_int(sc.tris[(size_t)tri * 3].w);
+    }
+    triOut[o] = orig;
+    primOut[o] = orig >= 0 ? sc.primId[orig] : 0u;
+    tOut[o] = t;
+    baryOut[3 * o] = b0; baryOut[3 * o + 1] = b1; baryOut[3 * o + 2] = b2;
 }
 // BSDF::f / Pdf / sample_f (Enigma/BxDF.cpp:885-985) of one material at a surface whose geometric and shading normal
 // are +z and whose dpdu is +x, for n (wo, wi, u) triples: out = f.rgb, Pdf, sampled f.rgb, sampled pdf, sampled wi.xyz, sampled type

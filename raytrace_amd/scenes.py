@@ -680,5 +680,77 @@ def big_mesh(grid=512, sphere_level=6, n_spheres=8, seed=0xE16A):
     return abi.SceneArrays(V, T, M, Lt, mats, lights)
 
 
+def big_mesh_fog(grid=512, sphere_level=6, n_spheres=8, seed=0xE16A):
+    """The defined part of the VolPathIntegrator configuration: the big_mesh scene as a TEXTURED mesh inside a homogeneous
+    medium.  The terrain carries uvs (16 x 16 tiles) and a trilinear Kd image texture; the spheres carry spherical uvs, one
+    kind of them is a plastic with trilinear Kd and Ks textures, one a smooth glass filled with a tinted absorbing medium.
+    A box of material-less triangles with scattering fog inside (MediumInterface fog | none) encloses terrain air space and
+    spheres; camera and light sit outside it, so every camera ray and every shadow ray crosses a medium boundary (camera
+    rays carry no medium of their own in the reference, Enigma/Camera.cpp:144-192).  Same triangle count as big_mesh + 12."""
+    base = big_mesh(grid, sphere_level, n_spheres, seed)
+    V, T = base.vertices, base.indices
+    nt_terrain = 2 * grid * grid
+    nv_terrain = (grid + 1) * (grid + 1)
+    sv, sf = _icosphere(sphere_level)
+    nt_bulk = nt_terrain + n_spheres * sf.shape[0]
+    nv_bulk = nv_terrain + n_spheres * sv.shape[0]
+    size = 1000.0
+    uv = np.zeros((V.shape[0], 2), dtype=np.float32)
+    uv[:nv_terrain, 0] = V[:nv_terrain, 0] / size * 16.0
+    uv[:nv_terrain, 1] = V[:nv_terrain, 2] / size * 16.0
+    suv = np.stack([np.arctan2(sv[:, 2], sv[:, 0]) / (2 * math.pi) + 0.5, np.arccos(np.clip(sv[:, 1], -1, 1)) / math.pi], axis=1)
+    for s_ in range(n_spheres):
+        a = nv_terrain + s_ * sv.shape[0]
+        uv[a:a + sv.shape[0]] = suv * (4.0, 2.0)
+    flags = np.zeros(T.shape[0], dtype=np.uint32)
+    flags[:nt_bulk] = abi.TRI_HAS_UVS
+    img = test_pattern(64, 64, seed=0xF06)
+    textures = [abi.image_texture(img, trilinear=True), abi.image_texture(0.25 + 0.6 * test_pattern(32, 32, seed=5), trilinear=True, su=2.0, sv=2.0),
+                abi.image_texture(0.2 + 0.5 * test_pattern(16, 32, seed=9), trilinear=True)]
+    mats = [base.materials[i] for i in range(base.n_materials)]
+    mats[0] = abi.matte((0.55, 0.5, 0.45)); mats[0].tex_kd = 1
+    mats[4] = abi.plastic((0.3, 0.3, 0.3), (0.4, 0.4, 0.4), roughness=0.08); mats[4].tex_kd = 2; mats[4].tex_ks = 3
+    mats[5] = abi.glass(1.5, 0.1, 0.1)
+    mats[6] = abi.glass(1.5, 0.0, 0.0)
+    fog = abi.homogeneous_medium((0.0001, 0.0001, 0.0001), (0.0012, 0.0013, 0.0015), 0.3)
+    tint = abi.homogeneous_medium((0.002, 0.004, 0.008), (0.0005, 0.0005, 0.0005), 0.0)
+    m_in = np.full(T.shape[0], -1, dtype=np.int32)
+    m_out = np.full(T.shape[0], -1, dtype=np.int32)
+    glass_filled = base.tri_material == 6      # the smooth-glass spheres: tinted medium inside, the fog outside
+    m_in[glass_filled] = 1
+    m_out[glass_filled] = 0
+    # the fog box: material-less triangles, fog inside
+    b = MeshBuilder()
+    lo, hi = np.array([20.0, 60.0, 35.0]), np.array([980.0, 450.0, 980.0])
+    c = (lo + hi) / 2
+    for axis in range(3):
+        for side, val in ((-1, lo[axis]), (1, hi[axis])):
+            u, w = (axis + 1) % 3, (axis + 2) % 3
+            q = []
+            for du, dw in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = np.zeros(3)
+                p[axis] = val
+                p[u] = hi[u] if du else lo[u]
+                p[w] = hi[w] if dw else lo[w]
+                q.append(tuple(p))
+            outward = c.copy()
+            outward[axis] = val + side * 100.0
+            b.add_quad(q, abi.NO_MATERIAL, toward=tuple(outward))
+    bv = np.asarray(b.v, dtype=np.float32)
+    bt = np.asarray(b.t, dtype=np.uint32) + V.shape[0]
+    nb = bt.shape[0]
+    V2 = np.concatenate([V, bv])
+    T2 = np.concatenate([T, bt])
+    uv2 = np.concatenate([uv, np.zeros((bv.shape[0], 2), dtype=np.float32)])
+    M2 = np.concatenate([base.tri_material, np.full(nb, abi.NO_MATERIAL, dtype=np.uint32)])
+    L2 = np.concatenate([base.tri_light, np.full(nb, -1, dtype=np.int32)])
+    F2 = np.concatenate([flags, np.zeros(nb, dtype=np.uint32)])
+    in2 = np.concatenate([m_in, np.zeros(nb, dtype=np.int32)])
+    out2 = np.concatenate([m_out, np.full(nb, -1, dtype=np.int32)])
+    lights = [base.lights[i] for i in range(base.n_lights)]
+    return abi.SceneArrays(V2, T2, M2, L2, mats, lights, tri_flags=F2, media=[fog, tint], tri_medium_inside=in2, tri_medium_outside=out2,
+                           uvs=uv2, textures=textures)
+
+
 def big_mesh_camera(xres, yres):
     return camera_desc((500, 330, 20), (500, 140, 560), (0, 1, 0), 50.0, xres, yres)

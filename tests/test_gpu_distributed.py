@@ -105,7 +105,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ENIGMA_BENCH_ONE_GPU="1", ENIGMA_BENCH_BACKEND="gloo")
+    env = dict(os.environ, ENIGMA_BENCH_ONE_GPU="1", ENIGMA_BENCH_BACKEND="gloo", ENIGMA_BENCH_ALLOW_FALLBACK="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--variant", "microfacet"],
@@ -117,7 +117,27 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["spp_rendered"] == 2 * 2 * 16  # ranks x steps x 16 spp
     assert "torch.distributed reduce" in line["config"]["parallelism"] and line["rccl_ranks"] == 1
+    assert line["reduce"] == "torch-fallback"            # said at the top level, so that nobody credits the library with torch's reduce
     per_sample = line["rays"]["per_sample"]
     assert 3.5 < per_sample < 4.0  # the Cornell box's rays per camera sample: both ranks' work is in the totals
     samples = 1920 * 1080 * line["config"]["spp_rendered"]
     assert abs(line["msamples_per_s"] * 1e6 * line["ms_per_step"] * 1e-3 * line["steps"] / samples - 1.0) < 1e-6
+
+
+def test_bench_refuses_to_fall_back_unasked():
+    """Without ENIGMA_BENCH_ALLOW_FALLBACK a run whose native communicator does not come up must not produce a number:
+    the same two ranks on one GPU end with a non-zero exit code and a line that says why."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ENIGMA_BENCH_ONE_GPU="1", ENIGMA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ENIGMA_BENCH_ALLOW_FALLBACK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--variant", "microfacet"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode != 0
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["reduce"] == "torch-fallback" and line["value"] is None and "ENIGMA_BENCH_ALLOW_FALLBACK" in line["error"]

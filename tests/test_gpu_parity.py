@@ -91,6 +91,64 @@ def _hit_check(r, o, rays7, allow_ambiguous=True):
     return ho, int(amb.sum())
 
 
+def _primary_tap_check(r, o, region, sample_nums, n_triangles=None):
+    """enigma_debug_primary_hits -- k_generate + the closest-hit kernel of a real pass, hit records read out of the path
+    state -- against the oracle's Scene::intersect of the same camera rays, bit for bit.  region = x0, y0, x1, y1 of the
+    render region.  Returns the number of rays compared and of rays that hit."""
+    x0, y0, x1, y1 = region
+    ys, xs = np.mgrid[y0:y1, x0:x1]
+    P = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)
+    n_hit = 0
+    for sn in sample_nums:
+        rays, _ = o.camera_rays(P, np.full(P.shape[0], sn, dtype=np.int64))
+        ho = o.intersect(common.rays_from_camera(rays))
+        hg = r.primary_hits(sn, (x1 - x0, y1 - y0))
+        ok = ho["ambiguous"] == 0
+        assert ok.mean() > 0.99
+        assert np.array_equal(ho["prim_id"][ok], hg["prim_id"].ravel()[ok])
+        assert np.array_equal(ho["tri"][ok], hg["tri"].ravel()[ok])
+        assert np.array_equal(u32(ho["t"][ok]), u32(hg["t"].ravel()[ok]))
+        on_tri = ok if n_triangles is None else ok & (ho["tri"] < n_triangles)   # a sphere hit carries its object-space point there
+        assert np.array_equal(u32(ho["bary"][on_tri]), u32(hg["bary"].reshape(-1, 3)[on_tri]))
+        assert np.allclose(ho["t"][~ok], hg["t"].ravel()[~ok], rtol=2e-6)   # exact ties on shared edges: same distance
+        n_hit += int((ho["tri"] >= 0).sum())
+    return P.shape[0] * len(sample_nums), n_hit
+
+
+def test_primary_hits_of_the_production_kernel_cornell_512():
+    """BASELINE configs[0] at its own size: the hit of every camera ray of sample numbers 0, 7 and 15 out of the kernel
+    that renders (scene staged into LDS, ray pool, voted steps), for the three integrators' builds of it."""
+    sc, cam, film, integ = common.cornell_setup(res=512, spp=16, variant="diffuse")
+    r, o = pair((sc, cam, film, integ))
+    n, hits = _primary_tap_check(r, o, (0, 0, 512, 512), (0, 7, 15))
+    assert hits > 0.9 * n
+    # the tap leaves the film alone and a render after it is unchanged
+    r.render(0, 4)
+    a = r.film()
+    r.clear(); r.primary_hits(3, (512, 512)); r.render(0, 4)
+    assert np.array_equal(a, r.film())
+    for other in (scenes.direct_lighting_desc(film, 16, strategy=abi.DL_SAMPLE_ONE), scenes.volpath_desc(film, 16)):
+        r.set_integrator(other); o.set_integrator(other)
+        _primary_tap_check(r, o, (0, 0, 512, 512), (5,))
+    with pytest.raises(ra.EnigmaError):
+        r.primary_hits(16, (512, 512))            # sample number outside the sampler's range
+    with pytest.raises(ra.EnigmaError):
+        r.primary_hits(0, (511, 512))             # arrays of the wrong size
+    r.close(); o.close()
+
+
+def test_primary_hits_of_the_production_kernel_hbm_builds_and_spheres():
+    """The same tap on the builds that walk the tree in HBM: a mesh too large for LDS, and a scene with spheres."""
+    film = scenes.film_desc(96, 64)
+    integ = scenes.integrator_desc(film, 16)
+    for sc, cam in ((scenes.big_mesh(grid=96, sphere_level=4, n_spheres=4), scenes.big_mesh_camera(96, 64)),
+                    (scenes.cornell_spheres(), scenes.cornell_camera(96, 64))):
+        r, o = pair((sc, cam, film, integ))
+        n, hits = _primary_tap_check(r, o, (0, 0, 96, 64), (0, 9), n_triangles=sc.indices.shape[0])
+        assert hits > 0.5 * n
+        r.close(); o.close()
+
+
 @pytest.mark.parametrize("variant", ["diffuse", "microfacet"])
 def test_primary_hits_bit_exact_cornell(variant):
     r, o = pair(common.cornell_setup(res=512, spp=16, variant=variant))
@@ -898,6 +956,8 @@ def test_full_size_film_invariants_1080p():
     a, b = r.image()[win], o.image()[win]
     assert np.allclose(img[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)    # the window is a piece of the whole job
     assert common.mean_relative_error(a, b) < 1e-4
+    # tier 1 on the kernel that renders: the window's primary hits of the first and last sample numbers out of the path state
+    _primary_tap_check(r, o, (500, 500, 756, 660), (0, 1023))
     r.close(); o.close()
 
 
@@ -958,6 +1018,9 @@ def test_full_size_big_mesh_1080p():
     assert np.allclose(whole[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)   # the window is a piece of the whole job
     assert common.mean_relative_error(a, b) < 0.01
     assert np.median(np.abs(a - b) / np.maximum(b, 1e-3)) < 1e-5
+    # tier 1 on the kernel that renders (the HBM build, 1.18 M triangles): the window's primary hits out of the path state
+    n, hits = _primary_tap_check(r, o, (600, 600, 792, 708), (0, 1023))
+    assert hits == n                                            # closed sky box: every camera ray hits something
     r.close(); o.close()
 
 

@@ -169,3 +169,50 @@ def test_volpath_full_size_1080p_invariants_and_window():
     assert np.allclose(whole[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)
     assert common.mean_relative_error(a, b) < 5e-3
     r.close(); o.close()
+
+
+def test_volpath_textured_big_mesh_in_fog_full_size_1080p():
+    """The defined part of BASELINE configs[4] at its full size: the 1.18 M-triangle mesh with uvs and trilinear image
+    textures inside a homogeneous medium, VolPathIntegrator, 1920 x 1080, 512-spp sampler (the reference's heterogeneous
+    medium is a stub, Enigma/Medium.cpp:51-64: nothing to match there).  Film invariants over the whole film, additivity
+    of sample ranges, a window of the same job against the oracle pixel by pixel, ray counts, and the window's primary
+    hits out of the closest-hit kernel that renders."""
+    sc = scenes.big_mesh_fog()
+    assert sc.indices.shape[0] >= 1 << 20 and sc.n_textures == 3 and sc.n_media == 2
+    cam = scenes.big_mesh_camera(1920, 1080)
+    film = scenes.film_desc(1920, 1080)
+    integ = scenes.volpath_desc(film, 512)
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    r.render(510, 512)
+    f = r.film()
+    st = r.stats()
+    assert st["camera_samples"] == 1920 * 1080 * 2 and st["stack_overflows"] == 0
+    assert f[..., 3].min() >= 2 and f[..., 3].sum() - 2 * 1920 * 1080 < 0.01 * 2 * 1920 * 1080
+    assert np.isfinite(f).all() and f[..., :3].min() >= 0
+    assert (f[..., :3].sum(axis=2) > 0).mean() > 0.99           # in-scattered light everywhere
+    whole = ra.resolve(f)
+    r.clear(); r.render(510, 511); r.render(511, 512)
+    assert np.allclose(ra.resolve(r.film()), whole, rtol=1e-4, atol=1e-5)
+    integ_w = scenes.volpath_desc(film, 512)
+    integ_w.pixel_bounds[:] = [600, 600, 792, 708]
+    r.set_integrator(integ_w)
+    r.clear()
+    before = r.stats()
+    r.render(510, 512)
+    after = r.stats()
+    o = orc.Oracle(sc, cam, film, integ_w)
+    o.render(510, 512, threads=16)
+    fg, fo = r.film(), o.film_xyzw()
+    assert np.array_equal(fg[..., 3], fo[..., 3])
+    win = (slice(600, 708), slice(600, 792))
+    a, b = r.image()[win], o.image()[win]
+    assert np.allclose(whole[win][1:-1, 1:-1], a[1:-1, 1:-1], rtol=1e-4, atol=1e-5)   # the window is a piece of the whole job
+    assert common.mean_relative_error(a, b) < 0.01                                  # the north star's bound
+    assert np.median(np.abs(a - b) / np.maximum(b, 1e-3)) < 1e-5                    # what is reached: the same paths
+    so = o.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(after[k] - before[k]) - int(so[k])) <= 2e-3 * so[k] + 2, k
+    # tier 1 on the kernel that renders (the VolPathIntegrator's build of it)
+    import test_gpu_parity
+    test_gpu_parity._primary_tap_check(r, o, (600, 600, 792, 708), (0, 511))
+    r.close(); o.close()

@@ -963,3 +963,41 @@ def test_sphere_without_material_bounds_its_medium():
     assert np.allclose(img[22, 0], L, rtol=1e-5) and np.allclose(img[5, 44], L, rtol=1e-5)
     with pytest.raises(RuntimeError):
         orc.Oracle(sc, cam, film, scenes.direct_lighting_desc(film, 16)).render(0, 1, threads=1)
+
+
+def test_tie_count_through_the_tree_equals_the_count_over_all_triangles():
+    """The oracle flags rays whose closest hit is tied with other triangles (shared edges and vertices): for large scenes
+    it counts the ties by walking its tree instead of testing every triangle.  Both counts on rays aimed at mesh vertices,
+    edge midpoints and face interiors of a 15 k-triangle mesh, in two processes (the choice is read once per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import orc
+from raytrace_amd import scenes
+sc = scenes.big_mesh(grid=48, sphere_level=3, n_spheres=8)
+cam, film = scenes.big_mesh_camera(32, 32), scenes.film_desc(32, 32)
+o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, 4))
+rng = np.random.RandomState(3)
+T = sc.indices[rng.randint(0, sc.indices.shape[0], 600)]
+V = sc.vertices
+w = rng.dirichlet((1, 1, 1), 600).astype(np.float32)
+w[:200] = (1, 0, 0); w[200:400] = (0.5, 0.5, 0)
+target = (V[T[:, 0]] * w[:, :1] + V[T[:, 1]] * w[:, 1:2] + V[T[:, 2]] * w[:, 2:]).astype(np.float32)
+org = np.array([500, 330, 20], dtype=np.float32) + rng.uniform(-50, 50, (600, 3)).astype(np.float32)
+rays = np.concatenate([org, target - org, np.full((600, 1), np.inf, dtype=np.float32)], axis=1)
+h = o.intersect(rays)
+print(" ".join(str(int(v)) for v in h["ambiguous"]))
+'''
+    outs = []
+    for brute in (False, True):
+        env = dict(os.environ)
+        env.pop("ORACLE_BRUTE_FORCE_TIES", None)
+        if brute:
+            env["ORACLE_BRUTE_FORCE_TIES"] = "1"
+        run = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs.append(run.stdout.split())
+    assert outs[0] == outs[1]
+    assert sum(int(v) > 0 for v in outs[0]) > 50      # rays through vertices and edges do tie

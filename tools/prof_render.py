@@ -10,12 +10,14 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 xres, yres = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
 if variant == "bigmesh":
     scene, camera = scenes.big_mesh(), scenes.big_mesh_camera(xres, yres)
+elif variant == "bigmesh_fog":
+    scene, camera = scenes.big_mesh_fog(), scenes.big_mesh_camera(xres, yres)
 elif variant == "manylights":
     scene, camera = scenes.many_lights(), scenes.cornell_camera(xres, yres)
 else:
-    scene, camera = scenes.cornell_box(variant), scenes.cornell_camera(xres, yres)
+    scene, camera = (scenes.cornell_fog("microfacet") if variant == "fog" else scenes.cornell_box(variant)), scenes.cornell_camera(xres, yres)
 film = scenes.film_desc(xres, yres, "box")
-integ = scenes.integrator_desc(film, 1024)
+integ = scenes.volpath_desc(film, 512) if variant in ("bigmesh_fog", "fog") else scenes.integrator_desc(film, 1024)
 r = ra.Renderer(0).configure(scene, camera, film, integ)
 for i in range(steps):
     r.render(i * 16, i * 16 + 16)
