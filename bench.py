@@ -435,7 +435,10 @@ def main():
     main_res = run_workload(args, first, args.steps, ctx)
     big_res = None
     if args.variant == "default" and args.integrator == "path":
-        big_res = run_workload(args, "bigmesh", max(4, args.steps // 4), ctx)
+        # the north star's job itself: 1024 spp of the 1.18 M-triangle scene at 1080p = 64 steps, shared by the ranks, one
+        # film reduce at the end; measured whole (4.2 s on one GPU), not scaled up from a few steps
+        job_steps = JOB_SPP.get("bigmesh", 1024) // SPP_PER_STEP
+        big_res = run_workload(args, "bigmesh", max(1, job_steps // world), ctx)
 
     if rank == 0:
         line = {"metric": "Mrays/s", "value": main_res.pop("value"), "unit": main_res.pop("unit"),

@@ -13,7 +13,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libenigma_hip.so")
+# ENIGMA_LIB: another build of the library (experiment builds made by tools/build_exp.sh); the product is the one beside this file
+LIB_PATH = os.environ.get("ENIGMA_LIB") or os.path.join(_HERE, "libenigma_hip.so")
 
 # every symbol include/enigma_hip.h declares
 SYMBOLS = [

@@ -38,8 +38,18 @@ DEV RaySetup setupRayWith(F3 o, F3 d, F3 invDir) {
 }
 DEV RaySetup setupRay(F3 o, F3 d) { return setupRayWith(o, d, F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)); } // Inverted(), MathCommon.h:225-230
 
-// Triangle::intersects, Enigma/TriangleMesh.cpp:491-602.
-DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o) {
+// What the triangle test reads of a ray (RaySetup has it all; a lane that tests another lane's ray gathers just this)
+struct TriRay {
+    F3 o;
+    bool kz0, kz1;
+    float Sx, Sy, Sz;
+};
+
+// Triangle::intersects, Enigma/TriangleMesh.cpp:491-602.  tScaledOut / detOut: the two values that the test compares
+// the ray's tMax with -- the only place tMax enters -- so that a caller whose tMax has shrunk since can repeat exactly
+// that comparison (triangleStillInRange) instead of the whole test.
+template <class RAY>
+DEV bool triangleTestEx(const RAY& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o, float* tScaledOut, float* detOut) {
     F3 p0t = permuteK(p0 - r.o, r.kz0, r.kz1);
     F3 p1t = permuteK(p1 - r.o, r.kz0, r.kz1);
     F3 p2t = permuteK(p2 - r.o, r.kz0, r.kz1);
@@ -78,7 +88,16 @@ DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, flo
     float deltaT = 3 * (gammaf(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
     if (t <= deltaT) return false;
     *tOut = t; *b0o = b0; *b1o = b1; *b2o = b2;
+    *tScaledOut = tScaled; *detOut = det;
     return true;
+}
+DEV bool triangleTest(const RaySetup& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o) {
+    float tScaled, det;
+    return triangleTestEx(r, tMaxRay, p0, p1, p2, tOut, b0o, b1o, b2o, &tScaled, &det);
+}
+// The range comparison of the test above for a hit found under a larger tMax (det is never 0 for a hit)
+DEV bool triangleStillInRange(float tScaled, float det, float tMaxRay) {
+    return det < 0 ? !(tScaled < tMaxRay * det) : !(tScaled > tMaxRay * det);
 }
 
 struct Hit { int tri; float t, b0, b1, b2; };

@@ -30,6 +30,15 @@
 namespace edev {
 
 constexpr int kNode8Vec4 = 5;      // 16-byte pieces per node in global memory
+// Triangle steps dealt out over the wave (dealTriangles): measured on the 1.18 M-triangle scene, the any-hit walker gains
+// 5 % by it (2.66 -> 2.54 ms per launch of the streaming shadow kernel, no register spilled), the closest-hit walker
+// loses 15 % (5.82 -> 6.71 ms: the gathered ray, the pairs and the returned hit records on top of a kernel that is
+// already at its 80 registers take the spills from 16 to 59).  Hence on for any-hit rays only; both paths give the same
+// bits (ENIGMA_SHARED_TRI: bit 0 = any-hit walker, bit 1 = closest-hit walker, for experiments).
+#ifndef ENIGMA_SHARED_TRI
+#define ENIGMA_SHARED_TRI 1
+#endif
+constexpr bool kSharedTriangleStepsAny = (ENIGMA_SHARED_TRI & 1) != 0, kSharedTriangleStepsClosest = (ENIGMA_SHARED_TRI & 2) != 0;
 constexpr uint32_t kNodeHits = 0xff000000u;
 // (A lower bound of the children's entry distances kept with a stacked group, to drop the group unfetched once the ray
 // has a nearer hit, was measured and bought nothing: the bound includes the child taken first, whose subtree is what
@@ -56,6 +65,64 @@ DEV uint32_t uniformAdd(uint32_t a, uint32_t b) { return (uint32_t)__builtin_amd
 DEV float ubyteToFloat(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); } // v_cvt_f32_ubyte<b>
 typedef float Pair __attribute__((ext_vector_type(2)));
 DEV Pair pairFma(Pair a, Pair b, Pair c) { return __builtin_elementwise_fma(a, b, c); } // each half rounded once, like fmaf
+
+// Cross-lane moves of a wave (all 64 lanes must be active): gatherLane reads v from lane `src`, scatterLane sends v to
+// lane `dst` (the destinations of the wave must be a permutation of the lanes).
+DEV uint32_t gatherLane(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+DEV float gatherLaneF(float v, uint32_t src) { return __uint_as_float(gatherLane(__float_as_uint(v), src)); }
+DEV uint32_t scatterLane(uint32_t v, uint32_t dst) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)v); }
+
+// A triangle step shared by the wave.  Lanes that hold triangles ("owners") hand up to two of them to the wave; the
+// (owner, triangle) pairs -- at most 64 -- are dealt out one per lane, whoever the lane is, so that the test runs with
+// as many lanes busy as there are pairs instead of once per owner for its first triangle and once more for its second.
+// Pairs are numbered: the owners' first triangles in lane order, then their second ones in lane order (as many as still
+// fit 64).  posA / posB: the lanes that work on this lane's pairs; worker lanes learn their owner through two
+// permutations of the lane numbers.
+struct TrianglePairs {
+    uint32_t triA, triB;   // owner: the triangles handed over
+    uint32_t posA, posB;   // owner: the lanes that test them
+    bool hasA, hasB;       // owner: pairs exist
+    uint32_t owner;        // worker: the lane whose ray this lane tests (valid when `work`)
+    uint32_t tri;          // worker: the triangle
+    bool work;
+};
+template <class WALKER>
+DEV TrianglePairs dealTriangles(WALKER& w) {
+    TrianglePairs P;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    P.hasA = w.ty != 0;
+    P.triA = P.hasA ? w.takeTriangle() : 0u;
+    const bool wantB = w.ty != 0;
+    const unsigned long long mA = __ballot(P.hasA), mWant = __ballot(wantB);
+    const uint32_t cA = __popcll(mA);
+    P.posA = __popcll(mA & below);
+    P.posB = cA + __popcll(mWant & below);
+    P.hasB = wantB && P.posB < 64u;        // in lane order: the lanes that still fit are the first ones that want to
+    P.triB = P.hasB ? w.takeTriangle() : 0u;
+    const unsigned long long mB = __ballot(P.hasB);
+    const uint32_t cB = __popcll(mB);
+    // two permutations of the lanes: owners send their number to the lanes of their pairs, the others fill the rest
+    const uint32_t dstA = P.hasA ? P.posA : cA + __popcll(~mA & below);
+    const uint32_t dstB = (P.hasB ? P.posB : cA + cB + __popcll(~mB & below)) & 63u;
+    const uint32_t fromA = scatterLane(lane, dstA), fromB = scatterLane(lane, dstB);
+    P.work = lane < cA + cB;
+    const bool second = lane >= cA;
+    P.owner = second ? fromB : fromA;
+    const uint32_t ta = gatherLane(P.triA, P.owner), tb = gatherLane(P.triB, P.owner);
+    P.tri = second ? tb : ta;
+    return P;
+}
+// the owner's ray as the triangle test needs it, gathered by the worker
+template <class WALKER>
+DEV TriRay gatherTriRay(const WALKER& w, uint32_t owner) {
+    TriRay r;
+    r.o = F3(gatherLaneF(w.r.o.x, owner), gatherLaneF(w.r.o.y, owner), gatherLaneF(w.r.o.z, owner));
+    r.Sx = gatherLaneF(w.r.Sx, owner); r.Sy = gatherLaneF(w.r.Sy, owner); r.Sz = gatherLaneF(w.r.Sz, owner);
+    const uint32_t kz = gatherLane((w.r.kz0 ? 1u : 0u) | (w.r.kz1 ? 2u : 0u), owner);
+    r.kz0 = (kz & 1u) != 0; r.kz1 = (kz & 2u) != 0;
+    return r;
+}
 
 // One node against the ray: the node group (first inner child, hit bits in visiting order | inner mask) and the
 // triangle group (first triangle, one bit per triangle of the hit leaves).
@@ -249,7 +316,43 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2;
         }
     }
-    // one kind of work per wave step, whichever has more lanes waiting (see ClosestWalker::step)
+    // The wave's triangle step (scenes without spheres): up to 64 (owner, triangle) pairs, one per lane.  A pair is tested
+    // with the distance its owner had when the step began; an owner applies its first pair's result, then its second
+    // pair's -- in the order the reference tests them -- repeating the one comparison that involves the ray's tMax if
+    // the first has shortened the ray meanwhile (triangleStillInRange).  Same operations on the same operands as one
+    // test after the other: hits, distances and barycentrics are bit for bit those of testOne.
+    DEV void sharedTriangleStep(const float4* tris) {
+        TrianglePairs P = dealTriangles(*this);
+        const TriRay ray = gatherTriRay(*this, P.owner);
+        const float tMaxOwner = gatherLaneF(h.t, P.owner);
+        float t = -1.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, tScaled = 0.f, det = 0.f;
+        if (P.work) {
+            const float4* tp = tris + (size_t)P.tri * 3;
+            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float tt, c0, c1, c2, ts, dd;
+            if (triangleTestEx(ray, tMaxOwner, xyz(v0), xyz(v1), xyz(v2), &tt, &c0, &c1, &c2, &ts, &dd) &&
+                triangleAccepted(xyz(v0), xyz(v1), xyz(v2), __float_as_uint(v1.w), spheres.shade, P.tri)) {
+                t = tt; b0 = c0; b1 = c1; b2 = c2; tScaled = ts; det = dd;
+            }
+        }
+        // back to the owners (a hit has t > 0, a miss carries -1)
+        const float tA = gatherLaneF(t, P.posA), tB = gatherLaneF(t, P.posB & 63u);
+        const bool hitA = P.hasA && tA > 0.f;
+        bool hitB = P.hasB && tB > 0.f;
+        if (__ballot(hitA || hitB) == 0) return;
+        const float a0 = gatherLaneF(b0, P.posA), a1 = gatherLaneF(b1, P.posA), a2 = gatherLaneF(b2, P.posA);
+        if (hitA) { h.t = tA; h.tri = (int)P.triA; h.b0 = a0; h.b1 = a1; h.b2 = a2; }
+        if (__ballot(hitB) == 0) return;
+        const uint32_t pb = P.posB & 63u;
+        const float sB = gatherLaneF(tScaled, pb), dB = gatherLaneF(det, pb);
+        const float e0 = gatherLaneF(b0, pb), e1 = gatherLaneF(b1, pb), e2 = gatherLaneF(b2, pb);
+        if (hitB && hitA) hitB = triangleStillInRange(sB, dB, h.t);
+        if (hitB) { h.t = tB; h.tri = (int)P.triB; h.b0 = e0; h.b1 = e1; h.b2 = e2; }
+    }
+    // one kind of work per wave step, whichever has more lanes waiting.  FULL_WAVE: the caller keeps all 64 lanes of the
+    // wave in its loop (the pooled kernels do); otherwise the shared triangle step, which moves data between lanes, is
+    // taken only when the wave happens to be complete.
+    template <bool FULL_WAVE = true>
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
         const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
@@ -258,6 +361,11 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             this->nodeVisits = uniformAdd(this->nodeVisits, cn);
             if (!n) return;
             Base::nodeStep(nodes, h.t);
+        } else if (!SPH && kSharedTriangleStepsClosest && (FULL_WAVE || __ballot(true) == ~0ull)) {
+            this->triSteps = uniformAdd(this->triSteps, 1u);
+            const uint32_t before = LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(this->ty != 0)) + (uint32_t)__popcll(__ballot((this->ty & (this->ty - 1u)) != 0));
+            sharedTriangleStep(tris);
+            this->triVisits = uniformAdd(this->triVisits, ct + (LANE_TALLY ? 0u : min(before, 64u) - ct));
         } else {
             this->triSteps = uniformAdd(this->triSteps, 1u);
             if (t) testOne(tris);
@@ -305,6 +413,23 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         float t, b0, b1, b2;
         if (triangleTest(this->r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) { occluded = true; Base::finish(); }
     }
+    // the wave's triangle step, as ClosestWalker8::sharedTriangleStep: any pair that hits ends its owner's ray
+    DEV void sharedTriangleStep(const float4* tris) {
+        TrianglePairs P = dealTriangles(*this);
+        const TriRay ray = gatherTriRay(*this, P.owner);
+        const float tMaxOwner = gatherLaneF(tMax, P.owner);
+        uint32_t hit = 0u;
+        if (P.work) {
+            const float4* tp = tris + (size_t)P.tri * 3;
+            const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            float t, b0, b1, b2, ts, dd;
+            hit = triangleTestEx(ray, tMaxOwner, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2, &ts, &dd) ? 1u : 0u;
+        }
+        if (__ballot(hit != 0u) == 0) return;
+        const uint32_t hA = gatherLane(hit, P.posA), hB = gatherLane(hit, P.posB & 63u);
+        if ((P.hasA && hA) || (P.hasB && hB)) { occluded = true; Base::finish(); }
+    }
+    template <bool FULL_WAVE = true>
     DEV void step(const float4* nodes, const float4* tris) {
         const bool n = Base::atNode(), t = Base::atTriangles();
         const uint32_t cn = __popcll(__ballot(n)), ct = __popcll(__ballot(t));
@@ -313,6 +438,11 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             this->nodeVisits = uniformAdd(this->nodeVisits, cn);
             if (!n) return;
             Base::nodeStep(nodes, tMax);
+        } else if (!SPH && kSharedTriangleStepsAny && (FULL_WAVE || __ballot(true) == ~0ull)) {
+            this->triSteps = uniformAdd(this->triSteps, 1u);
+            const uint32_t before = LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(this->ty != 0)) + (uint32_t)__popcll(__ballot((this->ty & (this->ty - 1u)) != 0));
+            sharedTriangleStep(tris);
+            this->triVisits = uniformAdd(this->triVisits, ct + (LANE_TALLY ? 0u : min(before, 64u) - ct));
         } else {
             this->triSteps = uniformAdd(this->triSteps, 1u);
             if (t) testOne(tris);
@@ -348,7 +478,7 @@ DEV Hit traceClosest(const float4* nodes, const float4* tris, F3 o, F3 d, float 
     uint32_t spill[spillWords(OVF)];
     typename WalkerSel<LDSN, OVF, STRIDE, LDS_SCENE, SPH>::Closest w(column, spill, sr);
     w.start(o, d, tMax);
-    while (__ballot(!w.done()) != 0) w.step(nodes, tris); // step() votes wave-wide: all lanes stay in the loop
+    while (__ballot(!w.done()) != 0) w.template step<false>(nodes, tris); // step() votes wave-wide: the caller's lanes stay in the loop together
     return w.h;
 }
 template <int LDSN, int OVF, int STRIDE, bool SPH = false>
@@ -356,7 +486,7 @@ DEV bool traceAny(const float4* nodes, const float4* tris, F3 o, F3 d, float tMa
     uint32_t spill[spillWords(OVF)];
     typename WalkerSel<LDSN, OVF, STRIDE, false, SPH>::Any w(column, spill, sr);
     w.start(o, d, tMax);
-    while (__ballot(!w.done()) != 0) w.step(nodes, tris);
+    while (__ballot(!w.done()) != 0) w.template step<false>(nodes, tris);
     return w.occluded;
 }
 

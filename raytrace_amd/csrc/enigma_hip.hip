@@ -25,6 +25,15 @@
 
 using namespace edev;
 
+// ENIGMA_EXPERIMENT_BUILD (never the product): only the PathIntegrator on triangle scenes whose tree is at most 11 levels
+// deep or that fit LDS is compiled -- what a traversal experiment on the bench scenes needs, in a fifth of the compile time.
+// Everything else returns ENIGMA_E_UNSUPPORTED.
+#ifdef ENIGMA_EXPERIMENT_BUILD
+#define ENIGMA_FULL_BUILD 0
+#else
+#define ENIGMA_FULL_BUILD 1
+#endif
+
 namespace {
 
 template <class T>
@@ -1264,6 +1273,8 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                                                           direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
             // DirectLightingIntegrator: one step per level of the recursion still alive; the host reads the number of
             // continuing paths after each step (a camera sample is a chain of <= maxDepth steps, or a tree with glass)
+            if (!ENIGMA_FULL_BUILD && (direct || vol || h->scene.nSpheres || (!ldsScene && h->bvhStack > 11))) return h->fail(ENIGMA_E_UNSUPPORTED, "not compiled into this experiment build");
+#if ENIGMA_FULL_BUILD
             for (int step = 0; direct; ++step) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
@@ -1294,15 +1305,21 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 if (alive == 0) break;
                 if (iter > 4096) return h->fail(ENIGMA_E_DEVICE, "VolPathIntegrator: paths still alive after 4096 iterations");
             }
+#endif
             // PathIntegrator: one launch set per bounce.  With surfaces without a material in the scene a pass through one of
             // them is an iteration that is no bounce, so the iterations go on until no path is left (the host reads the count)
             for (int b = 0; !direct && !vol && (h->haveNoMaterial || b <= h->integ.maxDepth); ++b) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
+#if ENIGMA_FULL_BUILD
                 if (h->scene.nSpheres) launchBounce<11, 53, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else if (h->bvhStack <= 11) launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+#else
+                if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+#endif
                 h->stats.intersect_launches++;
                 if (h->haveNoMaterial) {
                     uint32_t alive = 0;
@@ -1608,9 +1625,15 @@ extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t*
 template <bool SPH>
 static void launchDebugIntersect(EnigmaCtx* h, int grid, uint32_t n, const float* dRays, int anyHit, int32_t* dTri, uint32_t* dPrim, float* dT, float* dB) {
     // ENIGMA_DEBUG_TINY_STACK keeps only two levels in LDS so that tests drive the private spill array hard
+#if !ENIGMA_FULL_BUILD
+    if (SPH || h->bvhStack > 12) return;
+    k_debug_intersect<12, 0, false><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+    return;
+#else
     if (getenv("ENIGMA_DEBUG_TINY_STACK")) k_debug_intersect<2, 62, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
     else if (h->bvhStack <= 12) k_debug_intersect<12, 0, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
     else k_debug_intersect<12, 52, SPH><<<grid, kBlock, 0, h->stream>>>(h->scene, n, dRays, anyHit, dTri, dPrim, dT, dB);
+#endif
 }
 
 // Launches the intersection tap over rays already on the device and brings the results back; the staging buffers
@@ -1650,10 +1673,15 @@ static int debugIntersect(EnigmaCtx* h, uint32_t n, const float* rays7, int anyH
 // ---- primary hits out of the production kernel ----
 template <int MODE>
 static void launchClosestFlavour(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int gridTrace, const uint32_t* pendCount) {
+#if ENIGMA_FULL_BUILD
     if (h->scene.nSpheres) launchClosest<11, 53, false, MODE, true>(h, P, nPaths, 0, gridTrace, pendCount);
     else if (sceneRunsFromLds(h)) launchClosest<12, 0, true, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
     else if (h->bvhStack <= 11) launchClosest<11, 0, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
     else launchClosest<11, 53, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+#else
+    if (MODE == 0 && sceneRunsFromLds(h)) launchClosest<12, 0, true, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    else if (MODE == 0) launchClosest<11, 0, false, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
+#endif
 }
 
 // The first two kernels of a real pass for ONE sample number of every pixel of the render region: k_generate, then the
@@ -1800,6 +1828,7 @@ extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, u
     if (e == hipSuccess) e = dOut.alloc((size_t)n * 12);
     if (e == hipSuccess) {
         const unsigned grid = (n + 255) / 256;
+#if ENIGMA_FULL_BUILD
         switch (d.kind) {
         case MK_MATTE: k_debug_bsdf<MK_MATTE><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         case MK_MATTE_ROUGH: k_debug_bsdf<MK_MATTE_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
@@ -1808,6 +1837,7 @@ extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, u
         case MK_GLASS_ROUGH: k_debug_bsdf<MK_GLASS_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         default: k_debug_bsdf<MK_PLASTIC><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         }
+#endif
         e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(out12, dOut.p, (size_t)n * 12 * sizeof(float), hipMemcpyDeviceToHost);
     }

@@ -191,6 +191,25 @@ def test_bvh_builder_extreme_coordinates(hostcheck):
         _bvh_checks(hostcheck, v, np.arange(150, dtype=np.uint32).reshape(50, 3))
 
 
+def test_bvh_builder_on_several_threads_builds_the_same_tree(hostcheck, monkeypatch):
+    """Scenes of 2^15 primitives and more are built on several threads: the large ranges in chunks, the subtrees below
+    them by workers, the collapse and the emission side by side.  The result -- primitive order and node count -- must not
+    depend on the number of threads, and the invariants must hold."""
+    sc = scenes.big_mesh(grid=192, sphere_level=5, n_spheres=4)      # 155,648 triangles
+    nT = sc.indices.shape[0]
+    assert nT > 1 << 17
+    results = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("ENIGMA_BVH_THREADS", threads)
+        order = np.zeros(nT, dtype=np.uint32)
+        checks = np.zeros(5, dtype=np.uint32)
+        nodes = hostcheck.hc_bvh(abi.ptr(sc.vertices), abi.ptr(sc.indices), nT, abi.ptr(np.zeros((1, 6), dtype=np.float32)), 0, abi.ptr(order), abi.ptr(checks))
+        assert checks[1] == nT and checks[2] == 0 and checks[3] == 0 and checks[4] == 0 and checks[0] <= 64
+        results.append((nodes, checks[0], order.copy()))
+    for nodes, depth, order in results[1:]:
+        assert nodes == results[0][0] and depth == results[0][1] and np.array_equal(order, results[0][2])
+
+
 def test_scene_builders():
     c = scenes.cornell_box("diffuse")
     assert c.indices.shape[0] == 32 and c.n_lights == 2
