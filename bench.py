@@ -170,7 +170,9 @@ def run_workload(args, variant, steps, ctx):
     else:
         scene, camera, label = scenes.cornell_box(variant), scenes.cornell_camera(XRES, YRES), "Cornell box (%s)" % variant
     film = scenes.film_desc(XRES, YRES, "box")
-    total_spp = pow2_at_least(max(1024, (K + 1) * N * SPP_PER_STEP + SPP_PER_STEP))
+    # the sampler's samples per pixel: the configuration's own (1024; 512 for the fog configuration) unless more are asked for;
+    # the warm-up renders the last 16 sample numbers of that range into a film that is cleared before the timed steps
+    total_spp = pow2_at_least(max(JOB_SPP.get(variant, 1024), K * N * SPP_PER_STEP))
     strategy = {"uniform": abi.LIGHTS_UNIFORM, "power": abi.LIGHTS_POWER, "spatial": abi.LIGHTS_SPATIAL}[args.light_strategy]
     if args.integrator == "path":
         integ = scenes.integrator_desc(film, total_spp, max_depth=5, rr_threshold=1.0, light_strategy=strategy)

@@ -375,12 +375,14 @@ int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float* rays7, int
  * them.  The rays it traces are counted in EnigmaStats like any others; the film is not touched.  max_depth >= 1. */
 int enigma_debug_primary_hits(EnigmaCtx* h, int64_t sample_num, uint64_t n_pixels, int32_t* tri_out,
                               uint32_t* prim_id_out, float* t_out, float* bary_out);
-/* enigma_debug_intersect for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the rays
+/* enigma_debug_intersect for callers that cannot allocate device memory (harnesses that forbid hipMalloc, loops that
+ * must not fragment or grow the device heap).  No counterpart in the reference.  Same arguments and results; the rays
  * and results are staged in a fixed array inside the library (13 words per ray, ENIGMA_NOALLOC_MAX_RAYS rays, 6.5 MiB
- * held on every GPU the library runs on until the process ends) instead of buffers allocated per call: no
- * hipMalloc / hipFree happens here.  More rays than ENIGMA_NOALLOC_MAX_RAYS: ENIGMA_E_INVALID.  All calls on one GPU
- * share that GPU's array: calls that overlap in time on one GPU (other handles, other threads) race. */
+ * held on every GPU the library runs on until the process ends) instead of buffers allocated per call: no device
+ * allocation or release happens here.  It is synchronous like the other taps -- it copies from and to the caller's
+ * pageable host arrays and waits for the library's stream -- and so cannot itself be captured into a HIP graph.  More
+ * rays than ENIGMA_NOALLOC_MAX_RAYS: ENIGMA_E_INVALID.  All calls on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU (other handles, other threads) race. */
 #define ENIGMA_NOALLOC_MAX_RAYS 131072u
 int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out,
                                    uint32_t* prim_id_out, float* t_out, float* bary_out);

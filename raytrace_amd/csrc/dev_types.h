@@ -93,7 +93,8 @@ struct DevScene {
     // table is made when a path first lands in the voxel: spatialSlot[voxel] = its row of the table, or kSpatialEmpty.
     float* spatialTable;
     uint32_t* spatialSlot;
-    uint32_t* spatialCtl;       // [0] rows in use, [1] rows claimed since the last fill, [2] voxels that found the table full
+    uint32_t* spatialCtl;       // [0] rows in use, [1] rows claimed since the last fill, [2] voxels that found the table full,
+                                // [3] lookups that found no row for their voxel (spatialLookup)
     uint32_t* spatialNew;       // the voxels claimed since the last fill
     uint32_t spatialCapacity;   // rows of the table
     int nVoxels[3];

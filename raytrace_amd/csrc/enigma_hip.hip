@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -946,6 +947,10 @@ static int buildLightDistribution(EnigmaCtx* h) {
         const size_t stride = 2 * (size_t)n + 2;
         size_t budget = (size_t)32 << 30; // a scene whose paths reach more voxels than this holds fails its render with a message
         if (const char* e = getenv("ENIGMA_SPATIAL_TABLE_BYTES")) budget = (size_t)atoll(e);
+        // ... and never more than half of what the device has free right now: a smaller GPU gets a smaller table (and the
+        // message below if the paths outgrow it), not a bare allocation failure
+        size_t freeBytes = 0, totalBytes = 0;
+        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) budget = std::min(budget, freeBytes / 2);
         const size_t capacity = std::max<size_t>(1, std::min(total, budget / (stride * sizeof(float))));
         std::vector<float> hal(5 * 128);
         auto radical = [](int base, uint64_t a) { // RadicalInverseSpecialized, Enigma/SamplerInclude.h:49-62
@@ -1145,7 +1150,8 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     *ev.shadeTimed = 1;
     if (h->scene.nLights > 0) {
         (void)hipEventRecord(ev.s0, s);
-        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShade, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr);
+        k_stage<<<1, 1, 0, s>>>(ctr, 3, cur, 0, 0);
+        k_shadow_tr<LDSN, OVF, LDS_SCENE, SPH><<<std::min(gridShade, h->residentTraceBlocks), kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, shq, ctr, h->refillIdle);
         (void)hipEventRecord(ev.s1, s);
         *ev.shadowTimed = 1;
         if (h->haveAreaLights) k_mis_tr<LDSN, OVF, LDS_SCENE, SPH><<<gridShadow, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, s>>>(h->scene, P, misq, ctr);
@@ -1329,21 +1335,29 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                     if (b > 4096) return h->fail(ENIGMA_E_DEVICE, "PathIntegrator: paths still alive after 4096 iterations");
                 }
             }
+            if (h->scene.spatialTable) {
+                // The pass's samples reach the film only if every one of its light picks read the table of its own voxel: a
+                // full table (ctl[2]) or a lookup without a row (ctl[3]) fails the render HERE, before the splat.  The film
+                // then holds the passes completed so far -- whole sample numbers, correctly lit -- and nothing of this one.
+                uint32_t ctl[4] = {0, 0, 0, 0};
+                HIPCHK(h, hipMemcpyAsync(ctl, h->spatialCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (ctl[2] || ctl[3]) {
+                    h->lightDistDirty = true; // the next render starts from an empty table
+                    const long long done = (long long)(c0 + s0);
+                    if (ctl[2]) return h->fail(ENIGMA_E_UNSUPPORTED, "the paths reached %u voxels of the spatial light distribution, the table holds %u (%d lights; ENIGMA_SPATIAL_TABLE_BYTES "
+                                                                   "and free device memory set the limit): sample numbers [%lld, %lld) were deposited, nothing after them -- use the power strategy",
+                                               ctl[0], h->scene.spatialCapacity, h->scene.nLights, (long long)sample_begin, (long long)sample_begin + done);
+                    return h->fail(ENIGMA_E_DEVICE, "%u light picks found no table for their voxel of the spatial light distribution (marking and lookup disagree): sample numbers "
+                                                  "[%lld, %lld) were deposited, nothing after them", ctl[3], (long long)sample_begin, (long long)sample_begin + done);
+                }
+            }
             k_film_splat<<<(nPixels + kBlock - 1) / kBlock, kBlock, 0, h->stream>>>(P, h->film, h->integ, nPixels, ks);
             HIPCHK(h, hipGetLastError());
         }
         HIPCHK(h, hipStreamSynchronize(h->stream)); // the constant table is re-uploaded per chunk
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->scene.spatialTable) {
-        uint32_t ctl[4] = {0, 0, 0, 0};
-        HIPCHK(h, hipMemcpy(ctl, h->spatialCtl.p, sizeof(ctl), hipMemcpyDeviceToHost));
-        if (ctl[2]) {
-            h->lightDistDirty = true; // the next render starts from an empty table
-            return h->fail(ENIGMA_E_UNSUPPORTED, "the paths reached %u voxels of the spatial light distribution, the table holds %u (%d lights; ENIGMA_SPATIAL_TABLE_BYTES raises the limit): the film holds samples lit from a wrong table -- use the power strategy",
-                           ctl[0], h->scene.spatialCapacity, h->scene.nLights);
-        }
-    }
     for (uint64_t i = 0; i < h->stats.intersect_launches; ++i) {
         float ms = 0.f;
         hipEvent_t* e = &h->evPool[i * kEventsPerStep];
@@ -1759,26 +1773,27 @@ static __device__ __align__(256) uint32_t scratch[(size_t)ENIGMA_NOALLOC_MAX_RAY
 // Device address of `scratch` per GPU.  In host code the array's name is only a handle for hipGetSymbolAddress; every
 // use of the memory below goes through the address resolved here, with that GPU current.
 constexpr int kMaxDevices = 64;
-static uint32_t* g_scratchPtr[kMaxDevices] = {};
+static std::atomic<uint32_t*> g_scratchPtr[kMaxDevices]; // zero-initialised; written once per device (contexts may be created on several threads)
 
 static hipError_t resolveScratch(int device) { // caller has made `device` current
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    if (g_scratchPtr[device]) return hipSuccess;
+    if (g_scratchPtr[device].load(std::memory_order_acquire)) return hipSuccess;
     uint32_t* ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!ptr) return hipErrorInvalidSymbol;
-    g_scratchPtr[device] = ptr;
+    g_scratchPtr[device].store(ptr, std::memory_order_release); // two threads racing here store the same address
     return hipSuccess;
 }
 
 extern "C" int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {
     if (!h || !rays7 || !tri_out || !prim_id_out || !t_out || !bary_out) return ENIGMA_E_INVALID;
+    return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->haveScene) return h->fail(ENIGMA_E_STATE, "scene not uploaded");
     if (n > ENIGMA_NOALLOC_MAX_RAYS) return h->fail(ENIGMA_E_INVALID, "%u rays exceed the %u the fixed staging array holds", n, (unsigned)ENIGMA_NOALLOC_MAX_RAYS);
     if (n == 0) return ENIGMA_OK;
-    uint32_t* base = (h->device >= 0 && h->device < kMaxDevices) ? g_scratchPtr[h->device] : nullptr;
+    uint32_t* base = (h->device >= 0 && h->device < kMaxDevices) ? g_scratchPtr[h->device].load(std::memory_order_acquire) : nullptr;
     if (!base) return h->fail(ENIGMA_E_STATE, "the staging array of device %d was not resolved when the context was created", h->device);
     // carve the array: every region starts on a 256-byte boundary for any n (the ray region is sized for the maximum)
     float* dRays = reinterpret_cast<float*>(base);
@@ -1791,6 +1806,7 @@ extern "C" int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const fl
     if (e == hipSuccess) e = debugIntersectRun(h, n, dRays, 0, dTri, dPrim, dT, dB, tri_out, prim_id_out, t_out, bary_out);
     if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_intersect_noalloc: %s", hipGetErrorString(e));
     return ENIGMA_OK;
+    });
 }
 
 extern "C" int enigma_debug_intersect(EnigmaCtx* h, uint32_t n, const float* rays7, int32_t* tri_out, uint32_t* prim_id_out, float* t_out, float* bary_out) {

@@ -36,51 +36,46 @@ struct EnvPyramid {
         float l = sinf(x) / x;
         return s * l;
     }
-    struct ResampleWeight { int firstTexel; float weight[4]; };
-    static std::vector<ResampleWeight> resampleWeights(int oldWidth, int newWidth) {
-        std::vector<ResampleWeight> wt(newWidth);
-        float filterwidth = 2.f;
-        for (int i = 0; i < newWidth; ++i) {
-            float center = (i + .5f) * oldWidth / newWidth;
-            wt[i].firstTexel = (int)floorf((center - filterwidth) + 0.5f);
-            for (int j = 0; j < 4; ++j) { float pos = wt[i].firstTexel + j + .5f; wt[i].weight[j] = lanczos((pos - center) / filterwidth); }
-            float invSumWts = 1.f / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
-            for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
-        }
-        return wt;
-    }
     static uint32_t roundUpPow2(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
-    std::vector<Rgb> resizeImage(const std::vector<Rgb>& img, int oldWidth, int oldHeight, int* newWidth, int* newHeight) const {
-        const uint32_t sPow2 = roundUpPow2((uint32_t)oldWidth), tPow2 = roundUpPow2((uint32_t)oldHeight);
-        std::vector<ResampleWeight> sWeights = resampleWeights(oldWidth, (int)sPow2);
-        std::vector<Rgb> out((size_t)sPow2 * tPow2, Rgb{0.f, 0.f, 0.f});
-        for (uint32_t t = 0; t < (uint32_t)oldHeight; ++t)
-            for (uint32_t s = 0; s < sPow2; ++s) {
-                Rgb acc = Rgb{0.f, 0.f, 0.f};
-                for (int j = 0; j < 4; ++j) {
-                    int origS = sWeights[s].firstTexel + j;
-                    if (wrap == 0) origS = origS % oldWidth;
-                    else if (wrap == 2) origS = std::min(std::max(origS, 0), oldWidth - 1);
-                    if (origS >= 0 && origS < oldWidth) acc = acc + img[(size_t)t * oldWidth + origS] * sWeights[s].weight[j];
-                }
-                out[(size_t)t * sPow2 + s] = acc;
+    // One axis of the zoom.  A new texel is the normalised sum of four old ones under the windowed sinc above, two texel
+    // widths wide, centred on the new texel's centre in old coordinates; a tap outside the image is wrapped, clamped or
+    // dropped by the wrap mode (repeat wraps with the signed remainder of the reference, which leaves taps left of the image
+    // outside it: they are dropped after the weights were normalised).  The image is given as `lines` lines of oldN texels,
+    // texel k of line l at src[l * lineStep + k * texelStep], so rows and columns go through the same code; the result has
+    // the same shape with newN texels a line.  floorNegative: Spectrum::Clamp() of the finished texel.
+    void zoomAxis(const Rgb* src, size_t srcLineStep, size_t srcTexelStep, Rgb* dst, size_t dstLineStep, size_t dstTexelStep, int lines, int oldN, int newN,
+                  bool floorNegative) const {
+        const float halfWidth = 2.f;
+        for (int i = 0; i < newN; ++i) {
+            const float center = (i + .5f) * oldN / newN;
+            const int first = (int)floorf((center - halfWidth) + 0.5f);
+            float w[4];
+            for (int j = 0; j < 4; ++j) w[j] = lanczos(((first + j + .5f) - center) / halfWidth);
+            const float invSum = 1.f / (w[0] + w[1] + w[2] + w[3]);
+            int from[4];
+            for (int j = 0; j < 4; ++j) {
+                w[j] *= invSum;
+                int k = first + j;
+                if (wrap == 0) k = k % oldN;
+                else if (wrap == 2) k = std::min(std::max(k, 0), oldN - 1);
+                from[j] = (k >= 0 && k < oldN) ? k : -1;
             }
-        std::vector<ResampleWeight> tWeights = resampleWeights(oldHeight, (int)tPow2);
-        std::vector<Rgb> work(tPow2);
-        for (uint32_t s = 0; s < sPow2; ++s) {
-            for (uint32_t t = 0; t < tPow2; ++t) {
+            for (int l = 0; l < lines; ++l) {
                 Rgb acc = Rgb{0.f, 0.f, 0.f};
-                for (int j = 0; j < 4; ++j) {
-                    int offset = tWeights[t].firstTexel + j;
-                    if (wrap == 0) offset = offset % oldHeight;
-                    else if (wrap == 2) offset = std::min(std::max(offset, 0), oldHeight - 1);
-                    if (offset >= 0 && offset < oldHeight) acc = acc + out[(size_t)offset * sPow2 + s] * tWeights[t].weight[j];
-                }
-                work[t] = acc;
+                for (int j = 0; j < 4; ++j)
+                    if (from[j] >= 0) acc = acc + src[(size_t)l * srcLineStep + (size_t)from[j] * srcTexelStep] * w[j];
+                if (floorNegative) acc = Rgb{std::max(acc.r, 0.f), std::max(acc.g, 0.f), std::max(acc.b, 0.f)};
+                dst[(size_t)l * dstLineStep + (size_t)i * dstTexelStep] = acc;
             }
-            for (uint32_t t = 0; t < tPow2; ++t) out[(size_t)t * sPow2 + s] = Rgb{std::max(work[t].r, 0.f), std::max(work[t].g, 0.f), std::max(work[t].b, 0.f)};
         }
-        *newWidth = (int)sPow2; *newHeight = (int)tPow2;
+    }
+    // MipMap::resizeImage (Enigma/MipMap.h:155-237): the rows first, then the columns of what the rows became
+    std::vector<Rgb> resizeImage(const std::vector<Rgb>& img, int oldWidth, int oldHeight, int* newWidth, int* newHeight) const {
+        const int wide = (int)roundUpPow2((uint32_t)oldWidth), tall = (int)roundUpPow2((uint32_t)oldHeight);
+        std::vector<Rgb> rows((size_t)wide * oldHeight), out((size_t)wide * tall);
+        zoomAxis(img.data(), (size_t)oldWidth, 1, rows.data(), (size_t)wide, 1, oldHeight, oldWidth, wide, false);
+        zoomAxis(rows.data(), 1, (size_t)wide, out.data(), 1, (size_t)wide, wide, oldHeight, tall, true);
+        *newWidth = wide; *newHeight = tall;
         return out;
     }
     void build(int w, int h, std::vector<Rgb> img) {

@@ -567,8 +567,13 @@ DEV uint32_t spatialVoxel(const DevScene& sc, F3 p) {
     return ((uint32_t)px * (uint32_t)sc.nVoxels[1] + (uint32_t)py) * (uint32_t)sc.nVoxels[2] + (uint32_t)pz;
 }
 // ... and its table, filled before the kernel that asks started (k_spatial_mark saw the same point)
+// A voxel without a row -- the table was full when the voxel was claimed (kSpatialClaimed), or no table was made for the
+// point at all (kSpatialEmpty: the marking pass and this lookup would have to disagree about the point) -- is counted in
+// spatialCtl[3] and answered from row 0 so that the read stays inside the table; the host sees the count before the pass's
+// samples reach the film and fails the render instead of depositing samples lit from another voxel's table.
 DEV const float* spatialLookup(const DevScene& sc, F3 p) {
-    const uint32_t row = min(sc.spatialSlot[spatialVoxel(sc, p)], sc.spatialCapacity - 1u); // a full table fails the render; stay inside it meanwhile
+    uint32_t row = sc.spatialSlot[spatialVoxel(sc, p)];
+    if (row >= sc.spatialCapacity) { atomicAdd(&sc.spatialCtl[3], 1u); row = 0u; }
     return sc.spatialTable + (size_t)row * (2 * (size_t)sc.nLights + 2);
 }
 
@@ -1416,7 +1421,7 @@ __global__ void __launch_bounds__(kBlock) k_film_splat(DevPaths P, DevFilm F, De
 }
 
 // Between stages: account rays, reset the queues the next stage fills.
-// phase 0: before a bounce's k_intersect_closest.  phase 1: after the shade kernels.  phase 2: after shadow/mis.
+// phase 0: before a bounce's k_intersect_closest.  phase 1: after the shade kernels.  phase 3: only the shadow queue's cursor.
 __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t countImm, int useImm) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (phase == 0) {
@@ -1427,6 +1432,8 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
     } else if (phase == 1) {
         ctr->raysShadow += ctr->shadowCount.v;
         ctr->raysMis += ctr->misCount.v;
+        ctr->shadowCursor.v = 0;
+    } else if (phase == 3) { // before a streaming shadow kernel that counts its rays itself (VolPathIntegrator)
         ctr->shadowCursor.v = 0;
     }
 }

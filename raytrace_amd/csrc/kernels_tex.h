@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(kBlock) k_spatial_mark(DevScene sc, DevPaths P
             if (atomicCAS(&sc.spatialSlot[voxel], kSpatialEmpty, kSpatialClaimed) != kSpatialEmpty) continue;
             const uint32_t row = atomicAdd(&sc.spatialCtl[0], 1u);
             if (row < sc.spatialCapacity) { sc.spatialNew[atomicAdd(&sc.spatialCtl[1], 1u)] = voxel; sc.spatialSlot[voxel] = row; }
-            else atomicAdd(&sc.spatialCtl[2], 1u); // the voxel stays claimed; the render reports the full table when it ends
+            else atomicAdd(&sc.spatialCtl[2], 1u); // the voxel stays claimed; the host checks this count before the pass's samples reach the film
         }
     }
 }

@@ -198,65 +198,90 @@ DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, 
 // end point p1: each segment is a closest-hit query; a surface with a material blocks the light, a surface
 // without one ends the segment, the medium of the segment attenuates it, and the next segment starts on the
 // far side of that surface (isect.SpawnRayTo(p1)).  Every query counts as a shadow ray.
+// Every wave streams on its own, like k_shadow_stream: it reserves runs of kShadowRun queue positions from the queue's
+// cursor and hands them to its lanes as their chains end, so a lane does not sit out the longest chain of its wave (one
+// chain per lane and launch, the wave waiting for its last: 5.2 ms per launch on the 1.18 M-triangle fog scene).
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
-__global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr) {
+__global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
     using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t red[2 * kWavesPerBlock];
     extern __shared__ float4 sceneLds[];
     uint32_t spill[spillWords(OVF)];
     const uint32_t count = ctr->shadowCount.v;
-    if (blockIdx.x * kBlock >= count) return;
+    if (blockIdx.x * kBlock >= count) return; // more blocks than rays
     const float4* nodes = sc.nodes;
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
     uint32_t nQueries = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
-        uint32_t i = base + threadIdx.x;
-        bool active = i < count;
-        Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
-        uint32_t p = 0, med = 0;
-        F3 o(0.f), d(0.f), contrib(0.f), Tr(1.f), lp(0.f), lpErr(0.f), ln(0.f);
-        if (active) {
-            p = shq.idx[i];
-            float4 a = shq.o[p], b = shq.d[p], tp = shq.tgtP[p];
-            o = F3(a.x, a.y, a.z); d = F3(a.w, b.x, b.y);
-            contrib = F3(b.z, b.w, shq.wz[p]);
-            lp = xyz(tp); med = __float_as_uint(tp.w);
-            lpErr = xyz(shq.tgtE[p]); ln = xyz(shq.tgtN[p]);
-            w.start(o, d, 1 - kShadowEpsilon);
-            ++nQueries;
-        }
-        while (__ballot(active) != 0) {
-            if (active && w.done()) {
-                Hit h = w.h;
-                bool hit = h.tri >= 0;
-                uint32_t kind = MK_NONE;
-                if (hit) kind = triKind(primWord<SPH>(sc, tris, h.tri));
-                if (hit && kind != MK_NONE) { Tr = F3(0.f); active = false; }
-                else {
-                    if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
-                    if (!hit) active = false;
-                    else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
-                        F3 gp, ge, gn;
-                        boundaryGeometry<SPH>(sc, tris, h, d, p, &gp, &ge, &gn);
-                        o = offsetRayOrigin(gp, ge, gn, lp - gp);
-                        F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
-                        d = target - o;
-                        med = mediumBeyond(sc, h.tri, med, gn, d);
-                        w.start(o, d, 1 - kShadowEpsilon);
-                        ++nQueries;
-                    }
-                }
-                if (!active && !isBlack(Tr)) {
-                    F3 add = contrib * Tr;
-                    float4 L = P.L[p]; // the path's only shadow ray in this launch
-                    P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+    const uint32_t lane = threadIdx.x & 63u;
+    Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
+    bool active = false; // the lane is working on a chain
+    uint32_t p = 0, med = 0;
+    F3 o(0.f), d(0.f), contrib(0.f), Tr(1.f), lp(0.f), lpErr(0.f), ln(0.f);
+    uint32_t runLo = 0, runHi = 0;
+    bool exhausted = false;
+    for (;;) {
+        if (active && w.done()) { // a segment is through: the chain ends here, or goes on behind the boundary
+            Hit h = w.h;
+            bool hit = h.tri >= 0;
+            uint32_t kind = MK_NONE;
+            if (hit) kind = triKind(primWord<SPH>(sc, tris, h.tri));
+            if (hit && kind != MK_NONE) { Tr = F3(0.f); active = false; }
+            else {
+                if (med) Tr = Tr * mediumTr(sc.media[med - 1u], d, hit ? h.t : 1 - kShadowEpsilon);
+                if (!hit) active = false;
+                else { // isect.SpawnRayTo(p1), Enigma/Interaction.cpp:58-64
+                    F3 gp, ge, gn;
+                    boundaryGeometry<SPH>(sc, tris, h, d, p, &gp, &ge, &gn);
+                    o = offsetRayOrigin(gp, ge, gn, lp - gp);
+                    F3 target = offsetRayOrigin(lp, lpErr, ln, o - lp);
+                    d = target - o;
+                    med = mediumBeyond(sc, h.tri, med, gn, d);
+                    w.start(o, d, 1 - kShadowEpsilon);
+                    ++nQueries;
                 }
             }
-            w.template advance<LDS_SCENE>(nodes, tris);
+            if (!active && !isBlack(Tr)) {
+                F3 add = contrib * Tr;
+                float4 L = P.L[p]; // the path's only shadow ray in this launch
+                P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, 0.f);
+            }
         }
+        const unsigned long long idleMask = __ballot(!active);
+        const uint32_t nIdle = __popcll(idleMask);
+        if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
+            if (!exhausted && runLo == runHi) {
+                uint32_t r = 0;
+                if (lane == 0) r = atomicAdd(&ctr->shadowCursor.v, kShadowRun);
+                r = __shfl(r, 0);
+                if (r >= count) exhausted = true;
+                else { runLo = r; runHi = min(r + kShadowRun, count); }
+            }
+            if (!exhausted) {
+                const uint32_t rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                const uint32_t take = min(nIdle, runHi - runLo);
+                if (!active && rank < take) {
+                    p = shq.idx[runLo + rank];
+                    float4 a = shq.o[p], b = shq.d[p], tp = shq.tgtP[p];
+                    o = F3(a.x, a.y, a.z); d = F3(a.w, b.x, b.y);
+                    contrib = F3(b.z, b.w, shq.wz[p]);
+                    lp = xyz(tp); med = __float_as_uint(tp.w);
+                    lpErr = xyz(shq.tgtE[p]); ln = xyz(shq.tgtN[p]);
+                    Tr = F3(1.f);
+                    w.start(o, d, 1 - kShadowEpsilon);
+                    active = true;
+                    ++nQueries;
+                }
+                runLo += take;
+            }
+            if (__ballot(active) == 0) {
+                if (exhausted) break;
+                continue; // the run ended exactly here: reserve the next one
+            }
+        }
+        w.template advance<LDS_SCENE>(nodes, tris);
     }
     for (int off = 32; off > 0; off >>= 1) nQueries += __shfl_down(nQueries, off);
     if ((threadIdx.x & 63u) == 0 && nQueries) atomicAdd(&ctr->raysShadow, (unsigned long long)nQueries);

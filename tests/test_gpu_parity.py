@@ -820,6 +820,7 @@ def test_spatial_tables_are_made_on_demand_within_a_memory_limit(monkeypatch):
     with pytest.raises(ra.EnigmaError) as e:
         r.render(0, 8)
     assert e.value.code == -4 and "voxels" in str(e.value)
+    assert not r.film().any()                                   # the failing pass was stopped before its samples reached the film
     r.set_integrator(scenes.integrator_desc(film, 8))           # the power strategy, as the message says
     r.clear()
     r.render(0, 8)

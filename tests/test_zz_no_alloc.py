@@ -37,6 +37,14 @@ def _same(a, b):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
 
 
+def _free_device_bytes(r):
+    """hipMemGetInfo through the HIP runtime the library itself is linked to."""
+    import ctypes as C
+    free, total = C.c_size_t(), C.c_size_t()
+    assert r.L.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
 def test_no_alloc_intersect_matches_the_allocating_entry_point():
     rng = np.random.RandomState(77)
     sc, cam, film, integ = common.cornell_setup(res=64, spp=16, variant="microfacet")
@@ -46,7 +54,9 @@ def test_no_alloc_intersect_matches_the_allocating_entry_point():
     want_first, want_second = r.intersect(first), r.intersect(second)
     assert (want_first["tri"] >= 0).mean() > 0.5
     _same(r.intersect(first, noalloc=True), want_first)
+    before = _free_device_bytes(r)
     _same(r.intersect(second, noalloc=True), want_second)
+    assert _free_device_bytes(r) == before      # nothing was allocated (or left allocated) on the device by the call
     # and a larger one again, up to the limit; one ray more is refused
     full = _rays(rng, MAX_RAYS, 0.0, 556.0)
     _same(r.intersect(full, noalloc=True), r.intersect(full))
