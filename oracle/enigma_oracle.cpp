@@ -2650,6 +2650,8 @@ struct DirectLightingIntegrator {
             for (const Light& light : scene.lights) L += light.LeRay(ray);
             return L;
         }
+        // a surface without a material has no BSDF: the ray goes on behind it at the same depth (DirectLightingIntegrator.cpp:51-54)
+        if (scene.triMaterial[isect.primIndex] == ENIGMA_NO_MATERIAL) return Li(isect.SpawnRay(ray.d), scene, sampler, depth);
         // allowMultipleLobes defaults to false here (Interaction.h:68): smooth glass = two specular lobes
         std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false, ray, &scene.textures));
         Vec3 wo = isect.wo;
@@ -2989,9 +2991,6 @@ int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_
         BBox2i sb = h->o.film->GetSampleBounds();
         if (sb.mn.x < sb.mn.y) { h->o.error = "sample bounds with min.x < min.y: reference result undefined"; return -4; }
     }
-    if (h->o.useDirect)
-        for (uint32_t m : h->o.scene.triMaterial)
-            if (m == ENIGMA_NO_MATERIAL) { h->o.error = "surfaces without a material are not restated for the DirectLightingIntegrator"; return -4; }
     if (h->o.useDirect) { // SpecularReflect / SpecularTransmit carry ray differentials on (Integrator.cpp:329-444): not restated
         bool trilinear = false, smoothGlass = false;
         for (const ImageTex& t : h->o.scene.textures.tex) trilinear = trilinear || t.mip.doTrilinear;

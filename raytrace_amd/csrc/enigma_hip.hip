@@ -1048,11 +1048,11 @@ static int acquireStepEvents(EnigmaCtx* h, StepEvents* ev) {
 
 // Evaluates the trilinear image textures at this bounce's hits (the material queues of the kinds that have a textured
 // material), between the closest-hit kernel and the shade kernels.
-static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid) {
+static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid, int noneQueue = MK_NONE) {
     if (h->scene.nSpheres) // the surface interactions of this bounce's sphere hits
         for (int k = 0; k < MK_COUNT; ++k)
             if (h->kindPresent[k]) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[k].p, k, h->counters.p);
-    if (h->scene.nSpheres && h->haveNoMaterial) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, h->counters.p);
+    if (h->scene.nSpheres && h->haveNoMaterial) k_sphere_surface<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->matQ[noneQueue].p, noneQueue, h->counters.p);
     if (!h->haveTrilinear) return;
     const float diffScale = 1 / std::sqrt((float)h->spp); // RayDifferential::scaleDifferentials, Enigma/Integrator.cpp:276
     for (int k = 0; k < MK_COUNT; ++k)
@@ -1107,7 +1107,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     // surfaces without a material: the ray goes on behind them and the vertex does not count as a bounce (Enigma/PathIntegrator.cpp:87-93)
-    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
+    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
     *ev.shadeTimed = 1;
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
@@ -1145,7 +1145,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
-    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, nextQ, cur ^ 1u, ctr);
+    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
     *ev.shadeTimed = 1;
     if (h->scene.nLights > 0) {
@@ -1174,7 +1174,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
     const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     (void)hipEventRecord(ev.h0, s);
-    launchTextures(h, P, gridShade);
+    launchTextures(h, P, gridShade, kQueueMedium);
     if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
@@ -1182,6 +1182,8 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
+    // surfaces without a material: Li goes on behind them at the same depth (Enigma/DirectLightingIntegrator.cpp:51-54)
+    if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[kQueueMedium].p, kQueueMedium, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
     *ev.shadeTimed = 1;
     k_stage<<<1, 1, 0, s>>>(ctr, 1, cur, 0, 0);
@@ -1225,7 +1227,6 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (direct && h->haveTrilinear && h->smoothGlass)
         return h->fail(ENIGMA_E_UNSUPPORTED, "trilinear textures with a smooth glass under the DirectLightingIntegrator: its specular rays carry ray differentials on "
                                              "(Enigma/Integrator.cpp:329-444), which is not supported");
-    if (h->haveNoMaterial && direct) return h->fail(ENIGMA_E_UNSUPPORTED, "the scene has surfaces without a material (medium boundaries): the DirectLightingIntegrator's recursion through them (Enigma/DirectLightingIntegrator.cpp:41-55) is not supported; the PathIntegrator and the VolPathIntegrator render them");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
     size_t basePaths = (size_t)32 << 20; // ~11 GB of path state at 330 B per path; larger launches run closer to the hardware's rates

@@ -436,6 +436,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
         }
         if (DL || (int)bounces < I.maxDepth) {
             kind = triKind(mw) + 1u;
+            if (DL && triKind(mw) == MK_NONE) kind = (uint32_t)kQueueMedium + 1u; // its queue MK_COUNT holds the paths that resume a branch
             P.hit[p] = make_float4(__int_as_float(h.tri), h.b0, h.b1, h.b2);
         }
     } else {
@@ -460,7 +461,9 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
-    constexpr int NK = MODE == 2 ? kQueueKinds : MK_COUNT + 1; // queue MK_COUNT: surfaces without a material / (MODE 1) paths that resume a branch
+    // queue MK_COUNT: surfaces without a material / (MODE 1) paths that resume a branch; queue MK_COUNT + 1: medium interactions /
+    // (MODE 1) surfaces without a material
+    constexpr int NK = MODE == 0 ? MK_COUNT + 1 : kQueueKinds;
     using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Closest;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t binCnt[kQueueKinds * kWavesPerBlock];

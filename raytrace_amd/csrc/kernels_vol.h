@@ -158,9 +158,11 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
 
 // Paths at a surface without a material: the ray goes on in its direction from the far side of the surface, in
 // the medium on that side; the vertex does not count as a bounce and consumes no samples.
-__global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, const uint32_t* queue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
+// (Enigma/PathIntegrator.cpp:87-93, Enigma/VolPathIntegrator.cpp:105-111, Enigma/DirectLightingIntegrator.cpp:51-54: the
+// recursion goes on at the same depth.)  kind: the queue these paths wait in.
+__global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, const uint32_t* queue, int kind, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[kWavesPerBlock + 1];
-    const uint32_t count = ctr->matCount[MK_NONE].v;
+    const uint32_t count = ctr->matCount[kind].v;
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < count;

@@ -593,11 +593,18 @@ def test_image_parity_spheres_without_material():
             for key in ("rays_closest", "rays_shadow", "rays_mis"):
                 assert abs(st[key] - so[key]) <= max(8, 1e-3 * so[key]), (key, st[key], so[key])
             r.close(); o.close()
-    r = ra.Renderer(0).configure(sc, cam, film, scenes.direct_lighting_desc(film, 4))
-    with pytest.raises(ra.EnigmaError) as e:       # refused when a render is asked for, as for triangles without a material
-        r.render(0, 4)
-    assert e.value.code == -4
-    r.close()
+    # DirectLightingIntegrator::Li goes on behind a surface without a material at the same depth (Enigma/DirectLightingIntegrator.cpp:51-54)
+    for strat in (abi.DL_SAMPLE_ALL, abi.DL_SAMPLE_ONE):
+        integ = scenes.direct_lighting_desc(film, 8, strategy=strat)
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 8); o.render(0, 8, threads=8)
+        assert o.image().max() > 0
+        assert common.mean_relative_error(r.image(), o.image()) < 2e-3
+        so, st = o.stats(), r.stats()
+        for key in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[key] - so[key]) <= max(8, 1e-3 * so[key]), (key, st[key], so[key])
+        r.close(); o.close()
 
 
 def test_path_integrator_passes_through_surfaces_without_a_material():
@@ -632,6 +639,21 @@ def test_path_integrator_passes_through_surfaces_without_a_material():
                             np.concatenate([base.tri_light, np.full(12, -1, dtype=np.int32)]),
                             list(base.materials)[:base.n_materials], list(base.lights)[:base.n_lights])
     cam, film = scenes.cornell_camera(48, 48), scenes.film_desc(48, 48)
+    # the same box under the DirectLightingIntegrator (both strategies, with a smooth glass block whose recursion resumes behind it)
+    glassy = abi.SceneArrays(boxed.vertices, boxed.indices, boxed.tri_material, boxed.tri_light,
+                             [abi.glass(1.5, 0.0, 0.0, kt=(0, 0, 0)) if i == 0 else m for i, m in enumerate(list(base.materials)[:base.n_materials])],
+                             list(base.lights)[:base.n_lights])
+    for scene, strat in ((boxed, abi.DL_SAMPLE_ALL), (boxed, abi.DL_SAMPLE_ONE), (glassy, abi.DL_SAMPLE_ALL)):
+        integ = scenes.direct_lighting_desc(film, 8, max_depth=4, strategy=strat)
+        r = ra.Renderer(0).configure(scene, cam, film, integ)
+        o = orc.Oracle(scene, cam, film, integ)
+        r.render(0, 8); o.render(0, 8, threads=8)
+        assert o.image().max() > 0 and not o.read_past_arrays()
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+        so, st = o.stats(), r.stats()
+        for key in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(st[key] - so[key]) <= max(4, 1e-4 * so[key]), (key, st[key], so[key])
+        r.close(); o.close()
     integ = scenes.integrator_desc(film, 16)
     imgs = []
     for scene in (boxed, base):
