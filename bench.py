@@ -414,6 +414,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    watchdog = arm_watchdog() if world > 1 else None  # spawn_ranks has the same deadline; a foreign launcher has none
 
     import torch
     import torch.distributed as dist
@@ -455,6 +456,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

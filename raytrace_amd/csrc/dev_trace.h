@@ -8,6 +8,23 @@
 
 namespace edev {
 
+// Sensitivity knobs for experiment builds: N extra vector instructions without any effect in every node test
+// (ENIGMA_EXP_PAD_NODE) or triangle test (ENIGMA_EXP_PAD_TRI).  How the run time follows N says whether a traversal
+// kernel is bound by instruction issue (time grows with the instruction count) or by memory latency (it does not).
+#ifndef ENIGMA_EXP_PAD_NODE
+#define ENIGMA_EXP_PAD_NODE 0
+#endif
+#ifndef ENIGMA_EXP_PAD_TRI
+#define ENIGMA_EXP_PAD_TRI 0
+#endif
+template <int N> DEV void padVectorIssue() {
+    if (N > 0) {
+        float x = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("v_mul_f32 %0, 1.0, %0" : "+v"(x));
+    }
+}
+
 struct RaySetup {
     F3 o, d, invDir;
     bool negX, negY, negZ;   // dirIsNeg
@@ -50,6 +67,7 @@ struct TriRay {
 // that comparison (triangleStillInRange) instead of the whole test.
 template <class RAY>
 DEV bool triangleTestEx(const RAY& r, float tMaxRay, F3 p0, F3 p1, F3 p2, float* tOut, float* b0o, float* b1o, float* b2o, float* tScaledOut, float* detOut) {
+    padVectorIssue<ENIGMA_EXP_PAD_TRI>();
     F3 p0t = permuteK(p0 - r.o, r.kz0, r.kz1);
     F3 p1t = permuteK(p1 - r.o, r.kz0, r.kz1);
     F3 p2t = permuteK(p2 - r.o, r.kz0, r.kz1);

@@ -30,15 +30,40 @@
 namespace edev {
 
 constexpr int kNode8Vec4 = 5;      // 16-byte pieces per node in global memory
-// Triangle steps dealt out over the wave (dealTriangles): measured on the 1.18 M-triangle scene, the any-hit walker gains
-// 5 % by it (2.66 -> 2.54 ms per launch of the streaming shadow kernel, no register spilled), the closest-hit walker
-// loses 15 % (5.82 -> 6.71 ms: the gathered ray, the pairs and the returned hit records on top of a kernel that is
-// already at its 80 registers take the spills from 16 to 59).  Hence on for any-hit rays only; both paths give the same
-// bits (ENIGMA_SHARED_TRI: bit 0 = any-hit walker, bit 1 = closest-hit walker, for experiments).
+// Triangle steps dealt out over the wave (dealTriangles), for scenes in global memory: on the 1.18 M-triangle scene the
+// streaming shadow kernel gains 4 % by it (2.44 -> 2.34 ms per launch) and the closest-hit kernel 6 % (4.95 -> 4.67).  The
+// closest-hit walker pays for it in registers (the gathered ray, the pairs, the returned hit records): in a build whose
+// register allocation was already tight (device code at -O3: 59 registers spilled instead of 16) it LOST 15 %.  Both paths
+// give the same bits (ENIGMA_SHARED_TRI: bit 0 = any-hit walker, bit 1 = closest-hit walker, for experiments).
 #ifndef ENIGMA_SHARED_TRI
-#define ENIGMA_SHARED_TRI 1
+#define ENIGMA_SHARED_TRI 3
 #endif
 constexpr bool kSharedTriangleStepsAny = (ENIGMA_SHARED_TRI & 1) != 0, kSharedTriangleStepsClosest = (ENIGMA_SHARED_TRI & 2) != 0;
+// Wave priorities (ENIGMA_WAVE_PRIO: the raised level, 0 = off).  A traversal wave alternates between long stretches of
+// arithmetic (a node test, a triangle test, a ray's set-up) and the housekeeping in between that ends in the next fetch
+// (stack, refill, vote, address).  Housekeeping runs at the raised priority, arithmetic at priority 0: a wave that is on
+// its way to a fetch overtakes the waves of its SIMD that are computing, its loads are out sooner, and their latency is
+// spent under the others' arithmetic.  Measured on the 1.18 M-triangle scene: closest-hit kernel 5.35 -> 5.06 ms per
+// launch, streaming shadow kernel 2.45 -> 2.34 (5.83 -> 5.52 and 2.52 -> 2.40 in the -O3 build; raising the priority
+// only from the start of a step to its loads gave a fifth of that).  The same switch around the fetches of the shade
+// kernels and around a ray's set-up changed nothing.
+#ifndef ENIGMA_WAVE_PRIO
+#define ENIGMA_WAVE_PRIO 2
+#endif
+// after: the value whose computation must be complete first (keeps the compiler from moving the switch)
+DEV void arithmeticBegins() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ENIGMA_WAVE_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+#endif
+}
+DEV void arithmeticEnds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ENIGMA_WAVE_PRIO != 0) __builtin_amdgcn_s_setprio(ENIGMA_WAVE_PRIO);
+#endif
+}
+template <class T> DEV void pinHere(const T* p) { asm volatile("" :: "v"(p)); }
+DEV void pinHere(uint32_t a, uint32_t b) { asm volatile("" :: "v"(a), "v"(b)); }
+DEV void pinHere(float a) { asm volatile("" :: "v"(a)); }
 constexpr uint32_t kNodeHits = 0xff000000u;
 // (A lower bound of the children's entry distances kept with a stacked group, to drop the group unfetched once the ray
 // has a nearer hit, was measured and bought nothing: the bound includes the child taken first, whose subtree is what
@@ -64,7 +89,15 @@ DEV Ray8 makeRay8(const RaySetup& r) {
 DEV uint32_t uniformAdd(uint32_t a, uint32_t b) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(a + b)); }
 DEV float ubyteToFloat(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); } // v_cvt_f32_ubyte<b>
 typedef float Pair __attribute__((ext_vector_type(2)));
-DEV Pair pairFma(Pair a, Pair b, Pair c) { return __builtin_elementwise_fma(a, b, c); } // each half rounded once, like fmaf
+#ifndef ENIGMA_PACKED_NODE_TEST
+#define ENIGMA_PACKED_NODE_TEST 0
+#endif
+// v_pk_fma_f32 saves an instruction per plane pair and still loses: 2 % on the closest-hit and 3 % on the shadow kernel
+// of the 1.18 M-triangle scene (the packed form wants its operands in register pairs, and the moves cost more)
+DEV Pair pairFma(Pair a, Pair b, Pair c) { // each half rounded once, like fmaf
+    if (ENIGMA_PACKED_NODE_TEST) return __builtin_elementwise_fma(a, b, c);
+    return Pair{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
 
 // Cross-lane moves of a wave (all 64 lanes must be active): gatherLane reads v from lane `src`, scatterLane sends v to
 // lane `dst` (the destinations of the wave must be a permutation of the lanes).
@@ -124,12 +157,23 @@ DEV TriRay gatherTriRay(const WALKER& w, uint32_t owner) {
     return r;
 }
 
+// The five 16-byte pieces of a node
+struct Node8Words { uint4 n0, n1, n2, n3, n4; };
+template <int NS>
+DEV Node8Words fetchNode8(const float4* nodes, uint32_t index) {
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + (size_t)index * NS);
+    Node8Words w;
+    w.n0 = np[0]; w.n1 = np[1]; w.n2 = np[2]; w.n3 = np[3]; w.n4 = np[4];
+    pinHere(np);
+    return w;
+}
+
 // One node against the ray: the node group (first inner child, hit bits in visiting order | inner mask) and the
 // triangle group (first triangle, one bit per triangle of the hit leaves).
-template <int NS>
-DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, float tMax, uint32_t* gx, uint32_t* gy, uint32_t* tx, uint32_t* ty) {
-    const uint4* np = reinterpret_cast<const uint4*>(nodes + (size_t)index * NS);
-    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+DEV void testNode8(const Node8Words& w, const Ray8& r, float tMax, uint32_t* gx, uint32_t* gy, uint32_t* tx, uint32_t* ty) {
+    const uint4 n0 = w.n0, n1 = w.n1, n2 = w.n2, n3 = w.n3, n4 = w.n4;
+    arithmeticBegins(); // the loads are out
+    padVectorIssue<ENIGMA_EXP_PAD_NODE>();
     const uint32_t ew = n0.w;
     const float Ax = __uint_as_float((ew & 0xffu) << 23) * r.ix;
     const float Ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * r.iy;
@@ -139,7 +183,7 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
     const float Bz = (__uint_as_float(n0.z) - r.oz) * r.iz;
     const float kSlack = 0x1p-21f;
     const float sx = __builtin_fmaf(256.f, fabsf(Ax), fabsf(Bx)), sy = __builtin_fmaf(256.f, fabsf(Ay), fabsf(By)), sz = __builtin_fmaf(256.f, fabsf(Az), fabsf(Bz));
-    // entry and exit plane of an axis side by side: one packed multiply-add (v_pk_fma_f32) gives both distances
+    // entry and exit plane of an axis side by side (pairFma)
     const Pair Bx2 = {__builtin_fmaf(-kSlack, sx, Bx), __builtin_fmaf(kSlack, sx, Bx)};
     const Pair By2 = {__builtin_fmaf(-kSlack, sy, By), __builtin_fmaf(kSlack, sy, By)};
     const Pair Bz2 = {__builtin_fmaf(-kSlack, sz, Bz), __builtin_fmaf(kSlack, sz, Bz)};
@@ -170,6 +214,12 @@ DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, floa
     }
     *gx = n1.x; *gy = (hitmask & kNodeHits) | (ew >> 24);
     *tx = n1.y; *ty = hitmask & ~kNodeHits;
+    pinHere(*gy, *ty); arithmeticEnds();
+}
+
+template <int NS>
+DEV void intersectNode8(const float4* nodes, uint32_t index, const Ray8& r, float tMax, uint32_t* gx, uint32_t* gy, uint32_t* tx, uint32_t* ty) {
+    testNode8(fetchNode8<NS>(nodes, index), r, tMax, gx, gy, tx, ty);
 }
 
 // Per-lane stack of node groups, two words an entry; the first LDSN levels in LDS (entry l of a lane at words
@@ -238,6 +288,8 @@ struct Walker8Base {
         const uint32_t rest = gy & ~(1u << bit);
         const uint32_t slot = (bit - 24u) ^ (q.oct4 & 7u);
         const uint32_t child = gx + __popc(rest & 0xffu & ((1u << slot) - 1u)); // inner slots below it
+        // (the push behind the node's loads instead of in front of them: the twenty registers of a node then live across
+        // the push's branches, more is spilled, and the closest-hit kernel runs 3 % slower)
         if (rest & kNodeHits) st.push(gx, rest);
         intersectNode8<NS>(nodes, child, q, tMax, &gx, &gy, &tx, &ty);
     }
@@ -287,7 +339,9 @@ struct SphereRefs {
 DEV bool slotIsSphere(float4 v0) { return (__float_as_uint(v0.w) >> 31) != 0; }
 DEV uint32_t slotSphere(float4 v0) { return __float_as_uint(v0.w) & 0x7fffffffu; }
 
-template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false, bool LANE_TALLY = true>
+// SHARED_TRI: triangle steps dealt out over the wave (scenes in global memory; for a scene in LDS, whose triangle
+// fetches cost next to nothing, the dealing costs more than the second test it saves: 0.64 -> 0.71 ms per Cornell launch)
+template <int LDSN, int OVF, int STRIDE, int NS = kNode8Vec4, bool SPH = false, bool LANE_TALLY = true, bool SHARED_TRI = true>
 struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
     using Base = Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY>;
     static constexpr int kWords = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kWords, kRows = GroupStack<LDSN, OVF, STRIDE, LANE_TALLY>::kRows;
@@ -311,10 +365,12 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             return;
         }
         float4 v1 = tp[1], v2 = tp[2];
+        pinHere(tp); arithmeticBegins();
         float t, b0, b1, b2;
         if (triangleTest(this->r, h.t, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2) && triangleAccepted(xyz(v0), xyz(v1), xyz(v2), __float_as_uint(v1.w), spheres.shade, tri)) {
             h.t = t; h.tri = (int)tri; h.b0 = b0; h.b1 = b1; h.b2 = b2;
         }
+        pinHere(h.t); arithmeticEnds();
     }
     // The wave's triangle step (scenes without spheres): up to 64 (owner, triangle) pairs, one per lane.  A pair is tested
     // with the distance its owner had when the step began; an owner applies its first pair's result, then its second
@@ -329,12 +385,14 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         if (P.work) {
             const float4* tp = tris + (size_t)P.tri * 3;
             const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            pinHere(tp); arithmeticBegins();
             float tt, c0, c1, c2, ts, dd;
             if (triangleTestEx(ray, tMaxOwner, xyz(v0), xyz(v1), xyz(v2), &tt, &c0, &c1, &c2, &ts, &dd) &&
                 triangleAccepted(xyz(v0), xyz(v1), xyz(v2), __float_as_uint(v1.w), spheres.shade, P.tri)) {
                 t = tt; b0 = c0; b1 = c1; b2 = c2; tScaled = ts; det = dd;
             }
         }
+        pinHere(t); arithmeticEnds();
         // back to the owners (a hit has t > 0, a miss carries -1)
         const float tA = gatherLaneF(t, P.posA), tB = gatherLaneF(t, P.posB & 63u);
         const bool hitA = P.hasA && tA > 0.f;
@@ -361,7 +419,7 @@ struct ClosestWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             this->nodeVisits = uniformAdd(this->nodeVisits, cn);
             if (!n) return;
             Base::nodeStep(nodes, h.t);
-        } else if (!SPH && kSharedTriangleStepsClosest && (FULL_WAVE || __ballot(true) == ~0ull)) {
+        } else if (!SPH && SHARED_TRI && kSharedTriangleStepsClosest && (FULL_WAVE || __ballot(true) == ~0ull)) {
             this->triSteps = uniformAdd(this->triSteps, 1u);
             const uint32_t before = LANE_TALLY ? 0u : (uint32_t)__popcll(__ballot(this->ty != 0)) + (uint32_t)__popcll(__ballot((this->ty & (this->ty - 1u)) != 0));
             sharedTriangleStep(tris);
@@ -410,8 +468,10 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
             return;
         }
         float4 v1 = tp[1], v2 = tp[2];
+        pinHere(tp); arithmeticBegins();
         float t, b0, b1, b2;
         if (triangleTest(this->r, tMax, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2)) { occluded = true; Base::finish(); }
+        pinHere(this->gy, this->ty); arithmeticEnds();
     }
     // the wave's triangle step, as ClosestWalker8::sharedTriangleStep: any pair that hits ends its owner's ray
     DEV void sharedTriangleStep(const float4* tris) {
@@ -422,9 +482,11 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
         if (P.work) {
             const float4* tp = tris + (size_t)P.tri * 3;
             const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+            pinHere(tp); arithmeticBegins();
             float t, b0, b1, b2, ts, dd;
             hit = triangleTestEx(ray, tMaxOwner, xyz(v0), xyz(v1), xyz(v2), &t, &b0, &b1, &b2, &ts, &dd) ? 1u : 0u;
         }
+        pinHere(hit, hit); arithmeticEnds();
         if (__ballot(hit != 0u) == 0) return;
         const uint32_t hA = gatherLane(hit, P.posA), hB = gatherLane(hit, P.posB & 63u);
         if ((P.hasA && hA) || (P.hasB && hB)) { occluded = true; Base::finish(); }
@@ -467,7 +529,7 @@ struct AnyWalker8 : Walker8Base<LDSN, OVF, STRIDE, NS, LANE_TALLY> {
 constexpr int kLdsNodePitch = kNode8Vec4;
 template <int LDSN, int OVF, int STRIDE, bool LDS_SCENE, bool SPH = false, bool LANE_TALLY = true> struct WalkerSel {
     static constexpr int NS = LDS_SCENE ? kLdsNodePitch : kNode8Vec4;
-    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS, SPH, LANE_TALLY>;
+    using Closest = ClosestWalker8<LDSN, OVF, STRIDE, NS, SPH, LANE_TALLY, !LDS_SCENE>;
     using Any = AnyWalker8<LDSN, OVF, STRIDE, NS, SPH, LANE_TALLY>;
 };
 constexpr int spillWords(int ovf) { return 2 * (ovf > 0 ? ovf : 1); }

@@ -3,6 +3,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -94,3 +95,14 @@ def test_bench_spawned_ranks_end_together_when_one_fails():
         assert p.returncode == 0, err[-2000:]
     else:
         assert p.returncode != 0 and b"ranks exited with" in err
+
+
+def test_bench_rank_under_a_foreign_launcher_ends_itself_at_the_deadline():
+    """Under torch.distributed.run nobody watches bench.py's ranks: each arms a timer that ends the process, with a
+    message and exit code 3, when ENIGMA_BENCH_DEADLINE_S has passed (a peer lost inside a collective never returns)."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.arm_watchdog(); time.sleep(30)" % ROOT)
+    env = dict(os.environ, ENIGMA_BENCH_DEADLINE_S="0.5", RANK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=60)
+    assert p.returncode == 3 and b"rank 1 still running" in p.stderr
+    assert time.time() - t0 < 25

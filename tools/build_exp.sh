@@ -7,6 +7,6 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/exp" /tmp/expbuild
 cd "$root/raytrace_amd/csrc"
 make -s build/bvh_build.o build/sobol_host.o build/spectrum_host.o
-hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Wno-unused-variable -DENIGMA_EXPERIMENT_BUILD "$@" -c -o /tmp/expbuild/$name.o enigma_hip.hip
+hipcc --offload-arch=gfx950 -std=c++17 ${ENIGMA_EXP_OPT:--O1} -fPIC -ffp-contract=off -Wno-unused-variable -DENIGMA_EXPERIMENT_BUILD "$@" -c -o /tmp/expbuild/$name.o enigma_hip.hip
 hipcc --offload-arch=gfx950 -shared -o "$root/exp/libenigma_$name.so" /tmp/expbuild/$name.o build/bvh_build.o build/sobol_host.o build/spectrum_host.o
 echo "built exp/libenigma_$name.so"
