@@ -29,7 +29,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SPP_PER_STEP = 16
 XRES, YRES = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: lane operations per second, in 1e12
+# 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: lane operations per second, in 1e12 (a SIMD finishes a wave64 instruction every two
+# cycles; the 157 TFLOP/s of fp32 vector peak are two flops per such lane operation)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 JOB_SPP = {"bigmesh_fog": 512}  # samples per pixel of the configuration's whole job (1024 unless named here)
 # bytes the closest-hit kernel moves per ray besides the tree: the 64-byte path record read, the 16-byte hit record
 # written, the queue word read and the material-queue word written
@@ -330,12 +332,18 @@ def run_workload(args, variant, steps, ctx):
                 valu = rec["valu_issue_share"] * rec["valu_lane_use"]
         hbm_frac = e.get("hbm_frac_counter") or e["hbm_algorithmic"]["frac"]
         if valu is not None and rec["valu_issue_share"] >= hbm_frac:
-            # VALU issue binds: the fraction of the chip's lane slots (CUs x 4 SIMDs x 16 lanes x clock) that did work
+            # VALU issue is the nearer roof: the fraction of the chip's lane slots (CUs x 4 SIMDs x 32 lanes x clock) that did work
             e.update({"bound": "valu", "frac": valu, "achieved": valu * VALU_PEAK_TLANEOPS, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                       "frac_is": "recorded VALU issue share x lanes active per instruction"})
         else:
             e.update({"bound": "hbm", "frac": hbm_frac, "achieved": hbm_frac * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac_is": "recorded HBM bytes per launch / live launch time" if e.get("hbm_frac_counter") else "algorithmic bytes per launch / live launch time (no counter pass recorded for this workload)"})
+        wt = (rec or {}).get("wave_time")
+        if wt:
+            # neither roof is close when the waves spend most of their time parked on a fetch: the kernel then runs at the speed
+            # of its dependent loads times the waves a CU holds, and `frac` says how far from the nearer roof that leaves it
+            e["limited_by"] = ("latency of dependent fetches (waves parked on memory %.0f %% of their time, issuing %.0f %%)" % (100 * wt["waiting_on_memory_or_barrier"], 100 * wt["issuing"])
+                               if wt["waiting_on_memory_or_barrier"] > wt["issuing"] else "instruction issue (waves issuing %.0f %% of their time)" % (100 * wt["issuing"]))
         e.update(extra)
         return e
 

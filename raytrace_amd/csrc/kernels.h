@@ -855,6 +855,8 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
 // spilled), three for the microfacet ones (168).  The kernels wait on memory more than they compute; measured against
 // the unconstrained builds (165 to 199 registers): Cornell 3 % faster per step, BigMesh 1 %; one wave more each
 // (96 / 128 registers, a hundred spilled) is 15 % slower.
+// (re-measured with device code at -O1, where nothing is spilled at four / three waves: five / four 9-16 % slower, three /
+// three 3 % slower, four / four and four / two the same within 1 %)
 template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false>
 __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUGH || MK == MK_GLASS_SMOOTH) ? 4 : 3) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {

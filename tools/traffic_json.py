@@ -5,7 +5,8 @@ One entry per workload, keyed as bench.py keys its workloads ("<variant>_<integr
 family (closest = k_intersect_closest, shadow = the shadow-ray kernel of the workload, shade = the largest k_shade kernel):
 HBM bytes per launch ((2 * FETCH_SIZE + WRITE_SIZE) KB over the launches of one 16-spp step: rocprofv3 reports both
 counters in KB, and on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads are doubled), L2 hit rate, share
-of VALU issue slots used and lanes active per VALU instruction.  --commit names the tree the passes were taken on; bench.py
+of VALU issue slots used (a wave64 instruction every two cycles per SIMD), lanes active per VALU instruction, and the split
+of the waves' time into waiting on memory, waiting to issue and issuing.  --commit names the tree the passes were taken on; bench.py
 prints it beside the figures it reads from here.
 
     python tools/traffic_json.py profiles/traffic.json --commit <hash> microfacet_path_power=profiles/<cornell table>.json ...
@@ -24,8 +25,12 @@ out = {"unit": "bytes per launch", "note": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 /
 
 def row_of(table, name):
     r = table[name]
-    return {"kernel": name, "bytes_per_launch": r["hbm_GB"] * 1e9 / r["launches"], "ms_per_launch": r["ms_per_step"] / r["launches"], "l2_hit": r["l2_hit_rate"],
-            "valu_issue_share": r["valu_issue_share"], "valu_lane_use": r["valu_lane_use"]}
+    row = {"kernel": name, "bytes_per_launch": r["hbm_GB"] * 1e9 / r["launches"], "ms_per_launch": r["ms_per_step"] / r["launches"], "l2_hit": r["l2_hit_rate"],
+           "valu_issue_share": r["valu_issue_share"], "valu_lane_use": r["valu_lane_use"]}
+    for k in ("wave_time", "clock_GHz", "l1_to_l2_read_latency_cycles"):   # where the waves' time goes (pmc_table.py)
+        if r.get(k) is not None:
+            row[k] = r[k]
+    return row
 
 
 for arg in args:

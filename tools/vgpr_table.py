@@ -6,7 +6,7 @@ import os, re, subprocess, sys, tempfile
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = os.path.join(tempfile.gettempdir(), "enigma_dev.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-Wno-unused-function", "-Wno-unused-result",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-unused-function", "-Wno-unused-result",
                        "-Wno-unused-command-line-argument", "--cuda-device-only", "-S", "-o", asm, "enigma_hip.hip"], cwd=os.path.join(root, "raytrace_amd", "csrc"))
 rows = []
 for b in open(asm).read().split("- .agpr_count")[1:]:
