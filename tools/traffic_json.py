@@ -52,6 +52,8 @@ for arg in args:
                             "l2_hit": sum(table[k]["l2_hit_rate"] * table[k]["ms_per_step"] for k in shades) / t,
                             "valu_issue_share": sum(table[k]["valu_issue_share"] * table[k]["ms_per_step"] for k in shades) / t,
                             "valu_lane_use": sum(table[k]["valu_lane_use"] * table[k]["ms_per_step"] for k in shades) / t}
+        if all(table[k].get("wave_time") for k in shades):
+            kernels["shade"]["wave_time"] = {f: round(sum(table[k]["wave_time"][f] * table[k]["ms_per_step"] for k in shades) / t, 2) for f in table[shades[0]]["wave_time"]}
     out[key] = {"commit": commit, "source": src, "kernels": kernels}
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
