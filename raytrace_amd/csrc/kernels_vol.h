@@ -225,7 +225,14 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
     uint32_t runLo = 0, runHi = 0;
     bool exhausted = false;
     for (;;) {
-        if (active && w.done()) { // a segment is through: the chain ends here, or goes on behind the boundary
+        // Ends of segments are worked on together, like refills: what a lane does there (the medium's transmittance, the
+        // boundary's geometry, the next segment's set-up with its three divisions) runs once per wave however few lanes
+        // need it, so the wave waits until kRefillIdle lanes have a segment to end or a ray to fetch -- or nobody can step.
+        const bool segmentEnd = active && w.done();
+        const uint32_t nEnds = __popcll(__ballot(segmentEnd));
+        const bool noneSteps = __ballot(active && !w.done()) == 0;
+        const bool turn = noneSteps || nEnds + (exhausted ? 0u : (uint32_t)__popcll(__ballot(!active))) >= kRefillIdle;
+        if (turn && segmentEnd) { // a segment is through: the chain ends here, or goes on behind the boundary
             Hit h = w.h;
             bool hit = h.tri >= 0;
             uint32_t kind = MK_NONE;
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(kBlock) k_shadow_tr(DevScene sc, DevPaths P, D
         }
         const unsigned long long idleMask = __ballot(!active);
         const uint32_t nIdle = __popcll(idleMask);
-        if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
+        if (nIdle == 64u || (turn && !exhausted && nIdle != 0u)) {
             if (!exhausted && runLo == runHi) {
                 uint32_t r = 0;
                 if (lane == 0) r = atomicAdd(&ctr->shadowCursor.v, kShadowRun);
