@@ -536,6 +536,12 @@ def compare_bsdf(seed, n=4000):
     zero[rim, 4:11] = False
     # away from the rim the same cancellation costs 2.4e-7 / z^2 of relative accuracy: the sampled columns get that much more room
     room = 2.4e-7 / np.maximum(want[:, 10] ** 2, 1e-12)
+    # a sharp microfacet lobe magnifies the last bits of the sampled direction (the two libms' sine and cosine: some 1e-6
+    # rad) in its value and density: D falls off over an angle alpha, so a step d(theta) changes it by about
+    # 4 tan(theta) d(theta) / alpha^2 of itself -- 7e-4 at alpha = 0.01, seen at seed 900080, identical in -O1 and -O3 builds
+    alpha = min(float(m.uroughness), float(m.vroughness))
+    if alpha > 0:
+        room = room + 8e-8 / alpha ** 2
     err[:, 4:11] = np.maximum(err[:, 4:11] - room[:, None], 0)
     rows = lobes | (fin_g != fin_w).any(axis=1) | (err > 2e-4).any(axis=1) | zero.any(axis=1)
     out.update(points=int(n), lobe_diff=int(lobes.sum()), finite_diff=int((fin_g != fin_w).any(axis=1).sum()), value_diff=int((err > 2e-4).any(axis=1).sum()),
