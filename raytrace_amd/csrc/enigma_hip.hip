@@ -1200,7 +1200,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
 // traversal flavour: scene in LDS (small scene, shallow tree) | all stack levels in LDS | 11 levels in LDS + a private spill array;
 // scenes with spheres: the last one, with the sphere test compiled in
 static bool sceneRunsFromLds(const EnigmaCtx* h) {
-    return h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= 12 &&
+    return h->scene.nSpheres == 0 && !(h->integDesc.light_strategy == ENIGMA_LIGHTS_SPATIAL && !h->useDirect && h->scene.nLights > 1) && h->bvhStack <= kLdsSceneLevels &&
            sceneLdsBytes(h) <= kLdsSceneBytes && shadeLdsBytes(h) <= kLdsSceneBytes && !getenv("ENIGMA_NO_LDS_SCENE");
 }
 // Paths per chunk of the traversal kernels' grids
@@ -1286,7 +1286,10 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchDirectStep<11, 53, false, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
-                else if (ldsScene) launchDirectStep<12, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) {
+                    if (h->bvhStack <= kLdsShallowLevels) launchDirectStep<kLdsShallowLevels, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                    else launchDirectStep<kLdsSceneLevels, 0, true>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (h->bvhStack <= 11) launchDirectStep<11, 0, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 else launchDirectStep<11, 53, false>(h, P, D, shq, misq, nPaths, step, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
@@ -1302,7 +1305,10 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 StepEvents ev;
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
                 if (h->scene.nSpheres) launchVolBounce<11, 53, false, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
-                else if (ldsScene) launchVolBounce<12, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) {
+                    if (h->bvhStack <= kLdsShallowLevels) launchVolBounce<kLdsShallowLevels, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                    else launchVolBounce<kLdsSceneLevels, 0, true>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (h->bvhStack <= 11) launchVolBounce<11, 0, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 else launchVolBounce<11, 53, false>(h, P, shq, misq, nPaths, iter, gridTrace, gridShadow, gridShade, ev);
                 h->stats.intersect_launches++;
@@ -1320,11 +1326,17 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
                 { int rc = acquireStepEvents(h, &ev); if (rc) return rc; }
 #if ENIGMA_FULL_BUILD
                 if (h->scene.nSpheres) launchBounce<11, 53, false, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
-                else if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                else if (ldsScene) {
+                    if (h->bvhStack <= kLdsShallowLevels) launchBounce<kLdsShallowLevels, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                    else launchBounce<kLdsSceneLevels, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                }
                 else if (h->bvhStack <= 11) launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
                 else launchBounce<11, 53, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
 #else
-                if (ldsScene) launchBounce<12, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                if (ldsScene) {
+                    if (h->bvhStack <= kLdsShallowLevels) launchBounce<kLdsShallowLevels, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                    else launchBounce<kLdsSceneLevels, 0, true>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
+                }
                 else launchBounce<11, 0, false>(h, P, shq, misq, nPaths, b, gridTrace, gridShadow, gridShade, ev);
 #endif
                 h->stats.intersect_launches++;
@@ -1690,11 +1702,17 @@ template <int MODE>
 static void launchClosestFlavour(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int gridTrace, const uint32_t* pendCount) {
 #if ENIGMA_FULL_BUILD
     if (h->scene.nSpheres) launchClosest<11, 53, false, MODE, true>(h, P, nPaths, 0, gridTrace, pendCount);
-    else if (sceneRunsFromLds(h)) launchClosest<12, 0, true, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    else if (sceneRunsFromLds(h)) {
+        if (h->bvhStack <= kLdsShallowLevels) launchClosest<kLdsShallowLevels, 0, true, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+        else launchClosest<kLdsSceneLevels, 0, true, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    }
     else if (h->bvhStack <= 11) launchClosest<11, 0, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
     else launchClosest<11, 53, false, MODE, false>(h, P, nPaths, 0, gridTrace, pendCount);
 #else
-    if (MODE == 0 && sceneRunsFromLds(h)) launchClosest<12, 0, true, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    if (MODE == 0 && sceneRunsFromLds(h)) {
+        if (h->bvhStack <= kLdsShallowLevels) launchClosest<kLdsShallowLevels, 0, true, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
+        else launchClosest<kLdsSceneLevels, 0, true, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
+    }
     else if (MODE == 0) launchClosest<11, 0, false, 0, false>(h, P, nPaths, 0, gridTrace, pendCount);
 #endif
 }

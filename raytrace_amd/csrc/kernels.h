@@ -350,6 +350,12 @@ constexpr int kTraceItems = kTraceChunk / kBlock;
 static_assert(kTraceItems >= 1 && kTraceItems <= 16, "the chunk's material kinds are packed four bits per item into 64 bits");
 
 constexpr uint32_t kNoRay = 0xffffffffu;
+// Kernels of scenes staged into LDS come in two builds: trees at most kLdsShallowLevels deep (the Cornell boxes: 3) keep
+// that many stack levels per lane in LDS, which leaves room for six blocks per CU instead of five (80 registers, nothing
+// spilled that matters: closest-hit kernel 0.634 -> 0.605 ms, shadow kernel 0.260 -> 0.242 ms per Cornell launch; seven
+// blocks at 72 registers lose it again); deeper trees of small scenes keep kLdsSceneLevels and five blocks.
+constexpr int kLdsSceneLevels = 12, kLdsShallowLevels = 6;
+constexpr int ldsSceneBlocks(int ldsn) { return ldsn <= kLdsShallowLevels ? 6 : 5; }
 
 // lanes in idleMask take consecutive pool positions; returns this lane's position (valid for idle lanes)
 DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t* baseOut) {
@@ -457,7 +463,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
 // samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
 // medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
 template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
-__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
+__global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
@@ -1176,7 +1182,7 @@ __global__ void __launch_bounds__(kBlock) k_resume_pending(DevPaths P, DevIntegr
 // VisibilityTester::Unoccluded for the shadow rays of one bounce (any-hit; unoccluded rays add their
 // contribution to the path's L).  Same ray-pool scheme as k_intersect_closest.
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
-__global__ void __launch_bounds__(kBlock, LDS_SCENE ? 5 : 6) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
+__global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) k_shadow(DevScene sc, DevPaths P, DevRayQueue shq, DevCounters* ctr, uint32_t kRefillIdle) {
     using Walker = typename WalkerSel<LDSN, OVF, kBlock, LDS_SCENE, SPH>::Any;
     __shared__ uint32_t stack[Walker::kWords * kBlock];
     __shared__ uint32_t poolNext;
