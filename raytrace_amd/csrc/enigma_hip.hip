@@ -99,6 +99,10 @@ struct EnigmaCtx {
     int residentTraceBlocks = 256 * 6; // blocks of a traversal kernel the chip holds at once: its waves stream rays until the queue is empty
     DevScene scene{};
     uint32_t bvhDepth = 0, bvhNodes = 0, bvhStack = 0;
+    // grid of the shade kernels, in blocks per CU (their threads stride over the queues).  Measured per bounce on Cornell /
+    // the 1.18 M-triangle scene: 4: 1.02 / 2.91 ms, 8: 0.95 / 2.72, 16: 0.93 / 2.67, 32: 0.92 / 2.62, 64: 0.93 / 2.62, 512: 0.99 /
+    // 2.63 (a block of a scene in LDS stages its tables first)
+    int shadeBlocksPerCu = 32;
     double msBvhBuild = 0;
 
     // camera / film / integrator
@@ -1236,6 +1240,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     int64_t nSamples = sample_end - sample_begin;
     const int64_t chunkMax = 4096; // sample slots addressable per constant table
     if (const char* e = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(e);
+    if (const char* e = getenv("ENIGMA_SHADE_BLOCKS_PER_CU")) h->shadeBlocksPerCu = std::max(1, atoi(e));
     const bool ldsScene = sceneRunsFromLds(h);
     h->stats.scene_in_lds = ldsScene ? 1 : 0;
     const int cus = deviceCus(h);
@@ -1275,7 +1280,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             // few enough that launches late in a pass (short queues) do not drown in empty blocks
             int gridTrace = traceGrid(nPaths, cus);
             int gridShadow = std::min(gridAll, cus * 4); // MIS rays: few per bounce
-            int gridShade = std::min(gridAll, cus * 8);
+            int gridShade = std::min(gridAll, cus * h->shadeBlocksPerCu);
             k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
                                                           direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
             // DirectLightingIntegrator: one step per level of the recursion still alive; the host reads the number of
