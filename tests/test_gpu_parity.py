@@ -1119,3 +1119,43 @@ def test_scene_without_lights_and_empty_scene():
     r.render(0, 4)
     assert r.film()[..., 3].min() >= 4 and r.image().max() == 0
     r.close()
+
+
+def _nested_shelves(n=120, ratio=0.82):
+    """A small scene whose tree is deep: quads in a geometric progression of sizes towards a corner (each split of the
+    builder peels the few largest off the rest), above a floor, under a lamp.  A few hundred triangles: it runs from LDS."""
+    b = scenes.MeshBuilder()
+    white = b.add_material(abi.matte((0.7, 0.7, 0.7)))
+    red = b.add_material(abi.matte((0.7, 0.2, 0.2)))
+    metal = b.add_material(abi.metal((0.2, 0.9, 1.1), (3.9, 2.4, 2.2), roughness=0.05))
+    b.add_quad([(-300, 0, -300), (-300, 0, 300), (300, 0, 300), (300, 0, -300)], white, toward=(0, 1, 0))
+    x, s = -200.0, 80.0
+    for k in range(n):
+        y = 20.0 + 3.0 * (k % 5)
+        m = (white, red, metal)[k % 3]
+        b.add_quad([(x, y, -s), (x, y, s), (x + s, y + 0.3 * s, s), (x + s, y + 0.3 * s, -s)], m, toward=(x, 1e4, 0))
+        x += s * 1.05
+        s *= ratio
+    b.add_quad([(-60, 250, -60), (-60, 250, 60), (60, 250, 60), (60, 250, -60)], white, toward=(0, -1, 0), emit=(25.0, 25.0, 25.0))
+    return b.arrays()
+
+
+def test_small_scene_with_a_deep_tree_takes_the_deep_lds_build():
+    """Scenes that fit LDS run one of two builds of the traversal kernels: trees up to six levels deep (every Cornell
+    scene) keep six stack levels per lane, deeper ones twelve.  This scene is small AND deep: hits bit for bit, image and
+    ray counts against the oracle, for the three integrators' builds of the kernel."""
+    sc = _nested_shelves()
+    cam = scenes.camera_desc((150, 260, -420), (120, 10, 0), (0, 1, 0), 40.0, 96, 64)
+    film = scenes.film_desc(96, 64)
+    for integ in (scenes.integrator_desc(film, 16), scenes.direct_lighting_desc(film, 16, max_depth=3, strategy=abi.DL_SAMPLE_ONE), scenes.volpath_desc(film, 16)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 8); o.render(0, 8, threads=8)
+        st = r.stats()
+        assert st["scene_in_lds"] == 1 and 6 < st["bvh_depth"] <= 12, (st["scene_in_lds"], st["bvh_depth"], st["bvh_nodes"])
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+        so = o.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert st[k] == so[k], (k, st[k], so[k])
+        _primary_tap_check(r, o, (0, 0, 96, 64), (0, 5))
+        r.close(); o.close()
