@@ -244,3 +244,28 @@ def test_shard_range_partitions():
         parts = [distributed.shard_range(b, e, r, w) for r in range(w)]
         assert parts[0][0] == b and parts[-1][1] == e
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+
+
+def test_recorded_bench_line_keeps_the_contract():
+    """The last default bench line kept under profiles/ carries every key the driver reads, the roofline object is
+    consistent with itself, and the figures read from a counter pass are labelled with the commit of that pass."""
+    import glob
+    import json
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_bench_default.json")))
+    assert lines
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "Mrays/s" and d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for name in ("roofline", "roofline_shadow", "roofline_shade"):
+        r = d[name]
+        assert r["bound"] in ("hbm", "valu") and r["unit"] in ("GB/s", "Tlane-op/s")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1.5
+        assert r["avg_launch_ms"] > 0 and r["launches"] > 0
+        if r.get("recorded"):
+            assert r["recorded"].get("commit") and r["recorded"].get("source")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    b = d["bigmesh"]
+    assert b["job_measured"] is True and b["job_spp"] == 1024 and b["ms_bvh_build"] > 0 and b["reduce"].startswith(("none", "native"))
