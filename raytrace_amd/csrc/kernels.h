@@ -350,6 +350,11 @@ constexpr int kTraceItems = kTraceChunk / kBlock;
 static_assert(kTraceItems >= 1 && kTraceItems <= 16, "the chunk's material kinds are packed four bits per item into 64 bits");
 
 constexpr uint32_t kNoRay = 0xffffffffu;
+// medium boundaries a VolPathIntegrator ray crosses inside the closest-hit kernel before the path takes the boundary queue (0 = never)
+#ifndef ENIGMA_INLINE_CROSSINGS
+#define ENIGMA_INLINE_CROSSINGS 16
+#endif
+constexpr uint32_t kInlineCrossings = ENIGMA_INLINE_CROSSINGS;
 // Kernels of scenes staged into LDS come in two builds: trees at most kLdsShallowLevels deep (the Cornell boxes: 3) keep
 // that many stack levels per lane in LDS, which leaves room for six blocks per CU instead of five (80 registers, nothing
 // spilled that matters: closest-hit kernel 0.634 -> 0.605 ms, shadow kernel 0.260 -> 0.242 ms per Cornell launch; seven
@@ -368,13 +373,35 @@ DEV uint32_t poolTake(uint32_t* poolNext, unsigned long long idleMask, uint32_t*
     return base + __popcll(idleMask & ((1ull << lane) - 1ull));
 }
 
+// medium + 1 on the side of triangle `tri` that w points into, for a ray that arrived in medium rayMed (+1)
+DEV uint32_t mediumBeyond(const DevScene& sc, int tri, uint32_t rayMed, F3 n, F3 w) {
+    uint32_t in = rayMed, out = rayMed;
+    if (sc.triMedium) {
+        uint32_t tm = sc.triMedium[tri], a = tm & 0xffffu, b = tm >> 16;
+        if (a != b) { in = a; out = b; }
+    }
+    return dot(w, n) > 0 ? out : in;
+}
+// Position, error bounds and normal of a hit on a surface without a material, for the rays that are not the path's own
+// (their sphere hits have no record from k_sphere_surface: worked out here).
+template <bool SPH>
+DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, F3 d, uint32_t path, F3* gp, F3* ge, F3* gn) {
+    if (isSpherePrim<SPH>(sc, h.tri)) {
+        F3 dpdu, wo;
+        sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), d, gp, ge, gn, &dpdu, &wo);
+    } else {
+        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, path);
+        *gp = g.p; *ge = g.pError; *gn = g.n;
+    }
+}
+
 // The head of the Li loop for a ray that has finished its walk (Enigma/PathIntegrator.cpp:62-87; MODE 1: the
 // DirectLightingIntegrator's, MODE 2: the VolPathIntegrator's with its medium sampling): emitted radiance, the depth
 // test, the hit record.  Returns the queue the path goes to + 1 (its material kind, the boundary / resume queue, the
 // medium queue), 0 when the path has ended.
 template <int MODE, bool SPH, class Walker>
 DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevIntegrator& I, const DevSampler& S, const float4* tris, const Walker& w,
-                           uint32_t p, uint32_t state, const uint32_t* pendCount) {
+                           uint32_t p, uint32_t& state, const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     uint32_t kind = 0;
     Hit h = w.h;
@@ -467,6 +494,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
+    constexpr bool kCrossInline = VOL && LDS_SCENE && kInlineCrossings > 0;
     // queue MK_COUNT: surfaces without a material / (MODE 1) paths that resume a branch; queue MK_COUNT + 1: medium interactions /
     // (MODE 1) surfaces without a material
     constexpr int NK = MODE == 0 ? MK_COUNT + 1 : kQueueKinds;
@@ -484,7 +512,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
     const float4* tris = sc.tris;
     if (LDS_SCENE) { stageSceneToLds(sc, sceneLds); nodes = sceneLds; tris = sceneLds + sc.nNodes * kLdsNodePitch; }
     blockZeroVisits(stack + threadIdx.x, Walker::kRows, kBlock);
-    uint32_t nodeSteps = 0, triSteps = 0;
+    uint32_t nodeSteps = 0, triSteps = 0, inlineRays = 0;
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     for (uint32_t chunk = blockIdx.x * kTraceChunk; chunk < count; chunk += gridDim.x * kTraceChunk) {
@@ -492,7 +520,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
         if (threadIdx.x == 0) poolNext = 0;
         __syncthreads();
         Walker w(stack + threadIdx.x, spill, SphereRefs(sc));
-        uint32_t pos = kNoRay, p = 0, state = 0;
+        uint32_t pos = kNoRay, p = 0, state = 0, crossings = 0;
         bool exhausted = false;
         for (;;) {
             bool idle = w.done();
@@ -501,14 +529,40 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
                     const uint32_t kind = finishPathRay<MODE, SPH>(sc, P, I, S, tris, w, p, state, pendCount);
-                    kindOf[pos] = (uint8_t)kind;
-                    pos = kNoRay;
+                    // VolPathIntegrator: a ray that has reached a surface without a material -- a medium boundary -- and was not
+                    // stopped by the medium before goes on from the far side, in the medium there, without a bounce counted or a
+                    // sample drawn (Enigma/VolPathIntegrator.cpp:105-111).  The lane does that here and keeps its ray instead of
+                    // sending the path through the boundary queue and the next launch: same arithmetic as k_interface, which
+                    // still serves the paths that cross more than kInlineCrossings boundaries in a row and the primary-hit tap.
+                    // For scenes in LDS only (Cornell in fog: 16 -> 6 launch sets per pass, 26.1 -> 22.7 ms per step); the build for
+                    // scenes in global memory pays for the crossing code with twenty more spilled registers in every step of
+                    // every ray (the 1.18 M-triangle scene in fog: 126.9 -> 131.0 ms) and keeps the queue.
+                    if (kCrossInline && kind == (uint32_t)MK_NONE + 1u && sc.hitT == nullptr && crossings < kInlineCrossings) {
+                        F3 gp, ge, gn;
+                        const F3 d = w.r.d;
+                        boundaryGeometry<SPH>(sc, tris, w.h, d, p, &gp, &ge, &gn);
+                        const F3 no = offsetRayOrigin(gp, ge, gn, d); // isect.SpawnRay(ray.m_dir)
+                        state = packState(mediumBeyond(sc, w.h.tri, stMedium(state), gn, d), stDim(state), stBounces(state), stSpec(state)) | kStNoDifferentials;
+                        P.rayO[p] = mk4(no, 0.f);
+                        P.rayD[p] = mk4(d, __uint_as_float(state));
+                        w.start(no, d, EDEV_INF);
+                        ++crossings; ++inlineRays;
+                    } else {
+                        kindOf[pos] = (uint8_t)kind;
+                        pos = kNoRay;
+                    }
+                }
+                if (kCrossInline) { // lanes that went on through a boundary take no new ray
+                    idle = w.done();
+                    idleMask = __ballot(idle);
+                    nIdle = __popcll(idleMask);
                 }
                 if (!exhausted) {
                     uint32_t base;
                     uint32_t mine = poolTake(&poolNext, idleMask, &base);
                     if (idle && mine < chunkCount) {
                         pos = mine;
+                        crossings = 0;
                         p = queue ? queue[chunk + mine] : chunk + mine;
                         float4 rd = P.rayD[p];
                         state = __float_as_uint(rd.w);
@@ -559,6 +613,10 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
             }
         }
         __syncthreads(); // binCnt / binBase / kindOf / poolNext are rewritten by the next chunk
+    }
+    if (kCrossInline) { // the rays traced behind boundaries were in no queue: counted here
+        for (int off = 32; off > 0; off >>= 1) inlineRays += __shfl_down(inlineRays, off);
+        if (lane == 0 && inlineRays) atomicAdd(&ctr->raysClosest, (unsigned long long)inlineRays);
     }
     blockFlushVisits(stack + threadIdx.x, Walker::kRows, kBlock, sc.visits, kVisitClosest, binCnt);
     waveFlushSteps(sc.visits, kVisitClosest, nodeSteps, triSteps);

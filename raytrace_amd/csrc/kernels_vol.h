@@ -33,15 +33,6 @@ DEV float hgSample(float g, F3 wo, F3* wi, float u0, float u1) {
     return phaseHG(cosTheta, g);
 }
 
-// medium + 1 on the side of triangle `tri` that w points into, for a ray that arrived in medium rayMed (+1)
-DEV uint32_t mediumBeyond(const DevScene& sc, int tri, uint32_t rayMed, F3 n, F3 w) {
-    uint32_t in = rayMed, out = rayMed;
-    if (sc.triMedium) {
-        uint32_t tm = sc.triMedium[tri], a = tm & 0xffffu, b = tm >> 16;
-        if (a != b) { in = a; out = b; }
-    }
-    return dot(w, n) > 0 ? out : in;
-}
 // HomogeneousMedium::Tr (Enigma/Medium.cpp:78-81) of a ray of direction d and parametric length tMax
 DEV F3 mediumTr(const DevMedium& m, F3 d, float tMax) {
     float s = smin(tMax * length(d), EDEV_MAXF);
@@ -180,19 +171,6 @@ __global__ void __launch_bounds__(kBlock) k_interface(DevScene sc, DevPaths P, c
         }
         uint32_t s = blockReserve(active, &ctr->extCount[nextIdx].v, lds);
         if (active) nextQueue[s] = p;
-    }
-}
-
-// Position, error bounds and normal of a hit on a surface without a material, for the rays that are not the path's own
-// (their sphere hits have no record from k_sphere_surface: worked out here).
-template <bool SPH>
-DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, F3 d, uint32_t path, F3* gp, F3* ge, F3* gn) {
-    if (isSpherePrim<SPH>(sc, h.tri)) {
-        F3 dpdu, wo;
-        sphereSurface(sc.spheres[h.tri - (int)sc.nTris], F3(h.b0, h.b1, h.b2), d, gp, ge, gn, &dpdu, &wo);
-    } else {
-        HitGeom g = hitGeometry(sc, tris, h.tri, h.b0, h.b1, h.b2, d, path);
-        *gp = g.p; *ge = g.pError; *gn = g.n;
     }
 }
 
