@@ -1006,6 +1006,27 @@ def test_cornell_512x512_16spp_against_the_oracle():
     r.close(); o.close()
 
 
+def test_many_lights_512x512_16spp_against_the_oracle():
+    """BASELINE configs[3] at its own size: 512 emissive triangles + 64 point lights, 512 x 512, 16 spp, the whole image
+    against the CPU restatement, for the two integrators the configuration compares (PathIntegrator with the power
+    distribution, DirectLightingIntegrator sampling one light) and for the reference's default light strategy (spatial)."""
+    sc = scenes.many_lights()
+    cam, film = scenes.cornell_camera(512, 512), scenes.film_desc(512, 512)
+    for integ in (scenes.integrator_desc(film, 16), scenes.direct_lighting_desc(film, 16, strategy=abi.DL_SAMPLE_ONE),
+                  scenes.integrator_desc(film, 16, light_strategy=abi.LIGHTS_SPATIAL)):
+        r = ra.Renderer(0).configure(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ)
+        r.render(0, 16); o.render(0, 16, threads=16)
+        a, b = r.image(), o.image()
+        assert np.array_equal(r.film()[..., 3], o.film_xyzw()[..., 3])
+        mre = common.mean_relative_error(a, b)
+        assert mre < 0.01 and mre < 1e-4, mre
+        gs, os_ = r.stats(), o.stats()
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):   # 576 lights: now and then the last bit of a cosine decides whether a sample faces its light
+            assert abs(int(gs[k]) - int(os_[k])) <= max(2, 5e-5 * os_[k]), (k, gs[k], os_[k])
+        r.close(); o.close()
+
+
 def test_full_size_big_mesh_1080p():
     """The >= 1 M triangle configuration at its full size (1,179,662 triangles, 1920x1080 sampler).  The whole
     film is checked through invariants; a 192x108 window of the same job (pixel bounds, full-size Sobol indices,
