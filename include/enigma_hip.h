@@ -116,12 +116,20 @@ typedef struct EnigmaLight {
 #define ENIGMA_TRI_REVERSE_ORIENTATION 8u /* m_reverseOrientation alone: flips the shading bitangent (:369) */
 
 /* HomogeneousMedium (Enigma/Medium.cpp:69-108) with its HenyeyGreenstein phase function
- * (Enigma/MediumInterface.cpp:159-200).  Read by the VolPathIntegrator only. */
+ * (Enigma/MediumInterface.cpp:159-200).  Read by the VolPathIntegrator only.
+ * kind ENIGMA_MEDIUM_GRID_DENSITY: the reference's GridDensityMedium (MakeMedium "heterogeneous", Enigma/Api.cpp:303-326)
+ * exactly as it stands: its Tr and Sample return a default-constructed Spectrum -- black -- without reading the density
+ * grid or drawing a sample (Enigma/Medium.cpp:51-59).  A path segment inside such a medium ends the path with nothing
+ * added (VolPathIntegrator::Li multiplies the throughput by Sample's value and stops on black,
+ * Enigma/VolPathIntegrator.cpp:68-71), and a shadow or MIS ray through it carries nothing (VisibilityTester::Tr,
+ * Scene::intersectTr).  The grid itself never reaches the boundary: nothing on this path reads it. */
+#define ENIGMA_MEDIUM_HOMOGENEOUS 0u
+#define ENIGMA_MEDIUM_GRID_DENSITY 1u
 typedef struct EnigmaMedium {
     float sigma_a[3];
     float sigma_s[3];
     float g;
-    uint32_t reserved;
+    uint32_t kind;
 } EnigmaMedium;
 
 /* tri_material value of a GeometricPrimitive without a material (MakeMaterial "" / "none", Enigma/Api.cpp:135):

@@ -2379,7 +2379,11 @@ static Spectrum Exp3(const Spectrum& s) { return Spectrum(std::exp(s.c[0]), std:
 static Spectrum Neg3(const Spectrum& s) { return Spectrum(-s.c[0], -s.c[1], -s.c[2]); }
 static Spectrum SigmaT(const EnigmaMedium& m) { return spec3(m.sigma_s) + spec3(m.sigma_a); } // m_sigma_t(sigma_s + sigma_a)
 // HomogeneousMedium::Tr (Medium.cpp:78-81)
-static Spectrum MediumTr(const EnigmaMedium& m, const Ray& ray) { return Exp3(Neg3(SigmaT(m)) * std::min(ray.tMax * Length(ray.d), MaxF32)); }
+// GridDensityMedium::Tr (Medium.cpp:51-54) returns a default-constructed Spectrum: black
+static Spectrum MediumTr(const EnigmaMedium& m, const Ray& ray) {
+    if (m.kind == ENIGMA_MEDIUM_GRID_DENSITY) return Spectrum(0.f);
+    return Exp3(Neg3(SigmaT(m)) * std::min(ray.tMax * Length(ray.d), MaxF32));
+}
 // PhaseHG (MediumInterface.cpp:196-200)
 static float PhaseHG(float cosTheta, float g) {
     const float INV_FOUR_PI = 1.0f / (PI * 4.0f);
@@ -2404,6 +2408,7 @@ static float HGSample_p(float g, const Vec3& wo, Vec3* wi, const Vec2& u) {
 struct MediumInteraction : Interaction { bool valid = false; float g = 0; };
 // HomogeneousMedium::Sample (Medium.cpp:83-108)
 static Spectrum MediumSample(const EnigmaMedium& m, int mediumIndex, const Ray& ray, SobolSampler& sampler, MediumInteraction* mi) {
+    if (m.kind == ENIGMA_MEDIUM_GRID_DENSITY) return Spectrum(0.f); // GridDensityMedium::Sample (Medium.cpp:56-59): black, no sample drawn, mi untouched
     Spectrum sigma_t = SigmaT(m), sigma_s = spec3(m.sigma_s);
     int channel = std::min((int)(sampler.Get1D() * 3), 3 - 1);
     float dist = -std::log(1 - sampler.Get1D()) / sigma_t.c[channel];

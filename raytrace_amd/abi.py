@@ -40,7 +40,7 @@ class EnigmaLight(C.Structure):
 
 
 class EnigmaMedium(C.Structure):
-    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("reserved", C.c_uint32)]
+    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("g", C.c_float), ("kind", C.c_uint32)]
 
 
 
@@ -244,11 +244,21 @@ def plastic(kd, ks, roughness=0.1, remap=True):
     return m
 
 
+MEDIUM_HOMOGENEOUS, MEDIUM_GRID_DENSITY = 0, 1
+
+
 def homogeneous_medium(sigma_a, sigma_s, g=0.0):
     m = EnigmaMedium()
     m.sigma_a[:] = sigma_a
     m.sigma_s[:] = sigma_s
     m.g = g
+    return m
+
+
+def grid_density_medium(sigma_a, sigma_s, g=0.0):
+    """The reference's GridDensityMedium as it stands: Tr and Sample return black (Enigma/Medium.cpp:51-59)."""
+    m = homogeneous_medium(sigma_a, sigma_s, g)
+    m.kind = MEDIUM_GRID_DENSITY
     return m
 
 

@@ -17,7 +17,7 @@ constexpr int kQueueKinds = MK_COUNT + 2;
 constexpr int kQueueMedium = MK_COUNT + 1;
 
 // HomogeneousMedium (Enigma/Medium.cpp:69-108): sigma_t = sigma_s + sigma_a, Henyey-Greenstein g
-struct DevMedium { float sigmaT[3]; float g; float sigmaS[3]; float pad; };
+struct DevMedium { float sigmaT[3]; float g; float sigmaS[3]; float opaque; }; // opaque != 0: the reference's GridDensityMedium, whose Tr and Sample return black (Enigma/Medium.cpp:51-59)
 
 struct DevMaterial {        // 64 bytes
     uint32_t kind;          // MatKind

@@ -648,7 +648,8 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
         for (size_t i = 0; i < md.size(); ++i) {
             const EnigmaMedium& m = s->media[i];
             for (int c = 0; c < 3; ++c) { md[i].sigmaT[c] = m.sigma_s[c] + m.sigma_a[c]; md[i].sigmaS[c] = m.sigma_s[c]; }
-            md[i].g = m.g; md[i].pad = 0.f;
+            if (m.kind > ENIGMA_MEDIUM_GRID_DENSITY) return h->fail(ENIGMA_E_INVALID, "medium %zu: kind %u is not a medium kind", i, m.kind);
+            md[i].g = m.g; md[i].opaque = m.kind == ENIGMA_MEDIUM_GRID_DENSITY ? 1.f : 0.f;
         }
         std::vector<uint32_t> tm(haveMedia ? std::max(1u, nSlots) + s->n_spheres : 0, 0u); // by primitive number on the device: slots, then spheres
         for (uint32_t i = 0; haveMedia && i < s->n_spheres; ++i) { // spheres follow the triangles; their ABI fields already hold index + 1

@@ -15,9 +15,9 @@
 //
 // Inside the subset: trianglemesh (with N, uv / st) and sphere shapes; matte, metal (default spectra: the reference's
 // copper), glass, plastic and "none" materials; constant and imagemap (PFM) textures; point, spot, distant, infinite
-// and diffuse area lights; homogeneous named media (with the measured presets) and medium interfaces; the path, directlighting and volpath
+// and diffuse area lights; named media (homogeneous with the measured presets; heterogeneous as the reference has them: black) and medium interfaces; the path, directlighting and volpath
 // integrators; the sobol sampler, the perspective camera, the image film with its five filters.  Outside it (other
-// shapes and texture classes, spectra other than rgb, object instancing, heterogeneous media, other samplers / cameras /
+// shapes and texture classes, spectra other than rgb, object instancing, other samplers / cameras /
 // lights / integrators) the front end throws std::runtime_error naming the directive; it never renders something
 // else silently.
 #pragma once
@@ -310,8 +310,7 @@ public:
     void pbrtMakeNamedMedium(const std::string& name, const ParamSet& p) {
         std::string type = p.FindOneString("type", "");
         if (type.empty()) throw std::runtime_error("No parameter string \"type\" found in MakeNamedMedium");
-        if (type == "heterogeneous") throw std::runtime_error("MakeNamedMedium \"heterogeneous\": the reference's GridDensityMedium is a stub (Tr and Sample return black); only \"homogeneous\" media are supported");
-        if (type != "homogeneous") throw std::runtime_error("Medium \"" + type + "\" unknown.");
+        if (type != "homogeneous" && type != "heterogeneous") throw std::runtime_error("Medium \"" + type + "\" unknown.");
         Spectrum sigA(.0011f, .0024f, .014f), sigS(2.55f, 3.21f, 3.77f);
         // GetMediumScatteringProperties (Enigma/MediumInterface.cpp:184-194): a measured medium by name; an unknown name keeps the defaults
         const std::string preset = p.FindOneString("preset", "");
@@ -329,6 +328,22 @@ public:
         EnigmaMedium m{};
         for (int c = 0; c < 3; ++c) { m.sigma_a[c] = sa[c] * scale; m.sigma_s[c] = ss[c] * scale; }
         m.g = p.FindOneFloat("g", 0.0f);
+        if (type == "heterogeneous") {
+            // GridDensityMedium (Enigma/Api.cpp:303-326, Enigma/Medium.cpp:16-64): the factory's checks are the reference's; the
+            // medium itself is the reference's too -- its Tr and Sample return black whatever the grid holds -- so the grid is
+            // read for those checks and goes no further
+            const std::vector<float> data = p.FindFloat("density");
+            const int nitems = (int)data.size();
+            if (data.empty()) throw std::runtime_error("No \"density\" values provided for heterogeneous medium?");
+            const int nx = p.FindOneInt("nx", 1), ny = p.FindOneInt("ny", 1), nz = p.FindOneInt("nz", 1);
+            (void)p.FindOnePoint3f("p0", Vector3f(0.f, 0.f, 0.f));
+            (void)p.FindOnePoint3f("p1", Vector3f(1.f, 1.f, 1.f));
+            if (nitems != nx * ny * nz)
+                throw std::runtime_error("GridDensityMedium has " + std::to_string(nitems) + " density values; expected nx*ny*nz = " + std::to_string(nx * ny * nz));
+            if (!(m.sigma_a[0] + m.sigma_s[0] == m.sigma_a[1] + m.sigma_s[1] && m.sigma_a[0] + m.sigma_s[0] == m.sigma_a[2] + m.sigma_s[2]))
+                Warn("GridDensityMedium requires a spectrally uniform attenuation coefficient!");
+            m.kind = ENIGMA_MEDIUM_GRID_DENSITY;
+        }
         m_namedMedia[name] = m_res->scene.AddMedium(m);
         NoteUnused("MakeNamedMedium", p);
     }

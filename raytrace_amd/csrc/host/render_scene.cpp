@@ -97,7 +97,7 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o << "],\n\"media\":[";
     for (size_t i = 0; i < R.scene.m_media.size(); ++i) {
         const EnigmaMedium& m = R.scene.m_media[i];
-        o << (i ? "," : "") << "{\"sigma_a\":"; arr(m.sigma_a, 3); o << ",\"sigma_s\":"; arr(m.sigma_s, 3); o << ",\"g\":"; arr(&m.g, 1); o << "}";
+        o << (i ? "," : "") << "{\"sigma_a\":"; arr(m.sigma_a, 3); o << ",\"sigma_s\":"; arr(m.sigma_s, 3); o << ",\"g\":"; arr(&m.g, 1); o << ",\"kind\":" << m.kind << "}";
     }
     o << "],\n\"lights\":[";
     for (size_t i = 0; i < R.scene.m_lights.size(); ++i) {

@@ -407,7 +407,12 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
     Hit h = w.h;
     if (sc.hitT) sc.hitT[p] = h.tri >= 0 ? h.t : EDEV_INF; // the primary-hit tap reads the walk's own distance; no render sets the pointer
     bool proceed = true; // VolPathIntegrator: false once the medium has ended the path or produced a medium interaction
-    if (VOL && stMedium(state) != 0) {
+    if (VOL && stMedium(state) != 0 && sc.media[stMedium(state) - 1u].opaque != 0.f) {
+        // GridDensityMedium::Sample returns black and draws nothing (Enigma/Medium.cpp:56-59): the throughput is black, the loop ends
+        float4 be = P.beta[p];
+        P.beta[p] = make_float4(0.f, 0.f, 0.f, be.w);
+        proceed = false;
+    } else if (VOL && stMedium(state) != 0) {
         const DevMedium md = sc.media[stMedium(state) - 1u];
         uint32_t px, py, slot;
         pathPixel(I, S, p, &px, &py, &slot);

@@ -35,6 +35,7 @@ DEV float hgSample(float g, F3 wo, F3* wi, float u0, float u1) {
 
 // HomogeneousMedium::Tr (Enigma/Medium.cpp:78-81) of a ray of direction d and parametric length tMax
 DEV F3 mediumTr(const DevMedium& m, F3 d, float tMax) {
+    if (m.opaque != 0.f) return F3(0.f); // GridDensityMedium::Tr, Enigma/Medium.cpp:51-54
     float s = smin(tMax * length(d), EDEV_MAXF);
     return F3(expf(-m.sigmaT[0] * s), expf(-m.sigmaT[1] * s), expf(-m.sigmaT[2] * s));
 }

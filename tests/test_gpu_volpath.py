@@ -2,6 +2,8 @@
 (Enigma/Medium.cpp:69-108) and the Henyey-Greenstein phase function, through the C ABI; the CPU oracle is the checker.
 Tolerances as for the other integrators: mean relative error < 1 % (north star), in practice ~1e-4: same samples, same
 arithmetic up to expf / logf / sinf / cosf and the order in which a contribution's factors are multiplied."""
+import os
+
 import numpy as np
 import pytest
 
@@ -123,6 +125,46 @@ def test_volpath_absorbing_slab_beer_lambert_on_the_gpu():
     r.close()
 
 
+def test_grid_density_medium_is_black_like_the_references_on_the_gpu():
+    """MakeMedium "heterogeneous" makes the reference's GridDensityMedium, whose Tr and Sample return black
+    (Enigma/Medium.cpp:51-59).  A slab of it before an emissive wall: black behind it, the wall beside it; then the Cornell
+    box in a fog of that kind, where paths end at their first segment in the medium and no light crosses it: images and ray
+    counts of library and oracle, the LDS build and the build for scenes in global memory."""
+    sc = _slab_scene((0.01, 0.01, 0.01), (0.0, 0.0, 0.0), thickness=4.0)
+    sc.media[0].kind = abi.MEDIUM_GRID_DENSITY
+    film = scenes.film_desc(32, 32)
+    wide = scenes.camera_desc((0, 0, -20), (0, 0, 0), (0, 1, 0), 120.0, 32, 32)       # the slab in the middle, the wall around it
+    integ = scenes.volpath_desc(film, 16, max_depth=3)
+    r = ra.Renderer(0).configure(sc, wide, film, integ); o = orc.Oracle(sc, wide, film, integ)
+    r.render(0, 16); o.render(0, 16, threads=4)
+    a, b = r.image(), o.image()
+    assert np.all(a[14:18, 14:18] == 0) and a[0, 0].sum() > 0
+    assert common.mean_relative_error(a, b) < 1e-5
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert r.stats()[k] == o.stats()[k], k
+    r.close(); o.close()
+    for no_lds in (False, True):
+        fog = scenes.cornell_fog("microfacet")
+        for m in fog.media[:fog.n_media]:
+            m.kind = abi.MEDIUM_GRID_DENSITY
+        cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+        integ = scenes.volpath_desc(film, 16)
+        if no_lds:
+            os.environ["ENIGMA_NO_LDS_SCENE"] = "1"
+        try:
+            r = ra.Renderer(0).configure(fog, cam, film, integ)
+            r.render(0, 8)
+        finally:
+            os.environ.pop("ENIGMA_NO_LDS_SCENE", None)
+        o = orc.Oracle(fog, cam, film, integ)
+        o.render(0, 8, threads=8)
+        assert r.stats()["scene_in_lds"] == (0 if no_lds else 1)
+        assert common.mean_relative_error(r.image(), o.image()) < 1e-4
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(r.stats()[k] - o.stats()[k]) <= 2, (k, r.stats()[k], o.stats()[k])
+        r.close(); o.close()
+
+
 def test_volpath_delta_lights_through_fog_and_sample_ranges_add_up():
     """Spot and distant lights seen through the fog (VisibilityTester::Tr towards a point / a far point)."""
     base = scenes.cornell_fog("diffuse")
@@ -173,9 +215,9 @@ def test_volpath_full_size_1080p_invariants_and_window():
 
 
 def test_volpath_textured_big_mesh_in_fog_full_size_1080p():
-    """The defined part of BASELINE configs[4] at its full size: the 1.18 M-triangle mesh with uvs and trilinear image
+    """The useful part of BASELINE configs[4] at its full size: the 1.18 M-triangle mesh with uvs and trilinear image
     textures inside a homogeneous medium, VolPathIntegrator, 1920 x 1080, 512-spp sampler (the reference's heterogeneous
-    medium is a stub, Enigma/Medium.cpp:51-64: nothing to match there).  Film invariants over the whole film, additivity
+    medium returns black from both of its methods, Enigma/Medium.cpp:51-64; the test after this one covers it).  Film invariants over the whole film, additivity
     of sample ranges, a window of the same job against the oracle pixel by pixel, ray counts, and the window's primary
     hits out of the closest-hit kernel that renders."""
     sc = scenes.big_mesh_fog()
@@ -216,4 +258,30 @@ def test_volpath_textured_big_mesh_in_fog_full_size_1080p():
     # tier 1 on the kernel that renders (the VolPathIntegrator's build of it)
     import test_gpu_parity
     test_gpu_parity._primary_tap_check(r, o, (600, 600, 792, 708), (0, 511))
+    r.close(); o.close()
+
+
+def test_volpath_big_mesh_in_the_references_heterogeneous_medium_1080p_window():
+    """BASELINE configs[4] as it is worded -- a heterogeneous medium -- and as the reference defines such a medium: its
+    GridDensityMedium returns black from Tr and Sample (Enigma/Medium.cpp:51-59).  The textured 1.18 M-triangle mesh with its
+    fog box filled by that medium, 1080p, 512-spp sampler: a window of the job against the oracle, ray for ray.  Paths end at
+    their first segment inside the box, so only what the camera sees before the box, and nothing lit through it, remains."""
+    sc = scenes.big_mesh_fog()
+    for m in sc.media[:sc.n_media]:
+        m.kind = abi.MEDIUM_GRID_DENSITY
+    cam = scenes.big_mesh_camera(1920, 1080)
+    film = scenes.film_desc(1920, 1080)
+    integ = scenes.volpath_desc(film, 512)
+    integ.pixel_bounds[:] = [600, 600, 792, 708]
+    r = ra.Renderer(0).configure(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ)
+    r.render(510, 512); o.render(510, 512, threads=16)
+    win = (slice(600, 708), slice(600, 792))
+    a, b = r.image()[win], o.image()[win]
+    assert np.array_equal(r.film()[..., 3], o.film_xyzw()[..., 3])
+    assert np.isfinite(a).all() and np.allclose(a, b, rtol=1e-4, atol=1e-6)
+    sg, so = r.stats(), o.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(sg[k]) - int(so[k])) <= 2e-3 * so[k] + 2, (k, sg[k], so[k])
+    assert sg["rays_closest"] <= 2.1 * sg["camera_samples"]     # the box's face, then one segment inside: the path is over
     r.close(); o.close()

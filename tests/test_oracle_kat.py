@@ -409,6 +409,27 @@ def test_volpath_absorbing_slab_follows_beer_lambert():
     q.close()
 
 
+def test_grid_density_medium_is_black_like_the_references():
+    """The reference's GridDensityMedium::Tr and ::Sample return a default-constructed Spectrum (Enigma/Medium.cpp:51-59):
+    whatever its coefficients and its grid, a path segment inside it ends the path with nothing added, and light that would
+    have to cross it does not arrive.  Behind a slab of it the emissive wall is black, beside the slab it shines."""
+    sc = _slab_scene((0.01, 0.01, 0.01), (0.0, 0.0, 0.0), thickness=4.0)
+    sc.media[0].kind = abi.MEDIUM_GRID_DENSITY
+    film = scenes.film_desc(8, 8)
+    narrow = scenes.camera_desc((0, 0, -20), (0, 0, 0), (0, 1, 0), 4.0, 8, 8)      # every ray crosses the slab
+    o = orc.Oracle(sc, narrow, film, scenes.volpath_desc(film, 16, max_depth=3))
+    o.render(0, 16, threads=2)
+    img, s = o.image(), o.stats()
+    o.close()
+    assert np.all(img == 0)
+    assert s["rays_closest"] == 2 * s["samples"]      # the slab's face, then the segment inside it: Sample returns black, the loop ends
+    # the PathIntegrator knows nothing of media: the slab's faces are passed, the wall is seen
+    p = orc.Oracle(sc, narrow, film, scenes.integrator_desc(film, 4, max_depth=3))
+    p.render(0, 4, threads=1)
+    assert np.allclose(p.image().astype(np.float64).mean(axis=(0, 1)), [1.0, 2.0, 3.0], rtol=1e-5)
+    p.close()
+
+
 def test_volpath_scattering_slab_conserves_energy_inside_a_furnace():
     """Albedo 1 inside a uniformly emitting closed box: whatever the scattering does, every path ends on a wall of
     radiance 1, so the estimate is 1 up to the depth cut-off."""

@@ -286,14 +286,33 @@ def test_media_medium_interfaces_and_the_volpath_integrator(tmp_path):
         tri_mat += [m["material"]] * n; tri_in += [m["medium_inside"]] * n; tri_out += [m["medium_outside"]] * n
     assert tri_in == list(sc.tri_medium_inside) and tri_out == list(sc.tri_medium_outside)
     assert [(-1 if int(x) == abi.NO_MATERIAL else int(x)) for x in sc.tri_material] == tri_mat
-    # a medium named before it is made, a heterogeneous medium: reported, not guessed
+    # a medium named before it is made, a heterogeneous medium without its grid or with a grid of the wrong size: reported, not guessed
     head = 'Camera "perspective"\nFilm "image" "integer xresolution" 4 "integer yresolution" 4\nSampler "sobol"\nWorldBegin\n'
     for body, msg in (('MediumInterface "fog" ""\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "undefined"),
-                      ('MakeNamedMedium "a" "string type" "heterogeneous" "float density" [1]\nWorldEnd\n', "stub")):
+                      ('MakeNamedMedium "a" "string type" "heterogeneous"\nWorldEnd\n', "No \"density\" values"),
+                      ('MakeNamedMedium "a" "string type" "heterogeneous" "float density" [1 2 3] "integer nx" 2\nWorldEnd\n', "expected nx*ny*nz = 2"),
+                      ('MakeNamedMedium "a" "string type" "foam"\nWorldEnd\n', "unknown")):
         f = tmp_path / "bad.pbrt"
         f.write_text(head + body)
         p = subprocess.run([EXE, "--dump", str(f), str(tmp_path / "bad.json")], capture_output=True, text=True)
         assert p.returncode != 0 and msg in p.stderr
+
+
+def test_heterogeneous_medium_is_the_references_grid_density_medium(tmp_path):
+    """MakeNamedMedium "heterogeneous" (Enigma/Api.cpp:303-326) makes the reference's GridDensityMedium, whose Tr and Sample
+    return black (Enigma/Medium.cpp:51-59): the front end runs the factory's checks and hands the medium on as that kind."""
+    f = tmp_path / "grid.pbrt"
+    f.write_text('Camera "perspective"\nFilm "image" "integer xresolution" 4 "integer yresolution" 4\nSampler "sobol"\nWorldBegin\n'
+                 'MakeNamedMedium "smoke" "string type" "heterogeneous" "rgb sigma_a" [1 1 1] "rgb sigma_s" [2 2 2] "float g" 0.3 "float scale" 2 '
+                 '"integer nx" 2 "integer ny" 2 "integer nz" 1 "float density" [0.1 0.2 0.3 0.4] "point p0" [0 0 0] "point p1" [1 2 3]\n'
+                 'MakeNamedMedium "fog" "string type" "homogeneous"\n'
+                 'MediumInterface "smoke" ""\nMaterial ""\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "integer indices" [0 1 2]\nWorldEnd\n')
+    out = tmp_path / "grid.json"
+    p = subprocess.run([EXE, "--dump", str(f), str(out)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    media = json.loads(out.read_text())["media"]
+    assert [m["kind"] for m in media] == [abi.MEDIUM_GRID_DENSITY, abi.MEDIUM_HOMOGENEOUS]
+    assert media[0]["sigma_a"] == [2.0, 2.0, 2.0] and media[0]["sigma_s"] == [4.0, 4.0, 4.0] and abs(media[0]["g"][0] - 0.3) < 1e-7
 
 
 def _presets():
