@@ -35,27 +35,41 @@ extern "C" {
 #define ENIGMA_E_UNSUPPORTED (-4) /* feature of the reference that is out of scope */
 
 /* Material kinds: Enigma/Material.cpp:76-93 (matte), :115-136 (metal),
- * :176-220 (glass), :232-255 (plastic).  Parameters are the values the
+ * :176-220 (glass), :232-255 (plastic), :318-328 (mirror), :276-309 (translucent),
+ * :424-448 (substrate), :536-592 (uber), :146-163 (mix).  Parameters are the values the
  * reference's ConstantTexture::Evaluate would return (Enigma/Texture.h:119-131). */
-enum { ENIGMA_MAT_MATTE = 0, ENIGMA_MAT_METAL = 1, ENIGMA_MAT_GLASS = 2, ENIGMA_MAT_PLASTIC = 3 };
+enum { ENIGMA_MAT_MATTE = 0, ENIGMA_MAT_METAL = 1, ENIGMA_MAT_GLASS = 2, ENIGMA_MAT_PLASTIC = 3,
+       ENIGMA_MAT_MIRROR = 4, ENIGMA_MAT_TRANSLUCENT = 5, ENIGMA_MAT_SUBSTRATE = 6, ENIGMA_MAT_UBER = 7,
+       ENIGMA_MAT_MIX = 8 };
 
 typedef struct EnigmaMaterial {
     uint32_t type;            /* ENIGMA_MAT_* */
     uint32_t remap_roughness; /* remaproughness flag (metal / glass / plastic) */
-    float kd[3];              /* matte, plastic: Kd */
-    float ks[3];              /* plastic: Ks */
-    float kr[3];              /* glass: Kr */
-    float kt[3];              /* glass: Kt */
+    float kd[3];              /* matte, plastic, translucent, substrate, uber: Kd */
+    float ks[3];              /* plastic, translucent, substrate, uber: Ks */
+    float kr[3];              /* glass, mirror, uber: Kr */
+    float kt[3];              /* glass, uber: Kt */
     float eta[3];             /* metal: eta (RGB) */
     float k[3];               /* metal: k (RGB) */
     float sigma;              /* matte: sigma in degrees, clamped to [0, 90]; 0 = LambertianReflection, else OrenNayer
                                  (Enigma/Material.cpp:86-91) */
-    float uroughness;         /* metal / glass: u roughness; plastic: roughness */
-    float vroughness;         /* metal / glass: v roughness; plastic: roughness */
-    float index;              /* glass: index of refraction */
+    float uroughness;         /* metal / glass / substrate: u roughness; plastic / translucent: roughness; uber: "uroughness" if
+                                 the scene gives it, else "roughness" (Enigma/Material.cpp:563-566) */
+    float vroughness;         /* metal / glass / substrate: v roughness; plastic / translucent: roughness; uber: "vroughness" if
+                                 the scene gives it, else the u value (Enigma/Material.cpp:567-570) */
+    float index;              /* glass: index of refraction; uber: "eta", else "index" (Enigma/Material.cpp:729-731) */
     /* Image textures bound to the spectrum parameters: index + 1 into EnigmaSceneDesc.textures, 0 = the constant
      * above (a ConstantTexture, Enigma/Texture.h:119-131).  The float parameters stay constants. */
     uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_eta, tex_k;
+    /* Parameters of the mirror, translucent, substrate, uber and mix materials.  These five take constants only (a
+     * texture bound to one of them: ENIGMA_E_UNSUPPORTED), and so do the materials a mix names. */
+    float reflect[3];         /* translucent: reflect */
+    float transmit[3];        /* translucent: transmit */
+    float opacity[3];         /* uber: opacity */
+    float amount[3];          /* mix: amount (the weight of the first material; the second gets 1 - amount, both clamped) */
+    uint32_t mix_a, mix_b;    /* mix: "namedmaterial1" / "namedmaterial2" as indices into the array this material is in;
+                                 both must be lower than this material's own index (a named material exists before it is
+                                 used, Enigma/Api.cpp:157-173) */
 } EnigmaMaterial;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (Enigma/Texture.h:313-415, Enigma/Texture.cpp:22-29,412-453).
@@ -400,6 +414,12 @@ int enigma_debug_intersect_noalloc(EnigmaCtx* h, uint32_t n, const float* rays7,
  * (wo, wi, u): out12 = f.rgb, Pdf, sampled f.rgb, sampled pdf, sampled wi.xyz, sampled BxDFType as a float. */
 int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, uint32_t n, const float* wo3, const float* wi3,
                       const float* u2, float* out12);
+/* The same for material `which` of an array of n_materials (a mix names other entries of its array), with
+ * allowMultipleLobes = multiple_lobes != 0: the PathIntegrator and VolPathIntegrator pass true, the
+ * DirectLightingIntegrator false, which turns smooth glass into two specular lobes (Enigma/Material.cpp:191-218). */
+int enigma_debug_bsdf_of(EnigmaCtx* h, const EnigmaMaterial* materials, uint32_t n_materials, uint32_t which,
+                         uint32_t multiple_lobes, uint32_t n, const float* wo3, const float* wi3, const float* u2,
+                         float* out12);
 /* FilmTile::AddSample footprint (Enigma/Film.cpp:269-292) for n film positions:
  * up to max_per (pixel x, pixel y) pairs and filter weights each, count in counts. */
 int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per,

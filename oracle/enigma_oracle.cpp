@@ -27,6 +27,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 #include <string>
@@ -1374,6 +1375,67 @@ struct MicrofacetTransmission : BxDF { // BxDF.cpp:1007-1073 (TransportMode::Rad
     }
 };
 
+struct LambertianTransmission : BxDF { // BxDF.cpp:1160-1190
+    Spectrum T;
+    explicit LambertianTransmission(const Spectrum& t) : BxDF(BSDF_TRANSMISSION | BSDF_DIFFUSE), T(t) {}
+    Spectrum f(const Vec3&, const Vec3&) const override { return T * INV_PI; }
+    Spectrum sample_f(const Vec3& wo, Vec3* wi, const Vec2& u, float* pdfOut, int*) const override {
+        *wi = CosineSampleHemisphere(u);
+        if (wo.z > 0) wi->z *= -1;
+        *pdfOut = pdf(wo, *wi);
+        return f(wo, *wi);
+    }
+    float pdf(const Vec3& wo, const Vec3& wi) const override { return !SameHemisphere(wo, wi) ? AbsCosTheta(wi) * INV_PI : 0; }
+};
+struct FresnelNoOp : Fresnel { Spectrum evaluate(float) const override { return Spectrum(1.f); } }; // BxDF.h:216-220
+struct FresnelBlend : BxDF { // BxDF.cpp:781-839
+    Spectrum Rd, Rs; const TrowbridgeReitzDistribution* distribution;
+    FresnelBlend(const Spectrum& d, const Spectrum& sp, const TrowbridgeReitzDistribution* dist)
+        : BxDF(BSDF_REFLECTION | BSDF_GLOSSY), Rd(d), Rs(sp), distribution(dist) {}
+    static float pow5(float v) { return (v * v) * (v * v) * v; }
+    Spectrum SchlickFresnel(float cosTheta) const { return Rs + pow5(1 - cosTheta) * (Spectrum(1.) - Rs); }
+    Spectrum f(const Vec3& wo, const Vec3& wi) const override {
+        Spectrum diffuse = (28.f / (23.f * PI)) * Rd * (Spectrum(1.f) - Rs) * (1 - pow5(1 - .5f * AbsCosTheta(wi))) * (1 - pow5(1 - .5f * AbsCosTheta(wo)));
+        Vec3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spectrum(0);
+        wh = Normalize(wh);
+        Spectrum specular = distribution->D(wh) / (4 * AbsDot(wi, wh) * std::max(AbsCosTheta(wi), AbsCosTheta(wo))) * SchlickFresnel(Dot(wi, wh));
+        return diffuse + specular;
+    }
+    Spectrum sample_f(const Vec3& wo, Vec3* wi, const Vec2& uOrig, float* pdfOut, int*) const override {
+        Vec2 u = uOrig;
+        if (u[0] < .5) {
+            u[0] = std::min(2 * u[0], OneMinusEpsilon);
+            *wi = CosineSampleHemisphere(u);
+            if (wo.z < 0) wi->z *= -1;
+        } else {
+            u[0] = std::min(2 * (u[0] - .5f), OneMinusEpsilon);
+            Vec3 wh = distribution->Sample_wh(wo, u);
+            *wi = Reflect(wo, wh);
+            if (!SameHemisphere(wo, *wi)) return Spectrum(0.f);
+        }
+        *pdfOut = pdf(wo, *wi);
+        return f(wo, *wi);
+    }
+    float pdf(const Vec3& wo, const Vec3& wi) const override {
+        if (!SameHemisphere(wo, wi)) return 0;
+        Vec3 wh = Normalize(wo + wi);
+        float pdf_wh = distribution->Pdf(wo, wh);
+        return .5f * (AbsCosTheta(wi) * INV_PI + pdf_wh / (4 * Dot(wo, wh)));
+    }
+};
+// BxDF.cpp:610-635, BxDF.h:157-170.  The class does not override pdf(): a scaled lobe answers BSDF::Pdf and the pdf sums
+// of BSDF::sample_f with the base class's cosine-hemisphere density whatever it wraps; its own samples carry the wrapped
+// lobe's density, which sample_f passes through.
+struct ScaledBxDF : BxDF {
+    std::unique_ptr<BxDF> bxdf; Spectrum scale;
+    ScaledBxDF(BxDF* b, const Spectrum& sc) : BxDF(b->type), bxdf(b), scale(sc) {}
+    Spectrum f(const Vec3& wo, const Vec3& wi) const override { return scale * bxdf->f(wo, wi); }
+    Spectrum sample_f(const Vec3& wo, Vec3* wi, const Vec2& u, float* pdfOut, int* sampledType) const override {
+        return scale * bxdf->sample_f(wo, wi, u, pdfOut, sampledType);
+    }
+};
+
 // BxDF.cpp:843-985
 struct BSDF {
     static const int MAX_BxDFS = 8;
@@ -1381,7 +1443,11 @@ struct BSDF {
     Vec3 ng, ns, ss, ts;
     int nBxDFs = 0;
     BxDF* bxdfs[MAX_BxDFS];
-    std::unique_ptr<TrowbridgeReitzDistribution> distrib; // arena stand-in
+    struct DistribSlot { // arena stand-in: the distribution the material made last; a mix keeps those of both its materials
+        std::vector<std::unique_ptr<TrowbridgeReitzDistribution>> all;
+        void reset(TrowbridgeReitzDistribution* d) { all.emplace_back(d); }
+        const TrowbridgeReitzDistribution* get() const { return all.back().get(); }
+    } distrib;
     BSDF(const SurfaceInteraction& si, float e = 1.0f)
         : eta(e), ng(si.n), ns(si.shading.n), ss(Normalize(si.shading.dpdu)), ts(Cross(ns, ss)) {}
     ~BSDF() { for (int i = 0; i < nBxDFs; ++i) delete bxdfs[i]; }
@@ -1452,9 +1518,15 @@ struct ParamEval {
     Spectrum operator()(const float v[3], uint32_t tex) const { return tex && ts ? EvaluateImageTexture(*ts, tex - 1, si) : Spectrum(v[0], v[1], v[2]); }
 };
 // SurfaceInteraction::ComputeScatteringFunctions (Interaction.cpp:152-159): differentials first, then the material
-static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes, const Ray& ray, const TextureSet* ts) {
+// table: the array m is an element of (a mix names two other elements)
+static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes, const TextureSet* ts);
+static BSDF* ComputeScatteringFunctions(const EnigmaMaterial* table, const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes, const Ray& ray, const TextureSet* ts) {
     si.ComputeDifferentials(ray);
+    return MaterialScatteringFunctions(table, m, si, allowMultipleLobes, ts);
+}
+static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const EnigmaMaterial& m, const SurfaceInteraction& si, bool allowMultipleLobes, const TextureSet* ts) {
     ParamEval spec3{ts, si};
+    auto remap = [&](float r) { return m.remap_roughness ? TrowbridgeReitzDistribution::RoughnessToAlpha(r) : r; };
     switch (m.type) {
     case ENIGMA_MAT_MATTE: {
         BSDF* bsdf = new BSDF(si);
@@ -1516,6 +1588,73 @@ static BSDF* ComputeScatteringFunctions(const EnigmaMaterial& m, const SurfaceIn
             bsdf->distrib.reset(new TrowbridgeReitzDistribution(rough, rough));
             bsdf->addBxDF(new MicrofacetReflection(ks, bsdf->distrib.get(), fresnel));
         }
+        return bsdf;
+    }
+    case ENIGMA_MAT_MIRROR: { // Material.cpp:318-328
+        BSDF* bsdf = new BSDF(si);
+        Spectrum R = spec3(m.kr, 0).Clamp();
+        if (!R.IsBlack()) bsdf->addBxDF(new SpecularReflection(R, new FresnelNoOp()));
+        return bsdf;
+    }
+    case ENIGMA_MAT_TRANSLUCENT: { // Material.cpp:276-309
+        float eta = 1.5f;
+        BSDF* bsdf = new BSDF(si, eta);
+        Spectrum r = spec3(m.reflect, 0).Clamp(), t = spec3(m.transmit, 0).Clamp();
+        if (r.IsBlack() && t.IsBlack()) return bsdf;
+        Spectrum kd = spec3(m.kd, 0).Clamp();
+        if (!kd.IsBlack()) {
+            if (!r.IsBlack()) bsdf->addBxDF(new LambertianReflection(r * kd));
+            if (!t.IsBlack()) bsdf->addBxDF(new LambertianTransmission(t * kd));
+        }
+        Spectrum ks = spec3(m.ks, 0).Clamp();
+        if (!ks.IsBlack() && (!r.IsBlack() || !t.IsBlack())) {
+            float rough = remap(m.uroughness);
+            bsdf->distrib.reset(new TrowbridgeReitzDistribution(rough, rough));
+            if (!r.IsBlack()) bsdf->addBxDF(new MicrofacetReflection(r * ks, bsdf->distrib.get(), new FresnelDielectric(1.f, eta)));
+            if (!t.IsBlack()) bsdf->addBxDF(new MicrofacetTransmission(t * ks, bsdf->distrib.get(), 1.f, eta));
+        }
+        return bsdf;
+    }
+    case ENIGMA_MAT_SUBSTRATE: { // Material.cpp:424-448
+        BSDF* bsdf = new BSDF(si);
+        Spectrum d = spec3(m.kd, 0).Clamp(), sp = spec3(m.ks, 0).Clamp();
+        if (!d.IsBlack() || !sp.IsBlack()) {
+            bsdf->distrib.reset(new TrowbridgeReitzDistribution(remap(m.uroughness), remap(m.vroughness)));
+            bsdf->addBxDF(new FresnelBlend(d, sp, bsdf->distrib.get()));
+        }
+        return bsdf;
+    }
+    case ENIGMA_MAT_UBER: { // Material.cpp:536-592
+        float e = m.index;
+        Spectrum op = spec3(m.opacity, 0).Clamp();
+        Spectrum t = (Spectrum(1.f) - op).Clamp(); // (-op + Spectrum(1.f)).Clamp()
+        BSDF* bsdf;
+        if (!t.IsBlack()) {
+            bsdf = new BSDF(si, 1.f);
+            bsdf->addBxDF(new SpecularTransmission(t, 1.f, 1.f));
+        } else bsdf = new BSDF(si, e);
+        Spectrum kd = op * spec3(m.kd, 0).Clamp();
+        if (!kd.IsBlack()) bsdf->addBxDF(new LambertianReflection(kd));
+        Spectrum ks = op * spec3(m.ks, 0).Clamp();
+        if (!ks.IsBlack()) {
+            bsdf->distrib.reset(new TrowbridgeReitzDistribution(remap(m.uroughness), remap(m.vroughness)));
+            bsdf->addBxDF(new MicrofacetReflection(ks, bsdf->distrib.get(), new FresnelDielectric(1.f, e)));
+        }
+        Spectrum kr = op * spec3(m.kr, 0).Clamp();
+        if (!kr.IsBlack()) bsdf->addBxDF(new SpecularReflection(kr, new FresnelDielectric(1.f, e)));
+        Spectrum kt = op * spec3(m.kt, 0).Clamp();
+        if (!kt.IsBlack()) bsdf->addBxDF(new SpecularTransmission(kt, 1.f, e));
+        return bsdf;
+    }
+    case ENIGMA_MAT_MIX: { // Material.cpp:146-163: the first material's BSDF with its lobes scaled, then the second's lobes scaled
+        Spectrum s1 = spec3(m.amount, 0).Clamp();
+        Spectrum s2 = (Spectrum(1.f) - s1).Clamp();
+        BSDF* bsdf = MaterialScatteringFunctions(table, table[m.mix_a], si, allowMultipleLobes, ts);
+        std::unique_ptr<BSDF> second(MaterialScatteringFunctions(table, table[m.mix_b], si, allowMultipleLobes, ts));
+        for (int i = 0; i < bsdf->nBxDFs; ++i) bsdf->bxdfs[i] = new ScaledBxDF(bsdf->bxdfs[i], s1);
+        for (int i = 0; i < second->nBxDFs; ++i) bsdf->addBxDF(new ScaledBxDF(second->bxdfs[i], s2));
+        second->nBxDFs = 0; // its lobes and distributions now belong to the first
+        for (auto& d : second->distrib.all) bsdf->distrib.all.push_back(std::move(d));
         return bsdf;
     }
     }
@@ -2338,7 +2477,7 @@ struct PathIntegrator {
                 bounces--;
                 continue;
             }
-            std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
+            std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials.data(), scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
             const Distribution1D* distrib = Lookup(isect.p); // PathIntegrator.cpp:95
             if (bsdf->numComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                 Spectrum Ld = beta * UniformSampleOneLight(isect, *bsdf, scene, sampler, distrib);
@@ -2582,7 +2721,7 @@ struct VolPathIntegrator {
                     bounces--;
                     continue;
                 }
-                std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
+                std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials.data(), scene.materials[scene.triMaterial[isect.primIndex]], isect, true, ray, &scene.textures));
                 L += beta * UniformSampleOneLightVol(isect, isect.shading.n, bsdf.get(), 0.f, scene, sampler, Lookup(isect.p));
                 Vec3 wo = -ray.d, wi;
                 float pdf = 0;
@@ -2658,7 +2797,7 @@ struct DirectLightingIntegrator {
         // a surface without a material has no BSDF: the ray goes on behind it at the same depth (DirectLightingIntegrator.cpp:51-54)
         if (scene.triMaterial[isect.primIndex] == ENIGMA_NO_MATERIAL) return Li(isect.SpawnRay(ray.d), scene, sampler, depth);
         // allowMultipleLobes defaults to false here (Interaction.h:68): smooth glass = two specular lobes
-        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials[scene.triMaterial[isect.primIndex]], isect, false, ray, &scene.textures));
+        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(scene.materials.data(), scene.materials[scene.triMaterial[isect.primIndex]], isect, false, ray, &scene.textures));
         Vec3 wo = isect.wo;
         L += Le(scene, isect, wo);
         if (scene.lights.size() > 0) {
@@ -2840,6 +2979,8 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
     for (auto& m : sc.materials) {
         for (uint32_t t : {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_eta, m.tex_k})
             if (t > s->n_textures) { h->o.error = "texture index out of range"; return -1; }
+        const size_t self = (size_t)(&m - sc.materials.data());
+        if (m.type == ENIGMA_MAT_MIX && (m.mix_a >= self || m.mix_b >= self)) { h->o.error = "a mix names materials that come before it"; return -1; }
     }
     // ImageTexture::getTexture (Texture.h:331-372): flip in y, ConvertIn = pow(texel * scale, gamma), MipMap
     sc.textures.tex.clear(); sc.textures.tex.resize(s->n_textures);
@@ -2999,7 +3140,18 @@ int oracle_render(OracleCtx* h, int64_t sample_begin, int64_t sample_end, int n_
     if (h->o.useDirect) { // SpecularReflect / SpecularTransmit carry ray differentials on (Integrator.cpp:329-444): not restated
         bool trilinear = false, smoothGlass = false;
         for (const ImageTex& t : h->o.scene.textures.tex) trilinear = trilinear || t.mip.doTrilinear;
-        for (const EnigmaMaterial& m : h->o.scene.materials) smoothGlass = smoothGlass || (m.type == ENIGMA_MAT_GLASS && m.uroughness == 0 && m.vroughness == 0);
+        const std::vector<EnigmaMaterial>& mats = h->o.scene.materials;
+        std::function<bool(const EnigmaMaterial&)> specular = [&](const EnigmaMaterial& m) { // the material can make a specular lobe
+            auto lit = [](const float c[3]) { return c[0] > 0 || c[1] > 0 || c[2] > 0; };
+            switch (m.type) {
+            case ENIGMA_MAT_GLASS: return m.uroughness == 0 && m.vroughness == 0;
+            case ENIGMA_MAT_MIRROR: return lit(m.kr);
+            case ENIGMA_MAT_UBER: return lit(m.kr) || lit(m.kt) || !(m.opacity[0] >= 1 && m.opacity[1] >= 1 && m.opacity[2] >= 1);
+            case ENIGMA_MAT_MIX: return specular(mats[m.mix_a]) || specular(mats[m.mix_b]);
+            default: return false;
+            }
+        };
+        for (const EnigmaMaterial& m : mats) smoothGlass = smoothGlass || specular(m);
         if (trilinear && smoothGlass) { h->o.error = "trilinear textures with specular recursion of the DirectLightingIntegrator are not restated"; return -4; }
     }
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency(); // NumSystemCores, Misc.h:8-14
@@ -3124,11 +3276,22 @@ int oracle_debug_film_footprint(OracleCtx* h, uint32_t n, const float* pfilm, ui
 
 // BxDF point evaluation tap: evaluates BSDF::f, BSDF::Pdf and BSDF::sample_f of the material on a
 // canonical surface (n = +z, dpdu = +x) for n (wo, wi, u) triples.  out: f(3) pdf(1) | sampled f(3) pdf(1) wi(3) type(1)
+int oracle_debug_bsdf_of(const EnigmaMaterial* table, uint32_t nMaterials, uint32_t which, uint32_t multipleLobes, uint32_t n, const float* wo3,
+                         const float* wi3, const float* u2, float* out12);
 int oracle_debug_bsdf(const EnigmaMaterial* m, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
+    if (m->type == ENIGMA_MAT_MIX) return -1; // a mix needs the array it lives in
+    return oracle_debug_bsdf_of(m, 1, 0, 1, n, wo3, wi3, u2, out12);
+}
+int oracle_debug_bsdf_of(const EnigmaMaterial* table, uint32_t nMaterials, uint32_t which, uint32_t multipleLobes, uint32_t n, const float* wo3,
+                         const float* wi3, const float* u2, float* out12) {
+    if (which >= nMaterials) return -1;
+    for (uint32_t k = 0; k <= which; ++k)
+        if (table[k].type == ENIGMA_MAT_MIX && (table[k].mix_a >= k || table[k].mix_b >= k)) return -1;
+    const EnigmaMaterial* m = &table[which];
     SurfaceInteraction si;
     si.n = si.shading.n = Vec3(0, 0, 1); si.dpdu = si.shading.dpdu = Vec3(1, 0, 0); si.dpdv = si.shading.dpdv = Vec3(0, 1, 0);
     for (uint32_t i = 0; i < n; ++i) {
-        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(*m, si, true, Ray(), nullptr));
+        std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(table, *m, si, multipleLobes != 0, Ray(), nullptr));
         Vec3 wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
         float* o = &out12[12 * (size_t)i];
         Spectrum f = bsdf->f(wo, wi, BSDF_ALL);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
     "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
-    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_primary_hits", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_default_metal_spectra",
+    "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_primary_hits", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_debug_bsdf_of", "enigma_default_metal_spectra",
     "enigma_comm_unique_id", "enigma_comm_init", "enigma_comm_info", "enigma_film_reduce", "enigma_comm_destroy",
 ]
 
@@ -59,6 +59,7 @@ def load_library():
         L.enigma_debug_intersect_any.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.enigma_debug_primary_hits.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_bsdf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.enigma_debug_bsdf_of.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.enigma_debug_film_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -232,6 +233,17 @@ class Renderer:
         u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((wo.shape[0], 12), dtype=np.float32)
         self._chk(self.L.enigma_debug_bsdf(self.h, C.byref(material), wo.shape[0], abi.ptr(wo), abi.ptr(wi), abi.ptr(u), abi.ptr(out)))
+        return out
+
+    def bsdf_eval_of(self, materials, which, wo, wi, u, multiple_lobes=True):
+        """bsdf_eval for entry `which` of a list of materials (a mix names other entries), with allowMultipleLobes as given."""
+        wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+        wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((wo.shape[0], 12), dtype=np.float32)
+        table = (abi.EnigmaMaterial * len(materials))(*materials)
+        self._chk(self.L.enigma_debug_bsdf_of(self.h, table, len(materials), which, int(bool(multiple_lobes)), wo.shape[0], abi.ptr(wo), abi.ptr(wi),
+                                              abi.ptr(u), abi.ptr(out)))
         return out
 
     def film_footprint(self, pfilm, max_per=64):

@@ -4,6 +4,7 @@ import ctypes as C
 import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
+MAT_MIRROR, MAT_TRANSLUCENT, MAT_SUBSTRATE, MAT_UBER, MAT_MIX = 4, 5, 6, 7, 8
 LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE = 0, 1, 2, 3, 4, 5
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
@@ -21,7 +22,9 @@ class EnigmaMaterial(C.Structure):
                 ("eta", C.c_float * 3), ("k", C.c_float * 3),
                 ("sigma", C.c_float), ("uroughness", C.c_float), ("vroughness", C.c_float), ("index", C.c_float),
                 ("tex_kd", C.c_uint32), ("tex_ks", C.c_uint32), ("tex_kr", C.c_uint32), ("tex_kt", C.c_uint32),
-                ("tex_eta", C.c_uint32), ("tex_k", C.c_uint32)]
+                ("tex_eta", C.c_uint32), ("tex_k", C.c_uint32),
+                ("reflect", C.c_float * 3), ("transmit", C.c_float * 3), ("opacity", C.c_float * 3), ("amount", C.c_float * 3),
+                ("mix_a", C.c_uint32), ("mix_b", C.c_uint32)]
 
 
 WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
@@ -241,6 +244,61 @@ def plastic(kd, ks, roughness=0.1, remap=True):
     m.uroughness = roughness
     m.vroughness = roughness
     m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def mirror(kr=(0.9, 0.9, 0.9)):
+    m = EnigmaMaterial()
+    m.type = MAT_MIRROR
+    m.kr[:] = kr
+    return m
+
+
+def translucent(kd=(0.25,) * 3, ks=(0.25,) * 3, reflect=(0.5,) * 3, transmit=(0.5,) * 3, roughness=0.1, remap=True):
+    m = EnigmaMaterial()
+    m.type = MAT_TRANSLUCENT
+    m.kd[:] = kd
+    m.ks[:] = ks
+    m.reflect[:] = reflect
+    m.transmit[:] = transmit
+    m.uroughness = m.vroughness = roughness
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def substrate(kd=(0.5,) * 3, ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remap=True):
+    m = EnigmaMaterial()
+    m.type = MAT_SUBSTRATE
+    m.kd[:] = kd
+    m.ks[:] = ks
+    m.uroughness, m.vroughness = uroughness, vroughness
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def uber(kd=(0.25,) * 3, ks=(0.25,) * 3, kr=(0, 0, 0), kt=(0, 0, 0), opacity=(1, 1, 1), roughness=0.1, uroughness=None, vroughness=None,
+         index=1.5, remap=True):
+    """uroughness / vroughness as UberMaterial resolves them (Enigma/Material.cpp:563-570): u = uroughness or roughness, v = vroughness or u."""
+    m = EnigmaMaterial()
+    m.type = MAT_UBER
+    m.kd[:] = kd
+    m.ks[:] = ks
+    m.kr[:] = kr
+    m.kt[:] = kt
+    m.opacity[:] = opacity
+    m.uroughness = roughness if uroughness is None else uroughness
+    m.vroughness = m.uroughness if vroughness is None else vroughness
+    m.index = index
+    m.remap_roughness = 1 if remap else 0
+    return m
+
+
+def mix(a, b, amount=(0.5, 0.5, 0.5)):
+    """a, b: indices of the two materials in the scene's material array, both before the mix itself."""
+    m = EnigmaMaterial()
+    m.type = MAT_MIX
+    m.mix_a, m.mix_b = a, b
+    m.amount[:] = amount
     return m
 
 

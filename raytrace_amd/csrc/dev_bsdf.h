@@ -14,14 +14,18 @@
 namespace edev {
 
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_OREN_NAYAR };
+enum LobeKind : int { LOBE_LAMBERT, LOBE_MICRO_REFL_CONDUCTOR, LOBE_MICRO_REFL_DIELECTRIC, LOBE_MICRO_TRANS, LOBE_FRESNEL_SPECULAR, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_OREN_NAYAR,
+                      // lobes of the MK_GENERAL materials only: LambertianTransmission (Enigma/BxDF.cpp:1160-1190), SpecularReflection over
+                      // FresnelNoOp (the mirror, Enigma/Material.cpp:326-327), FresnelBlend (Enigma/BxDF.cpp:781-839)
+                      LOBE_LAMBERT_TRANS, LOBE_SPEC_REFL_NOOP, LOBE_FRESNEL_BLEND };
 
 DEV constexpr int lobeType(int k) {
     return (k == LOBE_LAMBERT || k == LOBE_OREN_NAYAR) ? (BSDF_REFLECTION | BSDF_DIFFUSE)
-         : (k == LOBE_MICRO_REFL_CONDUCTOR || k == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
+         : (k == LOBE_MICRO_REFL_CONDUCTOR || k == LOBE_MICRO_REFL_DIELECTRIC || k == LOBE_FRESNEL_BLEND) ? (BSDF_REFLECTION | BSDF_GLOSSY)
          : k == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
-         : k == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
+         : (k == LOBE_SPEC_REFL || k == LOBE_SPEC_REFL_NOOP) ? (BSDF_REFLECTION | BSDF_SPECULAR)
          : k == LOBE_SPEC_TRANS ? (BSDF_TRANSMISSION | BSDF_SPECULAR)
+         : k == LOBE_LAMBERT_TRANS ? (BSDF_TRANSMISSION | BSDF_DIFFUSE)
          : (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
 }
 
@@ -185,14 +189,14 @@ struct Bsdf {
                            // GEOMETRIC normal as its third axis (not the shading normal; not orthonormal when they differ)
 };
 
-DEV F3 toLocal(const Bsdf& b, F3 v) { return F3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ng)); }
-DEV F3 toWorld(const Bsdf& b, F3 v) {
+template <class B> DEV F3 toLocal(const B& b, F3 v) { return F3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ng)); }
+template <class B> DEV F3 toWorld(const B& b, F3 v) {
     return F3(b.ss.x * v.x + b.ts.x * v.y + b.ng.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ng.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ng.z * v.z);
 }
 
 // Material::computeScatteringFunctions for the four materials (Enigma/Material.cpp:76-93,115-136,176-220,232-255).
 template <int MK>
-DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b, const float4* texColors = nullptr) {
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b, const float4* texColors = nullptr, const DevLobe* = nullptr, bool = true) {
     b->ng = ng;
     b->ss = normalize(dpdu);
     b->ts = cross(ns, b->ss);
@@ -221,15 +225,7 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, Bsdf* b, const fl
     }
 }
 
-DEV constexpr bool lobeMatches(int kind, int flags) {
-    int t = (kind == LOBE_LAMBERT || kind == LOBE_OREN_NAYAR) ? (BSDF_REFLECTION | BSDF_DIFFUSE)
-          : (kind == LOBE_MICRO_REFL_CONDUCTOR || kind == LOBE_MICRO_REFL_DIELECTRIC) ? (BSDF_REFLECTION | BSDF_GLOSSY)
-          : kind == LOBE_MICRO_TRANS ? (BSDF_TRANSMISSION | BSDF_GLOSSY)
-          : kind == LOBE_SPEC_REFL ? (BSDF_REFLECTION | BSDF_SPECULAR)
-          : kind == LOBE_SPEC_TRANS ? (BSDF_TRANSMISSION | BSDF_SPECULAR)
-          : kind == LOBE_FRESNEL_SPECULAR ? (BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR) : 0;
-    return kind >= 0 && (t & flags) == t;
-}
+DEV constexpr bool lobeMatches(int kind, int flags) { return kind >= 0 && (lobeType(kind) & flags) == lobeType(kind); } // BxDF::matchesFlags
 // slot I of material kind MK exists at this hit and matches flags
 template <int MK, int I>
 DEV bool lobeOn(const Bsdf& b, int flags) { return lobeMatches(LobeOf<MK, I>::kind, flags) && (I == 0 ? b.has0 : b.has1); }
@@ -508,6 +504,187 @@ DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf
         f += sideF<MK, 0>(b, wo, wi, flags, refl);
         f += sideF<MK, 1>(b, wo, wi, flags, refl);
     }
+    return f;
+}
+
+// ---------------------------------------------------------------- MK_GENERAL: a list of lobes walked at run time
+// Mirror, translucent, substrate, uber and mix materials (Enigma/Material.cpp:318-328, :276-309, :424-448, :536-592,
+// :146-163).  Which lobes exist was decided when the scene was uploaded (constant parameters: the IsBlack tests of
+// computeScatteringFunctions have one answer per material); the shade kernel of this kind follows BSDF::f / Pdf / sample_f
+// (Enigma/BxDF.cpp:885-985) over the list as the reference does over its BxDF pointers.
+struct BsdfG {
+    const DevLobe* lobes;  // in global memory
+    int n;
+    float eta;             // BSDF::m_eta
+    F3 ng, ss, ts;         // as in Bsdf
+};
+template <int MK> struct BsdfOf { using T = Bsdf; };
+template <> struct BsdfOf<MK_GENERAL> { using T = BsdfG; };
+
+template <int MK>
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, BsdfG* b, const float4* = nullptr, const DevLobe* lobes = nullptr, bool multipleLobes = true) {
+    b->ng = ng;
+    b->ss = normalize(dpdu);
+    b->ts = cross(ns, b->ss);
+    b->eta = m.eta;
+    const uint32_t nMulti = m.lobeInfo & 0xffu, nSingle = (m.lobeInfo >> 8) & 0xffu;
+    b->lobes = lobes + m.lobeOff + (multipleLobes ? 0u : nMulti);
+    b->n = (int)(multipleLobes ? nMulti : nSingle);
+}
+
+// the lobe's parameters in the shape the per-kind lobe functions above read them
+DEV Bsdf lobeParams(const DevLobe& l) {
+    Bsdf t;
+    t.has0 = t.has1 = true;
+    t.col0 = F3(l.col[0], l.col[1], l.col[2]); t.col1 = F3(l.col2[0], l.col2[1], l.col2[2]);
+    t.cEta = t.col0; t.cK = t.col1;
+    t.ax = l.ax; t.ay = l.ay;
+    t.eta = 1.f;
+    t.dEtaI = l.etaI; t.dEtaT = l.etaT;
+    t.ng = t.ss = t.ts = F3(0.f);
+    return t;
+}
+DEV float pow5(float v) { return (v * v) * (v * v) * v; }
+// FresnelBlend::f, Enigma/BxDF.cpp:788-809
+DEV F3 fresnelBlendF(const Bsdf& t, F3 Rd, F3 Rs, F3 wo, F3 wi) {
+    F3 diffuse = (28.f / (23.f * kPi)) * Rd * (F3(1.f) - Rs) * (1 - pow5(1 - .5f * absCosTheta(wi))) * (1 - pow5(1 - .5f * absCosTheta(wo)));
+    F3 wh = wi + wo;
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3(0.f);
+    wh = normalize(wh);
+    F3 schlick = Rs + pow5(1 - dot(wi, wh)) * (F3(1.f) - Rs);
+    F3 specular = trD(t.ax, t.ay, wh) / (4 * absdot(wi, wh) * smax(absCosTheta(wi), absCosTheta(wo))) * schlick;
+    return diffuse + specular;
+}
+// FresnelBlend::pdf, Enigma/BxDF.cpp:833-839
+DEV float fresnelBlendPdf(const Bsdf& t, F3 wo, F3 wi) {
+    if (!sameHemisphere(wo, wi)) return 0.f;
+    F3 wh = normalize(wo + wi);
+    float pdf_wh = trPdf(t.ax, t.ay, wo, wh);
+    return .5f * (absCosTheta(wi) * kInvPi + pdf_wh / (4 * dot(wo, wh)));
+}
+DEV F3 lobeScale(const DevLobe& l, F3 f) { return l.scaled ? F3(l.scale[0], l.scale[1], l.scale[2]) * f : f; } // ScaledBxDF::f / sample_f, Enigma/BxDF.cpp:617-625
+DEV F3 lobeFRt(const DevLobe& l, F3 wo, F3 wi) {
+    const Bsdf t = lobeParams(l);
+    F3 f(0.f);
+    switch (l.kind) {
+    case LOBE_LAMBERT: case LOBE_LAMBERT_TRANS: f = t.col0 * kInvPi; break;
+    case LOBE_OREN_NAYAR: f = orenNayarF(t, t.col0, wo, wi); break;
+    case LOBE_MICRO_REFL_CONDUCTOR: f = microReflF<LOBE_MICRO_REFL_CONDUCTOR>(t, F3(1.f), wo, wi); break; // R = 1 (Enigma/Material.cpp:131)
+    case LOBE_MICRO_REFL_DIELECTRIC: f = microReflF<LOBE_MICRO_REFL_DIELECTRIC>(t, t.col0, wo, wi); break;
+    case LOBE_MICRO_TRANS: f = microTransF(t, t.col0, wo, wi); break;
+    case LOBE_FRESNEL_BLEND: f = fresnelBlendF(t, t.col0, t.col1, wo, wi); break;
+    default: break; // the specular lobes
+    }
+    return lobeScale(l, f);
+}
+DEV float lobePdfRt(const DevLobe& l, F3 wo, F3 wi) {
+    if (l.scaled) return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f; // BxDF::pdf: ScaledBxDF has none of its own
+    const Bsdf t = lobeParams(l);
+    switch (l.kind) {
+    case LOBE_LAMBERT: case LOBE_OREN_NAYAR: return sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f;
+    case LOBE_LAMBERT_TRANS: return !sameHemisphere(wo, wi) ? absCosTheta(wi) * kInvPi : 0.f;
+    case LOBE_MICRO_REFL_CONDUCTOR: case LOBE_MICRO_REFL_DIELECTRIC: return microReflPdf(t, wo, wi);
+    case LOBE_MICRO_TRANS: return microTransPdf(t, wo, wi);
+    case LOBE_FRESNEL_BLEND: return fresnelBlendPdf(t, wo, wi);
+    default: return 0.f;
+    }
+}
+// the wrapped lobe's sample_f; its density is passed through unscaled (Enigma/BxDF.cpp:622-625)
+DEV F3 lobeSampleRt(const DevLobe& l, F3 wo, float u0, float u1, F3* wi, float* pdf, int* sampledType) {
+    const Bsdf t = lobeParams(l);
+    F3 f(0.f);
+    switch (l.kind) {
+    case LOBE_LAMBERT: f = lobeSample<LOBE_LAMBERT>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_OREN_NAYAR: f = lobeSample<LOBE_OREN_NAYAR>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_LAMBERT_TRANS: // Enigma/BxDF.cpp:1179-1190
+        *wi = cosineSampleHemisphere(u0, u1);
+        if (wo.z > 0) wi->z *= -1;
+        *pdf = !sameHemisphere(wo, *wi) ? absCosTheta(*wi) * kInvPi : 0.f;
+        f = t.col0 * kInvPi;
+        break;
+    case LOBE_MICRO_REFL_CONDUCTOR: f = lobeSample<LOBE_MICRO_REFL_CONDUCTOR>(t, F3(1.f), wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_MICRO_REFL_DIELECTRIC: f = lobeSample<LOBE_MICRO_REFL_DIELECTRIC>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_MICRO_TRANS: f = lobeSample<LOBE_MICRO_TRANS>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_SPEC_REFL: f = lobeSample<LOBE_SPEC_REFL>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_SPEC_TRANS: f = lobeSample<LOBE_SPEC_TRANS>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_FRESNEL_SPECULAR: f = lobeSample<LOBE_FRESNEL_SPECULAR>(t, t.col0, wo, u0, u1, wi, pdf, sampledType); break;
+    case LOBE_SPEC_REFL_NOOP: // SpecularReflection::sample_f over FresnelNoOp, Enigma/BxDF.cpp:674-679
+        *pdf = 1.0f;
+        *wi = F3(-wo.x, -wo.y, wo.z);
+        f = (F3(1.f) * t.col0) / absCosTheta(*wi);
+        break;
+    case LOBE_FRESNEL_BLEND: { // Enigma/BxDF.cpp:813-831
+        bool ok = true;
+        if (u0 < .5f) {
+            *wi = cosineSampleHemisphere(smin(2 * u0, kOneMinusEpsilon), u1);
+            if (wo.z < 0) wi->z *= -1;
+        } else {
+            F3 wh = trSampleWh(t.ax, t.ay, wo, smin(2 * (u0 - .5f), kOneMinusEpsilon), u1);
+            *wi = reflect(wo, wh);
+            if (!sameHemisphere(wo, *wi)) ok = false;
+        }
+        if (ok) { *pdf = fresnelBlendPdf(t, wo, *wi); f = fresnelBlendF(t, t.col0, t.col1, wo, *wi); }
+        break;
+    }
+    default: break;
+    }
+    return lobeScale(l, f);
+}
+
+template <int MK>
+DEV int numComponents(const BsdfG& b, int flags) {
+    int n = 0;
+    for (int i = 0; i < b.n; ++i) n += lobeMatches((int)b.lobes[i].kind, flags) ? 1 : 0;
+    return n;
+}
+DEV F3 generalSideF(const BsdfG& b, F3 wo, F3 wi, int flags, bool refl) {
+    F3 f(0.f);
+    for (int i = 0; i < b.n; ++i) {
+        const DevLobe& l = b.lobes[i];
+        const int t = lobeType((int)l.kind);
+        if (lobeMatches((int)l.kind, flags) && ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION)))) f += lobeFRt(l, wo, wi);
+    }
+    return f;
+}
+template <int MK>
+DEV F3 bsdfF(const BsdfG& b, F3 woW, F3 wiW, int flags) { // BSDF::f, Enigma/BxDF.cpp:972-985
+    F3 wi = toLocal(b, wiW), wo = toLocal(b, woW);
+    if (wo.z == 0) return F3(0.f);
+    return generalSideF(b, wo, wi, flags, dot(wiW, b.ng) * dot(woW, b.ng) > 0);
+}
+template <int MK>
+DEV float bsdfPdf(const BsdfG& b, F3 woW, F3 wiW, int flags) { // BSDF::Pdf, Enigma/BxDF.cpp:954-970
+    if (b.n == 0) return 0.f;
+    F3 wo = toLocal(b, woW), wi = toLocal(b, wiW);
+    float pdf = 0.f; int matching = 0;
+    for (int i = 0; i < b.n; ++i)
+        if (lobeMatches((int)b.lobes[i].kind, flags)) { ++matching; pdf += lobePdfRt(b.lobes[i], wo, wi); }
+    return matching > 0 ? pdf / matching : 0.f;
+}
+template <int MK>
+DEV F3 bsdfSample(const BsdfG& b, F3 woW, F3* wiW, float u0, float u1, float* pdf, int flags, int* sampledType) { // BSDF::sample_f, Enigma/BxDF.cpp:885-952
+    *pdf = 0; *sampledType = 0;
+    const int matching = numComponents<MK>(b, flags);
+    if (matching == 0) return F3(0.f);
+    const int comp = min((int)floorf(u0 * matching), matching - 1);
+    int chosen = -1, count = comp;
+    for (int i = 0; i < b.n && chosen < 0; ++i)
+        if (lobeMatches((int)b.lobes[i].kind, flags) && count-- == 0) chosen = i;
+    const float ur0 = smin(u0 * matching - comp, kOneMinusEpsilon);
+    F3 wo = toLocal(b, woW), wi(0.f);
+    if (wo.z == 0) return F3(0.f);
+    const DevLobe& l = b.lobes[chosen];
+    const int type = lobeType((int)l.kind);
+    *sampledType = type;
+    F3 f = lobeSampleRt(l, wo, ur0, u1, &wi, pdf, sampledType);
+    if (*pdf == 0) { *sampledType = 0; return F3(0.f); }
+    *wiW = toWorld(b, wi);
+    const bool specular = (type & BSDF_SPECULAR) != 0;
+    if (!specular && matching > 1)
+        for (int i = 0; i < b.n; ++i)
+            if (i != chosen && lobeMatches((int)b.lobes[i].kind, flags)) *pdf += lobePdfRt(b.lobes[i], wo, wi);
+    if (matching > 1) *pdf /= matching;
+    if (!specular) f = generalSideF(b, wo, wi, flags, dot(*wiW, b.ng) * dot(woW, b.ng) > 0);
     return f;
 }
 

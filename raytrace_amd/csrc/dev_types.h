@@ -8,9 +8,11 @@ namespace edev {
 // upload: a smooth glass is one FresnelSpecular lobe (allowMultipleLobes is always true on the
 // PathIntegrator path, Enigma/PathIntegrator.cpp:89, Enigma/Material.cpp:190-194).
 enum MatKind : uint32_t { MK_MATTE = 0, MK_METAL = 1, MK_GLASS_SMOOTH = 2, MK_GLASS_ROUGH = 3, MK_PLASTIC = 4,
-                          MK_MATTE_ROUGH = 5 /* matte with sigma != 0: Oren-Nayar instead of Lambert */, MK_COUNT = 6,
-                          MK_NONE = 6 /* a triangle without a material: a medium boundary (VolPathIntegrator) */,
-                          MK_DL_GLASS = 7 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
+                          MK_MATTE_ROUGH = 5 /* matte with sigma != 0: Oren-Nayar instead of Lambert */,
+                          MK_GENERAL = 6 /* mirror, translucent, substrate, uber, mix: a list of lobes (DevLobe) walked at run time */,
+                          MK_COUNT = 7,
+                          MK_NONE = 7 /* a triangle without a material: a medium boundary (VolPathIntegrator) */,
+                          MK_DL_GLASS = 8 /* lobe set of smooth glass under DirectLightingIntegrator; never stored in a scene */ };
 // One queue per material kind, then queue MK_COUNT: DirectLightingIntegrator paths that resume a pending branch /
 // VolPathIntegrator paths at a material-less surface; queue MK_COUNT + 1: VolPathIntegrator medium interactions.
 constexpr int kQueueKinds = MK_COUNT + 2;
@@ -26,8 +28,23 @@ struct DevMaterial {        // 64 bytes
     float c0[3]; float eta; // matte/plastic: Kd.  metal: eta rgb.  glass: Kr; eta = index
     float c1[3]; float pad; // plastic: Ks.  metal: k rgb.  glass: Kt
     uint32_t tex0, tex1;    // device texture index + 1 bound to c0 / c1 (trilinear image textures), 0 = the constant
-    float pad2[2];
+    uint32_t lobeOff;       // MK_GENERAL: first entry in DevScene::lobes of the list built with allowMultipleLobes = true, ...
+    uint32_t lobeInfo;      // ... its length | length of the allowMultipleLobes = false list << 8 (it follows the first); eta = BSDF::m_eta
 };
+
+// One BxDF of an MK_GENERAL material, in the order Material::computeScatteringFunctions adds them (Enigma/Material.cpp).
+// kind is a LobeKind (dev_bsdf.h).  scaled: the lobe sits inside a ScaledBxDF (MixMaterial, Enigma/Material.cpp:158-162):
+// its values are multiplied by scale, and because ScaledBxDF does not override pdf() (Enigma/BxDF.h:157-170) the lobe
+// answers density queries with the base class's cosine-hemisphere density (Enigma/BxDF.cpp:568-571) whatever it wraps.
+struct DevLobe {            // 64 bytes
+    uint32_t kind, scaled;
+    float ax, ay;           // the lobe's TrowbridgeReitz alphas (Oren-Nayar: A and B)
+    float col[3]; float etaI;  // R / T / Kd; conductor: eta.  Dielectric Fresnel / transmission interface: etaI, etaT
+    float col2[3]; float etaT; // conductor: k; FresnelSpecular: T; FresnelBlend: Rs
+    float scale[3]; float pad;
+};
+static_assert(sizeof(DevLobe) == 64, "four float4 per lobe");
+constexpr int kMaxLobes = 8; // MAX_BxDFS, Enigma/BxDF.h:8
 
 static_assert(sizeof(DevMaterial) == 64, "k_shade copies materials as four float4");
 
@@ -87,6 +104,7 @@ struct DevScene {
     const float4* nodes;        // 8-wide BVH nodes, 5 float4 each
     const float4* tris;         // triangles in BVH order, 3 float4 each (a sphere owns a slot too, see dev_trace8.h)
     const DevMaterial* materials;
+    const DevLobe* lobes;       // lobe lists of the MK_GENERAL materials; nullptr = none
     const DevLight* lights;
     // SpatialLightDistribution (Enigma/LightDist.cpp:80-267): per filled voxel nLights func values, nLights + 1 cdf values
     // and funcInt; nullptr = one table for the whole scene (lightCdf / lightFunc below).  As in the reference a voxel's

@@ -70,6 +70,7 @@ struct EnigmaCtx {
     bool haveScene = false;
     DevBuf<float4> nodes, tris;
     DevBuf<DevMaterial> materials;
+    DevBuf<DevLobe> lobes;
     DevBuf<DevLight> lights;
     DevBuf<float> lightCdf, lightFunc;
     DevBuf<uint32_t> primId;
@@ -127,6 +128,7 @@ struct EnigmaCtx {
     bool useDirect = false, directDirty = true;
     EnigmaDirectLightingDesc directDesc{};
     bool glassBranches = false, glassSpecular = false; // a smooth glass with Kr and Kt / with either
+    bool deferredLobeChoice = false; // a material with a specular reflection lobe and several specular transmission lobes
     DevBuf<uint32_t> bitConst, arrayOff, pendCount;
     DevBuf<float4> pendO, pendD, pendB;
     size_t rayCapacity = 0, pendCapacity = 0;
@@ -212,7 +214,7 @@ extern "C" void enigma_ctx_destroy(EnigmaCtx* h) {
     for (auto& b : h->envTexels) b->release();
     for (auto& b : h->envFloats) b->release();
     h->envMaps.release(); h->infiniteLights.release();
-    h->materials.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
+    h->materials.release(); h->lobes.release(); h->lights.release(); h->lightCdf.release(); h->lightFunc.release(); h->primId.release();
     h->filterTable.release(); h->tx.release(); h->ty.release(); h->sampleConst.release();
     h->extQ[0].release(); h->extQ[1].release();
     for (auto& q : h->matQ) q.release();
@@ -301,6 +303,140 @@ static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
     return pos == 3 ? 1 : neg == 3 ? -1 : 0;
 }
 
+// Material::computeScatteringFunctions with constant parameters, as the list of BxDFs it adds, in its order
+// (Enigma/Material.cpp:76-592; the IsBlack tests have one answer per material here).  Used for the materials the shade
+// kernels walk at run time: mirror, translucent, substrate, uber, and mix over any of the nine.  *eta: BSDF::m_eta.
+static bool materialLobes(const EnigmaMaterial* table, uint32_t idx, bool multipleLobes, std::vector<DevLobe>& out, float* eta, std::string& why) {
+    const EnigmaMaterial& m = table[idx];
+    if (m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k) { why = "textures on a mirror, translucent, substrate, uber or mix material (or on a material a mix names) are not supported"; return false; }
+    auto clamped = [](const float v[3], float o[3]) { for (int c = 0; c < 3; ++c) o[c] = v[c] < 0.f ? 0.f : v[c]; }; // Spectrum::Clamp()
+    auto black = [](const float v[3]) { return v[0] == 0.f && v[1] == 0.f && v[2] == 0.f; };
+    auto remap = [&](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
+        if (!m.remap_roughness) return r;
+        r = std::max(r, (float)1e-3);
+        float x = std::log(r);
+        return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+    };
+    auto lobe = [](uint32_t kind, const float col[3], float ax = 0.f, float ay = 0.f, float etaI = 1.f, float etaT = 1.f, const float* col2 = nullptr) {
+        DevLobe l;
+        memset(&l, 0, sizeof(l));
+        l.kind = kind;
+        l.ax = std::max(float(0.001), ax); l.ay = std::max(float(0.001), ay); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
+        for (int c = 0; c < 3; ++c) { l.col[c] = col[c]; l.col2[c] = col2 ? col2[c] : 0.f; l.scale[c] = 1.f; }
+        l.etaI = etaI; l.etaT = etaT;
+        return l;
+    };
+    auto times = [](const float a[3], const float b[3], float o[3]) { for (int c = 0; c < 3; ++c) o[c] = a[c] * b[c]; };
+    *eta = 1.f;
+    float kd[3], ks[3], kr[3], kt[3];
+    clamped(m.kd, kd); clamped(m.ks, ks); clamped(m.kr, kr); clamped(m.kt, kt);
+    switch (m.type) {
+    case ENIGMA_MAT_MATTE: { // :76-93
+        const float sig = std::min(std::max(m.sigma, 0.f), 90.f);
+        if (black(kd)) break;
+        if (sig == 0.f) { out.push_back(lobe(edev::LOBE_LAMBERT, kd)); break; }
+        const float sigma = sig * (3.1415926535897932384f / 180.0f), sigma2 = sigma * sigma;
+        DevLobe l = lobe(edev::LOBE_OREN_NAYAR, kd);
+        l.ax = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f))); // A and B travel in the alpha slots
+        l.ay = (0.45f * sigma2) / (sigma2 + 0.09f);
+        out.push_back(l);
+        break;
+    }
+    case ENIGMA_MAT_METAL: // :115-136
+        out.push_back(lobe(edev::LOBE_MICRO_REFL_CONDUCTOR, m.eta, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, m.k));
+        break;
+    case ENIGMA_MAT_GLASS: { // :176-220
+        *eta = m.index;
+        if (black(kr) && black(kt)) break;
+        const bool isSpecular = m.uroughness == 0.f && m.vroughness == 0.f;
+        if (isSpecular && multipleLobes) { out.push_back(lobe(edev::LOBE_FRESNEL_SPECULAR, kr, 0.f, 0.f, 1.f, m.index, kt)); break; }
+        const float ax = isSpecular ? 0.f : remap(m.uroughness), ay = isSpecular ? 0.f : remap(m.vroughness);
+        if (!black(kr)) out.push_back(lobe(isSpecular ? edev::LOBE_SPEC_REFL : edev::LOBE_MICRO_REFL_DIELECTRIC, kr, ax, ay, 1.f, m.index));
+        if (!black(kt)) out.push_back(lobe(isSpecular ? edev::LOBE_SPEC_TRANS : edev::LOBE_MICRO_TRANS, kt, ax, ay, 1.f, m.index));
+        break;
+    }
+    case ENIGMA_MAT_PLASTIC: // :232-255
+        if (!black(kd)) out.push_back(lobe(edev::LOBE_LAMBERT, kd));
+        if (!black(ks)) out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, ks, remap(m.uroughness), remap(m.uroughness), 1.5f, 1.f));
+        break;
+    case ENIGMA_MAT_MIRROR: // :318-328
+        if (!black(kr)) out.push_back(lobe(edev::LOBE_SPEC_REFL_NOOP, kr));
+        break;
+    case ENIGMA_MAT_TRANSLUCENT: { // :276-309
+        *eta = 1.5f;
+        float r[3], t[3], c[3];
+        clamped(m.reflect, r); clamped(m.transmit, t);
+        if (black(r) && black(t)) break;
+        if (!black(kd)) {
+            if (!black(r)) { times(r, kd, c); out.push_back(lobe(edev::LOBE_LAMBERT, c)); }
+            if (!black(t)) { times(t, kd, c); out.push_back(lobe(edev::LOBE_LAMBERT_TRANS, c)); }
+        }
+        if (!black(ks)) {
+            const float a = remap(m.uroughness);
+            if (!black(r)) { times(r, ks, c); out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, c, a, a, 1.f, 1.5f)); }
+            if (!black(t)) { times(t, ks, c); out.push_back(lobe(edev::LOBE_MICRO_TRANS, c, a, a, 1.f, 1.5f)); }
+        }
+        break;
+    }
+    case ENIGMA_MAT_SUBSTRATE: // :424-448
+        if (!black(kd) || !black(ks)) out.push_back(lobe(edev::LOBE_FRESNEL_BLEND, kd, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, ks));
+        break;
+    case ENIGMA_MAT_UBER: { // :536-592
+        const float e = m.index;
+        float op[3], t[3], c[3];
+        clamped(m.opacity, op);
+        for (int k = 0; k < 3; ++k) t[k] = std::max(-op[k] + 1.f, 0.f);
+        if (!black(t)) out.push_back(lobe(edev::LOBE_SPEC_TRANS, t, 0.f, 0.f, 1.f, 1.f));
+        else *eta = e;
+        times(op, kd, c);
+        if (!black(c)) out.push_back(lobe(edev::LOBE_LAMBERT, c));
+        times(op, ks, c);
+        if (!black(c)) out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, c, remap(m.uroughness), remap(m.vroughness), 1.f, e));
+        times(op, kr, c);
+        if (!black(c)) out.push_back(lobe(edev::LOBE_SPEC_REFL, c, 0.f, 0.f, 1.f, e));
+        times(op, kt, c);
+        if (!black(c)) out.push_back(lobe(edev::LOBE_SPEC_TRANS, c, 0.f, 0.f, 1.f, e));
+        break;
+    }
+    case ENIGMA_MAT_MIX: { // :146-163: the first material's BSDF, its lobes scaled; then the second material's lobes, scaled
+        if (m.mix_a >= idx || m.mix_b >= idx) { why = "a mix material names materials that come before it in the array"; return false; }
+        float s1[3], s2[3], etaB;
+        clamped(m.amount, s1);
+        for (int k = 0; k < 3; ++k) s2[k] = std::max(1.f - s1[k], 0.f);
+        const size_t first = out.size();
+        if (!materialLobes(table, m.mix_a, multipleLobes, out, eta, why)) return false;
+        const size_t second = out.size();
+        if (!materialLobes(table, m.mix_b, multipleLobes, out, &etaB, why)) return false;
+        for (size_t i = first; i < out.size(); ++i) {
+            for (int k = 0; k < 3; ++k) out[i].scale[k] *= (i < second ? s1 : s2)[k];
+            out[i].scaled = 1u;
+        }
+        break;
+    }
+    default:
+        why = "unknown material type";
+        return false;
+    }
+    if (out.size() > (size_t)edev::kMaxLobes) { why = "a material with more than 8 lobes: the reference's BSDF holds MAX_BxDFS = 8 (Enigma/BxDF.h:8)"; return false; }
+    return true;
+}
+// the two lists (allowMultipleLobes true, then false) of material idx appended to lobes; d describes them
+static bool generalMaterial(const EnigmaMaterial* table, uint32_t idx, std::vector<DevLobe>& lobes, DevMaterial& d, std::string& why) {
+    std::vector<DevLobe> multi, single;
+    float eta = 1.f, eta2 = 1.f;
+    if (!materialLobes(table, idx, true, multi, &eta, why) || !materialLobes(table, idx, false, single, &eta2, why)) return false;
+    memset(&d, 0, sizeof(d));
+    d.kind = MK_GENERAL;
+    d.eta = eta;
+    d.flags = multi.empty() ? 0u : 1u;
+    d.lobeOff = (uint32_t)lobes.size();
+    d.lobeInfo = (uint32_t)multi.size() | ((uint32_t)single.size() << 8);
+    lobes.insert(lobes.end(), multi.begin(), multi.end());
+    lobes.insert(lobes.end(), single.begin(), single.end());
+    return true;
+}
+static bool isGeneralMaterial(uint32_t type) { return type >= ENIGMA_MAT_MIRROR && type <= ENIGMA_MAT_MIX; }
+
 static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     HIPCHK(h, hipSetDevice(h->device));
     if (s->n_triangles && (!s->vertices || !s->indices || !s->tri_material || !s->tri_light)) return h->fail(ENIGMA_E_INVALID, "null geometry array");
@@ -388,11 +524,29 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     std::vector<DevMaterial> mats(s->n_materials);
     for (int k = 0; k < MK_COUNT; ++k) { h->kindPresent[k] = false; h->kindTextured[k] = false; }
     h->smoothGlass = false;
-    h->glassBranches = h->glassSpecular = false;
+    h->glassBranches = h->glassSpecular = h->deferredLobeChoice = false;
+    std::vector<DevLobe> lobeTable;
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         EnigmaMaterial m = s->materials[i];
         DevMaterial d;
         memset(&d, 0, sizeof(d));
+        if (isGeneralMaterial(m.type)) {
+            std::string why;
+            if (!generalMaterial(s->materials, i, lobeTable, d, why)) return h->fail(ENIGMA_E_UNSUPPORTED, "material %u: %s", i, why.c_str());
+            // the DirectLightingIntegrator's recursion follows the specular lobes of the allowMultipleLobes = false list
+            int specR = 0, specT = 0;
+            for (uint32_t k = 0; k < (d.lobeInfo >> 8); ++k) {
+                const uint32_t kind = lobeTable[d.lobeOff + (d.lobeInfo & 0xffu) + k].kind;
+                specR += (kind == edev::LOBE_SPEC_REFL || kind == edev::LOBE_SPEC_REFL_NOOP) ? 1 : 0;
+                specT += kind == edev::LOBE_SPEC_TRANS ? 1 : 0;
+            }
+            if (specR || specT) h->glassSpecular = h->smoothGlass = true;
+            if (specR && specT) h->glassBranches = true;
+            if (specR && specT > 1) h->deferredLobeChoice = true;
+            h->kindPresent[MK_GENERAL] = true;
+            mats[i] = d;
+            continue;
+        }
         // bound textures: constants for the EWA ones, a device texture for the trilinear ones (first / second colour of the kind)
         struct Bind { uint32_t tex; float* value; int slot; };
         const Bind binds[6] = {{m.tex_kd, m.kd, 0}, {m.tex_ks, m.ks, 1}, {m.tex_kr, m.kr, 0}, {m.tex_kt, m.kt, 1}, {m.tex_eta, m.eta, 0}, {m.tex_k, m.k, 1}};
@@ -687,6 +841,9 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     HIPCHK(h, h->nodes.upload(nodeData));
     HIPCHK(h, h->tris.upload(triData));
     HIPCHK(h, h->materials.upload(mats));
+    if (lobeTable.empty()) lobeTable.resize(1); // never a null table behind an MK_GENERAL material without lobes
+    HIPCHK(h, h->lobes.upload(lobeTable));
+    h->scene.lobes = h->lobes.p;
     HIPCHK(h, h->lights.upload(h->hostLights));
     HIPCHK(h, h->primId.upload(prim));
     h->scene.nodes = h->nodes.p;
@@ -1111,6 +1268,7 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GENERAL]) k_shade<MK_GENERAL, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
     // surfaces without a material: the ray goes on behind them and the vertex does not count as a bounce (Enigma/PathIntegrator.cpp:87-93)
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
@@ -1149,6 +1307,7 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GENERAL]) k_shade<MK_GENERAL, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
     if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
@@ -1186,6 +1345,7 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
     if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
+    if (h->kindPresent[MK_GENERAL]) k_shade_direct<MK_GENERAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     // surfaces without a material: Li goes on behind them at the same depth (Enigma/DirectLightingIntegrator.cpp:51-54)
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[kQueueMedium].p, kQueueMedium, nextQ, cur ^ 1u, ctr);
@@ -1232,6 +1392,10 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     if (direct && h->haveTrilinear && h->smoothGlass)
         return h->fail(ENIGMA_E_UNSUPPORTED, "trilinear textures with a smooth glass under the DirectLightingIntegrator: its specular rays carry ray differentials on "
                                              "(Enigma/Integrator.cpp:329-444), which is not supported");
+    if (direct && h->deferredLobeChoice)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "a material with a specular reflection lobe and two specular transmission lobes (an uber with Kr, Kt and opacity < 1, "
+                                             "or a mix that adds up to that) under the DirectLightingIntegrator: SpecularTransmit picks its lobe with a sample "
+                                             "drawn after the whole reflection subtree (Enigma/Integrator.cpp:329-444), which is not supported");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     // fewer paths in flight when each carries many ray slots / pending-branch entries (~4 GB of ray slots at most)
     size_t basePaths = (size_t)32 << 20; // ~11 GB of path state at 330 B per path; larger launches run closer to the hardware's rates
@@ -1741,6 +1905,10 @@ static int primaryHitsImpl(EnigmaCtx* h, int64_t sample_num, int32_t* triOut, ui
     HIPCHK(h, h->sampleConst.upload(consts));
     h->sampler.sampleConst = h->sampleConst.p;
     h->sampler.sampleBase = (unsigned long long)sample_num;
+    if (direct && h->deferredLobeChoice)
+        return h->fail(ENIGMA_E_UNSUPPORTED, "a material with a specular reflection lobe and two specular transmission lobes (an uber with Kr, Kt and opacity < 1, "
+                                             "or a mix that adds up to that) under the DirectLightingIntegrator: SpecularTransmit picks its lobe with a sample "
+                                             "drawn after the whole reflection subtree (Enigma/Integrator.cpp:329-444), which is not supported");
     const size_t raysPerPath = (size_t)std::max(1, h->integ.raysPerPath), pendingLevels = direct ? (size_t)h->integ.pendingLevels : 0;
     { int rc = ensureCapacity(h, nPixels, raysPerPath, pendingLevels); if (rc) return rc; }
     DevPaths P{{h->pathRec.p}, {h->pathRec.p + 1}, h->L.p, {h->pathRec.p + 2}, {h->pathRec.p + 3}, h->pfilm.p};
@@ -1850,23 +2018,34 @@ extern "C" int enigma_debug_intersect_any(EnigmaCtx* h, uint32_t n, const float*
     });
 }
 
-extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
-    if (!h || !material || !wo3 || !wi3 || !u2 || !out12) return ENIGMA_E_INVALID;
+extern "C" int enigma_debug_bsdf_of(EnigmaCtx* h, const EnigmaMaterial* materials, uint32_t n_materials, uint32_t which, uint32_t multiple_lobes, uint32_t n,
+                                    const float* wo3, const float* wi3, const float* u2, float* out12) {
+    if (!h || !materials || !wo3 || !wi3 || !u2 || !out12 || which >= n_materials) return ENIGMA_E_INVALID;
     return guarded(h, [&]() -> int {
     HIPCHK(h, hipSetDevice(h->device));
     if (n == 0) return ENIGMA_OK;
-    const EnigmaMaterial& m = *material;
-    if (m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k) return h->fail(ENIGMA_E_UNSUPPORTED, "the BSDF tap takes constant parameters only");
+    const EnigmaMaterial& m = materials[which];
     DevMaterial d;
     memset(&d, 0, sizeof(d));
-    if (!convertMaterial(m, d)) return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
-    const bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f, nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
-    d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
+    std::vector<DevLobe> lobeTable;
+    if (isGeneralMaterial(m.type)) {
+        std::string why;
+        if (!generalMaterial(materials, which, lobeTable, d, why)) return h->fail(ENIGMA_E_UNSUPPORTED, "material %u: %s", which, why.c_str());
+    } else {
+        if (m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k) return h->fail(ENIGMA_E_UNSUPPORTED, "the BSDF tap takes constant parameters only");
+        if (!convertMaterial(m, d)) return h->fail(ENIGMA_E_UNSUPPORTED, "material type %u is not supported", m.type);
+        const bool nb0 = d.c0[0] != 0.f || d.c0[1] != 0.f || d.c0[2] != 0.f, nb1 = d.c1[0] != 0.f || d.c1[1] != 0.f || d.c1[2] != 0.f;
+        d.flags = (nb0 ? 1u : 0u) | (nb1 ? 2u : 0u);
+    }
+    if (lobeTable.empty()) lobeTable.resize(1);
+    const bool multi = multiple_lobes != 0;
     DevBuf<float> dWo, dWi, dU, dOut;
+    DevBuf<DevLobe> dLobes;
     hipError_t e = dWo.upload(std::vector<float>(wo3, wo3 + 3 * (size_t)n));
     if (e == hipSuccess) e = dWi.upload(std::vector<float>(wi3, wi3 + 3 * (size_t)n));
     if (e == hipSuccess) e = dU.upload(std::vector<float>(u2, u2 + 2 * (size_t)n));
     if (e == hipSuccess) e = dOut.alloc((size_t)n * 12);
+    if (e == hipSuccess) e = dLobes.upload(lobeTable);
     if (e == hipSuccess) {
         const unsigned grid = (n + 255) / 256;
 #if ENIGMA_FULL_BUILD
@@ -1874,18 +2053,28 @@ extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, u
         case MK_MATTE: k_debug_bsdf<MK_MATTE><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         case MK_MATTE_ROUGH: k_debug_bsdf<MK_MATTE_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         case MK_METAL: k_debug_bsdf<MK_METAL><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
-        case MK_GLASS_SMOOTH: k_debug_bsdf<MK_GLASS_SMOOTH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_GLASS_SMOOTH: // without allowMultipleLobes a smooth glass is two specular lobes (Enigma/Material.cpp:204-218)
+            if (multi) k_debug_bsdf<MK_GLASS_SMOOTH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p);
+            else k_debug_bsdf<MK_DL_GLASS><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p);
+            break;
         case MK_GLASS_ROUGH: k_debug_bsdf<MK_GLASS_ROUGH><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
+        case MK_GENERAL: k_debug_bsdf<MK_GENERAL><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p, dLobes.p, multi); break;
         default: k_debug_bsdf<MK_PLASTIC><<<grid, 256, 0, h->stream>>>(d, n, dWo.p, dWi.p, dU.p, dOut.p); break;
         }
 #endif
         e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipMemcpy(out12, dOut.p, (size_t)n * 12 * sizeof(float), hipMemcpyDeviceToHost);
     }
-    dWo.release(); dWi.release(); dU.release(); dOut.release();
+    dWo.release(); dWi.release(); dU.release(); dOut.release(); dLobes.release();
     if (e != hipSuccess) return h->fail(ENIGMA_E_DEVICE, "debug_bsdf: %s", hipGetErrorString(e));
     return ENIGMA_OK;
     });
+}
+
+extern "C" int enigma_debug_bsdf(EnigmaCtx* h, const EnigmaMaterial* material, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
+    if (!h || !material) return ENIGMA_E_INVALID;
+    if (material->type == ENIGMA_MAT_MIX) return guarded(h, [&]() -> int { return h->fail(ENIGMA_E_INVALID, "a mix material names entries of its array: use enigma_debug_bsdf_of"); });
+    return enigma_debug_bsdf_of(h, material, 1, 0, 1, n, wo3, wi3, u2, out12);
 }
 
 extern "C" int enigma_debug_film_footprint(EnigmaCtx* h, uint32_t n, const float* pfilm_xy, uint32_t max_per, int32_t* pixels_xy_out, float* weights_out, uint32_t* counts_out) {

@@ -693,6 +693,10 @@ private:
             if (f->second.index) *tex = f->second.index;
             else put(dst, f->second.value);
         };
+        // the materials the device walks as lists of lobes take constants only
+        auto constantOnly = [&](const char* n) {
+            if (!p.FindTexture(n).empty()) throw std::runtime_error("Material \"" + name + "\": parameter \"" + std::string(n) + "\" refers to a texture; this material takes constant values only");
+        };
         m.remap_roughness = p.FindOneBool("remaproughness", true) ? 1u : 0u;
         if (name == "" || name == "none") return -2; // MakeMaterial returns no material (Enigma/Api.cpp:135): a medium boundary
         if (name == "matte") {
@@ -721,7 +725,61 @@ private:
             put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f))); bind("Kd", m.kd, &m.tex_kd);
             put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f))); bind("Ks", m.ks, &m.tex_ks);
             m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
-        } else throw std::runtime_error("Material \"" + name + "\" is not supported (matte, metal, glass, plastic)");
+        } else if (name == "mirror") { // CreateMirrorMaterial, Enigma/Material.cpp:648-653
+            m.type = ENIGMA_MAT_MIRROR;
+            constantOnly("Kr"); put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.9f)));
+        } else if (name == "translucent") { // CreateTranslucentMaterial, Enigma/Material.cpp:738-748
+            m.type = ENIGMA_MAT_TRANSLUCENT;
+            for (const char* n : {"Kd", "Ks", "reflect", "transmit"}) constantOnly(n);
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
+            put(m.reflect, p.FindOneSpectrum("reflect", Spectrum(0.5f)));
+            put(m.transmit, p.FindOneSpectrum("transmit", Spectrum(0.5f)));
+            m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
+        } else if (name == "substrate") { // CreateSubstrateMaterial, Enigma/Material.cpp:673-682
+            m.type = ENIGMA_MAT_SUBSTRATE;
+            for (const char* n : {"Kd", "Ks"}) constantOnly(n);
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(.5f)));
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(.5f)));
+            m.uroughness = p.FindOneFloat("uroughness", .1f);
+            m.vroughness = p.FindOneFloat("vroughness", .1f);
+        } else if (name == "uber") { // CreateUberMaterial, Enigma/Material.cpp:720-736
+            m.type = ENIGMA_MAT_UBER;
+            for (const char* n : {"Kd", "Ks", "Kr", "Kt", "opacity", "eta"}) constantOnly(n);
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
+            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.f)));
+            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(0.f)));
+            put(m.opacity, p.FindOneSpectrum("opacity", Spectrum(1.f)));
+            const float rough = p.FindOneFloat("roughness", .1f);
+            m.uroughness = p.Has("uroughness") ? p.FindOneFloat("uroughness", rough) : rough; // UberMaterial::computeScatteringFunctions, :563-570
+            m.vroughness = p.Has("vroughness") ? p.FindOneFloat("vroughness", m.uroughness) : m.uroughness;
+            m.index = p.Has("eta") ? p.FindOneFloat("eta", 1.5f) : p.FindOneFloat("index", 1.5f);
+        } else if (name == "mix") { // MakeMaterial's "mix" branch and CreateMixMaterial, Enigma/Api.cpp:153-176, Enigma/Material.cpp:617-621
+            m.type = ENIGMA_MAT_MIX;
+            constantOnly("amount");
+            const std::string names[2] = {p.FindOneString("namedmaterial1", ""), p.FindOneString("namedmaterial2", "")};
+            uint32_t* slots[2] = {&m.mix_a, &m.mix_b};
+            for (int k = 0; k < 2; ++k) {
+                auto it = m_gs.namedMaterials.find(names[k]);
+                int index;
+                if (it == m_gs.namedMaterials.end()) {
+                    Warn("Named material \"" + names[k] + "\" undefined.  Using \"matte\"");
+                    ParamSet forMatte = p; // the reference builds the stand-in from the mix's own parameters
+                    index = MakeMaterial("matte", forMatte);
+                } else index = it->second;
+                if (index < 0) throw std::runtime_error("Material \"mix\": named material \"" + names[k] + "\" is \"none\"; a mix needs two materials");
+                *slots[k] = (uint32_t)index;
+            }
+            put(m.amount, p.FindOneSpectrum("amount", Spectrum(0.5f)));
+        } else if (name == "fourier" || name == "subsurface" || name == "kdsubsurface" || name == "hair" || name == "disney") {
+            throw std::runtime_error("Material \"" + name + "\" is not supported (matte, metal, glass, plastic, mirror, translucent, substrate, uber, mix)");
+        } else { // Enigma/Api.cpp:189-192
+            Warn("Material \"" + name + "\" unknown. Using \"matte\".");
+            m.type = ENIGMA_MAT_MATTE;
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.5f))); bind("Kd", m.kd, &m.tex_kd);
+            m.sigma = p.FindOneFloat("sigma", 0.f);
+        }
         p.FindOneString("type", ""); // consumed by MakeNamedMaterial
         NoteUnused("Material", p);
         return m_res->scene.AddMaterial(m);

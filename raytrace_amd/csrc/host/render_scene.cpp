@@ -60,7 +60,9 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         o << (i ? "," : "") << "{\"type\":" << m.type << ",\"remap\":" << m.remap_roughness << ",\"kd\":"; arr(m.kd, 3);
         o << ",\"ks\":"; arr(m.ks, 3); o << ",\"kr\":"; arr(m.kr, 3); o << ",\"kt\":"; arr(m.kt, 3); o << ",\"eta\":"; arr(m.eta, 3); o << ",\"k\":"; arr(m.k, 3);
         o << ",\"sigma\":" << m.sigma << ",\"uroughness\":" << m.uroughness << ",\"vroughness\":" << m.vroughness << ",\"index\":" << m.index
-          << ",\"tex\":[" << m.tex_kd << "," << m.tex_ks << "," << m.tex_kr << "," << m.tex_kt << "," << m.tex_eta << "," << m.tex_k << "]}";
+          << ",\"tex\":[" << m.tex_kd << "," << m.tex_ks << "," << m.tex_kr << "," << m.tex_kt << "," << m.tex_eta << "," << m.tex_k << "]";
+        o << ",\"reflect\":"; arr(m.reflect, 3); o << ",\"transmit\":"; arr(m.transmit, 3); o << ",\"opacity\":"; arr(m.opacity, 3); o << ",\"amount\":"; arr(m.amount, 3);
+        o << ",\"mix\":[" << m.mix_a << "," << m.mix_b << "]}";
     }
     o << "],\n\"meshes\":[";
     for (size_t i = 0; i < R.scene.m_meshes.size(); ++i) {

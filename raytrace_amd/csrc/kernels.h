@@ -831,8 +831,8 @@ DEV float lightTrianglePdf(F3 o, F3 refP, F3 wi, F3 q0, F3 q1, F3 q2, float area
     }
     return pdf;
 }
-template <int MK, bool SPHL = false>
-DEV DirectSample estimateDirect(const DevScene& sc, const Bsdf& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
+template <int MK, bool SPHL = false, class BS = Bsdf>
+DEV DirectSample estimateDirect(const DevScene& sc, const BS& bsdf, const HitGeom& g, F3 woN, F3 ns, const DevLight& lt, const float4* tris,
                                 float ulx, float uly, float usx, float usy) {
     const int kNonSpecular = BSDF_ALL & ~BSDF_SPECULAR;
     DirectSample r;
@@ -956,8 +956,8 @@ __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUG
             F3 beta = xyz(bv);
             float etaScale = bv.w;
             HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w, d, p);
-            Bsdf bsdf;
-            makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
+            typename BsdfOf<MK>::T bsdf;
+            makeBsdf<MK>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr, sc.lobes, true);
             F3 ns = g.ns;
             F3 woN = g.wo; // Interaction::m_wo
             // medium + 1 on either side of the surface: the triangle's MediumInterface if it is a transition, else
@@ -1134,8 +1134,8 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             pathPixel(I, S, p, &px, &py, &slot);
             F3 beta = xyz(P.beta[p]);
             HitGeom g = hitGeometry(sc, tris, tri, hv.y, hv.z, hv.w, d, p);
-            Bsdf bsdf;
-            makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr);
+            typename BsdfOf<MKD>::T bsdf;
+            makeBsdf<MKD>(materials[g.matIdx], g.n, g.ns, g.dpdu, &bsdf, sc.texColors ? sc.texColors + (size_t)p * 2 : nullptr, sc.lobes, false);
             F3 ns = g.ns;
             F3 woN = g.wo; // isect.m_wo
             const size_t raySlot0 = (size_t)p * I.raysPerPath;
@@ -1184,10 +1184,19 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
             if ((int)depth + 1 < I.maxDepth) {
                 F3 wiR(0.f), wiT(0.f);
                 float pdfR, pdfT; int tyR, tyT;
-                dim += 2; // SpecularReflect's Get2D (a specular lobe ignores the values)
-                F3 fR = bsdfSample<MKD>(bsdf, woN, &wiR, 0.5f, 0.5f, &pdfR, BSDF_REFLECTION | BSDF_SPECULAR, &tyR);
+                // SpecularReflect's Get2D, then SpecularTransmit's.  A specular lobe ignores the values, but BSDF::sample_f picks
+                // among several matching lobes with the first (Enigma/BxDF.cpp:895): only a list of lobes can hold two specular
+                // lobes of one side.  With a reflection branch taken first, SpecularTransmit draws its values after that whole
+                // subtree; materials for which that matters are refused by the host under this integrator.
+                float uR0 = 0.5f, uR1 = 0.5f, uT0 = 0.5f, uT1 = 0.5f;
+                if (MKD == MK_GENERAL) {
+                    uR0 = sampleDimension(S, px, py, slot, dim); uR1 = sampleDimension(S, px, py, slot, dim + 1);
+                    uT0 = sampleDimension(S, px, py, slot, dim + 2); uT1 = sampleDimension(S, px, py, slot, dim + 3);
+                }
+                dim += 2;
+                F3 fR = bsdfSample<MKD>(bsdf, woN, &wiR, uR0, uR1, &pdfR, BSDF_REFLECTION | BSDF_SPECULAR, &tyR);
                 bool validR = pdfR > 0.f && !isBlack(fR) && absdot(wiR, ns) != 0.f;
-                F3 fT = bsdfSample<MKD>(bsdf, woN, &wiT, 0.5f, 0.5f, &pdfT, BSDF_TRANSMISSION | BSDF_SPECULAR, &tyT);
+                F3 fT = bsdfSample<MKD>(bsdf, woN, &wiT, uT0, uT1, &pdfT, BSDF_TRANSMISSION | BSDF_SPECULAR, &tyT);
                 bool validT = pdfT > 0.f && !isBlack(fT) && absdot(wiT, ns) != 0.f;
                 F3 betaT = validT ? beta * (fT * absdot(wiT, ns) / pdfT) : F3(0.f);
                 F3 oT = validT ? offsetRayOrigin(g.p, g.pError, g.n, wiT) : F3(0.f);
@@ -1582,11 +1591,12 @@ __global__ void __launch_bounds__(kBlock) k_debug_gather_primary(DevScene sc, De
 // BSDF::f / Pdf / sample_f (Enigma/BxDF.cpp:885-985) of one material at a surface whose geometric and shading normal
 // are +z and whose dpdu is +x, for n (wo, wi, u) triples: out = f.rgb, Pdf, sampled f.rgb, sampled pdf, sampled wi.xyz, sampled type
 template <int MK>
-__global__ void k_debug_bsdf(DevMaterial m, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12) {
+__global__ void k_debug_bsdf(DevMaterial m, uint32_t n, const float* wo3, const float* wi3, const float* u2, float* out12, const DevLobe* lobes = nullptr,
+                             bool multipleLobes = true) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Bsdf b;
-    makeBsdf<MK>(m, F3(0.f, 0.f, 1.f), F3(0.f, 0.f, 1.f), F3(1.f, 0.f, 0.f), &b);
+    typename BsdfOf<MK>::T b;
+    makeBsdf<MK>(m, F3(0.f, 0.f, 1.f), F3(0.f, 0.f, 1.f), F3(1.f, 0.f, 0.f), &b, nullptr, lobes, multipleLobes);
     const F3 wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
     float* o = out12 + 12 * (size_t)i;
     const F3 f = bsdfF<MK>(b, wo, wi, BSDF_ALL);

@@ -308,6 +308,7 @@ def cornell_box(variant="diffuse", delta_lights=False):
     white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
     red = b.add_material(abi.matte((0.65, 0.05, 0.05)))
     green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    walls = {}
     if variant == "diffuse":
         short_m = tall_m = white
     elif variant == "microfacet":
@@ -316,11 +317,29 @@ def cornell_box(variant="diffuse", delta_lights=False):
     elif variant == "specular":
         short_m = b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05))
         tall_m = b.add_material(abi.glass(1.5, 0.0, 0.0))
+    elif variant == "uber":
+        # the materials that are lists of lobes on the device: an uber block that is part diffuse, part glossy, part mirror,
+        # part glass and 20 % see-through; a translucent block; a substrate floor
+        short_m = b.add_material(abi.uber(kd=(0.25, 0.3, 0.6), ks=(0.3, 0.3, 0.3), kr=(0.2, 0.2, 0.2), kt=(0.3, 0.3, 0.3), opacity=(0.8, 0.8, 0.8),
+                                          roughness=0.05, index=1.4))
+        tall_m = b.add_material(abi.translucent(kd=(0.5, 0.45, 0.3), ks=(0.3, 0.3, 0.3), reflect=(0.5, 0.5, 0.5), transmit=(0.6, 0.5, 0.4), roughness=0.2))
+        walls["floor"] = b.add_material(abi.substrate(kd=(0.5, 0.4, 0.3), ks=(0.1, 0.1, 0.1), uroughness=0.05, vroughness=0.2))
+    elif variant == "mix":
+        # mixes over every base material, a mix of a mix, and a mirror wall
+        plastic = b.add_material(abi.plastic((0.25, 0.3, 0.6), (0.4, 0.4, 0.4), roughness=0.05))
+        copper = b.add_material(abi.metal(COPPER_ETA, COPPER_K, roughness=0.1, remap=True))
+        smooth = b.add_material(abi.glass(1.5, 0.0, 0.0))
+        rough = b.add_material(abi.glass(1.4, 0.1, 0.05))
+        short_m = b.add_material(abi.mix(plastic, copper, (0.4, 0.4, 0.4)))
+        inner = b.add_material(abi.mix(smooth, rough, (0.5, 0.5, 0.5)))
+        tall_m = b.add_material(abi.mix(inner, red, (0.7, 0.5, 0.9)))
+        walls["back"] = b.add_material(abi.mirror((0.8, 0.85, 0.9)))
+        walls["left"] = b.add_material(abi.mix(red, b.add_material(abi.matte((0.5, 0.5, 0.5), sigma=25.0)), (0.75, 0.75, 0.75)))
     else:
         raise ValueError(variant)
     c = CORNELL_CENTER
     for name, m in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
-        b.add_quad(_CORNELL[name], m, toward=c)
+        b.add_quad(_CORNELL[name], walls.get(name, m), toward=c)
     for name, m in (("short", short_m), ("tall", tall_m)):
         faces = _CORNELL[name]
         centre = np.mean([p for f in faces for p in f], axis=0)

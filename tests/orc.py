@@ -199,3 +199,17 @@ def bsdf_eval(material, wo, wi, u, fast=False):
     out = np.zeros((wo.shape[0], 12), dtype=np.float32)
     L.oracle_debug_bsdf(C.byref(material), wo.shape[0], abi.ptr(wo), abi.ptr(wi), abi.ptr(u), abi.ptr(out))
     return out
+
+
+def bsdf_eval_of(materials, which, wo, wi, u, multiple_lobes=True, fast=False):
+    """bsdf_eval for entry `which` of a list of materials (a mix names other entries), with allowMultipleLobes as given."""
+    L = lib(fast)
+    wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((wo.shape[0], 12), dtype=np.float32)
+    table = (abi.EnigmaMaterial * len(materials))(*materials)
+    rc = L.oracle_debug_bsdf_of(table, len(materials), which, int(bool(multiple_lobes)), wo.shape[0], abi.ptr(wo), abi.ptr(wi), abi.ptr(u), abi.ptr(out))
+    if rc != 0:
+        raise RuntimeError("oracle_debug_bsdf_of refused the material table")
+    return out

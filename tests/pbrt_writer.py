@@ -33,7 +33,8 @@ def texture_text(i, t, directory):
 
 
 def material_text(i, m):
-    t = {abi.MAT_MATTE: "matte", abi.MAT_METAL: "metal", abi.MAT_GLASS: "glass", abi.MAT_PLASTIC: "plastic"}[m.type]
+    t = {abi.MAT_MATTE: "matte", abi.MAT_METAL: "metal", abi.MAT_GLASS: "glass", abi.MAT_PLASTIC: "plastic", abi.MAT_MIRROR: "mirror",
+         abi.MAT_TRANSLUCENT: "translucent", abi.MAT_SUBSTRATE: "substrate", abi.MAT_UBER: "uber", abi.MAT_MIX: "mix"}[m.type]
     parts = ['MakeNamedMaterial "m%d" "string type" "%s"' % (i, t)]
     for name, tex in (("Kd", m.tex_kd), ("Ks", m.tex_ks), ("Kr", m.tex_kr), ("Kt", m.tex_kt), ("eta", m.tex_eta), ("k", m.tex_k)):
         if tex:
@@ -46,8 +47,19 @@ def material_text(i, m):
     elif t == "glass":
         parts += [_rgb("Kr", m.kr), _rgb("Kt", m.kt), '"float index" %.9g' % m.index, '"float uroughness" %.9g' % m.uroughness,
                   '"float vroughness" %.9g' % m.vroughness, remap]
-    else:
+    elif t == "plastic":
         parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), '"float roughness" %.9g' % m.uroughness, remap]
+    elif t == "mirror":
+        parts += [_rgb("Kr", m.kr)]
+    elif t == "translucent":
+        parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), _rgb("reflect", m.reflect), _rgb("transmit", m.transmit), '"float roughness" %.9g' % m.uroughness, remap]
+    elif t == "substrate":
+        parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), '"float uroughness" %.9g' % m.uroughness, '"float vroughness" %.9g' % m.vroughness, remap]
+    elif t == "uber":
+        parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), _rgb("Kr", m.kr), _rgb("Kt", m.kt), _rgb("opacity", m.opacity), '"float uroughness" %.9g' % m.uroughness,
+                  '"float vroughness" %.9g' % m.vroughness, '"float index" %.9g' % m.index, remap]
+    else:
+        parts += ['"string namedmaterial1" "m%d"' % m.mix_a, '"string namedmaterial2" "m%d"' % m.mix_b, _rgb("amount", m.amount)]
     return " ".join(parts)
 
 

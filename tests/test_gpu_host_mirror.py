@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""

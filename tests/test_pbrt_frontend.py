@@ -44,7 +44,7 @@ def flatten(d):
     return np.array(P, dtype=np.float32), mat, lights
 
 
-@pytest.mark.parametrize("variant", ["diffuse", "microfacet", "specular"])
+@pytest.mark.parametrize("variant", ["diffuse", "microfacet", "specular", "uber", "mix"])
 def test_cornell_scene_description_round_trip(tmp_path, variant):
     sc = scenes.cornell_box(variant)
     text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), FOV, 96, 64, 16)
@@ -62,10 +62,19 @@ def test_cornell_scene_description_round_trip(tmp_path, variant):
         assert got["type"] == ref.type
         for k in ("kd", "ks", "kr", "kt", "eta", "k"):
             if (ref.type, k) in ((abi.MAT_MATTE, "kd"), (abi.MAT_METAL, "eta"), (abi.MAT_METAL, "k"), (abi.MAT_GLASS, "kr"), (abi.MAT_GLASS, "kt"),
-                                 (abi.MAT_PLASTIC, "kd"), (abi.MAT_PLASTIC, "ks")):
+                                 (abi.MAT_PLASTIC, "kd"), (abi.MAT_PLASTIC, "ks"), (abi.MAT_MIRROR, "kr"), (abi.MAT_TRANSLUCENT, "kd"),
+                                 (abi.MAT_TRANSLUCENT, "ks"), (abi.MAT_SUBSTRATE, "kd"), (abi.MAT_SUBSTRATE, "ks"), (abi.MAT_UBER, "kd"),
+                                 (abi.MAT_UBER, "ks"), (abi.MAT_UBER, "kr"), (abi.MAT_UBER, "kt")):
                 assert np.array_equal(np.float32(got[k]), np.float32(list(getattr(ref, k))))
-        if ref.type != abi.MAT_MATTE:
-            assert np.float32(got["uroughness"]) == np.float32(ref.uroughness)
+        if ref.type not in (abi.MAT_MATTE, abi.MAT_MIRROR, abi.MAT_MIX):
+            assert np.float32(got["uroughness"]) == np.float32(ref.uroughness) and np.float32(got["vroughness"]) == np.float32(ref.vroughness)
+            assert got["remap"] == ref.remap_roughness
+        if ref.type == abi.MAT_TRANSLUCENT:
+            assert np.array_equal(np.float32(got["reflect"]), np.float32(list(ref.reflect))) and np.array_equal(np.float32(got["transmit"]), np.float32(list(ref.transmit)))
+        if ref.type == abi.MAT_UBER:
+            assert np.array_equal(np.float32(got["opacity"]), np.float32(list(ref.opacity))) and np.float32(got["index"]) == np.float32(ref.index)
+        if ref.type == abi.MAT_MIX:
+            assert got["mix"] == [ref.mix_a, ref.mix_b] and np.array_equal(np.float32(got["amount"]), np.float32(list(ref.amount)))
     # camera / film / sampler / integrator agree with the Python builders the parity tests use
     cam, film = scenes.cornell_camera(96, 64), scenes.film_desc(96, 64)
     assert np.allclose(d["camera"]["c2w"], list(cam.camera_to_world), rtol=1e-6, atol=1e-4)
@@ -172,6 +181,9 @@ WorldEnd
     ('WorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd\n', "cylinder"),
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
+    ('WorldBegin\nTexture "t" "spectrum" "constant"\nMaterial "uber" "texture Kd" "t"\nWorldEnd\n', "constant values only"),
+    ('WorldBegin\nMaterial "subsurface"\nWorldEnd\n', "subsurface"),
+    ('WorldBegin\nMakeNamedMaterial "a" "string type" "none"\nMaterial "mix" "string namedmaterial1" "a" "string namedmaterial2" "a"\nWorldEnd\n', "two materials"),
     ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),
     ('Sampler "halton"\nWorldBegin\nWorldEnd\n', "sobol"),
     ('Integrator "bdpt"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', "bdpt"),
@@ -197,6 +209,41 @@ def test_metal_without_eta_and_k_is_the_reference_copper(tmp_path):
     assert m0["type"] == abi.MAT_METAL and m0["remap"] == 1 and m0["uroughness"] == 0.5 and m0["vroughness"] == 0.5
     assert np.allclose(m0["eta"], eta, rtol=1e-6) and np.allclose(m0["k"], k, rtol=1e-6)
     assert np.allclose(m1["eta"], eta, rtol=1e-6) and m1["k"] == [1, 2, 3]        # each default on its own
+
+
+def test_defaults_of_the_lobe_list_materials_and_the_mix_of_an_unknown_name(tmp_path):
+    """Create{Mirror,Translucent,Substrate,Uber,Mix}Material's defaults (Enigma/Material.cpp:617-621,648-653,673-682,720-748);
+    an uber's roughnesses as its constructor resolves them (:563-570); a mix of a name nobody made takes a matte built from the
+    mix's own parameters (Enigma/Api.cpp:157-173); an unknown material is a matte, with a warning (:189-192)."""
+    tri = 'Shape "trianglemesh" "point P" [0 0 %d 1 0 %d 0 1 %d]\n'
+    text = 'Sampler "sobol"\nWorldBegin\n'
+    for k, m in enumerate(['Material "mirror"', 'Material "translucent"', 'Material "substrate"', 'Material "uber"',
+                           'Material "uber" "float roughness" 0.3 "float vroughness" 0.2 "float eta" 1.2 "float index" 1.9 "rgb opacity" [0.5 0.5 0.5]',
+                           'Material "uber" "float uroughness" 0.4',
+                           'MakeNamedMaterial "a" "string type" "mirror"\nMaterial "mix" "string namedmaterial1" "a" "string namedmaterial2" "nobody" "rgb Kd" [0.1 0.2 0.3]',
+                           'Material "frobnicate" "rgb Kd" [0.3 0.2 0.1]']):
+        text += m + "\n" + tri % (k, k, k)
+    d = dump(tmp_path, text + "WorldEnd\n")
+    ms = d["materials"]
+    f32 = np.float32
+    assert ms[0]["type"] == abi.MAT_MIRROR and np.allclose(ms[0]["kr"], 0.9)
+    t = ms[1]
+    assert t["type"] == abi.MAT_TRANSLUCENT and np.allclose(t["kd"], 0.25) and np.allclose(t["ks"], 0.25) and np.allclose(t["reflect"], 0.5) and np.allclose(t["transmit"], 0.5)
+    assert f32(t["uroughness"]) == f32(0.1) and t["remap"] == 1
+    sub = ms[2]
+    assert sub["type"] == abi.MAT_SUBSTRATE and np.allclose(sub["kd"], 0.5) and np.allclose(sub["ks"], 0.5) and f32(sub["uroughness"]) == f32(0.1) and f32(sub["vroughness"]) == f32(0.1)
+    u = ms[3]
+    assert u["type"] == abi.MAT_UBER and np.allclose(u["kd"], 0.25) and np.allclose(u["ks"], 0.25) and np.allclose(u["kr"], 0) and np.allclose(u["kt"], 0)
+    assert np.allclose(u["opacity"], 1) and f32(u["uroughness"]) == f32(0.1) and f32(u["vroughness"]) == f32(0.1) and f32(u["index"]) == f32(1.5)
+    assert f32(ms[4]["uroughness"]) == f32(0.3) and f32(ms[4]["vroughness"]) == f32(0.2) and f32(ms[4]["index"]) == f32(1.2) and np.allclose(ms[4]["opacity"], 0.5)
+    assert f32(ms[5]["uroughness"]) == f32(0.4) and f32(ms[5]["vroughness"]) == f32(0.4)
+    # materials in creation order: ..., the named mirror, the stand-in matte, the mix; then the unknown one as a matte
+    mirror, standin, mix, unknown = ms[6], ms[7], ms[8], ms[9]
+    assert mirror["type"] == abi.MAT_MIRROR and standin["type"] == abi.MAT_MATTE and np.allclose(standin["kd"], [0.1, 0.2, 0.3])
+    assert mix["type"] == abi.MAT_MIX and mix["mix"] == [6, 7] and np.allclose(mix["amount"], 0.5)
+    assert unknown["type"] == abi.MAT_MATTE and np.allclose(unknown["kd"], [0.3, 0.2, 0.1])
+    assert [m["material"] for m in d["meshes"]] == [0, 1, 2, 3, 4, 5, 8, 9]
+    assert any("nobody" in w for w in d["warnings"]) and any("frobnicate" in w for w in d["warnings"])
 
 
 def test_include_comments_and_named_materials(tmp_path):
