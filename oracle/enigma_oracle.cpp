@@ -1451,7 +1451,8 @@ struct BSDF {
     BSDF(const SurfaceInteraction& si, float e = 1.0f)
         : eta(e), ng(si.n), ns(si.shading.n), ss(Normalize(si.shading.dpdu)), ts(Cross(ns, ss)) {}
     ~BSDF() { for (int i = 0; i < nBxDFs; ++i) delete bxdfs[i]; }
-    void addBxDF(BxDF* b) { bxdfs[nBxDFs++] = b; }
+    bool overflow = false; // a ninth lobe: the reference asserts in debug builds and writes past m_pBxDFS otherwise (BxDF.cpp:854-858)
+    void addBxDF(BxDF* b) { if (nBxDFs == MAX_BxDFS) { overflow = true; delete b; return; } bxdfs[nBxDFs++] = b; }
     int numComponents(int flags) const { int n = 0; for (int i = 0; i < nBxDFs; ++i) if (bxdfs[i]->matchesFlags(flags)) ++n; return n; }
     Vec3 worldToLocal(const Vec3& v) const { return Vec3(Dot(v, ss), Dot(v, ts), Dot(v, ng)); } // sic: geometric normal
     Vec3 localToWorld(const Vec3& v) const {
@@ -2982,6 +2983,15 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         const size_t self = (size_t)(&m - sc.materials.data());
         if (m.type == ENIGMA_MAT_MIX && (m.mix_a >= self || m.mix_b >= self)) { h->o.error = "a mix names materials that come before it"; return -1; }
     }
+    for (auto& m : sc.materials) { // more than MAX_BxDFS lobes: undefined in the reference
+        if (m.type != ENIGMA_MAT_MIX) continue;
+        SurfaceInteraction si;
+        si.n = si.shading.n = Vec3(0, 0, 1); si.dpdu = si.shading.dpdu = Vec3(1, 0, 0); si.dpdv = si.shading.dpdv = Vec3(0, 1, 0);
+        for (bool multi : {true, false}) {
+            std::unique_ptr<BSDF> bsdf(MaterialScatteringFunctions(sc.materials.data(), m, si, multi, nullptr));
+            if (bsdf->overflow) { h->o.error = "a material with more than 8 lobes (MAX_BxDFS): undefined in the reference"; return -4; }
+        }
+    }
     // ImageTexture::getTexture (Texture.h:331-372): flip in y, ConvertIn = pow(texel * scale, gamma), MipMap
     sc.textures.tex.clear(); sc.textures.tex.resize(s->n_textures);
     for (uint32_t i = 0; i < s->n_textures; ++i) {
@@ -3292,6 +3302,7 @@ int oracle_debug_bsdf_of(const EnigmaMaterial* table, uint32_t nMaterials, uint3
     si.n = si.shading.n = Vec3(0, 0, 1); si.dpdu = si.shading.dpdu = Vec3(1, 0, 0); si.dpdv = si.shading.dpdv = Vec3(0, 1, 0);
     for (uint32_t i = 0; i < n; ++i) {
         std::unique_ptr<BSDF> bsdf(ComputeScatteringFunctions(table, *m, si, multipleLobes != 0, Ray(), nullptr));
+        if (bsdf->overflow) return -4; // more than MAX_BxDFS lobes
         Vec3 wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
         float* o = &out12[12 * (size_t)i];
         Spectrum f = bsdf->f(wo, wi, BSDF_ALL);

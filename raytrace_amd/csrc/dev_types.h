@@ -104,7 +104,6 @@ struct DevScene {
     const float4* nodes;        // 8-wide BVH nodes, 5 float4 each
     const float4* tris;         // triangles in BVH order, 3 float4 each (a sphere owns a slot too, see dev_trace8.h)
     const DevMaterial* materials;
-    const DevLobe* lobes;       // lobe lists of the MK_GENERAL materials; nullptr = none
     const DevLight* lights;
     // SpatialLightDistribution (Enigma/LightDist.cpp:80-267): per filled voxel nLights func values, nLights + 1 cdf values
     // and funcInt; nullptr = one table for the whole scene (lightCdf / lightFunc below).  As in the reference a voxel's
@@ -141,6 +140,8 @@ struct DevScene {
     uint32_t nTris;
     uint32_t nNodes;
     uint32_t nMaterials;
+    const DevLobe* lobes;       // lobe lists of the MK_GENERAL materials (last: the kernels that never read it keep the argument
+                                // offsets, and with them the scalar registers, they had without it)
 };
 
 struct DevCamera {

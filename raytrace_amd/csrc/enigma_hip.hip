@@ -1243,8 +1243,14 @@ static void launchClosest(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int 
     for (int k = 0; k < kQueueKinds; ++k) mq.q[k] = h->matQ[k].p;
     const uint32_t* queue = iter == 0 ? nullptr : h->extQ[cur].p;
     const uint32_t* countPtr = iter == 0 ? nullptr : &ctr->extCount[cur].v;
+    // the queues a finished ray can land in: the material kinds of the scene; surfaces without a material; under the
+    // DirectLightingIntegrator the paths that resume a branch, under the VolPathIntegrator the medium interactions
+    uint32_t queueMask = 0;
+    for (int k = 0; k < MK_COUNT; ++k) queueMask |= h->kindPresent[k] ? 1u << k : 0u;
+    if (MODE == 0) queueMask |= h->haveNoMaterial ? 1u << MK_NONE : 0u;
+    else queueMask |= (1u << MK_COUNT) | (1u << kQueueMedium);
     k_intersect_closest<LDSN, OVF, LDS_SCENE, MODE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, h->stream>>>(
-        h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount);
+        h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount, queueMask);
 }
 
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>

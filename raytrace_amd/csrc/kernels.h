@@ -497,7 +497,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
 template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
 __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
-                                                              const uint32_t* pendCount) {
+                                                              const uint32_t* pendCount, uint32_t queueMask) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
     constexpr bool kCrossInline = VOL && LDS_SCENE && kInlineCrossings > 0;
     // queue MK_COUNT: surfaces without a material / (MODE 1) paths that resume a branch; queue MK_COUNT + 1: medium interactions /
@@ -588,11 +588,14 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
             uint32_t j = wid * (kTraceChunk / kWavesPerBlock) + it * 64u + lane; // a wave bins one contiguous quarter of the chunk
             kinds |= (unsigned long long)(j < chunkCount ? (uint32_t)kindOf[j] : 0u) << (4 * it);
         }
+        // queueMask: the queues this scene and integrator can fill (bit k = queue k); the others cost a scalar test
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             uint32_t c = 0;
+            if ((queueMask >> k) & 1u) {
 #pragma unroll
-            for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot((uint32_t)((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
+                for (int it = 0; it < kTraceItems; ++it) c += __popcll(__ballot((uint32_t)((kinds >> (4 * it)) & 15u) == (uint32_t)k + 1u));
+            }
             if (lane == 0) binCnt[k * kWavesPerBlock + wid] = c;
         }
         __syncthreads();
@@ -604,6 +607,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
+            if (!((queueMask >> k) & 1u)) continue;
             uint32_t off = binBase[k];
             for (uint32_t w2 = 0; w2 < wid; ++w2) off += binCnt[k * kWavesPerBlock + w2];
 #pragma unroll
