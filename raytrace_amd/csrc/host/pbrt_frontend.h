@@ -23,6 +23,7 @@
 #pragma once
 #include "enigma_host.h"
 #include "medium_presets.inc"
+#include "ply_reader.h"
 
 #include <cctype>
 #include <cstdlib>
@@ -471,10 +472,11 @@ public:
         m_res->scene.AddDistantLight(m_ctm.ToFloat(), Lsc, Vector3f(from.x - to.x, from.y - to.y, from.z - to.z));
     }
     void pbrtAreaLightSource(const std::string& name, const ParamSet& p) { VerifyWorld("AreaLightSource"); m_gs.areaLight = name; m_gs.areaLightParams = p; }
-    void pbrtShape(const std::string& name, const ParamSet& p) {
+    void pbrtShape(const std::string& name, const ParamSet& p, const std::string& dir = "") {
         VerifyWorld("Shape");
         if (name == "sphere") { MakeSphere(p); return; }
-        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh, sphere)");
+        if (name == "plymesh") { MakePlyMesh(p, dir); return; }
+        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh, plymesh, sphere)");
         std::vector<int> vi = p.FindInt("indices");
         std::vector<double> P = p.FindPoint3("P");
         if (P.empty() || P.size() % 3) throw std::runtime_error("trianglemesh: \"point P\" missing or not a multiple of 3 values");
@@ -496,6 +498,25 @@ public:
         if (!uv.empty() && (int)uv.size() / 2 < nVerts) { Warn("Not enough of \"uv\"s for triangle mesh.  Discarding."); uv.clear(); }
         std::vector<double> N = p.FindNormal3("N");
         if (!N.empty() && (int)N.size() / 3 != nVerts) { Warn("Number of \"N\"s for triangle mesh must match \"P\"s"); N.clear(); }
+        AddMesh(vi, P, uv, N);
+        NoteUnused("Shape", p);
+    }
+    // CreatePLYMesh (Enigma/TriangleMesh.cpp:791-931): the file's vertices, normals, uvs and faces into CreateTriangleMesh
+    void MakePlyMesh(const ParamSet& p, const std::string& dir) {
+        std::string filename = p.FindOneString("filename", "");
+        if (!filename.empty() && filename[0] != '/') filename = dir + filename; // ParamSet::FindOneFilename: relative to the scene file
+        for (const auto& it : p.Items())
+            if (it.name == "alpha" || it.name == "shadowalpha") throw std::runtime_error("plymesh: alpha textures are not supported");
+        PlyMesh ply = PlyReader::Read(filename);
+        for (const std::string& w : ply.warnings) Warn(w);
+        if (ply.indices.empty()) { Warn("plymesh: \"" + filename + "\" holds no triangle or quad under the face property \"vertex_indices\"; no shape made"); NoteUnused("Shape", p); return; }
+        AddMesh(ply.indices, std::vector<double>(ply.p.begin(), ply.p.end()), std::vector<double>(ply.uv.begin(), ply.uv.end()),
+                std::vector<double>(ply.n.begin(), ply.n.end()));
+        NoteUnused("Shape", p);
+    }
+    // CreateTriangleMesh + the primitives MakeShapes wraps its triangles in (Enigma/TriangleMesh.cpp:662-682, Enigma/Api.cpp:843-874)
+    void AddMesh(const std::vector<int>& vi, const std::vector<double>& P, const std::vector<double>& uv, const std::vector<double>& N) {
+        const int nVerts = (int)P.size() / 3;
         TriangleMesh m;
         m.m_nTriangles = (int)vi.size() / 3; m.m_nVertices = nVerts;
         m.m_vertexIndices = vi;
@@ -529,7 +550,6 @@ public:
             m.twoSided = ap.FindOneBool("twosided", false);
         }
         m_res->scene.AddTriangleMesh(m);
-        NoteUnused("Shape", p);
     }
     // CreateSphereShape (Enigma/ShapeImp.cpp:723-732) + the primitive MakeShapes wraps it in (Enigma/Api.cpp:843-874)
     void MakeSphere(const ParamSet& p) {
@@ -908,7 +928,7 @@ private:
             else if (d == "NamedMaterial") pbrtNamedMaterial(c.str("NamedMaterial"));
             else if (d == "LightSource") { std::string n = c.str("LightSource"); pbrtLightSource(n, ParseParams(c)); }
             else if (d == "AreaLightSource") { std::string n = c.str("AreaLightSource"); pbrtAreaLightSource(n, ParseParams(c)); }
-            else if (d == "Shape") { std::string n = c.str("Shape"); pbrtShape(n, ParseParams(c)); }
+            else if (d == "Shape") { std::string n = c.str("Shape"); pbrtShape(n, ParseParams(c), dir); }
             else if (d == "Texture") { std::string n = c.str("Texture"), ty = c.str("Texture"), cl = c.str("Texture"); pbrtTexture(n, ty, cl, ParseParams(c), dir); }
             else if (d == "Include") {
                 std::string inc = c.str("Include");

@@ -32,6 +32,39 @@ def texture_text(i, t, directory):
             (i, i, "true" if t.trilinear else "false", "true" if t.gamma != 0 else "false", t.scale, wrap, t.su, t.sv, t.du, t.dv))
 
 
+def write_ply(path, verts, tris, normals=None, uvs=None, fmt="binary_little_endian", quads=None):
+    """A PLY file of a triangle mesh (quads: optional [n, 4] faces written after the triangles)."""
+    import struct
+    n = len(verts)
+    head = ["ply", "format %s 1.0" % fmt, "comment written by tests/pbrt_writer.py", "element vertex %d" % n,
+            "property float x", "property float y", "property float z"]
+    if normals is not None:
+        head += ["property float nx", "property float ny", "property float nz"]
+    if uvs is not None:
+        head += ["property float u", "property float v"]
+    nq = 0 if quads is None else len(quads)
+    head += ["element face %d" % (len(tris) + nq), "property list uchar int vertex_indices", "end_header"]
+    cols = [np.asarray(verts, dtype=np.float32)]
+    if normals is not None:
+        cols.append(np.asarray(normals, dtype=np.float32))
+    if uvs is not None:
+        cols.append(np.asarray(uvs, dtype=np.float32))
+    table = np.concatenate(cols, axis=1)
+    faces = [list(map(int, t)) for t in tris] + ([] if quads is None else [list(map(int, q)) for q in quads])
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        if fmt == "ascii":
+            for row in table:
+                f.write((" ".join("%.9g" % float(v) for v in row) + "\n").encode())
+            for fc in faces:
+                f.write(("%d %s\n" % (len(fc), " ".join(str(v) for v in fc))).encode())
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            f.write(table.astype(e + "f4").tobytes())
+            for fc in faces:
+                f.write(struct.pack(e + "B%di" % len(fc), len(fc), *fc))
+
+
 def material_text(i, m):
     t = {abi.MAT_MATTE: "matte", abi.MAT_METAL: "metal", abi.MAT_GLASS: "glass", abi.MAT_PLASTIC: "plastic", abi.MAT_MIRROR: "mirror",
          abi.MAT_TRANSLUCENT: "translucent", abi.MAT_SUBSTRATE: "substrate", abi.MAT_UBER: "uber", abi.MAT_MIX: "mix"}[m.type]
@@ -64,7 +97,8 @@ def material_text(i, m):
 
 
 def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
-               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens="", texture_dir=None):
+               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens="", texture_dir=None, ply_dir=None):
+    """ply_dir: the meshes go into <ply_dir>/mesh<k>.ply (formats in turn) and the scene names them with Shape "plymesh"."""
     out = ["# written by tests/pbrt_writer.py",
            "LookAt %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g" % (tuple(eye) + tuple(look) + tuple(up)),
            'Camera "perspective" "float fov" %.9g %s' % (fov, lens),
@@ -139,6 +173,15 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
             extra += ' "normal N" [%s]' % " ".join("%.9g" % float(v) for v in sc.normals[sc.indices[t:e].reshape(-1)].reshape(-1))
         if fl & abi.TRI_HAS_UVS:
             extra += ' "float uv" [%s]' % " ".join("%.9g" % float(v) for v in sc.uvs[sc.indices[t:e].reshape(-1)].reshape(-1))
+        if ply_dir is not None:
+            k = sum(1 for line in out if 'Shape "plymesh"' in line)
+            ids = sc.indices[t:e].reshape(-1)
+            write_ply(os.path.join(ply_dir, "mesh%d.ply" % k), verts, idx.reshape(-1, 3), normals=sc.normals[ids] if fl & abi.TRI_HAS_NORMALS else None,
+                      uvs=sc.uvs[ids] if fl & abi.TRI_HAS_UVS else None, fmt=("binary_little_endian", "ascii", "binary_big_endian")[k % 3])
+            out.append('  Shape "plymesh" "string filename" "mesh%d.ply"' % k)
+            out.append("AttributeEnd")
+            t = e
+            continue
         out.append('  Shape "trianglemesh" "integer indices" [%s] "point P" [%s]%s' %
                    (" ".join(str(int(v)) for v in idx), " ".join("%.9g" % float(v) for v in verts.reshape(-1)), extra))
         out.append("AttributeEnd")

@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath"), ("ply:smooth", "path"), ("ply:textured", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -88,6 +88,9 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     import pbrt_writer
     assert os.path.exists(EXE), "raytrace_amd/enigma_render is not built (make -C raytrace_amd/csrc)"
     xres, yres, spp = 72, 48, 8
+    ply_dir = None
+    if variant.startswith("ply:"):       # the meshes in PLY files (ascii and both binary byte orders in turn) under Shape "plymesh"
+        variant, ply_dir = variant.split(":")[1], str(tmp_path)
     if variant.startswith("fog:"):
         sc = scenes.cornell_fog(variant.split(":")[1])
     elif variant.startswith("sky:"):
@@ -106,7 +109,8 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
     itext = {"path": 'Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
              "volpath": 'Integrator "volpath" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
              "directlighting": 'Integrator "directlighting" "integer maxdepth" 5 "string strategy" "all"'}[integrator]
-    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp, integrator=itext, texture_dir=str(tmp_path))
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, xres, yres, spp, integrator=itext, texture_dir=str(tmp_path), ply_dir=ply_dir)
+    assert ply_dir is None or 'Shape "plymesh"' in text
     scene_file, out_file = str(tmp_path / "cornell.pbrt"), str(tmp_path / "out.pfm")
     with open(scene_file, "w") as f:
         f.write(text)

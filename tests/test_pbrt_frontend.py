@@ -246,6 +246,64 @@ def test_defaults_of_the_lobe_list_materials_and_the_mix_of_an_unknown_name(tmp_
     assert any("nobody" in w for w in d["warnings"]) and any("frobnicate" in w for w in d["warnings"])
 
 
+def test_plymesh_reads_what_the_references_rply_callbacks_keep(tmp_path):
+    """Shape "plymesh" (CreatePLYMesh and its callbacks, Enigma/TriangleMesh.cpp:98-174,791-931): ascii and both binary
+    byte orders; quads become (0 1 2) (3 0 2); faces of other sizes are skipped; normals and the first complete uv pair are
+    kept; other elements and properties are read past; the mesh goes through the CTM like a trianglemesh."""
+    rng = np.random.RandomState(5)
+    v = rng.uniform(-1, 1, (7, 3)).astype(np.float32)
+    nrm = rng.normal(size=(7, 3)).astype(np.float32)
+    uv = rng.uniform(0, 1, (7, 2)).astype(np.float32)
+    tris, quads = [[0, 1, 2], [2, 3, 4]], [[3, 4, 5, 6]]
+    want_idx = [0, 1, 2, 2, 3, 4, 3, 4, 5, 6, 3, 5]
+    for k, fmt in enumerate(("ascii", "binary_little_endian", "binary_big_endian")):
+        pbrt_writer.write_ply(str(tmp_path / ("m%d.ply" % k)), v, tris, normals=nrm, uvs=uv, fmt=fmt, quads=quads)
+    # a hand-written file: doubles, s / t names, a property and an element nobody reads, a pentagon, shorts as indices
+    with open(tmp_path / "hand.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment by hand\nelement vertex 5\nproperty double x\nproperty double y\nproperty double z\n"
+                "property uchar red\nproperty float s\nproperty float t\nelement edge 1\nproperty int a\nproperty int b\n"
+                "element face 3\nproperty list uchar short vertex_indices\nproperty int face_indices\nend_header\n")
+        for i in range(5):
+            f.write("%d.25 %d %d 200 0.%d 0.5\n" % (i, i * 2, -i, i))
+        f.write("7 9\n3 0 1 2 11\n5 0 1 2 3 4 12\n4 1 2 3 4 13\n")
+    text = 'Sampler "sobol"\nWorldBegin\nTranslate 1 2 3\nScale 2 2 2\n'
+    for k in range(3):
+        text += 'Shape "plymesh" "string filename" "m%d.ply"\n' % k
+    text += 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]\n' % (
+        " ".join(map(str, want_idx)), " ".join("%.9g" % x for x in v.reshape(-1)), " ".join("%.9g" % x for x in nrm.reshape(-1)), " ".join("%.9g" % x for x in uv.reshape(-1)))
+    text += 'Shape "plymesh" "string filename" "hand.ply"\nWorldEnd\n'
+    d = dump(tmp_path, text)
+    ref = d["meshes"][3]
+    for k in range(3):
+        m = d["meshes"][k]
+        assert m["indices"] == want_idx == ref["indices"]
+        for key in ("P", "N", "uv"):
+            assert np.array_equal(np.float32(m[key]), np.float32(d["meshes"][0][key])), (k, key)      # the three encodings hold the same floats
+            assert np.allclose(np.float32(m[key]), np.float32(ref[key]), rtol=1e-6, atol=1e-7), (k, key)   # the inline mesh goes through nine decimal digits
+    assert np.allclose(np.float32(ref["P"]).reshape(-1, 3), v * 2 + np.array([1, 2, 3], dtype=np.float32), rtol=1e-6)
+    hand = d["meshes"][4]
+    assert hand["indices"] == [0, 1, 2, 1, 2, 3, 4, 1, 3]                 # the pentagon is skipped, the quad split
+    P = np.float32(hand["P"]).reshape(-1, 3)
+    assert np.allclose(P[1], np.array([1.25, 2, -1]) * 2 + [1, 2, 3]) and np.allclose(np.float32(hand["uv"]).reshape(-1, 2)[3], [0.3, 0.5])
+    assert hand["N"] == [] and any("neither triangles nor quads" in w for w in d["warnings"])
+    # errors: a missing file, an index out of range, a truncated binary file, a file without faces
+    assert "Couldn't open PLY file" in dump(tmp_path, 'WorldBegin\nShape "plymesh" "string filename" "nope.ply"\nWorldEnd\n', expect_fail=True)
+    pbrt_writer.write_ply(str(tmp_path / "bad.ply"), v, [[0, 1, 9]], fmt="ascii")
+    assert "out of bounds" in dump(tmp_path, 'WorldBegin\nShape "plymesh" "string filename" "bad.ply"\nWorldEnd\n', expect_fail=True)
+    data = open(tmp_path / "m1.ply", "rb").read()
+    open(tmp_path / "cut.ply", "wb").write(data[:-7])
+    assert "unable to read the contents" in dump(tmp_path, 'WorldBegin\nShape "plymesh" "string filename" "cut.ply"\nWorldEnd\n', expect_fail=True)
+    with open(tmp_path / "nofaces.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n")
+    assert "No face/vertex elements" in dump(tmp_path, 'WorldBegin\nShape "plymesh" "string filename" "nofaces.ply"\nWorldEnd\n', expect_fail=True)
+    # the other common name of the face list is not the one the reference asks rply for: no shape, a warning
+    with open(tmp_path / "other.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                "property list uchar int vertex_index\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nShape "plymesh" "string filename" "other.ply"\nWorldEnd\n')
+    assert d["meshes"] == [] and any("vertex_indices" in w for w in d["warnings"])
+
+
 def test_include_comments_and_named_materials(tmp_path):
     with open(tmp_path / "geo.pbrt", "w") as f:
         f.write('# included file\nNamedMaterial "red"\nShape "trianglemesh" "point P" [0 0 0  1 0 0  0 1 0] # trailing comment\n')
