@@ -207,11 +207,18 @@ typedef struct EnigmaSceneDesc {
 /* PerspectiveCamera state read by GenerateRayDifferential (Enigma/Camera.cpp:144-192):
  * ProjectiveCamera::m_rasterToCamera, Camera::m_cameraToWorld (start transform),
  * m_lensRadius, m_focalDistance (Enigma/Camera.h:40-56). */
+#define ENIGMA_CAMERA_PERSPECTIVE 0u
+/* EnvironmentCamera (Enigma/Camera.cpp:364-383): the ray through film point (x, y) leaves the camera's origin along
+ * SphericalDirection(pi * y / yres, 2 pi * x / xres) -- the camera's z axis at the top row -- in camera space; its ray
+ * differentials are the rays one pixel further in x and in y (Camera::GenerateRayDifferential, Enigma/Camera.cpp:35-57).
+ * Reads camera_to_world only; the resolution is the film's full_resolution. */
+#define ENIGMA_CAMERA_ENVIRONMENT 1u
 typedef struct EnigmaCameraDesc {
     float raster_to_camera[16];
     float camera_to_world[16];
     float lens_radius;
     float focal_distance;
+    uint32_t type;            /* ENIGMA_CAMERA_* */
 } EnigmaCameraDesc;
 
 /* Film state read by GetSampleBounds/GetFilmTile/AddSample (Enigma/Film.cpp:73-99,

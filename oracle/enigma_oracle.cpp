@@ -239,12 +239,40 @@ static float PowerHeuristic(int nf, float fPdf, int ng, float gPdf) {
 struct PerspectiveCamera {
     Mat4 rasterToCamera, cameraToWorld;
     float lensRadius = 0, focalDistance = 0;
+    uint32_t type = ENIGMA_CAMERA_PERSPECTIVE;
+    int fullResX = 1, fullResY = 1; // Film::m_fullResolution, for the EnvironmentCamera
     Vec3 dxCamera, dyCamera;
+    // EnvironmentCamera::GenerateRay (Camera.cpp:370-383): no lens, no raster transform; the time is not used by anything here
+    float EnvironmentRay(float ix, float iy, Vec3* o, Vec3* d) const {
+        float theta = PI * iy / fullResY;
+        float phi = (PI * 2.0f) * ix / fullResX;
+        float sinTheta = sinf(theta), cosTheta = cosf(theta);
+        Vec3 dir(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta); // SphericalDirection, MathCommon.cpp:13-28
+        *d = cameraToWorld.transformVector(dir);
+        *o = cameraToWorld.transformPoint(Vec3(0, 0, 0));
+        return 1.0f;
+    }
+    // Camera::GenerateRayDifferential (Camera.cpp:35-57) over EnvironmentRay: the rays one pixel further in x and in y
+    float GenerateEnvironmentRay(const CameraSample& sample, Ray* ray) const {
+        Vec3 o, d;
+        float wt = EnvironmentRay(sample.image.x, sample.image.y, &o, &d);
+        *ray = Ray(o, d, InfinityF32);
+        float x = sample.image.x, y = sample.image.y;
+        ++x;
+        EnvironmentRay(x, y, &ray->rxOrigin, &ray->rxDirection);
+        --x;
+        ++y;
+        EnvironmentRay(x, y, &ray->ryOrigin, &ray->ryDirection);
+        ray->time = sample.time;
+        ray->hasDifferentials = true;
+        return wt;
+    }
     void init() {
         dxCamera = rasterToCamera.transformPoint(Vec3(1, 0, 0)) - rasterToCamera.transformPoint(Vec3(0, 0, 0));
         dyCamera = rasterToCamera.transformPoint(Vec3(0, 1, 0)) - rasterToCamera.transformPoint(Vec3(0, 0, 0));
     }
     float GenerateRay(const CameraSample& sample, Ray* ray) const {
+        if (type == ENIGMA_CAMERA_ENVIRONMENT) return GenerateEnvironmentRay(sample, ray);
         Vec3 Pras(sample.image.x, sample.image.y, 0);
         Vec3 Pcamera = rasterToCamera.transformPoint(Pras);
         *ray = Ray(Vec3(0, 0, 0), Normalize(Pcamera), InfinityF32);
@@ -3086,10 +3114,15 @@ int oracle_camera_set(OracleCtx* h, const EnigmaCameraDesc* c) {
     memcpy(h->o.camera.rasterToCamera.m, c->raster_to_camera, 64);
     memcpy(h->o.camera.cameraToWorld.m, c->camera_to_world, 64);
     h->o.camera.lensRadius = c->lens_radius; h->o.camera.focalDistance = c->focal_distance;
+    h->o.camera.type = c->type;
     h->o.camera.init();
     return 0;
 }
-int oracle_film_config(OracleCtx* h, const EnigmaFilmDesc* f) { h->o.film.reset(new Film(*f)); return 0; }
+int oracle_film_config(OracleCtx* h, const EnigmaFilmDesc* f) {
+    h->o.film.reset(new Film(*f));
+    h->o.camera.fullResX = f->full_resolution[0]; h->o.camera.fullResY = f->full_resolution[1];
+    return 0;
+}
 int oracle_film_sample_bounds(OracleCtx* h, int32_t out[4]) {
     BBox2i b = h->o.film->GetSampleBounds();
     out[0] = b.mn.x; out[1] = b.mn.y; out[2] = b.mx.x; out[3] = b.mx.y;

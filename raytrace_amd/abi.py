@@ -7,6 +7,7 @@ MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
 MAT_MIRROR, MAT_TRANSLUCENT, MAT_SUBSTRATE, MAT_UBER, MAT_MIX = 4, 5, 6, 7, 8
 LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE = 0, 1, 2, 3, 4, 5
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
+CAMERA_PERSPECTIVE, CAMERA_ENVIRONMENT = 0, 1
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
 TRI_HAS_NORMALS = 2
@@ -68,7 +69,7 @@ class EnigmaSceneDesc(C.Structure):
 
 class EnigmaCameraDesc(C.Structure):
     _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
-                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float), ("type", C.c_uint32)]
 
 
 class EnigmaFilmDesc(C.Structure):

@@ -148,6 +148,8 @@ struct DevCamera {
     float r2c[16];
     float c2w[16];
     float lensRadius, focalDistance;
+    uint32_t type;              // ENIGMA_CAMERA_*
+    float resX, resY;           // Film::m_fullResolution (the environment camera's angles are fractions of it)
 };
 
 struct DevFilm {

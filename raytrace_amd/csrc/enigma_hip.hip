@@ -869,8 +869,10 @@ extern "C" int enigma_camera_set(EnigmaCtx* h, const EnigmaCameraDesc* c) {
     if (!h || !c) return ENIGMA_E_INVALID;
     memcpy(h->camera.r2c, c->raster_to_camera, 64);
     memcpy(h->camera.c2w, c->camera_to_world, 64);
-    h->camera.lensRadius = c->lens_radius;
+    if (c->type > ENIGMA_CAMERA_ENVIRONMENT) return h->fail(ENIGMA_E_INVALID, "unknown camera type %u", c->type);
+    h->camera.lensRadius = c->type == ENIGMA_CAMERA_ENVIRONMENT ? 0.f : c->lens_radius; // the environment camera has no lens: no lens samples are drawn for it
     h->camera.focalDistance = c->focal_distance;
+    h->camera.type = c->type;
     h->haveCamera = true;
     return ENIGMA_OK;
 }
@@ -902,6 +904,7 @@ extern "C" int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* f) {
     h->film.maxSampleLuminance = f->max_sample_luminance;
     h->film.pixels = h->filmPixels.p;
     h->film.filterTable = h->filterTable.p;
+    h->camera.resX = (float)f->full_resolution[0]; h->camera.resY = (float)f->full_resolution[1];
     h->haveFilm = true;
     return enigma_film_clear(h);
 }

@@ -212,6 +212,7 @@ public:
     float m_lensRadius, m_focalDistance;
 };
 class PerspectiveCamera : public ProjectiveCamera { public: using ProjectiveCamera::ProjectiveCamera; };
+class EnvironmentCamera : public Camera { public: using Camera::Camera; }; // Enigma/Camera.h:96-104
 using CameraPtr = std::shared_ptr<Camera>;
 
 // ---- sampler (Enigma/Sampler.h:13-50,143-158) ----
@@ -423,10 +424,15 @@ public:
         check(enigma_scene_upload(h, &sd));
 
         const ProjectiveCamera* cam = dynamic_cast<const ProjectiveCamera*>(m_camera.get());
-        if (!cam) throw std::runtime_error("the GPU integrators need a PerspectiveCamera");
+        const bool environment = dynamic_cast<const EnvironmentCamera*>(m_camera.get()) != nullptr;
+        if (!cam && !environment) throw std::runtime_error("the GPU integrators need a PerspectiveCamera or an EnvironmentCamera");
         EnigmaCameraDesc cd{};
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { cd.raster_to_camera[4 * r + c] = cam->m_rasterToCamera.m_mat[r][c]; cd.camera_to_world[4 * r + c] = cam->m_cameraToWorld.m_mat[r][c]; }
-        cd.lens_radius = cam->m_lensRadius; cd.focal_distance = cam->m_focalDistance;
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+            cd.raster_to_camera[4 * r + c] = cam ? cam->m_rasterToCamera.m_mat[r][c] : (r == c ? 1.f : 0.f);
+            cd.camera_to_world[4 * r + c] = m_camera->m_cameraToWorld.m_mat[r][c];
+        }
+        cd.lens_radius = cam ? cam->m_lensRadius : 0.f; cd.focal_distance = cam ? cam->m_focalDistance : 1e30f;
+        cd.type = environment ? ENIGMA_CAMERA_ENVIRONMENT : ENIGMA_CAMERA_PERSPECTIVE;
         check(enigma_camera_set(h, &cd));
 
         Film& film = *m_camera->m_film;

@@ -613,7 +613,8 @@ public:
         std::unique_ptr<Film> film(new Film(Vector2i(xres, yres), crop, std::move(filter), diagonal, filename, scale, maxLum));
         Film* filmPtr = film.get();
         // camera (Enigma/Camera.cpp:385-432, 80-97)
-        if (m_opt.CameraName != "perspective") throw std::runtime_error("Camera \"" + m_opt.CameraName + "\" is not supported (perspective)");
+        if (m_opt.CameraName != "perspective" && m_opt.CameraName != "environment")
+            throw std::runtime_error("Camera \"" + m_opt.CameraName + "\" is not supported (perspective, environment)");
         const ParamSet& cp = m_opt.CameraParams;
         float lensradius = cp.FindOneFloat("lensradius", 0.f), focaldistance = cp.FindOneFloat("focaldistance", 1e30f);
         float frame = cp.FindOneFloat("frameaspectratio", float(xres) / float(yres));
@@ -632,8 +633,11 @@ public:
         Mat4d screenToRaster = ScaleD(xres, yres, 1) * ScaleD(1.0 / ((double)screen[1] - screen[0]), 1.0 / ((double)screen[2] - screen[3]), 1) *
                                TranslateD(-(double)screen[0], -(double)screen[3], 0);
         Mat4d rasterToCamera = cameraToScreen.Inverse() * screenToRaster.Inverse();
-        R.camera.reset(new PerspectiveCamera(m_opt.CameraToWorld.ToFloat(), rasterToCamera.ToFloat(), cp.FindOneFloat("shutteropen", 0.f),
-                                             cp.FindOneFloat("shutterclose", 1.f), lensradius, focaldistance, std::move(film)));
+        if (m_opt.CameraName == "environment") // CreateEnvironmentCamera (Enigma/Camera.cpp:476-510): lens and screen window are read and not used
+            R.camera.reset(new EnvironmentCamera(m_opt.CameraToWorld.ToFloat(), cp.FindOneFloat("shutteropen", 0.f), cp.FindOneFloat("shutterclose", 1.f), std::move(film)));
+        else
+            R.camera.reset(new PerspectiveCamera(m_opt.CameraToWorld.ToFloat(), rasterToCamera.ToFloat(), cp.FindOneFloat("shutteropen", 0.f),
+                                                 cp.FindOneFloat("shutterclose", 1.f), lensradius, focaldistance, std::move(film)));
         // sampler (Enigma/Sampler.cpp:554-559)
         if (m_opt.SamplerName != "sobol") throw std::runtime_error("Sampler \"" + m_opt.SamplerName + "\" is not supported: the GPU integrators reproduce the sobol sampler");
         R.sampler.reset(new SobolSampler(m_opt.SamplerParams.FindOneInt("pixelsamples", 16), filmPtr->GetSampleBounds()));

@@ -40,7 +40,9 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o.precision(9);
     auto arr = [&](const float* v, size_t n) { o << "["; for (size_t i = 0; i < n; ++i) o << (i ? "," : "") << (std::isinf(v[i]) ? (v[i] > 0 ? 1e39 : -1e39) : (double)v[i]); o << "]"; };
     const Film& film = R.camera->GetFilm();
-    const ProjectiveCamera& cam = static_cast<const ProjectiveCamera&>(*R.camera);
+    const bool environment = dynamic_cast<const EnvironmentCamera*>(R.camera.get()) != nullptr;
+    static const ProjectiveCamera noProjection(Transform(), Transform(), 0.f, 1.f, 0.f, 1e30f, nullptr);
+    const ProjectiveCamera& cam = environment ? noProjection : static_cast<const ProjectiveCamera&>(*R.camera);
     const SobolSampler& sob = static_cast<const SobolSampler&>(*R.sampler);
     const BBox2i &cb = film.m_croppedPixelBounds, &sb = sob.m_sampleBounds, &pb = R.pixelBounds;
     o << "{\"film\":{\"xres\":" << film.m_fullResolution.x << ",\"yres\":" << film.m_fullResolution.y << ",\"cropped\":[" << cb.m_min.x << "," << cb.m_min.y << ","
@@ -48,7 +50,7 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
       << "],\"filename\":\"" << film.m_filename << "\",\"max_sample_luminance\":";
     float msl = film.GetMaxSampleLuminance(); arr(&msl, 1);
     o << ",\"filter_table\":"; arr(film.GetFilterTable(), 256);
-    o << "},\n\"camera\":{\"c2w\":"; arr(&cam.m_cameraToWorld.m_mat[0][0], 16);
+    o << "},\n\"camera\":{\"type\":\"" << (environment ? "environment" : "perspective") << "\",\"c2w\":"; arr(&R.camera->m_cameraToWorld.m_mat[0][0], 16);
     o << ",\"r2c\":"; arr(&cam.m_rasterToCamera.m_mat[0][0], 16);
     o << ",\"lensradius\":"; arr(&cam.m_lensRadius, 1); o << ",\"focaldistance\":"; arr(&cam.m_focalDistance, 1);
     o << "},\n\"sampler\":{\"spp\":" << sob.m_samplesPerPixel << ",\"sample_bounds\":[" << sb.m_min.x << "," << sb.m_min.y << "," << sb.m_max.x << "," << sb.m_max.y << "]},\n";

@@ -97,7 +97,19 @@ DEV F3 xfPoint(const float* m, F3 p) { // Transform::transformPoint, Enigma/Tran
 DEV F3 xfVector(const float* m, F3 v) { // Transform::transformVector, Enigma/Transform.h:47-52
     return F3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
+// EnvironmentCamera::GenerateRay's direction in camera space (Enigma/Camera.cpp:372-377, Enigma/MathCommon.cpp:13-28)
+DEV F3 environmentDirection(const DevCamera& C, float fx, float fy) {
+    const float theta = kPi * fy / C.resY;
+    const float phi = (kPi * 2.0f) * fx / C.resX;
+    const float sinTheta = sinf(theta);
+    return F3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosf(theta));
+}
 DEV void cameraRay(const DevCamera& C, float fx, float fy, float lu, float lv, F3* o, F3* d) {
+    if (C.type == 1u) { // ENIGMA_CAMERA_ENVIRONMENT
+        *d = xfVector(C.c2w, environmentDirection(C, fx, fy));
+        *o = xfPoint(C.c2w, F3(0.f, 0.f, 0.f));
+        return;
+    }
     F3 Pcamera = xfPoint(C.r2c, F3(fx, fy, 0.f));
     F3 ro(0.f, 0.f, 0.f), rd = normalize(Pcamera);
     if (C.lensRadius > 0.f) {

@@ -129,7 +129,13 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
             const F3 dxCamera = xfPoint(C.r2c, F3(1.f, 0.f, 0.f)) - origin0, dyCamera = xfPoint(C.r2c, F3(0.f, 1.f, 0.f)) - origin0;
             const F3 Pcamera = xfPoint(C.r2c, F3(pf.x, pf.y, 0.f));
             F3 rxD, ryD;
-            if (C.lensRadius > 0.f) {
+            if (C.type == 1u) {
+                // EnvironmentCamera: the rays one pixel further in x, and -- from the x that ++ and -- leave behind -- in y
+                // (Camera::GenerateRayDifferential, Enigma/Camera.cpp:35-57)
+                const float xs = pf.x + 1.f, xb = xs - 1.f;
+                rxD = environmentDirection(C, xs, pf.y);
+                ryD = environmentDirection(C, xb, pf.y + 1.f);
+            } else if (C.lensRadius > 0.f) {
                 uint32_t px, py, slot;
                 pathPixel(I, S, p, &px, &py, &slot);
                 float lx, ly;

@@ -47,6 +47,16 @@ def perspective_raster_to_camera(fov_deg, xres, yres, n=1e-2, f=1000.0):
     return np.linalg.inv(cam_to_screen) @ np.linalg.inv(screen_to_raster)
 
 
+def environment_camera_desc(pos, look, up):
+    """EnvironmentCamera: every direction around pos; the camera's z axis (towards look) is the top row of the film."""
+    c = abi.EnigmaCameraDesc()
+    c.raster_to_camera[:] = np.eye(4, dtype=F32).reshape(-1).tolist()
+    c.camera_to_world[:] = look_at(pos, look, up).astype(F32).reshape(-1).tolist()
+    c.focal_distance = 1e30
+    c.type = abi.CAMERA_ENVIRONMENT
+    return c
+
+
 def camera_desc(pos, look, up, fov_deg, xres, yres, lens_radius=0.0, focal_distance=1e30):
     c = abi.EnigmaCameraDesc()
     r2c = perspective_raster_to_camera(fov_deg, xres, yres).astype(F32)

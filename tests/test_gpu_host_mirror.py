@@ -180,3 +180,25 @@ def test_scene_file_with_the_default_metal_renders_like_the_oracle_with_copper(t
     o.render(0, spp, threads=4)
     assert common.mean_relative_error(img, o.image()) < 1e-3
     o.close()
+
+
+def test_scene_description_with_the_environment_camera(tmp_path):
+    """Camera "environment" in a scene file (CreateEnvironmentCamera, Enigma/Camera.cpp:476-510) against the oracle."""
+    import pbrt_writer
+    sc = scenes.cornell_box("microfacet")
+    eye, look, up = (278.0, 273.0, 279.6), (278.0, 273.0, 600.0), (0.0, 1.0, 0.0)
+    text = pbrt_writer.scene_text(sc, eye, look, up, 40.0, 64, 32, 8)
+    lines = text.split("\n")
+    k = [i for i, l in enumerate(lines) if l.startswith('Camera "perspective"')]
+    assert len(k) == 1
+    lines[k[0]] = 'Camera "environment"'
+    scene_file, out_file = str(tmp_path / "env.pbrt"), str(tmp_path / "env.pfm")
+    with open(scene_file, "w") as f:
+        f.write("\n".join(lines))
+    p = subprocess.run([EXE, scene_file, out_file], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    film = scenes.film_desc(64, 32)
+    o = orc.Oracle(sc, scenes.environment_camera_desc(eye, look, up), film, scenes.integrator_desc(film, 8))
+    o.render(0, 8, threads=4)
+    assert common.mean_relative_error(_read_pfm(out_file), o.image()) < 1e-3
+    o.close()

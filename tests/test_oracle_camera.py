@@ -1,0 +1,65 @@
+"""Known answers for the oracle's EnvironmentCamera (Enigma/Camera.cpp:364-383; its ray differentials are the base
+class's, Enigma/Camera.cpp:35-57).  The reference holds no vector for it: parity unpinned."""
+import math
+
+import numpy as np
+
+import orc
+from raytrace_amd import abi, scenes
+
+
+def _setup(xres, yres, spp=4, pos=(278.0, 273.0, 250.0), look=(278.0, 273.0, 600.0), scene=None):
+    cam = scenes.environment_camera_desc(pos, look, (0, 1, 0))
+    film = scenes.film_desc(xres, yres)
+    return (scene or scenes.cornell_box("diffuse")), cam, film, scenes.integrator_desc(film, spp)
+
+
+def test_environment_rays_follow_the_spherical_direction_of_the_film_point():
+    xres, yres = 64, 32
+    sc, cam, film, integ = _setup(xres, yres)
+    o = orc.Oracle(sc, cam, film, integ)
+    P = np.array([(x, y) for y in range(0, yres, 3) for x in range(0, xres, 5)], dtype=np.int32)
+    rays, pf = o.camera_rays(P, np.full(P.shape[0], 2, dtype=np.int64))
+    o.close()
+    assert np.all(np.floor(pf) == P)                                   # the film point lies in its pixel
+    c2w = np.array(list(cam.camera_to_world), dtype=np.float64).reshape(4, 4)
+    theta, phi = math.pi * pf[:, 1] / yres, 2 * math.pi * pf[:, 0] / xres
+    local = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], axis=1)
+    assert np.allclose(rays[:, :3], c2w[:3, 3], atol=1e-4)             # every ray leaves the camera's origin
+    assert np.allclose(rays[:, 3:], local @ c2w[:3, :3].T, atol=2e-6)  # ... along SphericalDirection(theta, phi) of the camera frame
+    top = P[:, 1] == 0
+    z_axis = c2w[:3, 2]
+    assert np.all(rays[top, 3:] @ z_axis > 0.99)                       # the top row looks along the camera's z axis
+
+
+def test_environment_camera_inside_a_constant_sky_sees_the_sky_everywhere():
+    b = scenes.MeshBuilder()
+    b.add_material(abi.matte((0.5, 0.5, 0.5)))
+    L = (0.7, 0.9, 1.3)
+    b.lights.append(abi.infinite_light(L))
+    b.add_tri((1e4, 0, 0), (1e4, 1, 0), (1e4, 0, 1), 0)                 # a speck far away: the scene needs a bound
+    sc, cam, film, integ = _setup(32, 16, scene=b.arrays())
+    o = orc.Oracle(sc, cam, film, integ)
+    o.render(0, 4, threads=2)
+    img = o.image()
+    o.close()
+    assert np.allclose(img, np.array(L), rtol=1e-5)
+
+
+def test_environment_camera_in_the_cornell_box_sees_the_light_above_and_the_opening_behind():
+    """Camera at the box's centre looking at the back wall (z+), up = y: film row v holds the polar angle from the view axis,
+    column u the azimuth around it; the ceiling light is at azimuth 90 degrees (towards +y), the open front at the bottom row."""
+    sc, cam, film, integ = _setup(64, 32, spp=16, pos=(278.0, 273.0, 279.6))
+    o = orc.Oracle(sc, cam, film, integ)
+    o.render(0, 16, threads=4)
+    img = o.image()
+    o.close()
+    assert np.isfinite(img).all() and img.min() >= 0
+    lum = img.sum(axis=2)
+    y, x = np.unravel_index(np.argmax(lum), lum.shape)
+    c2w = np.array(list(cam.camera_to_world), dtype=np.float64).reshape(4, 4)
+    theta, phi = math.pi * (y + 0.5) / 32, 2 * math.pi * (x + 0.5) / 64
+    d = c2w[:3, :3] @ np.array([math.sin(theta) * math.cos(phi), math.sin(theta) * math.sin(phi), math.cos(theta)])
+    assert d[1] > 0.9                                                  # the brightest pixel looks up, at the light
+    assert lum[31].max() < 0.05 * lum.max()                            # the last row looks out of the open front: nothing there
+    assert lum[0].min() > 0                                            # the first row looks at the back wall

@@ -304,6 +304,15 @@ def test_plymesh_reads_what_the_references_rply_callbacks_keep(tmp_path):
     assert d["meshes"] == [] and any("vertex_indices" in w for w in d["warnings"])
 
 
+def test_environment_camera_reaches_the_dump(tmp_path):
+    d = dump(tmp_path, 'LookAt 1 2 3  1 2 10  0 1 0\nCamera "environment" "float lensradius" 3\nSampler "sobol"\nWorldBegin\nWorldEnd\n')
+    assert d["camera"]["type"] == "environment"
+    ref = scenes.environment_camera_desc((1, 2, 3), (1, 2, 10), (0, 1, 0))
+    assert np.allclose(d["camera"]["c2w"], list(ref.camera_to_world), atol=1e-6)
+    assert dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nWorldEnd\n')["camera"]["type"] == "perspective"
+    assert "orthographic" in dump(tmp_path, 'Camera "orthographic"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', expect_fail=True)
+
+
 def test_include_comments_and_named_materials(tmp_path):
     with open(tmp_path / "geo.pbrt", "w") as f:
         f.write('# included file\nNamedMaterial "red"\nShape "trianglemesh" "point P" [0 0 0  1 0 0  0 1 0] # trailing comment\n')
