@@ -273,6 +273,12 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
         fov, focal = float(f32(fov)), float(f32(focal))
         crop = tuple(float(f32(c)) for c in crop)
     cam = scenes.camera_desc(tuple(eye), tuple(look), tuple(up), fov, xres, yres, lens_radius=lens, focal_distance=focal if lens else 1e30)
+    # ---- a sixth stream: the environment camera now and then, and (scene files) the meshes in PLY files
+    cr = np.random.RandomState((seed * 1103515245 + 0xCA40) & 0x7fffffff)
+    environment = bool(cr.rand() < 0.12)
+    ply = bool(cr.rand() < 0.3)
+    if environment:
+        cam = scenes.environment_camera_desc(tuple(eye), tuple(look), tuple(up))
     fk = rng.choice(["box", "box", "triangle", "gaussian", "mitchell", "sinc"])
     # ---- a fourth stream: film and integrator options (filter radii, a luminance clamp, pixel bounds, samples per light,
     # more samples per pixel rendered in several calls)
@@ -310,9 +316,10 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
                                             pixel_bounds=pixel_bounds)
     if details is not None:
         details.update(spp=spp, splits=splits, eye=tuple(float(v) for v in eye), look=tuple(float(v) for v in look), up=tuple(float(v) for v in up), fov=fov, xres=int(xres), yres=int(yres),
-                       lens=lens, focal=float(cam.focal_distance), filter=str(fk), crop=crop, integ_kind=str(integ_kind), depth=depth, rr=rr, strategy=strategy)
-    label = "%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
-        integ_kind, depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), (" crop" if crop != (0.0, 1.0, 0.0, 1.0) else "") + (" options %s%s%s" % (sorted(film_kw), pixel_bounds or "", splits or "") if (film_kw or pixel_bounds or splits) else ""))
+                       lens=lens, focal=float(cam.focal_distance), filter=str(fk), crop=crop, integ_kind=str(integ_kind), depth=depth, rr=rr, strategy=strategy,
+                       environment=environment, ply=ply)
+    label = "%s%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
+        integ_kind, " environment-camera" if environment else "", depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), (" crop" if crop != (0.0, 1.0, 0.0, 1.0) else "") + (" options %s%s%s" % (sorted(film_kw), pixel_bounds or "", splits or "") if (film_kw or pixel_bounds or splits) else ""))
     return sc, cam, film, integ, label
 
 
@@ -733,7 +740,8 @@ def compare_file(seed, directory, res=24, spp=4):
     film_extra = "" if crop == (0.0, 1.0, 0.0, 1.0) else '"float cropwindow" [%.9g %.9g %.9g %.9g]' % crop
     lens = '"float lensradius" %.9g "float focaldistance" %.9g' % (d["lens"], d["focal"]) if d["lens"] else ""
     text = pbrt_writer.scene_text(sc, d["eye"], d["look"], d["up"], d["fov"], d["xres"], d["yres"], spp, integrator=itext,
-                                  pixel_filter='PixelFilter "%s"' % d["filter"], film_extra=film_extra, lens=lens, texture_dir=directory)
+                                  pixel_filter='PixelFilter "%s"' % d["filter"], film_extra=film_extra, lens=lens, texture_dir=directory,
+                                  ply_dir=directory if d["ply"] else None, camera="environment" if d["environment"] else "perspective")
     scene_file, out_file = os.path.join(directory, "s%d.pbrt" % seed), os.path.join(directory, "s%d.pfm" % seed)
     with open(scene_file, "w") as f:
         f.write(text)
