@@ -61,8 +61,9 @@ typedef struct EnigmaMaterial {
     /* Image textures bound to the spectrum parameters: index + 1 into EnigmaSceneDesc.textures, 0 = the constant
      * above (a ConstantTexture, Enigma/Texture.h:119-131).  The float parameters stay constants. */
     uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_eta, tex_k;
-    /* Parameters of the mirror, translucent, substrate, uber and mix materials.  These five take constants only (a
-     * texture bound to one of them: ENIGMA_E_UNSUPPORTED), and so do the materials a mix names. */
+    /* Parameters of the mirror, translucent, substrate, uber and mix materials.  Their Kd / Ks / Kr / Kt take image
+     * textures like those of the first four (tex_*); the parameters below are constants.  One such material -- a mix
+     * together with the materials it names -- may use two trilinear textures at most (ENIGMA_E_UNSUPPORTED beyond). */
     float reflect[3];         /* translucent: reflect */
     float transmit[3];        /* translucent: transmit */
     float opacity[3];         /* uber: opacity */

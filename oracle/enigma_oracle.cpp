@@ -248,6 +248,14 @@ struct PerspectiveCamera {
         float phi = (PI * 2.0f) * ix / fullResX;
         float sinTheta = sinf(theta), cosTheta = cosf(theta);
         Vec3 dir(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta); // SphericalDirection, MathCommon.cpp:13-28
+        // test knob: the direction one unit in the last place off in x and y, which is how far two libms' sinf / cosf are
+        // apart -- how much of a render (ray counts, pixels) hangs on those bits is a property of the scene
+        // (ORACLE_CAMERA_LAST_BIT=n: component n % 3, upwards for n / 3 even)
+        static const int lastBit = getenv("ORACLE_CAMERA_LAST_BIT") ? atoi(getenv("ORACLE_CAMERA_LAST_BIT")) : -1;
+        if (lastBit >= 0) {
+            float* c = lastBit % 3 == 0 ? &dir.x : (lastBit % 3 == 1 ? &dir.y : &dir.z);
+            *c = std::nextafter(*c, (lastBit / 3) % 2 == 0 ? InfinityF32 : -InfinityF32);
+        }
         *d = cameraToWorld.transformVector(dir);
         *o = cameraToWorld.transformPoint(Vec3(0, 0, 0));
         return 1.0f;
@@ -1621,7 +1629,7 @@ static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const Enig
     }
     case ENIGMA_MAT_MIRROR: { // Material.cpp:318-328
         BSDF* bsdf = new BSDF(si);
-        Spectrum R = spec3(m.kr, 0).Clamp();
+        Spectrum R = spec3(m.kr, m.tex_kr).Clamp();
         if (!R.IsBlack()) bsdf->addBxDF(new SpecularReflection(R, new FresnelNoOp()));
         return bsdf;
     }
@@ -1630,12 +1638,12 @@ static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const Enig
         BSDF* bsdf = new BSDF(si, eta);
         Spectrum r = spec3(m.reflect, 0).Clamp(), t = spec3(m.transmit, 0).Clamp();
         if (r.IsBlack() && t.IsBlack()) return bsdf;
-        Spectrum kd = spec3(m.kd, 0).Clamp();
+        Spectrum kd = spec3(m.kd, m.tex_kd).Clamp();
         if (!kd.IsBlack()) {
             if (!r.IsBlack()) bsdf->addBxDF(new LambertianReflection(r * kd));
             if (!t.IsBlack()) bsdf->addBxDF(new LambertianTransmission(t * kd));
         }
-        Spectrum ks = spec3(m.ks, 0).Clamp();
+        Spectrum ks = spec3(m.ks, m.tex_ks).Clamp();
         if (!ks.IsBlack() && (!r.IsBlack() || !t.IsBlack())) {
             float rough = remap(m.uroughness);
             bsdf->distrib.reset(new TrowbridgeReitzDistribution(rough, rough));
@@ -1646,7 +1654,7 @@ static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const Enig
     }
     case ENIGMA_MAT_SUBSTRATE: { // Material.cpp:424-448
         BSDF* bsdf = new BSDF(si);
-        Spectrum d = spec3(m.kd, 0).Clamp(), sp = spec3(m.ks, 0).Clamp();
+        Spectrum d = spec3(m.kd, m.tex_kd).Clamp(), sp = spec3(m.ks, m.tex_ks).Clamp();
         if (!d.IsBlack() || !sp.IsBlack()) {
             bsdf->distrib.reset(new TrowbridgeReitzDistribution(remap(m.uroughness), remap(m.vroughness)));
             bsdf->addBxDF(new FresnelBlend(d, sp, bsdf->distrib.get()));
@@ -1662,16 +1670,16 @@ static BSDF* MaterialScatteringFunctions(const EnigmaMaterial* table, const Enig
             bsdf = new BSDF(si, 1.f);
             bsdf->addBxDF(new SpecularTransmission(t, 1.f, 1.f));
         } else bsdf = new BSDF(si, e);
-        Spectrum kd = op * spec3(m.kd, 0).Clamp();
+        Spectrum kd = op * spec3(m.kd, m.tex_kd).Clamp();
         if (!kd.IsBlack()) bsdf->addBxDF(new LambertianReflection(kd));
-        Spectrum ks = op * spec3(m.ks, 0).Clamp();
+        Spectrum ks = op * spec3(m.ks, m.tex_ks).Clamp();
         if (!ks.IsBlack()) {
             bsdf->distrib.reset(new TrowbridgeReitzDistribution(remap(m.uroughness), remap(m.vroughness)));
             bsdf->addBxDF(new MicrofacetReflection(ks, bsdf->distrib.get(), new FresnelDielectric(1.f, e)));
         }
-        Spectrum kr = op * spec3(m.kr, 0).Clamp();
+        Spectrum kr = op * spec3(m.kr, m.tex_kr).Clamp();
         if (!kr.IsBlack()) bsdf->addBxDF(new SpecularReflection(kr, new FresnelDielectric(1.f, e)));
-        Spectrum kt = op * spec3(m.kt, 0).Clamp();
+        Spectrum kt = op * spec3(m.kt, m.tex_kt).Clamp();
         if (!kt.IsBlack()) bsdf->addBxDF(new SpecularTransmission(kt, 1.f, e));
         return bsdf;
     }

@@ -513,16 +513,17 @@ DEV F3 bsdfSample(const Bsdf& b, F3 woW, F3* wiW, float u0, float u1, float* pdf
 // computeScatteringFunctions have one answer per material); the shade kernel of this kind follows BSDF::f / Pdf / sample_f
 // (Enigma/BxDF.cpp:885-985) over the list as the reference does over its BxDF pointers.
 struct BsdfG {
-    const DevLobe* lobes;  // in global memory
+    const DevLobe* lobes;  // in global memory; `local` when a texture decides colours and lobes at this hit
     int n;
     float eta;             // BSDF::m_eta
     F3 ng, ss, ts;         // as in Bsdf
+    DevLobe local[kMaxLobes];
 };
 template <int MK> struct BsdfOf { using T = Bsdf; };
 template <> struct BsdfOf<MK_GENERAL> { using T = BsdfG; };
 
 template <int MK>
-DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, BsdfG* b, const float4* = nullptr, const DevLobe* lobes = nullptr, bool multipleLobes = true) {
+DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, BsdfG* b, const float4* texColors = nullptr, const DevLobe* lobes = nullptr, bool multipleLobes = true) {
     b->ng = ng;
     b->ss = normalize(dpdu);
     b->ts = cross(ns, b->ss);
@@ -530,6 +531,31 @@ DEV void makeBsdf(const DevMaterial& m, F3 ng, F3 ns, F3 dpdu, BsdfG* b, const f
     const uint32_t nMulti = m.lobeInfo & 0xffu, nSingle = (m.lobeInfo >> 8) & 0xffu;
     b->lobes = lobes + m.lobeOff + (multipleLobes ? 0u : nMulti);
     b->n = (int)(multipleLobes ? nMulti : nSingle);
+    if (!texColors || !(m.tex0 | m.tex1)) return;
+    // textured colours: the lobes that computeScatteringFunctions would add with the textures' values at this hit
+    int kept = 0;
+    for (int i = 0; i < b->n; ++i) {
+        DevLobe l = b->lobes[i];
+        const uint32_t t = l.tex;
+        bool lit0 = l.col[0] != 0.f || l.col[1] != 0.f || l.col[2] != 0.f, lit1 = l.col2[0] != 0.f || l.col2[1] != 0.f || l.col2[2] != 0.f;
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t slot = (t >> (8 * k)) & 0xffu;
+            if (!slot) continue;
+            const float4 c = texColors[slot - 1u];
+            F3 v(c.x, c.y, c.z);
+            if (!(t & kLobeNoClamp)) v = F3(smax(v.x, 0.f), smax(v.y, 0.f), smax(v.z, 0.f)); // Spectrum::Clamp()
+            const bool rawLit = v.x != 0.f || v.y != 0.f || v.z != 0.f;
+            float* dst = k == 0 ? l.col : l.col2;
+            dst[0] *= v.x; dst[1] *= v.y; dst[2] *= v.z;
+            const bool lit = (t & kLobeRaw) ? rawLit : (dst[0] != 0.f || dst[1] != 0.f || dst[2] != 0.f);
+            if (k == 0) lit0 = lit; else lit1 = lit;
+        }
+        if ((t & kLobeOwn) && !lit0) continue;
+        if ((t & kLobeEither) && !lit0 && !lit1) continue;
+        b->local[kept++] = l;
+    }
+    b->lobes = b->local;
+    b->n = kept;
 }
 
 // the lobe's parameters in the shape the per-kind lobe functions above read them

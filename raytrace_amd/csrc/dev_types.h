@@ -41,8 +41,17 @@ struct DevLobe {            // 64 bytes
     float ax, ay;           // the lobe's TrowbridgeReitz alphas (Oren-Nayar: A and B)
     float col[3]; float etaI;  // R / T / Kd; conductor: eta.  Dielectric Fresnel / transmission interface: etaI, etaT
     float col2[3]; float etaT; // conductor: k; FresnelSpecular: T; FresnelBlend: Rs
-    float scale[3]; float pad;
+    float scale[3];
+    uint32_t tex;           // 0: col / col2 are the colours.  Else a trilinear texture feeds a colour: bits 0-7 / 8-15 the slot + 1
+                            // (DevMaterial::tex0 / tex1, DevScene::texColors) behind col / col2, which then hold the factor the
+                            // texture's value is multiplied by; see kLobe* below
 };
+// DevLobe::tex, upper bits.  Which lobes exist at a hit is decided by the IsBlack tests of computeScatteringFunctions on
+// the values the textures have THERE: kLobeOwn -- the lobe exists if its colour is not black (tested on the texture's
+// value alone with kLobeRaw: TranslucentMaterial tests Kd and multiplies by reflect afterwards, Enigma/Material.cpp:288-293;
+// on the product otherwise: UberMaterial tests op * Kd, :553-554); kLobeEither -- if either of its two colours is not black
+// (FresnelBlend, FresnelSpecular: :439, :188).  kLobeNoClamp: the metal's eta and k are not clamped (:122-131).
+constexpr uint32_t kLobeRaw = 1u << 16, kLobeOwn = 1u << 17, kLobeEither = 1u << 18, kLobeNoClamp = 1u << 19;
 static_assert(sizeof(DevLobe) == 64, "four float4 per lobe");
 constexpr int kMaxLobes = 8; // MAX_BxDFS, Enigma/BxDF.h:8
 

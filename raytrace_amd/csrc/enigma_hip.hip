@@ -303,113 +303,134 @@ static int emitterNormalSide(const EnigmaSceneDesc* s, uint32_t t) {
     return pos == 3 ? 1 : neg == 3 ? -1 : 0;
 }
 
-// Material::computeScatteringFunctions with constant parameters, as the list of BxDFs it adds, in its order
-// (Enigma/Material.cpp:76-592; the IsBlack tests have one answer per material here).  Used for the materials the shade
-// kernels walk at run time: mirror, translucent, substrate, uber, and mix over any of the nine.  *eta: BSDF::m_eta.
-static bool materialLobes(const EnigmaMaterial* table, uint32_t idx, bool multipleLobes, std::vector<DevLobe>& out, float* eta, std::string& why) {
+// Material::computeScatteringFunctions as the list of BxDFs it adds, in its order (Enigma/Material.cpp:76-592).  Used for
+// the materials the shade kernels walk at run time: mirror, translucent, substrate, uber, and mix over any of the nine.
+// A constant colour decides its IsBlack tests here; a colour behind a trilinear texture (tex_* then holds the DEVICE
+// texture index + 1; textures that evaluate to a constant were folded into the values by the caller) leaves them to the
+// shade kernel: the lobe carries the texture's slot and the rule for its existence (DevLobe::tex).  *eta: BSDF::m_eta.
+struct LobeList {
+    std::vector<DevLobe> lobes;
+    std::vector<std::pair<uint32_t, uint32_t>> tex; // per lobe: device texture + 1 behind col / col2
+};
+static bool materialLobes(const EnigmaMaterial* table, uint32_t idx, bool multipleLobes, LobeList& out, float* eta, std::string& why) {
     const EnigmaMaterial& m = table[idx];
-    if (m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k) { why = "textures on a mirror, translucent, substrate, uber or mix material (or on a material a mix names) are not supported"; return false; }
-    auto clamped = [](const float v[3], float o[3]) { for (int c = 0; c < 3; ++c) o[c] = v[c] < 0.f ? 0.f : v[c]; }; // Spectrum::Clamp()
-    auto black = [](const float v[3]) { return v[0] == 0.f && v[1] == 0.f && v[2] == 0.f; };
+    struct Col { float v[3]; uint32_t tex; };
+    auto colour = [](const float v[3], uint32_t tex, bool clamp = true) {
+        Col c;
+        for (int k = 0; k < 3; ++k) c.v[k] = (clamp && v[k] < 0.f) ? 0.f : v[k]; // Spectrum::Clamp()
+        c.tex = tex;
+        return c;
+    };
+    auto black = [](const Col& c) { return !c.tex && c.v[0] == 0.f && c.v[1] == 0.f && c.v[2] == 0.f; }; // decided here only for constants
     auto remap = [&](float r) { // TrowbridgeReitzDistribution::RoughnessToAlpha, Enigma/MicrofacetDist.cpp:323-328
         if (!m.remap_roughness) return r;
         r = std::max(r, (float)1e-3);
         float x = std::log(r);
         return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
     };
-    auto lobe = [](uint32_t kind, const float col[3], float ax = 0.f, float ay = 0.f, float etaI = 1.f, float etaT = 1.f, const float* col2 = nullptr) {
+    const float one[3] = {1.f, 1.f, 1.f};
+    // a lobe whose colour is factor * c (and factor2 * c2); rule: how the lobe's existence follows from textured colours
+    auto add = [&](uint32_t kind, const Col& c, const float* factor, uint32_t rule, float ax = 0.f, float ay = 0.f, float etaI = 1.f, float etaT = 1.f,
+                   const Col* c2 = nullptr) {
         DevLobe l;
         memset(&l, 0, sizeof(l));
         l.kind = kind;
         l.ax = std::max(float(0.001), ax); l.ay = std::max(float(0.001), ay); // TrowbridgeReitzDistribution ctor, Enigma/MicrofacetDist.cpp:256-263
-        for (int c = 0; c < 3; ++c) { l.col[c] = col[c]; l.col2[c] = col2 ? col2[c] : 0.f; l.scale[c] = 1.f; }
+        for (int k = 0; k < 3; ++k) {
+            l.col[k] = c.tex ? factor[k] : factor[k] * c.v[k];
+            l.col2[k] = c2 ? c2->v[k] : 0.f;
+            if (c2 && c2->tex) l.col2[k] = 1.f;
+            l.scale[k] = 1.f;
+        }
         l.etaI = etaI; l.etaT = etaT;
-        return l;
+        const bool textured = c.tex || (c2 && c2->tex);
+        l.tex = textured ? rule : 0u; // slots are filled in once the material's textures are known
+        out.lobes.push_back(l);
+        out.tex.push_back({c.tex, c2 ? c2->tex : 0u});
     };
-    auto times = [](const float a[3], const float b[3], float o[3]) { for (int c = 0; c < 3; ++c) o[c] = a[c] * b[c]; };
+    using namespace edev;
     *eta = 1.f;
-    float kd[3], ks[3], kr[3], kt[3];
-    clamped(m.kd, kd); clamped(m.ks, ks); clamped(m.kr, kr); clamped(m.kt, kt);
+    const Col kd = colour(m.kd, m.tex_kd), ks = colour(m.ks, m.tex_ks), kr = colour(m.kr, m.tex_kr), kt = colour(m.kt, m.tex_kt);
     switch (m.type) {
     case ENIGMA_MAT_MATTE: { // :76-93
         const float sig = std::min(std::max(m.sigma, 0.f), 90.f);
         if (black(kd)) break;
-        if (sig == 0.f) { out.push_back(lobe(edev::LOBE_LAMBERT, kd)); break; }
+        if (sig == 0.f) { add(LOBE_LAMBERT, kd, one, kLobeOwn); break; }
         const float sigma = sig * (3.1415926535897932384f / 180.0f), sigma2 = sigma * sigma;
-        DevLobe l = lobe(edev::LOBE_OREN_NAYAR, kd);
-        l.ax = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f))); // A and B travel in the alpha slots
-        l.ay = (0.45f * sigma2) / (sigma2 + 0.09f);
-        out.push_back(l);
+        add(LOBE_OREN_NAYAR, kd, one, kLobeOwn);
+        out.lobes.back().ax = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f))); // A and B travel in the alpha slots
+        out.lobes.back().ay = (0.45f * sigma2) / (sigma2 + 0.09f);
         break;
     }
-    case ENIGMA_MAT_METAL: // :115-136
-        out.push_back(lobe(edev::LOBE_MICRO_REFL_CONDUCTOR, m.eta, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, m.k));
+    case ENIGMA_MAT_METAL: { // :115-136: eta and k are not clamped, the lobe is always there
+        const Col e = colour(m.eta, m.tex_eta, false), k = colour(m.k, m.tex_k, false);
+        add(LOBE_MICRO_REFL_CONDUCTOR, e, one, kLobeNoClamp, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, &k);
         break;
+    }
     case ENIGMA_MAT_GLASS: { // :176-220
         *eta = m.index;
         if (black(kr) && black(kt)) break;
         const bool isSpecular = m.uroughness == 0.f && m.vroughness == 0.f;
-        if (isSpecular && multipleLobes) { out.push_back(lobe(edev::LOBE_FRESNEL_SPECULAR, kr, 0.f, 0.f, 1.f, m.index, kt)); break; }
+        if (isSpecular && multipleLobes) { add(LOBE_FRESNEL_SPECULAR, kr, one, kLobeEither, 0.f, 0.f, 1.f, m.index, &kt); break; }
         const float ax = isSpecular ? 0.f : remap(m.uroughness), ay = isSpecular ? 0.f : remap(m.vroughness);
-        if (!black(kr)) out.push_back(lobe(isSpecular ? edev::LOBE_SPEC_REFL : edev::LOBE_MICRO_REFL_DIELECTRIC, kr, ax, ay, 1.f, m.index));
-        if (!black(kt)) out.push_back(lobe(isSpecular ? edev::LOBE_SPEC_TRANS : edev::LOBE_MICRO_TRANS, kt, ax, ay, 1.f, m.index));
+        if (!black(kr)) add(isSpecular ? LOBE_SPEC_REFL : LOBE_MICRO_REFL_DIELECTRIC, kr, one, kLobeOwn, ax, ay, 1.f, m.index);
+        if (!black(kt)) add(isSpecular ? LOBE_SPEC_TRANS : LOBE_MICRO_TRANS, kt, one, kLobeOwn, ax, ay, 1.f, m.index);
         break;
     }
     case ENIGMA_MAT_PLASTIC: // :232-255
-        if (!black(kd)) out.push_back(lobe(edev::LOBE_LAMBERT, kd));
-        if (!black(ks)) out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, ks, remap(m.uroughness), remap(m.uroughness), 1.5f, 1.f));
+        if (!black(kd)) add(LOBE_LAMBERT, kd, one, kLobeOwn);
+        if (!black(ks)) add(LOBE_MICRO_REFL_DIELECTRIC, ks, one, kLobeOwn, remap(m.uroughness), remap(m.uroughness), 1.5f, 1.f);
         break;
     case ENIGMA_MAT_MIRROR: // :318-328
-        if (!black(kr)) out.push_back(lobe(edev::LOBE_SPEC_REFL_NOOP, kr));
+        if (!black(kr)) add(LOBE_SPEC_REFL_NOOP, kr, one, kLobeOwn);
         break;
-    case ENIGMA_MAT_TRANSLUCENT: { // :276-309
+    case ENIGMA_MAT_TRANSLUCENT: { // :276-309: Kd and Ks are tested for black by themselves, then multiplied by reflect / transmit
         *eta = 1.5f;
-        float r[3], t[3], c[3];
-        clamped(m.reflect, r); clamped(m.transmit, t);
+        const Col r = colour(m.reflect, 0), t = colour(m.transmit, 0);
         if (black(r) && black(t)) break;
         if (!black(kd)) {
-            if (!black(r)) { times(r, kd, c); out.push_back(lobe(edev::LOBE_LAMBERT, c)); }
-            if (!black(t)) { times(t, kd, c); out.push_back(lobe(edev::LOBE_LAMBERT_TRANS, c)); }
+            if (!black(r)) add(LOBE_LAMBERT, kd, r.v, kLobeOwn | kLobeRaw);
+            if (!black(t)) add(LOBE_LAMBERT_TRANS, kd, t.v, kLobeOwn | kLobeRaw);
         }
         if (!black(ks)) {
             const float a = remap(m.uroughness);
-            if (!black(r)) { times(r, ks, c); out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, c, a, a, 1.f, 1.5f)); }
-            if (!black(t)) { times(t, ks, c); out.push_back(lobe(edev::LOBE_MICRO_TRANS, c, a, a, 1.f, 1.5f)); }
+            if (!black(r)) add(LOBE_MICRO_REFL_DIELECTRIC, ks, r.v, kLobeOwn | kLobeRaw, a, a, 1.f, 1.5f);
+            if (!black(t)) add(LOBE_MICRO_TRANS, ks, t.v, kLobeOwn | kLobeRaw, a, a, 1.f, 1.5f);
         }
         break;
     }
     case ENIGMA_MAT_SUBSTRATE: // :424-448
-        if (!black(kd) || !black(ks)) out.push_back(lobe(edev::LOBE_FRESNEL_BLEND, kd, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, ks));
+        if (!black(kd) || !black(ks)) add(LOBE_FRESNEL_BLEND, kd, one, kLobeEither, remap(m.uroughness), remap(m.vroughness), 1.f, 1.f, &ks);
         break;
-    case ENIGMA_MAT_UBER: { // :536-592
+    case ENIGMA_MAT_UBER: { // :536-592: every colour is multiplied by the opacity first and tested for black then
         const float e = m.index;
-        float op[3], t[3], c[3];
-        clamped(m.opacity, op);
-        for (int k = 0; k < 3; ++k) t[k] = std::max(-op[k] + 1.f, 0.f);
-        if (!black(t)) out.push_back(lobe(edev::LOBE_SPEC_TRANS, t, 0.f, 0.f, 1.f, 1.f));
+        const Col op = colour(m.opacity, 0);
+        Col t = op;
+        for (int k = 0; k < 3; ++k) t.v[k] = std::max(-op.v[k] + 1.f, 0.f);
+        if (!black(t)) add(LOBE_SPEC_TRANS, t, one, 0u, 0.f, 0.f, 1.f, 1.f);
         else *eta = e;
-        times(op, kd, c);
-        if (!black(c)) out.push_back(lobe(edev::LOBE_LAMBERT, c));
-        times(op, ks, c);
-        if (!black(c)) out.push_back(lobe(edev::LOBE_MICRO_REFL_DIELECTRIC, c, remap(m.uroughness), remap(m.vroughness), 1.f, e));
-        times(op, kr, c);
-        if (!black(c)) out.push_back(lobe(edev::LOBE_SPEC_REFL, c, 0.f, 0.f, 1.f, e));
-        times(op, kt, c);
-        if (!black(c)) out.push_back(lobe(edev::LOBE_SPEC_TRANS, c, 0.f, 0.f, 1.f, e));
+        auto lit = [&](const Col& c) { // op * c is not black (a textured c may be anything)
+            if (c.tex) return !black(op);
+            return op.v[0] * c.v[0] != 0.f || op.v[1] * c.v[1] != 0.f || op.v[2] * c.v[2] != 0.f;
+        };
+        if (lit(kd)) add(LOBE_LAMBERT, kd, op.v, kLobeOwn);
+        if (lit(ks)) add(LOBE_MICRO_REFL_DIELECTRIC, ks, op.v, kLobeOwn, remap(m.uroughness), remap(m.vroughness), 1.f, e);
+        if (lit(kr)) add(LOBE_SPEC_REFL, kr, op.v, kLobeOwn, 0.f, 0.f, 1.f, e);
+        if (lit(kt)) add(LOBE_SPEC_TRANS, kt, op.v, kLobeOwn, 0.f, 0.f, 1.f, e);
         break;
     }
     case ENIGMA_MAT_MIX: { // :146-163: the first material's BSDF, its lobes scaled; then the second material's lobes, scaled
         if (m.mix_a >= idx || m.mix_b >= idx) { why = "a mix material names materials that come before it in the array"; return false; }
-        float s1[3], s2[3], etaB;
-        clamped(m.amount, s1);
-        for (int k = 0; k < 3; ++k) s2[k] = std::max(1.f - s1[k], 0.f);
-        const size_t first = out.size();
+        const Col s1 = colour(m.amount, 0);
+        float s2[3], etaB;
+        for (int k = 0; k < 3; ++k) s2[k] = std::max(1.f - s1.v[k], 0.f);
+        const size_t first = out.lobes.size();
         if (!materialLobes(table, m.mix_a, multipleLobes, out, eta, why)) return false;
-        const size_t second = out.size();
+        const size_t second = out.lobes.size();
         if (!materialLobes(table, m.mix_b, multipleLobes, out, &etaB, why)) return false;
-        for (size_t i = first; i < out.size(); ++i) {
-            for (int k = 0; k < 3; ++k) out[i].scale[k] *= (i < second ? s1 : s2)[k];
-            out[i].scaled = 1u;
+        for (size_t i = first; i < out.lobes.size(); ++i) {
+            for (int k = 0; k < 3; ++k) out.lobes[i].scale[k] *= (i < second ? s1.v : s2)[k];
+            out.lobes[i].scaled = 1u;
         }
         break;
     }
@@ -417,22 +438,39 @@ static bool materialLobes(const EnigmaMaterial* table, uint32_t idx, bool multip
         why = "unknown material type";
         return false;
     }
-    if (out.size() > (size_t)edev::kMaxLobes) { why = "a material with more than 8 lobes: the reference's BSDF holds MAX_BxDFS = 8 (Enigma/BxDF.h:8)"; return false; }
+    if (out.lobes.size() > (size_t)edev::kMaxLobes) { why = "a material with more than 8 lobes: the reference's BSDF holds MAX_BxDFS = 8 (Enigma/BxDF.h:8)"; return false; }
     return true;
 }
 // the two lists (allowMultipleLobes true, then false) of material idx appended to lobes; d describes them
 static bool generalMaterial(const EnigmaMaterial* table, uint32_t idx, std::vector<DevLobe>& lobes, DevMaterial& d, std::string& why) {
-    std::vector<DevLobe> multi, single;
+    LobeList multi, single;
     float eta = 1.f, eta2 = 1.f;
     if (!materialLobes(table, idx, true, multi, &eta, why) || !materialLobes(table, idx, false, single, &eta2, why)) return false;
     memset(&d, 0, sizeof(d));
     d.kind = MK_GENERAL;
     d.eta = eta;
-    d.flags = multi.empty() ? 0u : 1u;
+    d.flags = multi.lobes.empty() ? 0u : 1u;
     d.lobeOff = (uint32_t)lobes.size();
-    d.lobeInfo = (uint32_t)multi.size() | ((uint32_t)single.size() << 8);
-    lobes.insert(lobes.end(), multi.begin(), multi.end());
-    lobes.insert(lobes.end(), single.begin(), single.end());
+    d.lobeInfo = (uint32_t)multi.lobes.size() | ((uint32_t)single.lobes.size() << 8);
+    // the material's trilinear textures take the two slots k_texture fills per hit
+    uint32_t slots[2] = {0u, 0u};
+    for (LobeList* list : {&multi, &single})
+        for (size_t i = 0; i < list->lobes.size(); ++i) {
+            uint32_t bits = 0u;
+            const uint32_t ids[2] = {list->tex[i].first, list->tex[i].second};
+            for (int k = 0; k < 2; ++k) {
+                if (!ids[k]) continue;
+                int slot = -1;
+                for (int q = 0; q < 2 && slot < 0; ++q)
+                    if (slots[q] == ids[k] || slots[q] == 0u) { slots[q] = ids[k]; slot = q; }
+                if (slot < 0) { why = "more than two trilinear textures on a mirror, translucent, substrate, uber or mix material (a mix counts those of the materials it names)"; return false; }
+                bits |= (uint32_t)(slot + 1) << (8 * k);
+            }
+            list->lobes[i].tex = bits ? (list->lobes[i].tex | bits) : 0u;
+        }
+    d.tex0 = slots[0]; d.tex1 = slots[1];
+    lobes.insert(lobes.end(), multi.lobes.begin(), multi.lobes.end());
+    lobes.insert(lobes.end(), single.lobes.begin(), single.lobes.end());
     return true;
 }
 static bool isGeneralMaterial(uint32_t type) { return type >= ENIGMA_MAT_MIRROR && type <= ENIGMA_MAT_MIX; }
@@ -526,13 +564,29 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
     h->smoothGlass = false;
     h->glassBranches = h->glassSpecular = h->deferredLobeChoice = false;
     std::vector<DevLobe> lobeTable;
+    // for the lobe lists: the materials with their textures resolved -- a texture that evaluates to a constant folded into
+    // the value, a trilinear one named by its device index + 1
+    std::vector<EnigmaMaterial> folded(s->materials, s->materials + s->n_materials);
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        EnigmaMaterial& fm = folded[i];
+        struct Slot { uint32_t* tex; float* value; };
+        const Slot slotsOf[6] = {{&fm.tex_kd, fm.kd}, {&fm.tex_ks, fm.ks}, {&fm.tex_kr, fm.kr}, {&fm.tex_kt, fm.kt}, {&fm.tex_eta, fm.eta}, {&fm.tex_k, fm.k}};
+        for (const Slot& sl : slotsOf) {
+            if (!*sl.tex) continue;
+            if (*sl.tex > s->n_textures) return h->fail(ENIGMA_E_INVALID, "material %u: texture index out of range", i);
+            const uint32_t dev = texDevice[*sl.tex - 1];
+            if (!dev) { const enigma::Rgb c = texConstant[*sl.tex - 1]; sl.value[0] = c.r; sl.value[1] = c.g; sl.value[2] = c.b; }
+            *sl.tex = dev;
+        }
+    }
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         EnigmaMaterial m = s->materials[i];
         DevMaterial d;
         memset(&d, 0, sizeof(d));
         if (isGeneralMaterial(m.type)) {
             std::string why;
-            if (!generalMaterial(s->materials, i, lobeTable, d, why)) return h->fail(ENIGMA_E_UNSUPPORTED, "material %u: %s", i, why.c_str());
+            if (!generalMaterial(folded.data(), i, lobeTable, d, why)) return h->fail(ENIGMA_E_UNSUPPORTED, "material %u: %s", i, why.c_str());
+            if (d.tex0 | d.tex1) h->kindTextured[MK_GENERAL] = true;
             // the DirectLightingIntegrator's recursion follows the specular lobes of the allowMultipleLobes = false list
             int specR = 0, specT = 0;
             for (uint32_t k = 0; k < (d.lobeInfo >> 8); ++k) {
@@ -2038,6 +2092,9 @@ extern "C" int enigma_debug_bsdf_of(EnigmaCtx* h, const EnigmaMaterial* material
     memset(&d, 0, sizeof(d));
     std::vector<DevLobe> lobeTable;
     if (isGeneralMaterial(m.type)) {
+        for (uint32_t k = 0; k <= which; ++k)
+            if (materials[k].tex_kd | materials[k].tex_ks | materials[k].tex_kr | materials[k].tex_kt | materials[k].tex_eta | materials[k].tex_k)
+                return h->fail(ENIGMA_E_UNSUPPORTED, "the BSDF tap takes constant parameters only");
         std::string why;
         if (!generalMaterial(materials, which, lobeTable, d, why)) return h->fail(ENIGMA_E_UNSUPPORTED, "material %u: %s", which, why.c_str());
     } else {

@@ -717,7 +717,7 @@ private:
             if (f->second.index) *tex = f->second.index;
             else put(dst, f->second.value);
         };
-        // the materials the device walks as lists of lobes take constants only
+        // parameters that have no texture slot in the ABI (reflect, transmit, opacity, amount, the uber's eta)
         auto constantOnly = [&](const char* n) {
             if (!p.FindTexture(n).empty()) throw std::runtime_error("Material \"" + name + "\": parameter \"" + std::string(n) + "\" refers to a texture; this material takes constant values only");
         };
@@ -751,29 +751,28 @@ private:
             m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
         } else if (name == "mirror") { // CreateMirrorMaterial, Enigma/Material.cpp:648-653
             m.type = ENIGMA_MAT_MIRROR;
-            constantOnly("Kr"); put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.9f)));
+            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.9f))); bind("Kr", m.kr, &m.tex_kr);
         } else if (name == "translucent") { // CreateTranslucentMaterial, Enigma/Material.cpp:738-748
             m.type = ENIGMA_MAT_TRANSLUCENT;
-            for (const char* n : {"Kd", "Ks", "reflect", "transmit"}) constantOnly(n);
-            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
-            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
+            for (const char* n : {"reflect", "transmit"}) constantOnly(n);
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f))); bind("Kd", m.kd, &m.tex_kd);
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f))); bind("Ks", m.ks, &m.tex_ks);
             put(m.reflect, p.FindOneSpectrum("reflect", Spectrum(0.5f)));
             put(m.transmit, p.FindOneSpectrum("transmit", Spectrum(0.5f)));
             m.uroughness = m.vroughness = p.FindOneFloat("roughness", .1f);
         } else if (name == "substrate") { // CreateSubstrateMaterial, Enigma/Material.cpp:673-682
             m.type = ENIGMA_MAT_SUBSTRATE;
-            for (const char* n : {"Kd", "Ks"}) constantOnly(n);
-            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(.5f)));
-            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(.5f)));
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(.5f))); bind("Kd", m.kd, &m.tex_kd);
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(.5f))); bind("Ks", m.ks, &m.tex_ks);
             m.uroughness = p.FindOneFloat("uroughness", .1f);
             m.vroughness = p.FindOneFloat("vroughness", .1f);
         } else if (name == "uber") { // CreateUberMaterial, Enigma/Material.cpp:720-736
             m.type = ENIGMA_MAT_UBER;
-            for (const char* n : {"Kd", "Ks", "Kr", "Kt", "opacity", "eta"}) constantOnly(n);
-            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f)));
-            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f)));
-            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.f)));
-            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(0.f)));
+            for (const char* n : {"opacity", "eta"}) constantOnly(n);
+            put(m.kd, p.FindOneSpectrum("Kd", Spectrum(0.25f))); bind("Kd", m.kd, &m.tex_kd);
+            put(m.ks, p.FindOneSpectrum("Ks", Spectrum(0.25f))); bind("Ks", m.ks, &m.tex_ks);
+            put(m.kr, p.FindOneSpectrum("Kr", Spectrum(0.f))); bind("Kr", m.kr, &m.tex_kr);
+            put(m.kt, p.FindOneSpectrum("Kt", Spectrum(0.f))); bind("Kt", m.kt, &m.tex_kt);
             put(m.opacity, p.FindOneSpectrum("opacity", Spectrum(1.f)));
             const float rough = p.FindOneFloat("roughness", .1f);
             m.uroughness = p.Has("uroughness") ? p.FindOneFloat("uroughness", rough) : rough; // UberMaterial::computeScatteringFunctions, :563-570

@@ -446,6 +446,51 @@ def cornell_textured(trilinear=True, wrap=abi.WRAP_REPEAT):
     return b.arrays()
 
 
+def cornell_textured_lobes(trilinear=True):
+    """The Cornell box with image textures on the materials that are lists of lobes: an uber floor whose Kd is a tiled
+    texture and whose Ks a second one; a substrate back wall (Kd textured); a mirror left wall whose Kr comes from a texture
+    made without "trilinear" (its average colour); a translucent short block whose Kd has BLACK texels -- where they
+    are, the two Lambertian lobes do not exist (Enigma/Material.cpp:288-294) --; a tall block that mixes a textured matte
+    with a smooth glass."""
+    b = MeshBuilder()
+    img = test_pattern()
+    holes = test_pattern(16, 16, seed=11)
+    holes[(np.indices((16, 16)).sum(axis=0) // 3) % 2 == 0] = 0.0
+    tiled = b.add_texture(abi.image_texture(img, trilinear=trilinear, su=3.0, sv=2.0, du=0.25))
+    plain = b.add_texture(abi.image_texture(img, trilinear=trilinear))
+    average = b.add_texture(abi.image_texture(img * 0.9, trilinear=False))
+    holed = b.add_texture(abi.image_texture(holes, trilinear=trilinear, su=2.0, sv=2.0))
+
+    def mat(m, **tex):
+        for k, v in tex.items():
+            setattr(m, k, v)
+        return b.add_material(m)
+    white = b.add_material(abi.matte((0.73, 0.73, 0.73)))
+    green = b.add_material(abi.matte((0.12, 0.45, 0.15)))
+    floor_m = mat(abi.uber((0.0, 0.0, 0.0), (0.3, 0.3, 0.3), kr=(0.1, 0.1, 0.1), opacity=(1.0, 0.9, 0.8), roughness=0.1), tex_kd=tiled, tex_ks=plain)
+    back_m = mat(abi.substrate((0.5, 0.5, 0.5), (0.08, 0.08, 0.08), 0.1, 0.3), tex_kd=plain)
+    left_m = mat(abi.mirror((0.9, 0.9, 0.9)), tex_kr=average)
+    short_m = mat(abi.translucent((0.5, 0.5, 0.5), (0.0, 0.0, 0.0), reflect=(0.7, 0.6, 0.5), transmit=(0.3, 0.4, 0.5)), tex_kd=holed)
+    matte_t = mat(abi.matte((0.5, 0.5, 0.5)), tex_kd=tiled)
+    glass = b.add_material(abi.glass(1.5, 0.0, 0.0))
+    tall_m = b.add_material(abi.mix(matte_t, glass, (0.6, 0.6, 0.6)))
+    c = CORNELL_CENTER
+    unit = [(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)]
+    b.add_quad(_CORNELL["floor"], floor_m, toward=c, uvs=unit)
+    b.add_quad(_CORNELL["ceiling"], white, toward=c)
+    b.add_quad(_CORNELL["back"], back_m, toward=c, uvs=unit)
+    b.add_quad(_CORNELL["right"], green, toward=c)
+    b.add_quad(_CORNELL["left"], left_m, toward=c, uvs=unit)
+    for name, m in (("short", short_m), ("tall", tall_m)):
+        faces = _CORNELL[name]
+        centre = np.mean([p for f in faces for p in f], axis=0)
+        centre[1] = centre[1] * 0.5
+        for f in faces:
+            b.add_quad(f, m, toward=np.mean(f, axis=0) * 2 - centre, uvs=unit)
+    b.add_quad(_CORNELL["light"], white, toward=(278, 0, 279.6), emit=(17.0, 12.0, 4.0))
+    return b.arrays()
+
+
 def _rotation(axis, degrees):
     a = np.asarray(axis, dtype=np.float64)
     a /= np.linalg.norm(a)

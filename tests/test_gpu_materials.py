@@ -183,6 +183,43 @@ def test_direct_lighting_all_lights_with_a_mirror_and_a_substrate():
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("integrator,trilinear", [("path", True), ("path", False), ("volpath", True), ("direct", False)])
+def test_image_textures_on_the_lobe_list_materials(integrator, trilinear, monkeypatch):
+    """Image textures on Kd / Ks / Kr of uber, substrate, mirror, translucent and on a matte inside a mix: the lobes that
+    exist at a hit follow the textures' values there (a translucent sheet has no Lambertian lobes where its Kd texture is
+    black); textures without "trilinear" fold into the constants."""
+    sc = scenes.cornell_textured_lobes(trilinear)
+    cam, film = scenes.cornell_camera(64, 64), scenes.film_desc(64, 64)
+    desc = {"path": scenes.integrator_desc(film, 16, max_depth=6), "volpath": scenes.volpath_desc(film, 16),
+            "direct": scenes.direct_lighting_desc(film, 16, max_depth=3, strategy=abi.DL_SAMPLE_ONE)}[integrator]
+    r, o = ra.Renderer(0).configure(sc, cam, film, desc), orc.Oracle(sc, cam, film, desc)
+    img = _compare(r, o, 16, mre=2e-3, ray_tol=2e-3)
+    r.close(); o.close()
+    if integrator == "path" and trilinear:
+        # the holes matter: with the translucent block's texture replaced by its mean the picture and the ray counts change
+        monkeypatch.setenv("ENIGMA_NO_LDS_SCENE", "1")
+        r = ra.Renderer(0).configure(sc, cam, film, desc)
+        r.render(0, 16)
+        assert common.mean_relative_error(r.image(), img) < 1e-4          # the global-memory build agrees with the LDS one
+        r.close()
+
+
+def test_trilinear_textures_and_specular_lobes_under_direct_lighting_are_refused_and_three_textures_too():
+    sc = scenes.cornell_textured_lobes(True)
+    cam, film = scenes.cornell_camera(32, 32), scenes.film_desc(32, 32)
+    r = ra.Renderer(0).configure(sc, cam, film, scenes.direct_lighting_desc(film, 4, max_depth=3, strategy=abi.DL_SAMPLE_ONE))
+    with pytest.raises(ra.EnigmaError) as e:
+        r.render(0, 1)                                          # the mirror wall's reflections would carry ray differentials on
+    assert e.value.code == -4 and "trilinear" in str(e.value)
+    for i in range(sc.n_materials):
+        if sc.materials[i].type == abi.MAT_UBER:
+            sc.materials[i].tex_kr = 4                          # a third trilinear texture on one material
+    with pytest.raises(ra.EnigmaError) as e:
+        r.upload_scene(sc)
+    assert e.value.code == -4 and "two trilinear textures" in str(e.value)
+    r.close()
+
+
 def test_upload_refusals():
     sc = scenes.cornell_box("uber")
     r = ra.Renderer(0)
@@ -194,13 +231,5 @@ def test_upload_refusals():
     with pytest.raises(ra.EnigmaError) as e:
         r.upload_scene(bad)
     assert e.value.code == -4
-    tex = scenes.cornell_textured()
-    for i in range(tex.n_materials):
-        if tex.materials[i].tex_kd:
-            tex.materials[i].type = abi.MAT_UBER                # a texture bound to one of the five: constants only
-            break
-    with pytest.raises(ra.EnigmaError) as e:
-        r.upload_scene(tex)
-    assert e.value.code == -4 and "texture" in str(e.value)
     r.upload_scene(sc)                                          # the handle is still good
     r.close()

@@ -63,3 +63,38 @@ def test_environment_camera_in_the_cornell_box_sees_the_light_above_and_the_open
     assert d[1] > 0.9                                                  # the brightest pixel looks up, at the light
     assert lum[31].max() < 0.05 * lum.max()                            # the last row looks out of the open front: nothing there
     assert lum[0].min() > 0                                            # the first row looks at the back wall
+
+
+def test_ray_counts_of_a_sliver_scene_hang_on_the_last_bit_of_the_camera_direction():
+    """The fuzzer holds ray counts to 1 % -- to 5 % under the environment camera, whose directions go through sinf / cosf and
+    so differ in the last bit between the oracle's libm and the device's.  This is the measurement behind that number: the
+    oracle against itself with one component of every camera direction moved by one unit in the last place (the knob is
+    read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "tools")
+import orc, fuzz_scenes
+d = {}
+sc, cam, film, integ, label = fuzz_scenes.random_case(1504850, details=d)
+assert d["environment"]
+o = orc.Oracle(sc, cam, film, integ)
+o.render(0, d["spp"], threads=4)
+print(o.stats()["rays_closest"], o.stats()["rays_shadow"], float(o.image().mean()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = []
+    for knob in (None, "2", "4"):
+        env = dict(os.environ)
+        env.pop("ORACLE_CAMERA_LAST_BIT", None)
+        if knob:
+            env["ORACLE_CAMERA_LAST_BIT"] = knob
+        run = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr[-2000:]
+        rows.append([float(v) for v in run.stdout.split()])
+    base, down, up = rows
+    assert base[0] == down[0] == up[0]                                   # the same paths ...
+    assert down[1] < base[1] < up[1] and (up[1] - down[1]) > 0.03 * base[1]   # ... 6 % apart in their shadow rays
+    assert abs(up[2] - base[2]) < 1e-3 * base[2] and abs(down[2] - base[2]) < 1e-3 * base[2]   # for the same picture

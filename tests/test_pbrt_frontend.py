@@ -181,7 +181,7 @@ WorldEnd
     ('WorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd\n', "cylinder"),
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
-    ('WorldBegin\nTexture "t" "spectrum" "constant"\nMaterial "uber" "texture Kd" "t"\nWorldEnd\n', "constant values only"),
+    ('WorldBegin\nTexture "t" "spectrum" "constant"\nMaterial "uber" "texture opacity" "t"\nWorldEnd\n', "constant values only"),
     ('WorldBegin\nMaterial "subsurface"\nWorldEnd\n', "subsurface"),
     ('WorldBegin\nMakeNamedMaterial "a" "string type" "none"\nMaterial "mix" "string namedmaterial1" "a" "string namedmaterial2" "a"\nWorldEnd\n', "two materials"),
     ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),

@@ -24,7 +24,7 @@ from raytrace_amd import abi, scenes  # noqa: E402
 
 
 DOCUMENTED_REFUSALS = ("reads past the sample arrays", "vertex normals lie on both sides", "trilinear textures", "area light on a surface without a material",
-                       "SpecularTransmit picks its lobe")
+                       "SpecularTransmit picks its lobe", "two trilinear textures")
 
 
 def _unit(rng):
@@ -240,12 +240,17 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
     # some of the scene's materials; a mix names materials made before it, itself a mix now and then
     gr = np.random.RandomState((seed * 22695477 + 0x10BE) & 0x7fffffff)
     if gr.rand() < 0.3:
-        textured = lambda m: bool(m.tex_kd | m.tex_ks | m.tex_kr | m.tex_kt | m.tex_eta | m.tex_k)
         moved = {}
         for i in range(len(b.materials)):
             if gr.rand() < 0.5:
-                plain = [k for k in range(len(b.materials)) if not textured(b.materials[k])]
-                b.materials.append(random_lobe_list_material(gr, b.materials, plain))
+                new = random_lobe_list_material(gr, b.materials, list(range(len(b.materials))))   # a mix may name textured materials
+                if b.textures and new.type != abi.MAT_MIX and gr.rand() < 0.4:
+                    fields = {abi.MAT_MIRROR: ["tex_kr"], abi.MAT_TRANSLUCENT: ["tex_kd", "tex_ks"], abi.MAT_SUBSTRATE: ["tex_kd", "tex_ks"],
+                              abi.MAT_UBER: ["tex_kd", "tex_ks", "tex_kr", "tex_kt"]}[new.type]
+                    for f in fields:
+                        if gr.rand() < 0.5:
+                            setattr(new, f, int(gr.randint(len(b.textures))) + 1)
+                b.materials.append(new)
                 moved[i] = len(b.materials) - 1
         b.mat = [moved.get(m, m) for m in b.mat]
         for sp in b.spheres:
@@ -446,7 +451,14 @@ def compare(seed, res=24, spp=4, shared=None):
         # each side uses, and an overflowed sample is scrubbed to zero (Enigma/Integrator.cpp:284-292).  Such images are
         # compared by their ray counts and their median pixel only.
         out["extreme"] = bool(max(float(np.nanmax(np.abs(a))), float(np.nanmax(np.abs(bimg)))) > 1e9)
-        return image_verdict(out, a, bimg, out["finite"] and out["median_rel"] < 1e-3 and apart <= 0.01 and out["stack_overflows"] == 0,
+        # The environment camera's directions go through sinf / cosf, which differ in the last bit between the host's libm
+        # and the device's: the two sides do not start from bit-equal rays (as with a thin lens).  In scenes of slivers and
+        # mirror-sharp lobes a percent or two of the shadow rays hang on such bits -- the oracle against itself with ONE
+        # component of the camera direction moved by one unit in the last place (ORACLE_CAMERA_LAST_BIT) traces 321 to 341
+        # shadow rays where it traces 331 unperturbed (seed 1504850; the library: 345), 4976 instead of 4963 closest-hit rays
+        # (seed 1503021; the library: 4983), pictures equal to 2e-4 and 6e-8.  Counts are held to 5 % for that camera.
+        limit = 0.05 if d["environment"] else 0.01
+        return image_verdict(out, a, bimg, out["finite"] and out["median_rel"] < 1e-3 and apart <= limit and out["stack_overflows"] == 0,
                              radius=tuple(float(v) for v in film.filter_radius), rays_apart=sum(abs(g - c) for g, c in counts.values()))
     finally:
         if r is not None and shared is None:
