@@ -476,7 +476,11 @@ public:
         VerifyWorld("Shape");
         if (name == "sphere") { MakeSphere(p); return; }
         if (name == "plymesh") { MakePlyMesh(p, dir); return; }
-        if (name != "trianglemesh") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh, plymesh, sphere)");
+        // MakeShapes (Enigma/Api.cpp:80-128): the factories of these three return no shape at all (Enigma/Curve.cpp:10-14,
+        // Enigma/SubDiv.cpp:6-9, Enigma/Nurbs.cpp:10-14), and a name the reference does not know is a warning there
+        if (name == "curve" || name == "loopsubdiv" || name == "nurbs") { Warn("Shape \"" + name + "\": the reference's factory returns no shape; none made"); return; }
+        if (name == "cylinder" || name == "disk") throw std::runtime_error("Shape \"" + name + "\" is not supported (trianglemesh, plymesh, sphere)");
+        if (name != "trianglemesh") { Warn("Shape \"" + name + "\" unknown."); return; }
         std::vector<int> vi = p.FindInt("indices");
         std::vector<double> P = p.FindPoint3("P");
         if (P.empty() || P.size() % 3) throw std::runtime_error("trianglemesh: \"point P\" missing or not a multiple of 3 values");

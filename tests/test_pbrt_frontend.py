@@ -313,6 +313,15 @@ def test_environment_camera_reaches_the_dump(tmp_path):
     assert "orthographic" in dump(tmp_path, 'Camera "orthographic"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', expect_fail=True)
 
 
+def test_shapes_whose_factories_are_empty_in_the_reference_make_nothing(tmp_path):
+    """curve, loopsubdiv and nurbs return no shape in the reference (Enigma/Curve.cpp:10-14, Enigma/SubDiv.cpp:6-9,
+    Enigma/Nurbs.cpp:10-14); an unknown shape name is a warning (Enigma/Api.cpp:123-124)."""
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nShape "loopsubdiv" "integer nlevels" 3\nShape "curve"\nShape "nurbs"\nShape "teapot"\n'
+                       'Shape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
+    assert len(d["meshes"]) == 1 and d["spheres"] == []
+    assert sum("no shape" in w for w in d["warnings"]) == 3 and any("teapot" in w and "unknown" in w for w in d["warnings"])
+
+
 def test_include_comments_and_named_materials(tmp_path):
     with open(tmp_path / "geo.pbrt", "w") as f:
         f.write('# included file\nNamedMaterial "red"\nShape "trianglemesh" "point P" [0 0 0  1 0 0  0 1 0] # trailing comment\n')
