@@ -248,17 +248,20 @@ struct PerspectiveCamera {
         float phi = (PI * 2.0f) * ix / fullResX;
         float sinTheta = sinf(theta), cosTheta = cosf(theta);
         Vec3 dir(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta); // SphericalDirection, MathCommon.cpp:13-28
-        // test knob: the direction one unit in the last place off in x and y, which is how far two libms' sinf / cosf are
-        // apart -- how much of a render (ray counts, pixels) hangs on those bits is a property of the scene
-        // (ORACLE_CAMERA_LAST_BIT=n: component n % 3, upwards for n / 3 even)
-        static const int lastBit = getenv("ORACLE_CAMERA_LAST_BIT") ? atoi(getenv("ORACLE_CAMERA_LAST_BIT")) : -1;
-        if (lastBit >= 0) {
-            float* c = lastBit % 3 == 0 ? &dir.x : (lastBit % 3 == 1 ? &dir.y : &dir.z);
-            *c = std::nextafter(*c, (lastBit / 3) % 2 == 0 ? InfinityF32 : -InfinityF32);
-        }
         *d = cameraToWorld.transformVector(dir);
         *o = cameraToWorld.transformPoint(Vec3(0, 0, 0));
+        LastBit(d);
         return 1.0f;
+    }
+    // Test knob (ORACLE_CAMERA_LAST_BIT=n): one component (n % 3) of every camera ray's direction moved by one unit in the
+    // last place (upwards for n / 3 even).  That is how far apart two libms put a direction that went through sinf / cosf
+    // (the environment camera, a thin lens); how much of a render -- ray counts, pixels -- hangs on such bits is a property
+    // of the scene, and this is how the fuzzer measures it before it calls a difference a defect.
+    static void LastBit(Vec3* d) {
+        static const int lastBit = getenv("ORACLE_CAMERA_LAST_BIT") ? atoi(getenv("ORACLE_CAMERA_LAST_BIT")) : -1;
+        if (lastBit < 0) return;
+        float* c = lastBit % 3 == 0 ? &d->x : (lastBit % 3 == 1 ? &d->y : &d->z);
+        *c = std::nextafter(*c, (lastBit / 3) % 2 == 0 ? InfinityF32 : -InfinityF32);
     }
     // Camera::GenerateRayDifferential (Camera.cpp:35-57) over EnvironmentRay: the rays one pixel further in x and in y
     float GenerateEnvironmentRay(const CameraSample& sample, Ray* ray) const {
@@ -315,6 +318,7 @@ struct PerspectiveCamera {
         Vec3 o = cameraToWorld.transformPoint(ray->o);
         ray->d = d;
         ray->o = o;
+        LastBit(&ray->d);
         ray->rxOrigin = cameraToWorld.transformPoint(ray->rxOrigin); ray->ryOrigin = cameraToWorld.transformPoint(ray->ryOrigin);
         ray->rxDirection = cameraToWorld.transformVector(ray->rxDirection); ray->ryDirection = cameraToWorld.transformVector(ray->ryDirection);
         ray->hasDifferentials = true;

@@ -66,9 +66,9 @@ def test_environment_camera_in_the_cornell_box_sees_the_light_above_and_the_open
 
 
 def test_ray_counts_of_a_sliver_scene_hang_on_the_last_bit_of_the_camera_direction():
-    """The fuzzer holds ray counts to 1 % -- to 5 % under the environment camera, whose directions go through sinf / cosf and
-    so differ in the last bit between the oracle's libm and the device's.  This is the measurement behind that number: the
-    oracle against itself with one component of every camera direction moved by one unit in the last place (the knob is
+    """The fuzzer holds ray counts to 1 % and pictures to 1 % mean, 0.1 % median -- unless the oracle is further than that
+    from ITSELF when every camera ray's direction is moved by one unit in the last place, which is how far two libms put
+    directions that went through sinf / cosf.  This is that measurement on one of the seeds that called for it (the knob is
     read once per process)."""
     import os
     import subprocess
@@ -86,7 +86,7 @@ print(o.stats()["rays_closest"], o.stats()["rays_shadow"], float(o.image().mean(
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rows = []
-    for knob in (None, "2", "4"):
+    for knob in (None, "0", "1", "2", "3", "4", "5"):
         env = dict(os.environ)
         env.pop("ORACLE_CAMERA_LAST_BIT", None)
         if knob:
@@ -94,7 +94,7 @@ print(o.stats()["rays_closest"], o.stats()["rays_shadow"], float(o.image().mean(
         run = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
         assert run.returncode == 0, run.stderr[-2000:]
         rows.append([float(v) for v in run.stdout.split()])
-    base, down, up = rows
-    assert base[0] == down[0] == up[0]                                   # the same paths ...
-    assert down[1] < base[1] < up[1] and (up[1] - down[1]) > 0.03 * base[1]   # ... 6 % apart in their shadow rays
-    assert abs(up[2] - base[2]) < 1e-3 * base[2] and abs(down[2] - base[2]) < 1e-3 * base[2]   # for the same picture
+    base, moved = rows[0], rows[1:]
+    assert all(m[0] == base[0] for m in moved)                            # the same paths ...
+    shadow = [m[1] for m in moved]
+    assert max(shadow) - min(shadow) > 0.03 * base[1]                     # ... whose shadow rays are 3 % and more apart

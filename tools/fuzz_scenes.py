@@ -375,14 +375,42 @@ def image_verdict(out, a, bimg, base_ok, radius=(4.0, 4.0), rays_apart=0):
     return out
 
 
+def last_bit_spread(seed, res, spp, base_stats, base_img):
+    """The oracle's distance from itself over the six one-unit moves of the camera directions' last place: the largest
+    ray-count distance, mean and median relative pixel difference (one process per move: the knob is read once)."""
+    import subprocess
+    import tempfile
+    worst = {"counts_apart": 0.0, "mre": 0.0, "median_rel": 0.0}
+    code = ("import sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport orc, fuzz_scenes\n"
+            "d = {}\nsc, cam, film, integ, label = fuzz_scenes.random_case(%d, %d, %d, details=d)\n"
+            "o = orc.Oracle(sc, cam, film, integ); o.render(0, d['spp'], threads=8)\n"
+            "np.save(sys.argv[1], o.image()); s = o.stats(); print(s['rays_closest'], s['rays_shadow'], s['rays_mis'])\n") % (
+                ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"), seed, res, spp)
+    with tempfile.TemporaryDirectory() as tmp:
+        for knob in range(6):
+            path = os.path.join(tmp, "k%d.npy" % knob)
+            run = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, ORACLE_CAMERA_LAST_BIT=str(knob)), capture_output=True, text=True, timeout=300)
+            if run.returncode != 0:
+                return None
+            counts = [int(v) for v in run.stdout.split()]
+            base = [int(base_stats[k]) for k in ("rays_closest", "rays_shadow", "rays_mis")]
+            img = np.load(path)
+            rel = np.abs(img - base_img) / channel_floor(base_img)
+            worst["counts_apart"] = max(worst["counts_apart"], max(abs(g - c) / max(1000, c) for g, c in zip(counts, base)))
+            worst["mre"] = max(worst["mre"], float(rel.mean()))
+            worst["median_rel"] = max(worst["median_rel"], float(np.median(rel)))
+    return worst
+
+
 def compare(seed, res=24, spp=4, shared=None):
-    """{"status": "ok" | "firefly" | "extreme" | "both-refuse" | "gpu-refuses" | "oracle-refuses" | "mismatch", ...} for one seed (image_verdict).
+    """{"status": "ok" | "firefly" | "extreme" | "sensitive" | "both-refuse" | "gpu-refuses" | "oracle-refuses" | "mismatch", ...} for one seed (image_verdict).
     shared: a one-element list holding a Renderer that is kept from seed to seed (scenes, films and integrators of every
     kind configured one after the other on one handle, refusals in between), instead of a fresh handle per seed."""
     import orc
     import raytrace_amd as ra
     import common
     d = {}
+    spp_in = spp
     sc, cam, film, integ, label = random_case(seed, res, spp, details=d)
     spp = d["spp"]
     out = {"seed": seed, "label": label}
@@ -451,15 +479,21 @@ def compare(seed, res=24, spp=4, shared=None):
         # each side uses, and an overflowed sample is scrubbed to zero (Enigma/Integrator.cpp:284-292).  Such images are
         # compared by their ray counts and their median pixel only.
         out["extreme"] = bool(max(float(np.nanmax(np.abs(a))), float(np.nanmax(np.abs(bimg)))) > 1e9)
-        # The environment camera's directions go through sinf / cosf, which differ in the last bit between the host's libm
-        # and the device's: the two sides do not start from bit-equal rays (as with a thin lens).  In scenes of slivers and
-        # mirror-sharp lobes a percent or two of the shadow rays hang on such bits -- the oracle against itself with ONE
-        # component of the camera direction moved by one unit in the last place (ORACLE_CAMERA_LAST_BIT) traces 321 to 341
-        # shadow rays where it traces 331 unperturbed (seed 1504850; the library: 345), 4976 instead of 4963 closest-hit rays
-        # (seed 1503021; the library: 4983), pictures equal to 2e-4 and 6e-8.  Counts are held to 5 % for that camera.
-        limit = 0.05 if d["environment"] else 0.01
-        return image_verdict(out, a, bimg, out["finite"] and out["median_rel"] < 1e-3 and apart <= limit and out["stack_overflows"] == 0,
-                             radius=tuple(float(v) for v in film.filter_radius), rays_apart=sum(abs(g - c) for g, c in counts.values()))
+        image_verdict(out, a, bimg, out["finite"] and out["median_rel"] < 1e-3 and apart <= 0.01 and out["stack_overflows"] == 0,
+                      radius=tuple(float(v) for v in film.filter_radius), rays_apart=sum(abs(g - c) for g, c in counts.values()))
+        if out["status"] == "mismatch" and out["finite"] and out["stack_overflows"] == 0:
+            # Before a difference is called a defect: how far is the oracle from ITSELF when every camera ray's direction is
+            # moved by one unit in the last place (tools: ORACLE_CAMERA_LAST_BIT)?  That is the distance two libms put between
+            # the two sides wherever a direction goes through sinf / cosf -- the environment camera, a thin lens, a point
+            # sampled on a sphere.  In scenes of slivers, mirror-sharp lobes or forward-peaked media a percent or two of the
+            # rays, and a third of the pixels, hang on such bits (seeds 1504850, 1609423, 1611671).  A library that is no
+            # further from the oracle than twice that is "sensitive", reported under that name.
+            spread = last_bit_spread(seed, res, spp_in, so, bimg)
+            out["last_bit_spread"] = spread
+            if spread and apart <= max(0.01, 2 * spread["counts_apart"]) and out["mre"] <= max(0.01, 2 * spread["mre"]) and \
+                    out["median_rel"] <= max(1e-3, 2 * spread["median_rel"]):
+                out["status"] = "sensitive"
+        return out
     finally:
         if r is not None and shared is None:
             r.close()
@@ -857,9 +891,9 @@ def main():
         print(json.dumps(res), flush=True)
     if len(sys.argv) > 3:
         json.dump(results, open(sys.argv[3], "w"), indent=1)
-    print("seeds %d..%d: %d ok, %d firefly, %d extreme, %d both refuse, %d refused by the library alone (documented), %d not restated by the oracle, %d mismatch" % (
+    print("seeds %d..%d: %d ok, %d firefly, %d extreme, %d sensitive, %d both refuse, %d refused by the library alone (documented), %d not restated by the oracle, %d mismatch" % (
         first, first + count - 1, sum(r["status"] == "ok" for r in results), sum(r["status"] == "firefly" for r in results), sum(r["status"] == "extreme" for r in results),
-        sum(r["status"] == "both-refuse" for r in results),
+        sum(r["status"] == "sensitive" for r in results), sum(r["status"] == "both-refuse" for r in results),
         sum(r["status"] == "gpu-refuses" for r in results), sum(r["status"] == "oracle-refuses" for r in results), bad))
     sys.exit(1 if bad else 0)
 
