@@ -309,6 +309,18 @@ int enigma_scene_upload(EnigmaCtx* h, const EnigmaSceneDesc* scene);
 int enigma_camera_set(EnigmaCtx* h, const EnigmaCameraDesc* cam);
 /* Replaces Film construction (Enigma/Film.cpp:39-71); clears the device film. */
 int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* film);
+/* Replaces RenderOptions::MakeSampler's choice by name (Enigma/Api.cpp:425-434) for the two GlobalSamplers:
+ * "sobol" (CreateSobolSampler, Enigma/Sampler.cpp:554-559) and "halton" (CreateHaltonSampler, :521-528; the
+ * reference's default when a scene names none, RenderOptions::SamplerName, Enigma/Api.h:82).  The choice is taken up by
+ * the next enigma_integrator_config / enigma_direct_lighting_config / enigma_volpath_config, whose samples_per_pixel
+ * and sample_bounds then construct that sampler; a new context starts with sobol.  For halton, samples_per_pixel is
+ * kept as given (not rounded to a power of two), sample_at_pixel_center is "samplepixelcenter", the digit
+ * permutations are the ones the reference's process makes (a default-seeded std::mt19937 behind RNG,
+ * Enigma/SamplerInclude.h:2639-2655, Enigma/RNG.cpp:18-38), and a configuration whose largest sample index
+ * ((samples_per_pixel x largest sample array + 1) x sample stride, the stride at most 128 x 243) does not fit 32 bits
+ * returns ENIGMA_E_UNSUPPORTED. */
+enum { ENIGMA_SAMPLER_SOBOL = 0, ENIGMA_SAMPLER_HALTON = 1 };
+int enigma_sampler_select(EnigmaCtx* h, uint32_t kind, uint32_t sample_at_pixel_center);
 /* Replaces CreatePathIntegrator + SobolSampler construction + PathIntegrator::Preprocess
  * (Enigma/PathIntegrator.cpp:41-44,182-201; Enigma/Sampler.cpp:211-222). */
 int enigma_integrator_config(EnigmaCtx* h, const EnigmaIntegratorDesc* integ);

@@ -29,6 +29,7 @@
 #include <memory>
 #include <functional>
 #include <mutex>
+#include <random>
 #include <unordered_map>
 #include <string>
 #include <thread>
@@ -68,6 +69,102 @@ static float SobolSampleFloat(int64_t a, int dimension, uint32_t scramble) {
 
 struct BBox2i { Vec2i mn, mx; };
 
+// ---------------------------------------------------------------------------
+// HaltonSampler's tables and radical inverses (Sampler.cpp:305-375, SamplerInclude.h:25-84,2397-2655)
+// ---------------------------------------------------------------------------
+static constexpr int PrimeTableSize = 1000;   // Misc.h:28
+static constexpr int kMaxResolution = 128;    // SamplerInclude.h:25
+struct PrimeTables {
+    int primes[PrimeTableSize], sums[PrimeTableSize]; // Primes / PrimeSums (SamplerInclude.h:2397,2481): the first 1000 primes and their running sums
+    PrimeTables() {
+        int n = 0, sum = 0;
+        for (int c = 2; n < PrimeTableSize; ++c) {
+            bool prime = true;
+            for (int d = 2; d * d <= c; ++d) if (c % d == 0) { prime = false; break; }
+            if (prime) { primes[n] = c; sums[n] = sum; sum += c; ++n; }
+        }
+    }
+};
+static const PrimeTables g_primes;
+// RNG (RNG.h:11-44, RNG.cpp:23-38): a default-constructed std::mt19937 (seed 5489; the constructor's seed argument is
+// never applied, :18-19) behind a uniform_int_distribution over all of uint32, which hands the engine's word through;
+// randomUInt(b) is the rejection loop of RNG.cpp:30-38.
+struct RNG {
+    std::mt19937 gen;
+    uint32_t randomUInt() { return (uint32_t)gen(); }
+    uint32_t randomUInt(uint32_t b) {
+        uint32_t threshold = (~b + 1u) % b;
+        for (;;) { uint32_t r = randomUInt(); if (r >= threshold) return r % b; }
+    }
+};
+// ComputeRadicalInversePermutations (SamplerInclude.h:2639-2655) with Shuffle (MonteCarlo.h:140-147)
+static std::vector<uint16_t> ComputeRadicalInversePermutations(RNG& rng) {
+    std::vector<uint16_t> perms((size_t)g_primes.sums[PrimeTableSize - 1] + g_primes.primes[PrimeTableSize - 1]);
+    uint16_t* p = perms.data();
+    for (int i = 0; i < PrimeTableSize; ++i) {
+        uint32_t count = (uint32_t)g_primes.primes[i];
+        for (uint32_t j = 0; j < count; ++j) p[j] = (uint16_t)j;
+        for (uint32_t j = 0; j < count; ++j) { uint32_t other = j + rng.randomUInt(count - j); std::swap(p[j], p[other]); }
+        p += count;
+    }
+    return perms;
+}
+// s_radicalInversePermutations (Sampler.cpp:310-313,375): made once, by a fresh RNG, when the first HaltonSampler is built
+static const std::vector<uint16_t>& RadicalInversePermutations() {
+    static const std::vector<uint16_t> perms = [] { RNG rng; return ComputeRadicalInversePermutations(rng); }();
+    return perms;
+}
+static uint64_t ReverseBits64(uint64_t n) {
+    uint64_t r = 0;
+    for (int i = 0; i < 64; ++i, n >>= 1) r = (r << 1) | (n & 1);
+    return r;
+}
+// RadicalInverseSpecialized / ScrambledRadicalInverseSpecialized (SamplerInclude.h:49-84) with the base as an argument:
+// the reference's switch over 1000 template instances (:87-2395, :2659-) selects the same arithmetic
+static float RadicalInverseBase(int base, uint64_t a) {
+    const float invBase = (float)1 / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint64_t next = a / (uint64_t)base;
+        uint64_t digit = a - next * (uint64_t)base;
+        reversedDigits = reversedDigits * (uint64_t)base + digit;
+        invBaseN *= invBase;
+        a = next;
+    }
+    return std::min(reversedDigits * invBaseN, OneMinusEpsilon);
+}
+static float ScrambledRadicalInverseBase(int base, const uint16_t* perm, uint64_t a) {
+    const float invBase = (float)1 / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint64_t next = a / (uint64_t)base;
+        uint64_t digit = a - next * (uint64_t)base;
+        reversedDigits = reversedDigits * (uint64_t)base + perm[digit];
+        invBaseN *= invBase;
+        a = next;
+    }
+    return std::min(invBaseN * (reversedDigits + invBase * perm[0] / (1 - invBase)), OneMinusEpsilon);
+}
+static float HaltonRadicalInverse(int baseIndex, uint64_t a) { // RadicalInverse, SamplerInclude.h:2659-2669
+    if (baseIndex == 0) return (float)(ReverseBits64(a) * 0x1p-64);
+    return RadicalInverseBase(g_primes.primes[baseIndex], a);
+}
+static int64_t ModI(int64_t a, int64_t b) { int64_t r = a - (a / b) * b; return r < 0 ? r + b : r; } // Mod, MathCommon.h
+static void extendedGCD(uint64_t a, uint64_t b, int64_t* x, int64_t* y) { // SamplerInclude.h:35-45
+    if (b == 0) { *x = 1; *y = 0; return; }
+    int64_t d = (int64_t)(a / b), xp, yp;
+    extendedGCD(b, a % b, &xp, &yp);
+    *x = yp; *y = xp - (d * yp);
+}
+static uint64_t multiplicativeInverse(int64_t a, int64_t n) { int64_t x, y; extendedGCD((uint64_t)a, (uint64_t)n, &x, &y); return (uint64_t)ModI(x, n); }
+static uint64_t InverseRadicalInverse(int base, uint64_t inverse, int nDigits) { // Misc.h:55-64
+    uint64_t index = 0;
+    for (int i = 0; i < nDigits; ++i) { uint64_t digit = inverse % (uint64_t)base; inverse /= (uint64_t)base; index = index * (uint64_t)base + digit; }
+    return index;
+}
+
 struct CameraSample { Vec2 image; Vec2 lens; float time = 0; };
 
 // Sampler.cpp:22-83,139-245 (Sampler + GlobalSampler + SobolSampler).  PathIntegrator requests no sample
@@ -75,10 +172,14 @@ struct CameraSample { Vec2 image; Vec2 lens; float time = 0; };
 // GlobalSampler::StartPixel fills every requested array for all samples of the pixel (Sampler.cpp:170-180):
 // entry j of array i is SampleDimension(GetIndexForSample(j), dim_i).  Here an entry is computed when it
 // is handed out, which gives the same values without the per-pixel fill.
+// The same struct is the HaltonSampler (Sampler.cpp:305-373) when `halton` is set: the two differ in the constructor,
+// GetIndexForSample and SampleDimension only.
 struct SobolSampler {
     int64_t samplesPerPixel;
     BBox2i sampleBounds;
     int resolution, log2Resolution;
+    bool halton = false, sampleAtPixelCenter = false;
+    int baseScales[2], baseExponents[2], sampleStride = 1, multInverse[2];
     Vec2i currentPixel;
     int64_t currentPixelSampleIndex = 0;
     int dimension = 0;
@@ -88,18 +189,52 @@ struct SobolSampler {
     std::vector<int> samples2DArraySizes;   // Request2DArray, Sampler.cpp:46-51
     size_t array1DOffset = 0, array2DOffset = 0;
     std::vector<Vec2> arrayScratch[2];
-    bool readPastArrays = false;            // the reference would index m_sampleArray2D out of range
+    mutable bool readPastArrays = false;    // the reference would index m_sampleArray2D (or, as the HaltonSampler, its prime table) out of range
 
     SobolSampler(int64_t spp, const BBox2i& sb) : samplesPerPixel(RoundUpPow2((uint32_t)spp)), sampleBounds(sb) {
         int dx = sb.mx.x - sb.mn.x, dy = sb.mx.y - sb.mn.y;
         resolution = RoundUpPow2((uint32_t)std::max(dx, dy));
         log2Resolution = Log2Int((float)resolution);
     }
+    // HaltonSampler ctor, Sampler.cpp:305-334 (spp is not rounded)
+    SobolSampler(int64_t spp, const BBox2i& sb, bool atCenter) : samplesPerPixel(spp), sampleBounds(sb), resolution(0), log2Resolution(0), halton(true), sampleAtPixelCenter(atCenter) {
+        (void)RadicalInversePermutations();
+        int res[2] = {sb.mx.x - sb.mn.x, sb.mx.y - sb.mn.y};
+        for (int i = 0; i < 2; ++i) {
+            int base = (i == 0) ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(res[i], kMaxResolution)) { scale *= base; ++exp; }
+            baseScales[i] = scale; baseExponents[i] = exp;
+        }
+        sampleStride = baseScales[0] * baseScales[1];
+        multInverse[0] = (int)multiplicativeInverse(baseScales[1], baseScales[0]);
+        multInverse[1] = (int)multiplicativeInverse(baseScales[0], baseScales[1]);
+    }
+    int64_t HaltonIndexForSample(int64_t sampleNum) const { // Sampler.cpp:336-356 (the cached offset recomputed)
+        int64_t offsetForCurrentPixel = 0;
+        if (sampleStride > 1) {
+            int pm[2] = {(int)ModI(currentPixel.x, kMaxResolution), (int)ModI(currentPixel.y, kMaxResolution)};
+            for (int i = 0; i < 2; ++i) {
+                uint64_t dimOffset = InverseRadicalInverse(i == 0 ? 2 : 3, (uint64_t)pm[i], baseExponents[i]);
+                offsetForCurrentPixel += dimOffset * (sampleStride / baseScales[i]) * multInverse[i];
+            }
+            offsetForCurrentPixel %= sampleStride;
+        }
+        return offsetForCurrentPixel + sampleNum * sampleStride;
+    }
+    float HaltonSampleDimension(int64_t index, int dim) const { // Sampler.cpp:358-367
+        if (sampleAtPixelCenter && (dim == 0 || dim == 1)) return 0.5f;
+        if (dim == 0) return HaltonRadicalInverse(dim, (uint64_t)(index >> baseExponents[0]));
+        if (dim == 1) return HaltonRadicalInverse(dim, (uint64_t)(index / baseScales[1]));
+        if (dim >= PrimeTableSize) { readPastArrays = true; dim = PrimeTableSize - 1; } // the reference indexes Primes / PrimeSums out of range (Sampler.h:137-139)
+        return ScrambledRadicalInverseBase(g_primes.primes[dim], &RadicalInversePermutations()[g_primes.sums[dim]], (uint64_t)index);
+    }
     int64_t GetIndexForSample(int64_t sampleNum) const {
+        if (halton) return HaltonIndexForSample(sampleNum);
         return SobolIntervalToIndex(log2Resolution, sampleNum,
                                     Vec2i(currentPixel.x - sampleBounds.mn.x, currentPixel.y - sampleBounds.mn.y));
     }
     float SampleDimension(int64_t index, int dim) const {
+        if (halton) return HaltonSampleDimension(index, dim);
         float s = SobolSampleFloat(index, dim, 0);
         if (dim == 0 || dim == 1) {
             s = s * resolution + sampleBounds.mn[dim];
@@ -2878,11 +3013,18 @@ struct Oracle {
     bool useDirect = false, useVolPath = false;
     std::atomic<bool> readPastArrays{false};
     EnigmaIntegratorDesc idesc;
+    int samplerKind = 0;            // 0 = SobolSampler, 1 = HaltonSampler
+    bool sampleAtPixelCenter = false;
     std::string error;
     Counters totals;
     double msRender = 0;
     std::vector<double> moments; // optional per-pixel [sumR,sumG,sumB,sumR2,sumG2,sumB2,n]
 };
+
+static SobolSampler MakeSampler(const Oracle& O, const BBox2i& sampleBounds) {
+    if (O.samplerKind == 1) return SobolSampler(O.idesc.samples_per_pixel, sampleBounds, O.sampleAtPixelCenter);
+    return SobolSampler(O.idesc.samples_per_pixel, sampleBounds);
+}
 
 static const int TileSize = 32; // Integrator.h:10
 
@@ -2907,7 +3049,7 @@ static void Render(Oracle& O, int64_t sampleBegin, int64_t sampleEnd, int nThrea
             int t = next.fetch_add(1);
             if (t >= total) break;
             Vec2i curTile(t % nTiles.x, t / nTiles.x);
-            SobolSampler tileSampler(O.idesc.samples_per_pixel, sampleBounds);
+            SobolSampler tileSampler = MakeSampler(O, sampleBounds);
             if (O.useDirect) { DirectLightingIntegrator pre = O.direct; pre.Preprocess(O.scene, tileSampler); } // the clone carries the array requests
             int x0 = sampleBounds.mn.x + curTile.x * TileSize;
             int x1 = std::min(x0 + TileSize, sampleBounds.mx.x);
@@ -3162,6 +3304,22 @@ int oracle_integrator_config(OracleCtx* h, const EnigmaIntegratorDesc* d) {
     }
     return 0;
 }
+// which sampler the integrators configured from here on clone per tile: 0 = "sobol", 1 = "halton" (CreateHaltonSampler,
+// Sampler.cpp:521-528: "samplepixelcenter")
+int oracle_sampler_select(OracleCtx* h, int kind, int sample_at_pixel_center) {
+    if (kind != 0 && kind != 1) { h->o.error = "unknown sampler kind"; return -4; }
+    h->o.samplerKind = kind; h->o.sampleAtPixelCenter = sample_at_pixel_center != 0;
+    return 0;
+}
+// the permutation table of the HaltonSampler, and the engine behind it, for known-answer tests
+int oracle_debug_halton_tables(uint32_t n_words, uint32_t* engine_words, uint32_t n_perm, uint16_t* perm_out, int32_t* primes_out, int32_t* sums_out) {
+    std::mt19937 gen;
+    for (uint32_t i = 0; i < n_words; ++i) engine_words[i] = (uint32_t)gen();
+    const std::vector<uint16_t>& p = RadicalInversePermutations();
+    for (uint32_t i = 0; i < n_perm && i < p.size(); ++i) perm_out[i] = p[i];
+    if (primes_out) for (int i = 0; i < PrimeTableSize; ++i) { primes_out[i] = g_primes.primes[i]; sums_out[i] = g_primes.sums[i]; }
+    return (int)p.size();
+}
 int oracle_direct_lighting_config(OracleCtx* h, const EnigmaDirectLightingDesc* d) {
     Oracle& O = h->o;
     O.idesc.max_depth = d->max_depth;
@@ -3239,7 +3397,7 @@ int oracle_reset_stats(OracleCtx* h) { h->o.totals = Counters(); return 0; }
 // ---- taps ----
 int oracle_debug_sobol(OracleCtx* h, uint32_t n, const int32_t* pixels, const int64_t* sampleNums, uint32_t nDims, uint64_t* indexOut, float* dimsOut) {
     BBox2i sb = {Vec2i(h->o.idesc.sample_bounds[0], h->o.idesc.sample_bounds[1]), Vec2i(h->o.idesc.sample_bounds[2], h->o.idesc.sample_bounds[3])};
-    SobolSampler s(h->o.idesc.samples_per_pixel, sb);
+    SobolSampler s = MakeSampler(h->o, sb);
     for (uint32_t i = 0; i < n; ++i) {
         s.StartPixel(Vec2i(pixels[2 * i], pixels[2 * i + 1]));
         s.SetSampleNumber(sampleNums[i]);
@@ -3250,7 +3408,7 @@ int oracle_debug_sobol(OracleCtx* h, uint32_t n, const int32_t* pixels, const in
 }
 int oracle_debug_camera_rays(OracleCtx* h, uint32_t n, const int32_t* pixels, const int64_t* sampleNums, float* outRay, float* outPfilm) {
     BBox2i sb = {Vec2i(h->o.idesc.sample_bounds[0], h->o.idesc.sample_bounds[1]), Vec2i(h->o.idesc.sample_bounds[2], h->o.idesc.sample_bounds[3])};
-    SobolSampler s(h->o.idesc.samples_per_pixel, sb);
+    SobolSampler s = MakeSampler(h->o, sb);
     for (uint32_t i = 0; i < n; ++i) {
         Vec2i px(pixels[2 * i], pixels[2 * i + 1]);
         s.StartPixel(px);

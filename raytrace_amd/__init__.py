@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("ENIGMA_LIB") or os.path.join(_HERE, "libenigma_hip.so
 # every symbol include/enigma_hip.h declares
 SYMBOLS = [
     "enigma_ctx_create", "enigma_ctx_destroy", "enigma_last_error", "enigma_scene_upload", "enigma_camera_set",
-    "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
+    "enigma_film_config", "enigma_sampler_select", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_volpath_config", "enigma_render", "enigma_film_read", "enigma_film_clear",
     "enigma_film_device_ptr", "enigma_film_resolve", "enigma_get_stats", "enigma_debug_sobol", "enigma_debug_camera_rays",
     "enigma_debug_intersect", "enigma_debug_intersect_any", "enigma_debug_primary_hits", "enigma_debug_film_footprint", "enigma_debug_intersect_noalloc", "enigma_debug_bsdf", "enigma_debug_bsdf_of", "enigma_default_metal_spectra",
     "enigma_comm_unique_id", "enigma_comm_init", "enigma_comm_info", "enigma_film_reduce", "enigma_comm_destroy",
@@ -47,6 +47,8 @@ def load_library():
         for name in ("enigma_scene_upload", "enigma_camera_set", "enigma_film_config", "enigma_integrator_config", "enigma_direct_lighting_config", "enigma_get_stats"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.enigma_film_clear.argtypes = [C.c_void_p]
+        if not os.environ.get("ENIGMA_LIB") or hasattr(L, "enigma_sampler_select"):  # experiment builds of an older tree lack it
+            L.enigma_sampler_select.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.enigma_comm_unique_id.argtypes = [C.c_void_p]
         L.enigma_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.enigma_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -98,12 +100,20 @@ class Renderer:
         except Exception:
             pass
 
-    def configure(self, scene, camera, film, integ):
+    def configure(self, scene, camera, film, integ, sampler="sobol", sample_at_pixel_center=False):
         self.upload_scene(scene)
         self.set_camera(camera)
         self.set_film(film)
+        self.select_sampler(sampler, sample_at_pixel_center)
         self.set_integrator(integ)
         return self
+
+    def select_sampler(self, name, sample_at_pixel_center=False):
+        """'sobol' | 'halton' for the integrators configured from here on (RenderOptions::MakeSampler, Enigma/Api.cpp:425-434)."""
+        kind = {"sobol": abi.SAMPLER_SOBOL, "halton": abi.SAMPLER_HALTON}[name]
+        if kind == abi.SAMPLER_SOBOL and os.environ.get("ENIGMA_LIB") and not hasattr(self.L, "enigma_sampler_select"):
+            return
+        self._chk(self.L.enigma_sampler_select(self.h, kind, 1 if sample_at_pixel_center else 0))
 
     def upload_scene(self, scene):
         d = scene.desc()

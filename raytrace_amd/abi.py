@@ -8,6 +8,7 @@ MAT_MIRROR, MAT_TRANSLUCENT, MAT_SUBSTRATE, MAT_UBER, MAT_MIX = 4, 5, 6, 7, 8
 LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE = 0, 1, 2, 3, 4, 5
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 CAMERA_PERSPECTIVE, CAMERA_ENVIRONMENT = 0, 1
+SAMPLER_SOBOL, SAMPLER_HALTON = 0, 1  # enigma_sampler_select
 DL_SAMPLE_ALL, DL_SAMPLE_ONE = 0, 1
 TRI_FLIP_NORMAL = 1
 TRI_HAS_NORMALS = 2

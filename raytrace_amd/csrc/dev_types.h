@@ -169,6 +169,9 @@ struct DevFilm {
     const float* filterTable;   // 16 x 16
 };
 
+// SobolSampler; with res == 0 the HaltonSampler, which keeps other data behind the same pointers: tx / ty = the two
+// terms of the pixel's index offset per column / row, sampleConst = the sample number of each slot, bitConst = its
+// parameters, primes and digit permutations (haltonDimension in kernels.h).
 struct DevSampler {
     const uint32_t* tx;         // [nDims][res] pixel-x XOR table
     const uint32_t* ty;         // [nDims][res]

@@ -9,6 +9,7 @@
 #include "envmap_host.h"
 #include <memory>
 #include "sobol_host.h"
+#include "halton_host.h"
 #include "spectrum_host.h"
 
 #include <rccl/rccl.h>
@@ -117,6 +118,9 @@ struct EnigmaCtx {
     DevIntegrator integ{};
     int64_t spp = 0;
     uint32_t log2Res = 0, resolution = 0, nDims = 0;
+    uint32_t samplerSelected = ENIGMA_SAMPLER_SOBOL, samplerKind = ENIGMA_SAMPLER_SOBOL; // chosen for the next configuration / of the configured integrator
+    bool centerSelected = false;
+    enigma::HaltonTables haltonSampler;
     DevBuf<uint32_t> tx, ty, sampleConst;
     DevSampler sampler{};
     bool lightDistDirty = true;
@@ -963,7 +967,45 @@ extern "C" int enigma_film_config(EnigmaCtx* h, const EnigmaFilmDesc* f) {
     return enigma_film_clear(h);
 }
 
-// SobolSampler construction + the pixels the tile loop visits; shared by both integrators.
+// Which sampler the integrators configured after this call clone per tile (Enigma/Api.cpp:425-434 selects by name).
+extern "C" int enigma_sampler_select(EnigmaCtx* h, uint32_t kind, uint32_t sample_at_pixel_center) {
+    if (!h) return ENIGMA_E_INVALID;
+    if (kind != ENIGMA_SAMPLER_SOBOL && kind != ENIGMA_SAMPLER_HALTON) return h->fail(ENIGMA_E_INVALID, "unknown sampler kind %u", kind);
+    h->samplerSelected = kind;
+    h->centerSelected = kind == ENIGMA_SAMPLER_HALTON && sample_at_pixel_center != 0;
+    return ENIGMA_OK;
+}
+
+// render region: the pixels the reference's tile loop visits (Enigma/Integrator.cpp:233-265).  Tile rows start
+// at sampleBounds.m_min.x, not m_min.y (:254): with a crop window whose x and y origins differ, the rows
+// [min.y, min.x) are never rendered.  Kept, because the film must match the reference's.
+static void setRenderRegion(EnigmaCtx* h, const int32_t* sb, const int32_t* pixel_bounds) {
+    int dy = sb[3] - sb[1];
+    int nTilesY = (dy + 31) / 32;
+    int tileY0 = sb[0], tileY1 = std::min(sb[0] + nTilesY * 32, sb[3]);
+    int rx0 = std::max(sb[0], pixel_bounds[0]), ry0 = std::max(tileY0, pixel_bounds[1]);
+    int rx1 = std::min(sb[2], pixel_bounds[2]), ry1 = std::min(tileY1, pixel_bounds[3]);
+    h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
+}
+
+// What the kernels need of the sample numbers in flight: per slot the Sobol' constants of its sample number, or, for the
+// HaltonSampler, the sample number itself.
+static int uploadSampleSlots(EnigmaCtx* h, const int64_t* sampleNums, int64_t first, size_t count) {
+    std::vector<uint32_t> consts;
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON) {
+        consts.assign(count + 16, 0u);
+        for (size_t s = 0; s < count; ++s) consts[s] = (uint32_t)(sampleNums ? sampleNums[s] : first + (int64_t)s);
+    } else {
+        consts.assign(count * h->nDims + 16, 0u);
+        for (size_t s = 0; s < count; ++s)
+            enigma::sample_constants(h->log2Res, (uint64_t)(sampleNums ? sampleNums[s] : first + (int64_t)s), h->nDims, &consts[s * h->nDims]);
+    }
+    HIPCHK(h, h->sampleConst.upload(consts));
+    h->sampler.sampleConst = h->sampleConst.p;
+    return ENIGMA_OK;
+}
+
+// SobolSampler / HaltonSampler construction + the pixels the tile loop visits; shared by the integrators.
 static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32_t* sb, const int32_t* pixel_bounds, uint32_t nDims) {
     if (samples_per_pixel <= 0 || samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
     if (sb[2] <= sb[0] || sb[3] <= sb[1]) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
@@ -975,6 +1017,29 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     // Arguments rejected above leave the configured integrator as it was.  From here on the sampler state is rewritten;
     // a failure below leaves it half rebuilt, so the handle has no integrator until the caller's configuration succeeds.
     h->haveInteg = false;
+    h->samplerKind = h->samplerSelected;
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON) {
+        // HaltonSampler ctor, Enigma/Sampler.cpp:305-334: the sample count is kept as given
+        // the VolPathIntegrator asks for every dimension its cursor can address (1023); the reference's prime table ends at
+        // dimension 999 and it indexes past it beyond (undefined): those dimensions repeat the last one here
+        if (nDims > 1023u) return h->fail(ENIGMA_E_INVALID, "dimension cursor overflow");
+        h->spp = samples_per_pixel;
+        h->resolution = 0; h->log2Res = 0;
+        enigma::build_halton_tables(sb, nDims, h->centerSelected, &h->haltonSampler);
+        // the device takes the digits of an index off with 32-bit divisions
+        if (((uint64_t)h->spp + 1ull) * h->haltonSampler.stride > (1ull << 32))
+            return h->fail(ENIGMA_E_UNSUPPORTED, "%lld samples per pixel at a sample stride of %u exceed the 32-bit Halton index of this build", (long long)h->spp, h->haltonSampler.stride);
+        h->nDims = nDims;
+        HIPCHK(h, h->tx.upload(h->haltonSampler.offX));
+        HIPCHK(h, h->ty.upload(h->haltonSampler.offY));
+        HIPCHK(h, h->bitConst.upload(h->haltonSampler.words));
+        h->sampler.tx = h->tx.p; h->sampler.ty = h->ty.p; h->sampler.bitConst = h->bitConst.p;
+        h->sampler.res = 0u; h->sampler.nDims = nDims; // res == 0 is how the kernels know the sampler
+        h->sampler.sbx0 = sb[0]; h->sampler.sby0 = sb[1];
+        h->sampler.resolutionF = 0.f;
+        setRenderRegion(h, sb, pixel_bounds);
+        return ENIGMA_OK;
+    }
     // SobolSampler ctor, Enigma/Sampler.cpp:211-222
     h->spp = (int64_t)roundUpPow2((uint32_t)samples_per_pixel);
     h->resolution = roundUpPow2((uint32_t)std::max(dx, dy));
@@ -1007,14 +1072,7 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     h->sampler.res = h->resolution; h->sampler.nDims = nDims;
     h->sampler.sbx0 = sb[0]; h->sampler.sby0 = sb[1];
     h->sampler.resolutionF = (float)(int)h->resolution;
-    // render region: the pixels the reference's tile loop visits (Enigma/Integrator.cpp:233-265).  Tile rows start
-    // at sampleBounds.m_min.x, not m_min.y (:254): with a crop window whose x and y origins differ, the rows
-    // [min.y, min.x) are never rendered.  Kept, because the film must match the reference's.
-    int nTilesY = (dy + 31) / 32;
-    int tileY0 = sb[0], tileY1 = std::min(sb[0] + nTilesY * 32, sb[3]);
-    int rx0 = std::max(sb[0], pixel_bounds[0]), ry0 = std::max(tileY0, pixel_bounds[1]);
-    int rx1 = std::min(sb[2], pixel_bounds[2]), ry1 = std::min(tileY1, pixel_bounds[3]);
-    h->integ.rx0 = rx0; h->integ.ry0 = ry0; h->integ.rw = std::max(0, rx1 - rx0); h->integ.rh = std::max(0, ry1 - ry0);
+    setRenderRegion(h, sb, pixel_bounds);
     return ENIGMA_OK;
 }
 
@@ -1112,13 +1170,19 @@ static int finishDirectLighting(EnigmaCtx* h) {
     // Li evaluations (nodes) per camera sample: 1 without specular lobes, a chain with one, a binary tree with two
     uint64_t nodes = !h->glassSpecular ? 1 : (!h->glassBranches ? (uint64_t)std::max(1, d.max_depth) : ((1ull << std::min(d.max_depth, 20)) - 1));
     uint64_t nDims = 5ull + 2ull * nArrays + nodes * (d.strategy == ENIGMA_DL_SAMPLE_ONE ? 9ull : 4ull);
-    if (nDims > (uint64_t)enigma::kNumSobolDimensions)
-        return h->fail(ENIGMA_E_UNSUPPORTED, "DirectLightingIntegrator needs %llu Sobol dimensions here (%u sample arrays); the reference has 1024",
-                       (unsigned long long)nDims, nArrays);
-    if ((uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res)))
+    const bool haltonNext = h->samplerSelected == ENIGMA_SAMPLER_HALTON;
+    if (nDims > (uint64_t)(haltonNext ? enigma::kHaltonDimensions : enigma::kNumSobolDimensions))
+        return h->fail(ENIGMA_E_UNSUPPORTED, "DirectLightingIntegrator needs %llu sample dimensions here (%u sample arrays); the reference's %s sampler has %d",
+                       (unsigned long long)nDims, nArrays, haltonNext ? "halton" : "sobol", haltonNext ? enigma::kHaltonDimensions : enigma::kNumSobolDimensions);
+    if (!haltonNext && (uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res)))
         return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the Sobol' index width", maxN, (long long)h->spp);
     int rc = configureSampler(h, d.samples_per_pixel, d.sample_bounds, d.pixel_bounds, (uint32_t)nDims);
     if (rc) { h->haveInteg = false; return rc; } // the sampler tables are half rebuilt
+    // entry k of a sample array of n entries is a sample of sample number (current sample number) * n + k (Enigma/Sampler.cpp:170-180)
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON && ((uint64_t)h->spp * std::max(1u, maxN) + 1ull) * h->haltonSampler.stride > (1ull << 32)) {
+        h->haveInteg = false;
+        return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the 32-bit Halton index of this build", maxN, (long long)h->spp);
+    }
     h->integ.maxDepth = d.max_depth;
     h->integ.rrThreshold = 0.f;
     h->integ.dlStrategy = d.strategy;
@@ -1275,7 +1339,10 @@ static void launchTextures(EnigmaCtx* h, const DevPaths& P, int grid, int noneQu
     if (!h->haveTrilinear) return;
     const float diffScale = 1 / std::sqrt((float)h->spp); // RayDifferential::scaleDifferentials, Enigma/Integrator.cpp:276
     for (int k = 0; k < MK_COUNT; ++k)
-        if (h->kindTextured[k]) k_texture<<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
+        if (h->kindTextured[k]) {
+            if (h->samplerKind == ENIGMA_SAMPLER_HALTON) k_texture<true><<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
+            else k_texture<false><<<grid, kBlock, 0, h->stream>>>(h->scene, P, h->sampler, h->integ, h->camera, diffScale, h->matQ[k].p, k, h->counters.p);
+        }
 }
 
 // The light-distribution tables of the voxels that this bounce's interactions lie in and that have none yet
@@ -1306,8 +1373,39 @@ static void launchClosest(EnigmaCtx* h, const DevPaths& P, uint32_t nPaths, int 
     for (int k = 0; k < MK_COUNT; ++k) queueMask |= h->kindPresent[k] ? 1u << k : 0u;
     if (MODE == 0) queueMask |= h->haveNoMaterial ? 1u << MK_NONE : 0u;
     else queueMask |= (1u << MK_COUNT) | (1u << kQueueMedium);
-    k_intersect_closest<LDSN, OVF, LDS_SCENE, MODE, SPH><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, h->stream>>>(
-        h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount, queueMask);
+    // only the VolPathIntegrator's build draws samples (the medium's free path): it alone exists per sampler
+    if (MODE == 2 && h->samplerKind == ENIGMA_SAMPLER_HALTON)
+        k_intersect_closest<LDSN, OVF, LDS_SCENE, MODE, SPH, MODE == 2><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, h->stream>>>(
+            h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount, queueMask);
+    else
+        k_intersect_closest<LDSN, OVF, LDS_SCENE, MODE, SPH, false><<<gridTrace, kBlock, LDS_SCENE ? sceneLdsBytes(h) : 0, h->stream>>>(
+            h->scene, P, h->integ, h->sampler, queue, countPtr, nPaths, mq, ctr, h->refillIdle, pendCount, queueMask);
+}
+
+// The shade kernels of one bounce, one per material kind present; compiled per sampler (HAL: the HaltonSampler).
+template <bool LDS_SCENE, bool VOL, bool SPH, bool HAL>
+static void launchShadeKinds(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t* nextQ, uint32_t next, int gridShade) {
+    DevCounters* ctr = h->counters.p;
+    hipStream_t s = h->stream;
+    const size_t lds = LDS_SCENE ? shadeLdsBytes(h) : 0;
+#define ENIGMA_SHADE_KIND(MK) \
+    if (h->kindPresent[MK]) k_shade<MK, LDS_SCENE, VOL, SPH, HAL><<<gridShade, kBlock, lds, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK].p, nextQ, next, ctr)
+    ENIGMA_SHADE_KIND(MK_MATTE); ENIGMA_SHADE_KIND(MK_METAL); ENIGMA_SHADE_KIND(MK_GLASS_SMOOTH); ENIGMA_SHADE_KIND(MK_GLASS_ROUGH);
+    ENIGMA_SHADE_KIND(MK_PLASTIC); ENIGMA_SHADE_KIND(MK_MATTE_ROUGH); ENIGMA_SHADE_KIND(MK_GENERAL);
+#undef ENIGMA_SHADE_KIND
+    if constexpr (VOL)
+        if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH, HAL><<<gridShade, kBlock, lds, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, next, ctr);
+}
+template <bool LDS_SCENE, bool SPH, bool HAL>
+static void launchShadeKindsDirect(EnigmaCtx* h, const DevPaths& P, const DevDirect& D, const DevRayQueue& shq, const DevRayQueue& misq, uint32_t* nextQ, uint32_t next, int gridShade) {
+    DevCounters* ctr = h->counters.p;
+    hipStream_t s = h->stream;
+    const size_t lds = LDS_SCENE ? shadeLdsBytes(h) : 0;
+#define ENIGMA_SHADE_KIND(MK) \
+    if (h->kindPresent[MK]) k_shade_direct<MK, LDS_SCENE, SPH, HAL><<<gridShade, kBlock, lds, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK].p, nextQ, next, ctr)
+    ENIGMA_SHADE_KIND(MK_MATTE); ENIGMA_SHADE_KIND(MK_METAL); ENIGMA_SHADE_KIND(MK_GLASS_SMOOTH); ENIGMA_SHADE_KIND(MK_GLASS_ROUGH);
+    ENIGMA_SHADE_KIND(MK_PLASTIC); ENIGMA_SHADE_KIND(MK_MATTE_ROUGH); ENIGMA_SHADE_KIND(MK_GENERAL);
+#undef ENIGMA_SHADE_KIND
 }
 
 template <int LDSN, int OVF, bool LDS_SCENE, bool SPH = false>
@@ -1325,13 +1423,8 @@ static void launchBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& shq
     (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade);
     launchSpatialFill(h, P, gridShade, MK_COUNT - 1);
-    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GENERAL]) k_shade<MK_GENERAL, LDS_SCENE, false, SPH><<<gridShade, kBlock, LDS_SCENE ? shadeLdsBytes(h) : 0, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON) launchShadeKinds<LDS_SCENE, false, SPH, true>(h, P, shq, misq, nextQ, cur ^ 1u, gridShade);
+    else launchShadeKinds<LDS_SCENE, false, SPH, false>(h, P, shq, misq, nextQ, cur ^ 1u, gridShade);
     // surfaces without a material: the ray goes on behind them and the vertex does not count as a bounce (Enigma/PathIntegrator.cpp:87-93)
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
@@ -1360,18 +1453,11 @@ static void launchVolBounce(EnigmaCtx* h, const DevPaths& P, const DevRayQueue& 
     launchClosest<LDSN, OVF, LDS_SCENE, 2, SPH>(h, P, nPaths, iter, gridTrace, nullptr);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
-    const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade);
     launchSpatialFill(h, P, gridShade, kQueueMedium);
-    if (h->kindPresent[MK_MATTE]) k_shade<MK_MATTE, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade<MK_METAL, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade<MK_GLASS_SMOOTH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade<MK_GLASS_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade<MK_PLASTIC, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade<MK_MATTE_ROUGH, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GENERAL]) k_shade<MK_GENERAL, LDS_SCENE, true, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->scene.triMedium) k_shade_medium<LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, shq, misq, h->matQ[kQueueMedium].p, nextQ, cur ^ 1u, ctr);
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON) launchShadeKinds<LDS_SCENE, true, SPH, true>(h, P, shq, misq, nextQ, cur ^ 1u, gridShade);
+    else launchShadeKinds<LDS_SCENE, true, SPH, false>(h, P, shq, misq, nextQ, cur ^ 1u, gridShade);
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[MK_NONE].p, MK_NONE, nextQ, cur ^ 1u, ctr);
     (void)hipEventRecord(ev.h1, s);
     *ev.shadeTimed = 1;
@@ -1399,16 +1485,10 @@ static void launchDirectStep(EnigmaCtx* h, const DevPaths& P, const DevDirect& D
     launchClosest<LDSN, OVF, LDS_SCENE, 1, SPH>(h, P, nPaths, step, gridTrace, D.pendCount);
     (void)hipEventRecord(ev.c1, s);
     uint32_t* nextQ = h->extQ[cur ^ 1u].p;
-    const size_t ldsShade = LDS_SCENE ? shadeLdsBytes(h) : 0;
     (void)hipEventRecord(ev.h0, s);
     launchTextures(h, P, gridShade, kQueueMedium);
-    if (h->kindPresent[MK_MATTE]) k_shade_direct<MK_MATTE, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_METAL]) k_shade_direct<MK_METAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_METAL].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_SMOOTH]) k_shade_direct<MK_GLASS_SMOOTH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_SMOOTH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GLASS_ROUGH]) k_shade_direct<MK_GLASS_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GLASS_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_PLASTIC]) k_shade_direct<MK_PLASTIC, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_PLASTIC].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_MATTE_ROUGH]) k_shade_direct<MK_MATTE_ROUGH, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_MATTE_ROUGH].p, nextQ, cur ^ 1u, ctr);
-    if (h->kindPresent[MK_GENERAL]) k_shade_direct<MK_GENERAL, LDS_SCENE, SPH><<<gridShade, kBlock, ldsShade, s>>>(h->scene, P, h->sampler, h->integ, D, shq, misq, h->matQ[MK_GENERAL].p, nextQ, cur ^ 1u, ctr);
+    if (h->samplerKind == ENIGMA_SAMPLER_HALTON) launchShadeKindsDirect<LDS_SCENE, SPH, true>(h, P, D, shq, misq, nextQ, cur ^ 1u, gridShade);
+    else launchShadeKindsDirect<LDS_SCENE, SPH, false>(h, P, D, shq, misq, nextQ, cur ^ 1u, gridShade);
     if (h->glassSpecular) k_resume_pending<<<gridShadow, kBlock, 0, s>>>(P, h->integ, D, h->matQ[MK_COUNT].p, nextQ, cur ^ 1u, ctr);
     // surfaces without a material: Li goes on behind them at the same depth (Enigma/DirectLightingIntegrator.cpp:51-54)
     if (h->haveNoMaterial) k_interface<<<gridShadow, kBlock, 0, s>>>(h->scene, P, h->matQ[kQueueMedium].p, kQueueMedium, nextQ, cur ^ 1u, ctr);
@@ -1475,10 +1555,7 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
     h->residentTraceBlocks = cus * 6;
     for (int64_t c0 = 0; c0 < nSamples; c0 += chunkMax) {
         int64_t cn = std::min(chunkMax, nSamples - c0);
-        std::vector<uint32_t> consts((size_t)cn * h->nDims + 16, 0u);
-        for (int64_t s = 0; s < cn; ++s) enigma::sample_constants(h->log2Res, (uint64_t)(sample_begin + c0 + s), h->nDims, &consts[(size_t)s * h->nDims]);
-        HIPCHK(h, h->sampleConst.upload(consts));
-        h->sampler.sampleConst = h->sampleConst.p;
+        { int rc = uploadSampleSlots(h, nullptr, sample_begin + c0, (size_t)cn); if (rc) return rc; }
         h->sampler.sampleBase = (unsigned long long)(sample_begin + c0);
         size_t passPathsMax = (size_t)nPixels * std::min<int64_t>(k, cn);
         { int rc = ensureCapacity(h, passPathsMax, raysPerPath, pendingLevels); if (rc) return rc; }
@@ -1509,7 +1586,9 @@ static int renderImpl(EnigmaCtx* h, int64_t sample_begin, int64_t sample_end) {
             int gridTrace = traceGrid(nPaths, cus);
             int gridShadow = std::min(gridAll, cus * 4); // MIS rays: few per bounce
             int gridShade = std::min(gridAll, cus * h->shadeBlocksPerCu);
-            k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
+            if (h->samplerKind == ENIGMA_SAMPLER_HALTON) k_generate<true><<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
+                                                          direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
+            else k_generate<false><<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPaths, nPixels, (uint32_t)s0, h->counters.p,
                                                           direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
             // DirectLightingIntegrator: one step per level of the recursion still alive; the host reads the number of
             // continuing paths after each step (a camera sample is a chain of <= maxDepth steps, or a tree with glass)
@@ -1815,17 +1894,17 @@ extern "C" int enigma_get_stats(EnigmaCtx* h, EnigmaStats* out) {
 static int debugSlots(EnigmaCtx* h, uint32_t n, const int32_t* pixels, const int64_t* sampleNums, DevBuf<int32_t>& dPix, DevBuf<uint32_t>& dSlots) {
     if (!h->haveInteg) return h->fail(ENIGMA_E_STATE, "integrator not configured");
     const int32_t* sb = h->integDesc.sample_bounds;
-    std::vector<uint32_t> consts((size_t)n * h->nDims), slots(n);
+    std::vector<uint32_t> slots(n);
     std::vector<int32_t> pix(pixels, pixels + 2 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i) {
         if (pixels[2 * i] < sb[0] || pixels[2 * i] >= sb[2] || pixels[2 * i + 1] < sb[1] || pixels[2 * i + 1] >= sb[3])
             return h->fail(ENIGMA_E_INVALID, "pixel %u outside the sample bounds", i);
         if (sampleNums[i] < 0) return h->fail(ENIGMA_E_INVALID, "negative sample number");
-        enigma::sample_constants(h->log2Res, (uint64_t)sampleNums[i], h->nDims, &consts[(size_t)i * h->nDims]);
+        if (h->samplerKind == ENIGMA_SAMPLER_HALTON && ((uint64_t)sampleNums[i] + 1ull) * h->haltonSampler.stride > (1ull << 32))
+            return h->fail(ENIGMA_E_UNSUPPORTED, "sample number %lld exceeds the 32-bit Halton index of this build", (long long)sampleNums[i]);
         slots[i] = i;
     }
-    HIPCHK(h, h->sampleConst.upload(consts));
-    h->sampler.sampleConst = h->sampleConst.p;
+    { int rc = uploadSampleSlots(h, sampleNums, 0, n); if (rc) return rc; }
     HIPCHK(h, dPix.upload(pix));
     HIPCHK(h, dSlots.upload(slots));
     return ENIGMA_OK;
@@ -1842,7 +1921,8 @@ extern "C" int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixel
     if (rc == ENIGMA_OK) {
         hipError_t e = dOut.alloc((size_t)n * n_dims);
         if (e == hipSuccess) {
-            k_debug_sobol<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, n, dPix.p, dSlots.p, n_dims, dOut.p);
+            if (h->samplerKind == ENIGMA_SAMPLER_HALTON) k_debug_sobol<true><<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, n, dPix.p, dSlots.p, n_dims, dOut.p);
+            else k_debug_sobol<false><<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, n, dPix.p, dSlots.p, n_dims, dOut.p);
             e = hipStreamSynchronize(h->stream);
             if (e == hipSuccess) e = hipMemcpy(dims_out, dOut.p, (size_t)n * n_dims * sizeof(float), hipMemcpyDeviceToHost);
         }
@@ -1851,7 +1931,9 @@ extern "C" int enigma_debug_sobol(EnigmaCtx* h, uint32_t n, const int32_t* pixel
     if (rc == ENIGMA_OK && index_out) {
         const int32_t* sb = h->integDesc.sample_bounds;
         for (uint32_t i = 0; i < n; ++i)
-            index_out[i] = enigma::sobol_interval_to_index(h->log2Res, (uint64_t)sample_nums[i], (uint32_t)(pixels_xy[2 * i] - sb[0]), (uint32_t)(pixels_xy[2 * i + 1] - sb[1]));
+            index_out[i] = h->samplerKind == ENIGMA_SAMPLER_HALTON
+                         ? enigma::halton_index(h->haltonSampler, (uint32_t)(pixels_xy[2 * i] - sb[0]), (uint32_t)(pixels_xy[2 * i + 1] - sb[1]), (uint64_t)sample_nums[i])
+                         : enigma::sobol_interval_to_index(h->log2Res, (uint64_t)sample_nums[i], (uint32_t)(pixels_xy[2 * i] - sb[0]), (uint32_t)(pixels_xy[2 * i + 1] - sb[1]));
     }
     dPix.release(); dSlots.release(); dOut.release();
     return rc;
@@ -1870,7 +1952,8 @@ extern "C" int enigma_debug_camera_rays(EnigmaCtx* h, uint32_t n, const int32_t*
         hipError_t e = dRay.alloc((size_t)n * 6);
         if (e == hipSuccess) e = dPf.alloc((size_t)n * 2);
         if (e == hipSuccess) {
-            k_debug_camera<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, h->camera, n, dPix.p, dSlots.p, dRay.p, dPf.p);
+            if (h->samplerKind == ENIGMA_SAMPLER_HALTON) k_debug_camera<true><<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, h->camera, n, dPix.p, dSlots.p, dRay.p, dPf.p);
+            else k_debug_camera<false><<<(n + 255) / 256, 256, 0, h->stream>>>(h->sampler, h->camera, n, dPix.p, dSlots.p, dRay.p, dPf.p);
             e = hipStreamSynchronize(h->stream);
             if (e == hipSuccess) e = hipMemcpy(out_ray, dRay.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(out_pfilm, dPf.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost);
@@ -1963,10 +2046,7 @@ static int primaryHitsImpl(EnigmaCtx* h, int64_t sample_num, int32_t* triOut, ui
     if (!direct && h->integ.maxDepth < 1) return h->fail(ENIGMA_E_INVALID, "the primary-hit tap needs max_depth >= 1 (at depth 0 the kernel writes no hit record)");
     const uint32_t nPixels = (uint32_t)h->integ.rw * (uint32_t)h->integ.rh;
     if (nPixels == 0) return ENIGMA_OK;
-    std::vector<uint32_t> consts((size_t)h->nDims + 16, 0u);
-    enigma::sample_constants(h->log2Res, (uint64_t)sample_num, h->nDims, consts.data());
-    HIPCHK(h, h->sampleConst.upload(consts));
-    h->sampler.sampleConst = h->sampleConst.p;
+    { int rc = uploadSampleSlots(h, nullptr, sample_num, 1); if (rc) return rc; }
     h->sampler.sampleBase = (unsigned long long)sample_num;
     if (direct && h->deferredLobeChoice)
         return h->fail(ENIGMA_E_UNSUPPORTED, "a material with a specular reflection lobe and two specular transmission lobes (an uber with Kr, Kt and opacity < 1, "
@@ -1991,7 +2071,8 @@ static int primaryHitsImpl(EnigmaCtx* h, int64_t sample_num, int32_t* triOut, ui
         const int gridAll = (int)((nPixels + kBlock - 1) / kBlock);
         if (const char* env = getenv("ENIGMA_REFILL_IDLE")) h->refillIdle = (uint32_t)atoi(env);
         h->scene.hitT = hitT.p;
-        k_generate<<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPixels, nPixels, 0u, h->counters.p, direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
+        if (h->samplerKind == ENIGMA_SAMPLER_HALTON) k_generate<true><<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPixels, nPixels, 0u, h->counters.p, direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
+        else k_generate<false><<<gridAll, kBlock, 0, h->stream>>>(P, h->sampler, h->camera, h->integ, nPixels, nPixels, 0u, h->counters.p, direct ? (uint32_t)h->integ.arrayEndDim : 5u, D);
         k_stage<<<1, 1, 0, h->stream>>>(h->counters.p, 0, 0u, nPixels, 1);
         const int gridTrace = traceGrid(nPixels, cus);
         if (direct) launchClosestFlavour<1>(h, P, nPixels, gridTrace, D.pendCount);

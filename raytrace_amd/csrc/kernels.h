@@ -31,9 +31,53 @@ constexpr int kWavesPerBlock = kBlock / 64;
 DEV uint32_t sobolBits(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t slot, uint32_t dim) {
     return S.tx[(size_t)dim * S.res + relx] ^ S.ty[(size_t)dim * S.res + rely] ^ S.sampleConst[(size_t)slot * S.nDims + dim];
 }
+// HaltonSampler::GetIndexForSample + SampleDimension (Enigma/Sampler.cpp:336-367) with RadicalInverseSpecialized /
+// ScrambledRadicalInverseSpecialized (Enigma/SamplerInclude.h:49-84), the base a run-time value instead of one of the
+// reference's 1000 template instances.  The index of (pixel, sample number) is below 2^32 (checked when the sampler is
+// configured), so the digits come off with 32-bit divisions; the reversed digits need 64 bits as in the reference.
+// DevSampler::bitConst holds, for this sampler: {stride, exponent of 2, scale of 3, sample-at-centre flag}, then per
+// dimension {prime, word offset of its digit permutation}, then the permutations, one word per digit value.
+// Kernels that draw samples are compiled once per sampler (template argument HAL): with the choice made at run time
+// the shade kernels of the Sobol' sampler, which never run this, were 3.5 % slower, inlined or not.  One copy per
+// module (not inlined): a shade kernel draws samples in a dozen places.
+static __device__ __noinline__ float haltonValue(const uint32_t* H, uint32_t off, uint32_t sampleNum, uint32_t dim) {
+    if (dim < 2u && H[3] != 0u) return 0.5f;
+    const uint32_t stride = H[0];
+    if (off >= stride) off -= stride;                // the sum of two terms, each already reduced modulo the stride
+    uint32_t a = off + sampleNum * stride;
+    if (dim == 0u) return (float)__brev(a >> H[1]) * 0x1p-32f; // ReverseBits64(a) * 2^-64, one rounding to float in both forms
+    const uint32_t base = H[4u + 2u * dim];
+    const float invBase = 1.0f / (float)base;
+    unsigned long long reversedDigits = 0;
+    float invBaseN = 1.f;
+    if (dim == 1u) {
+        a /= H[2];
+        while (a) {
+            uint32_t next = a / base, digit = a - next * base;
+            reversedDigits = reversedDigits * base + digit;
+            invBaseN *= invBase;
+            a = next;
+        }
+        return smin((float)reversedDigits * invBaseN, kOneMinusEpsilon);
+    }
+    const uint32_t* perm = H + H[5u + 2u * dim];
+    while (a) {
+        uint32_t next = a / base, digit = a - next * base;
+        reversedDigits = reversedDigits * base + perm[digit];
+        invBaseN *= invBase;
+        a = next;
+    }
+    return smin(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1.f - invBase)), kOneMinusEpsilon);
+}
+DEV float haltonDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t sampleNum, uint32_t dim) {
+    return haltonValue(S.bitConst, S.tx[relx] + S.ty[rely], sampleNum, dim);
+}
+
 // SobolSampleFloat + SobolSampler::SampleDimension (Enigma/SamplerInclude.h:2627-2637, Enigma/Sampler.cpp:229-240)
+template <bool HAL>
 DEV float sampleDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t slot, uint32_t dim) {
     // relx, rely: pixel relative to the sample-bounds origin (m_currentPixel - m_sampleBounds.m_min)
+    if constexpr (HAL) return haltonDimension(S, relx, rely, S.sampleConst[slot], dim); // HaltonSampler: one sample number per slot
     uint32_t v = sobolBits(S, relx, rely, slot, dim);
     float s = smin((float)v * 0x1p-32f, kOneMinusEpsilon);
     if (dim == 0 || dim == 1) {
@@ -46,7 +90,9 @@ DEV float sampleDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uin
 // Sample of an arbitrary sample number of the pixel (the entries of GlobalSampler's sample arrays,
 // Enigma/Sampler.cpp:170-180, are samples of OTHER sample numbers of the same pixel): the per-sample
 // constant is GF(2)-linear in the bits of the sample number, so it is XORed together from per-bit constants.
+template <bool HAL>
 DEV float sampleDimensionOf(const DevSampler& S, uint32_t relx, uint32_t rely, unsigned long long sampleNum, uint32_t dim) {
+    if constexpr (HAL) return haltonDimension(S, relx, rely, (uint32_t)sampleNum, dim);
     uint32_t v = S.tx[(size_t)dim * S.res + relx] ^ S.ty[(size_t)dim * S.res + rely];
     for (int b = 0; sampleNum != 0 && b < kSampleBits; ++b, sampleNum >>= 1)
         if (sampleNum & 1ull) v ^= S.bitConst[(size_t)dim * kSampleBits + b];
@@ -295,6 +341,7 @@ DEV uint32_t primWord(const DevScene& sc, const float4* tris, int prim) {
 }
 
 // ---------------------------------------------------------------- kernels
+template <bool HAL = false>
 __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, DevCamera C, DevIntegrator I, uint32_t nPaths, uint32_t nPixels,
                                                      uint32_t slotBase, DevCounters* ctr, uint32_t firstDim, DevDirect D) {
     __shared__ float4 recs[kBlock * 4];
@@ -308,10 +355,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(DevPaths P, DevSampler S, D
         int px = I.rx0 + (int)tx, py = I.ry0 + (int)ty;
         uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
         // GetCameraSample: image = pixel + Get2D (dims 0,1), time = Get1D (dim 2), lens = Get2D (dims 3,4)
-        float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
-        float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
+        float fx = (float)px + sampleDimension<HAL>(S, relx, rely, slot, 0);
+        float fy = (float)py + sampleDimension<HAL>(S, relx, rely, slot, 1);
         float lu = 0.f, lv = 0.f;
-        if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
+        if (C.lensRadius > 0.f) { lu = sampleDimension<HAL>(S, relx, rely, slot, 3); lv = sampleDimension<HAL>(S, relx, rely, slot, 4); }
         cameraRay(C, fx, fy, lu, lv, &o, &d);
         P.L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         P.pfilm[i] = make_float2(fx, fy);
@@ -411,7 +458,7 @@ DEV void boundaryGeometry(const DevScene& sc, const float4* tris, const Hit& h, 
 // DirectLightingIntegrator's, MODE 2: the VolPathIntegrator's with its medium sampling): emitted radiance, the depth
 // test, the hit record.  Returns the queue the path goes to + 1 (its material kind, the boundary / resume queue, the
 // medium queue), 0 when the path has ended.
-template <int MODE, bool SPH, class Walker>
+template <int MODE, bool SPH, bool HAL, class Walker>
 DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevIntegrator& I, const DevSampler& S, const float4* tris, const Walker& w,
                            uint32_t p, uint32_t& state, const uint32_t* pendCount) {
     constexpr bool DL = MODE == 1, VOL = MODE == 2;
@@ -429,7 +476,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
         uint32_t px, py, slot;
         pathPixel(I, S, p, &px, &py, &slot);
         uint32_t dim = stDim(state);
-        float uc = sampleDimension(S, px, py, slot, dim), ud = sampleDimension(S, px, py, slot, dim + 1);
+        float uc = sampleDimension<HAL>(S, px, py, slot, dim), ud = sampleDimension<HAL>(S, px, py, slot, dim + 1);
         state = packState(stMedium(state), dim + 2, stBounces(state), stSpec(state)) | (state & kStNoDifferentials);
         reinterpret_cast<float*>(&P.rayD[p])[3] = __uint_as_float(state);
         int channel = min((int)(uc * 3), 3 - 1);
@@ -506,7 +553,7 @@ DEV uint32_t finishPathRay(const DevScene& sc, const DevPaths& P, const DevInteg
 // MODE 2: the head of VolPathIntegrator::Li (Enigma/VolPathIntegrator.cpp:63-111): a ray that travels in a medium
 // samples it first (HomogeneousMedium::Sample, Enigma/Medium.cpp:83-108); a sampled medium interaction goes to the
 // medium queue, otherwise the surface is handled as in the PathIntegrator, material-less surfaces in a queue of their own.
-template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false>
+template <int LDSN, int OVF, bool LDS_SCENE, int MODE, bool SPH = false, bool HAL = false>
 __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) k_intersect_closest(DevScene sc, DevPaths P, DevIntegrator I, DevSampler S, const uint32_t* queue,
                                                               const uint32_t* countPtr, uint32_t countImm, MatQueues mq, DevCounters* ctr, uint32_t kRefillIdle,
                                                               const uint32_t* pendCount, uint32_t queueMask) {
@@ -545,7 +592,7 @@ __global__ void __launch_bounds__(kBlock, LDS_SCENE ? ldsSceneBlocks(LDSN) : 6) 
             uint32_t nIdle = __popcll(idleMask);
             if (nIdle == 64u || (!exhausted && nIdle >= kRefillIdle)) {
                 if (idle && pos != kNoRay) { // the head of the Li loop for a finished ray (Enigma/PathIntegrator.cpp:62-87)
-                    const uint32_t kind = finishPathRay<MODE, SPH>(sc, P, I, S, tris, w, p, state, pendCount);
+                    const uint32_t kind = finishPathRay<MODE, SPH, HAL>(sc, P, I, S, tris, w, p, state, pendCount);
                     // VolPathIntegrator: a ray that has reached a surface without a material -- a medium boundary -- and was not
                     // stopped by the medium before goes on from the far side, in the medium there, without a bounce counted or a
                     // sample drawn (Enigma/VolPathIntegrator.cpp:105-111).  The lane does that here and keeps its ray instead of
@@ -942,7 +989,7 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
 // (96 / 128 registers, a hundred spilled) is 15 % slower.
 // (re-measured with device code at -O1, where nothing is spilled at four / three waves: five / four 9-16 % slower, three /
 // three 3 % slower, four / four and four / two the same within 1 %)
-template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false>
+template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false, bool HAL = false>
 __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUGH || MK == MK_GLASS_SMOOTH) ? 4 : 3) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
@@ -998,11 +1045,11 @@ __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUG
                 const float* pickCdf = lightCdf;
                 float pickInt = sc.lightFuncInt;
                 if (!LDS_SCENE && sc.spatialTable) { pickFunc = spatialLookup(sc, g.p); pickCdf = pickFunc + sc.nLights; pickInt = pickFunc[2 * sc.nLights + 1]; }
-                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
+                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension<HAL>(S, px, py, slot, dim), &pick);
                 dim += 1;
                 if (pick != 0) {
-                    float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
-                    float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
+                    float ulx = sampleDimension<HAL>(S, px, py, slot, dim), uly = sampleDimension<HAL>(S, px, py, slot, dim + 1);
+                    float usx = sampleDimension<HAL>(S, px, py, slot, dim + 2), usy = sampleDimension<HAL>(S, px, py, slot, dim + 3);
                     dim += 4;
                     DirectSample ds = estimateDirect<MK, SPH>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     if (ds.shadow) {
@@ -1027,7 +1074,7 @@ __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUG
             // ---- BSDF sampling for the next path vertex (Enigma/PathIntegrator.cpp:114-175) ----
             F3 wo = -d, wi(0.f);
             float pdf; int flags;
-            float u0 = sampleDimension(S, px, py, slot, dim), u1 = sampleDimension(S, px, py, slot, dim + 1);
+            float u0 = sampleDimension<HAL>(S, px, py, slot, dim), u1 = sampleDimension<HAL>(S, px, py, slot, dim + 1);
             dim += 2;
             F3 f = bsdfSample<MK>(bsdf, wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
             if (!(isBlack(f) || pdf == 0.f)) {
@@ -1042,7 +1089,7 @@ __global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUG
                 F3 rrBeta = beta * etaScale;
                 if (maxComponentValue(rrBeta) < I.rrThreshold && bounces > 3) {
                     float q = smax(.05f, 1.0f - maxComponentValue(rrBeta));
-                    float ur = sampleDimension(S, px, py, slot, dim);
+                    float ur = sampleDimension<HAL>(S, px, py, slot, dim);
                     dim += 1;
                     if (ur < q) alive = false;
                     else beta = beta / (1 - q);
@@ -1121,7 +1168,7 @@ DEV bool resumePending(const DevPaths& P, const DevDirect& D, const DevIntegrato
 // of one material kind: direct lighting from all lights (sample arrays) or one uniformly chosen light,
 // then SpecularReflect / SpecularTransmit.  Smooth glass carries two specular lobes here (allowMultipleLobes
 // is false on this path).  A path's shadow / MIS rays go to its raysPerPath ray slots, packed from slot 0.
-template <int MK, bool LDS_SCENE, bool SPH = false>
+template <int MK, bool LDS_SCENE, bool SPH = false, bool HAL = false>
 __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevDirect D, DevRayQueue shq,
                                                          DevRayQueue misq, const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx,
                                                          DevCounters* ctr) {
@@ -1177,8 +1224,8 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                         const uint32_t dimL = 5u + 2u * (a + 2u * (uint32_t)l), dimS = dimL + 2u; // uLightArray, uScatteringArray
                         for (uint32_t k = 0; k < n; ++k) {
                             unsigned long long sn = sampleNum * n + k; // entry of the array that belongs to this sample
-                            float ulx = sampleDimensionOf(S, px, py, sn, dimL), uly = sampleDimensionOf(S, px, py, sn, dimL + 1);
-                            float usx = sampleDimensionOf(S, px, py, sn, dimS), usy = sampleDimensionOf(S, px, py, sn, dimS + 1);
+                            float ulx = sampleDimensionOf<HAL>(S, px, py, sn, dimL), uly = sampleDimensionOf<HAL>(S, px, py, sn, dimL + 1);
+                            float usx = sampleDimensionOf<HAL>(S, px, py, sn, dimS), usy = sampleDimensionOf<HAL>(S, px, py, sn, dimS + 1);
                             DirectSample ds = estimateDirect<MKD, SPH>(sc, bsdf, g, woN, ns, lt, tris, ulx, uly, usx, usy);
                             emit(ds, (float)n, l);
                         }
@@ -1186,10 +1233,10 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                     D.arrayOff[p] = a + 2u * (uint32_t)sc.nLights;
                 } else { // UniformSampleOneLight without a distribution, Enigma/Integrator.cpp:83-91
                     int nl = sc.nLights;
-                    int lightNum = min((int)(sampleDimension(S, px, py, slot, dim) * nl), nl - 1);
+                    int lightNum = min((int)(sampleDimension<HAL>(S, px, py, slot, dim) * nl), nl - 1);
                     float lightPdf = 1.0f / nl;
-                    float ulx = sampleDimension(S, px, py, slot, dim + 1), uly = sampleDimension(S, px, py, slot, dim + 2);
-                    float usx = sampleDimension(S, px, py, slot, dim + 3), usy = sampleDimension(S, px, py, slot, dim + 4);
+                    float ulx = sampleDimension<HAL>(S, px, py, slot, dim + 1), uly = sampleDimension<HAL>(S, px, py, slot, dim + 2);
+                    float usx = sampleDimension<HAL>(S, px, py, slot, dim + 3), usy = sampleDimension<HAL>(S, px, py, slot, dim + 4);
                     dim += 5;
                     DirectSample ds = estimateDirect<MKD, SPH>(sc, bsdf, g, woN, ns, lights[lightNum], tris, ulx, uly, usx, usy);
                     emit(ds, lightPdf, lightNum);
@@ -1206,8 +1253,8 @@ __global__ void __launch_bounds__(kBlock) k_shade_direct(DevScene sc, DevPaths P
                 // subtree; materials for which that matters are refused by the host under this integrator.
                 float uR0 = 0.5f, uR1 = 0.5f, uT0 = 0.5f, uT1 = 0.5f;
                 if (MKD == MK_GENERAL) {
-                    uR0 = sampleDimension(S, px, py, slot, dim); uR1 = sampleDimension(S, px, py, slot, dim + 1);
-                    uT0 = sampleDimension(S, px, py, slot, dim + 2); uT1 = sampleDimension(S, px, py, slot, dim + 3);
+                    uR0 = sampleDimension<HAL>(S, px, py, slot, dim); uR1 = sampleDimension<HAL>(S, px, py, slot, dim + 1);
+                    uT0 = sampleDimension<HAL>(S, px, py, slot, dim + 2); uT1 = sampleDimension<HAL>(S, px, py, slot, dim + 3);
                 }
                 dim += 2;
                 F3 fR = bsdfSample<MKD>(bsdf, woN, &wiR, uR0, uR1, &pdfR, BSDF_REFLECTION | BSDF_SPECULAR, &tyR);
@@ -1538,21 +1585,23 @@ __global__ void k_stage(DevCounters* ctr, int phase, uint32_t curIdx, uint32_t c
 }
 
 // ---------------------------------------------------------------- debug taps
+template <bool HAL>
 __global__ void k_debug_sobol(DevSampler S, uint32_t n, const int32_t* pixels, const uint32_t* slots, uint32_t nDims, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (uint32_t d = 0; d < nDims; ++d) out[(size_t)i * nDims + d] = sampleDimension(S, (uint32_t)(pixels[2 * i] - S.sbx0), (uint32_t)(pixels[2 * i + 1] - S.sby0), slots[i], d);
+    for (uint32_t d = 0; d < nDims; ++d) out[(size_t)i * nDims + d] = sampleDimension<HAL>(S, (uint32_t)(pixels[2 * i] - S.sbx0), (uint32_t)(pixels[2 * i + 1] - S.sby0), slots[i], d);
 }
+template <bool HAL>
 __global__ void k_debug_camera(DevSampler S, DevCamera C, uint32_t n, const int32_t* pixels, const uint32_t* slots, float* outRay, float* outPfilm) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int px = pixels[2 * i], py = pixels[2 * i + 1];
     uint32_t relx = (uint32_t)(px - S.sbx0), rely = (uint32_t)(py - S.sby0);
     uint32_t slot = slots[i];
-    float fx = (float)px + sampleDimension(S, relx, rely, slot, 0);
-    float fy = (float)py + sampleDimension(S, relx, rely, slot, 1);
+    float fx = (float)px + sampleDimension<HAL>(S, relx, rely, slot, 0);
+    float fy = (float)py + sampleDimension<HAL>(S, relx, rely, slot, 1);
     float lu = 0.f, lv = 0.f;
-    if (C.lensRadius > 0.f) { lu = sampleDimension(S, relx, rely, slot, 3); lv = sampleDimension(S, relx, rely, slot, 4); }
+    if (C.lensRadius > 0.f) { lu = sampleDimension<HAL>(S, relx, rely, slot, 3); lv = sampleDimension<HAL>(S, relx, rely, slot, 4); }
     F3 o, d;
     cameraRay(C, fx, fy, lu, lv, &o, &d);
     float* r = outRay + 6 * (size_t)i;

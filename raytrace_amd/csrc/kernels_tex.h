@@ -55,6 +55,7 @@ DEV bool solve2x2(float a00, float a01, float a10, float a11, float b0, float b1
 }
 DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 
+template <bool HAL>
 __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevCamera C, float diffScale,
                                                     const uint32_t* matQueue, int kind, DevCounters* ctr) {
     const uint32_t count = ctr->matCount[kind].v;
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) k_texture(DevScene sc, DevPaths P, Dev
                 uint32_t px, py, slot;
                 pathPixel(I, S, p, &px, &py, &slot);
                 float lx, ly;
-                concentricSampleDisk(sampleDimension(S, px, py, slot, 3), sampleDimension(S, px, py, slot, 4), &lx, &ly);
+                concentricSampleDisk(sampleDimension<HAL>(S, px, py, slot, 3), sampleDimension<HAL>(S, px, py, slot, 4), &lx, &ly);
                 lx *= C.lensRadius; ly *= C.lensRadius;
                 const F3 lens(lx, ly, 0.f);
                 F3 dx = normalize(Pcamera + dxCamera);

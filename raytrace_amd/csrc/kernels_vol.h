@@ -42,7 +42,7 @@ DEV F3 mediumTr(const DevMedium& m, F3 d, float tMax) {
 
 // The medium branch for the paths of the medium-interaction queue.  A medium interaction has no normal and no
 // error bounds: rays start at the point itself and stay in the interaction's medium.
-template <bool LDS_SCENE, bool SPH = false>
+template <bool LDS_SCENE, bool SPH = false, bool HAL = false>
 __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                          const uint32_t* queue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
@@ -80,11 +80,11 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
                 if (!LDS_SCENE && sc.spatialTable) { // lightDistrib->Lookup(mi.m_p), Enigma/VolPathIntegrator.cpp:76 (global-memory build only)
                     pickFunc = spatialLookup(sc, pm); pickCdf = pickFunc + sc.nLights; pickInt = pickFunc[2 * sc.nLights + 1];
                 }
-                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension(S, px, py, slot, dim), &pick);
+                int lightNum = sampleDiscrete(pickCdf, pickFunc, pickInt, sc.nLights, sampleDimension<HAL>(S, px, py, slot, dim), &pick);
                 dim += 1;
                 if (pick != 0) {
-                    float ulx = sampleDimension(S, px, py, slot, dim), uly = sampleDimension(S, px, py, slot, dim + 1);
-                    float usx = sampleDimension(S, px, py, slot, dim + 2), usy = sampleDimension(S, px, py, slot, dim + 3);
+                    float ulx = sampleDimension<HAL>(S, px, py, slot, dim), uly = sampleDimension<HAL>(S, px, py, slot, dim + 1);
+                    float usx = sampleDimension<HAL>(S, px, py, slot, dim + 2), usy = sampleDimension<HAL>(S, px, py, slot, dim + 3);
                     dim += 4;
                     const DevLight& lt = lights[lightNum];
                     LightSample ls = sampleLight<SPH>(sc, lt, tris, pm, ulx, uly);
@@ -121,14 +121,14 @@ __global__ void __launch_bounds__(kBlock) k_shade_medium(DevScene sc, DevPaths P
             }
             // ---- next direction (Enigma/VolPathIntegrator.cpp:83-86) and Russian roulette (:165-173) ----
             F3 wi(0.f);
-            float u0 = sampleDimension(S, px, py, slot, dim), u1 = sampleDimension(S, px, py, slot, dim + 1);
+            float u0 = sampleDimension<HAL>(S, px, py, slot, dim), u1 = sampleDimension<HAL>(S, px, py, slot, dim + 1);
             dim += 2;
             hgSample(g, wo, &wi, u0, u1);
             bool alive = true;
             F3 rrBeta = beta * etaScale;
             if (maxComponentValue(rrBeta) < I.rrThreshold && bounces > 3) {
                 float q = smax(.05f, 1 - maxComponentValue(rrBeta));
-                float ur = sampleDimension(S, px, py, slot, dim);
+                float ur = sampleDimension<HAL>(S, px, py, slot, dim);
                 dim += 1;
                 if (ur < q) alive = false;
                 else beta = beta / (1 - q);

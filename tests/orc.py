@@ -46,6 +46,16 @@ def lib(fast=False):
     return _libs[name]
 
 
+def halton_tables(n_words=10000, n_perm=100000):
+    """(first words of the engine behind the oracle's RNG, head of its digit-permutation table, primes, prime sums, table length)"""
+    words, perm = np.zeros(n_words, dtype=np.uint32), np.zeros(n_perm, dtype=np.uint16)
+    primes, sums = np.zeros(1000, dtype=np.int32), np.zeros(1000, dtype=np.int32)
+    L = lib()
+    L.oracle_debug_halton_tables.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    total = L.oracle_debug_halton_tables(n_words, abi.ptr(words), n_perm, abi.ptr(perm), abi.ptr(primes), abi.ptr(sums))
+    return words, perm, primes, sums, total
+
+
 def rgb_from_sampled(lam, v):
     """RGBSpectrum::FromSampled of the restatement."""
     lam = np.ascontiguousarray(lam, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
@@ -67,7 +77,7 @@ def spectral_tables():
 
 
 class Oracle:
-    def __init__(self, scene, camera, film, integ, fast=False, split_method="hlbvh", max_node_prims=128):
+    def __init__(self, scene, camera, film, integ, fast=False, split_method="hlbvh", max_node_prims=128, sampler="sobol", sample_at_pixel_center=False):
         self.L = lib(fast)
         self.h = C.c_void_p()
         self.L.oracle_create(C.byref(self.h))
@@ -76,6 +86,7 @@ class Oracle:
         self._chk(self.L.oracle_scene_upload(self.h, C.byref(d), 1 if split_method == "hlbvh" else 0, max_node_prims))
         self._chk(self.L.oracle_camera_set(self.h, C.byref(camera)))
         self._chk(self.L.oracle_film_config(self.h, C.byref(film)))
+        self._chk(self.L.oracle_sampler_select(self.h, {"sobol": 0, "halton": 1}[sampler], 1 if sample_at_pixel_center else 0))
         self.set_integrator(integ)
         b = film.cropped_pixel_bounds
         self.w, self.hgt = b[2] - b[0], b[3] - b[1]

@@ -308,6 +308,14 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
             spp = int(orr.choice([1, 2, 8, 16]))
             cuts = sorted(set(int(c) for c in orr.randint(0, spp + 1, size=2)))
             splits = [0] + cuts + [spp]
+    # ---- a seventh stream, for seeds from 1,700,000 on (the seeds recorded before keep their scenes): the HaltonSampler in
+    # place of the Sobol' one, with sample counts that are no powers of two, now and then all samples at the pixel centres
+    hr = np.random.RandomState((seed * 134775813 + 0x4A17) & 0x7fffffff)
+    sampler, center = "sobol", False
+    if seed >= 1700000 and hr.rand() < 0.35:
+        sampler, center = "halton", bool(hr.rand() < 0.15)
+        if splits is None and hr.rand() < 0.5:
+            spp = int(hr.choice([1, 3, 5, 6, 7, 12]))
     film = scenes.film_desc(xres, yres, fk, crop=crop, **film_kw)
     depth = int(rng.randint(1, 9))
     strategy = [abi.LIGHTS_UNIFORM, abi.LIGHTS_POWER, abi.LIGHTS_SPATIAL][rng.randint(3)]
@@ -322,9 +330,9 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
     if details is not None:
         details.update(spp=spp, splits=splits, eye=tuple(float(v) for v in eye), look=tuple(float(v) for v in look), up=tuple(float(v) for v in up), fov=fov, xres=int(xres), yres=int(yres),
                        lens=lens, focal=float(cam.focal_distance), filter=str(fk), crop=crop, integ_kind=str(integ_kind), depth=depth, rr=rr, strategy=strategy,
-                       environment=environment, ply=ply)
-    label = "%s%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
-        integ_kind, " environment-camera" if environment else "", depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), (" crop" if crop != (0.0, 1.0, 0.0, 1.0) else "") + (" options %s%s%s" % (sorted(film_kw), pixel_bounds or "", splits or "") if (film_kw or pixel_bounds or splits) else ""))
+                       environment=environment, ply=ply, sampler=sampler, center=center)
+    label = "%s%s%s depth %d rr %g strategy %d filter %s tris %d spheres %d lights %d media %d textures %d%s" % (
+        integ_kind, " environment-camera" if environment else "", (" halton%s spp %d" % ("-centre" if center else "", spp)) if sampler == "halton" else "", depth, rr, strategy, fk, sc.indices.shape[0], len(b.spheres), len(b.lights), len(b.media), len(b.textures), (" crop" if crop != (0.0, 1.0, 0.0, 1.0) else "") + (" options %s%s%s" % (sorted(film_kw), pixel_bounds or "", splits or "") if (film_kw or pixel_bounds or splits) else ""))
     return sc, cam, film, integ, label
 
 
@@ -383,7 +391,7 @@ def last_bit_spread(seed, res, spp, base_stats, base_img):
     worst = {"counts_apart": 0.0, "mre": 0.0, "median_rel": 0.0}
     code = ("import sys, numpy as np\nsys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport orc, fuzz_scenes\n"
             "d = {}\nsc, cam, film, integ, label = fuzz_scenes.random_case(%d, %d, %d, details=d)\n"
-            "o = orc.Oracle(sc, cam, film, integ); o.render(0, d['spp'], threads=8)\n"
+            "o = orc.Oracle(sc, cam, film, integ, sampler=d['sampler'], sample_at_pixel_center=d['center']); o.render(0, d['spp'], threads=8)\n"
             "np.save(sys.argv[1], o.image()); s = o.stats(); print(s['rays_closest'], s['rays_shadow'], s['rays_mis'])\n") % (
                 ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools"), seed, res, spp)
     with tempfile.TemporaryDirectory() as tmp:
@@ -423,18 +431,18 @@ def compare(seed, res=24, spp=4, shared=None):
                 if shared[0] is None:
                     shared[0] = ra.Renderer(0)
                 r = shared[0]
-                r.configure(sc, cam, film, integ)
+                r.configure(sc, cam, film, integ, sampler=d["sampler"], sample_at_pixel_center=d["center"])
                 r.clear()
                 before = r.stats()
             else:
-                r = ra.Renderer(0).configure(sc, cam, film, integ)
+                r = ra.Renderer(0).configure(sc, cam, film, integ, sampler=d["sampler"], sample_at_pixel_center=d["center"])
             cuts = d["splits"] or [0, spp]
             for a_, b_ in zip(cuts[:-1], cuts[1:]):   # the library in several calls, the oracle in one
                 r.render(a_, b_)
         except ra.EnigmaError as e:
             gerr = str(e)
         try:
-            o = orc.Oracle(sc, cam, film, integ)
+            o = orc.Oracle(sc, cam, film, integ, sampler=d["sampler"], sample_at_pixel_center=d["center"])
             o.render(0, spp, threads=8)
         except Exception as e:  # the oracle wrapper raises RuntimeError with its message
             oerr = str(e)
@@ -702,16 +710,22 @@ def compare_taps(seed):
         look = eye + (0, 0, 1)
     cam = scenes.camera_desc(tuple(eye), tuple(look), (0.1, 1.0, 0.05), float(rng.uniform(10, 140)), xres, yres)
     sc = scenes.cornell_box("diffuse")
-    out = {"seed": seed, "label": "%dx%d crop %s filter %s %s spp %d" % (xres, yres, crop, fk, kw.get("radius"), spp)}
+    # seeds from 1,700,000 on: the HaltonSampler for half of the films, with any sample count up to 2^16 (drawn last: the films of the seeds before stay)
+    sampler, center = "sobol", False
+    if seed >= 1700000 and rng.rand() < 0.5:
+        sampler, center = "halton", bool(rng.rand() < 0.1)
+        spp = int(rng.randint(1, 65537))
+        integ = scenes.integrator_desc(film, spp, max_depth=int(integ.max_depth))
+    out = {"seed": seed, "label": "%dx%d crop %s filter %s %s spp %d%s" % (xres, yres, crop, fk, kw.get("radius"), spp, " halton" + ("-centre" if center else "") if sampler == "halton" else "")}
     r = o = None
     try:
         gerr = oerr = None
         try:
-            r = ra.Renderer(0).configure(sc, cam, film, integ)
+            r = ra.Renderer(0).configure(sc, cam, film, integ, sampler=sampler, sample_at_pixel_center=center)
         except ra.EnigmaError as e:
             gerr = str(e)
         try:
-            o = orc.Oracle(sc, cam, film, integ)
+            o = orc.Oracle(sc, cam, film, integ, sampler=sampler, sample_at_pixel_center=center)
             sb = scenes.sample_bounds(film)
             if sb[0] < sb[1]:
                 oerr = "sample bounds with min.x < min.y: reference result undefined"
