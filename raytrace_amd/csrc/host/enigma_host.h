@@ -228,7 +228,18 @@ public:
     const BBox2i m_sampleBounds;
     int m_resolution, m_log2Resolution;
 };
+// Enigma/Sampler.h:115-141, Enigma/Sampler.cpp:305-334.  The reference keeps m_sampleAtPixelCenter private and does not
+// keep the sample bounds at all: inside Enigma the binding notes the flag where the sampler is created
+// (CreateHaltonSampler, Enigma/Sampler.cpp:521-528) and takes the bounds from the film, as that factory does.
+class HaltonSampler : public Sampler {
+public:
+    HaltonSampler(int nsamp, const BBox2i& sampleBounds, bool sampleAtCenter = false) : Sampler(nsamp), m_sampleBounds(sampleBounds), m_sampleAtPixelCenter(sampleAtCenter) {}
+    const BBox2i m_sampleBounds;
+    const bool m_sampleAtPixelCenter;
+};
 using SamplerPtr = std::shared_ptr<Sampler>;
+// what an integrator desc takes from either GlobalSampler
+struct SamplerFields { int64_t m_samplesPerPixel; BBox2i m_sampleBounds; };
 
 // ---- scene registry ----
 struct TriangleMesh { // Enigma/TriangleMesh.h:28-37: world-space m_p, m_vertexIndices, optional m_n (world space) and m_uv
@@ -445,8 +456,8 @@ public:
         fd.max_sample_luminance = film.GetMaxSampleLuminance();
         check(enigma_film_config(h, &fd));
 
-        const SobolSampler* sob = dynamic_cast<const SobolSampler*>(GetSampler().get());
-        if (!sob) throw std::runtime_error("the GPU integrators need a SobolSampler");
+        const SamplerFields samplerFields = SelectSampler(h);
+        const SamplerFields* sob = &samplerFields;
         check(ConfigureIntegrator(h, lights.size(), *sob));
 
         // one process per GPU: this rank's share of the sample numbers, then the films are summed onto rank 0
@@ -480,8 +491,21 @@ public:
         std::memcpy(m_commId, commId, ENIGMA_COMM_ID_BYTES);
     }
 protected:
-    virtual int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) = 0;
-    template <class DESC> void FillSamplerFields(DESC& id, const SobolSampler& sob) const {
+    // tells the library which GlobalSampler m_sampler is (Enigma/Api.cpp:425-434 made it by name)
+    SamplerFields SelectSampler(EnigmaCtx* h) const {
+        auto check = [&](int rc) { if (rc != ENIGMA_OK) throw std::runtime_error(std::string("enigma: ") + enigma_last_error(h)); };
+        if (const SobolSampler* sob = dynamic_cast<const SobolSampler*>(GetSampler().get())) {
+            check(enigma_sampler_select(h, ENIGMA_SAMPLER_SOBOL, 0));
+            return SamplerFields{sob->m_samplesPerPixel, sob->m_sampleBounds};
+        }
+        if (const HaltonSampler* hal = dynamic_cast<const HaltonSampler*>(GetSampler().get())) {
+            check(enigma_sampler_select(h, ENIGMA_SAMPLER_HALTON, hal->m_sampleAtPixelCenter ? 1u : 0u));
+            return SamplerFields{hal->m_samplesPerPixel, hal->m_sampleBounds};
+        }
+        throw std::runtime_error("the GPU integrators need a SobolSampler or a HaltonSampler");
+    }
+    virtual int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SamplerFields& sob) = 0;
+    template <class DESC> void FillSamplerFields(DESC& id, const SamplerFields& sob) const {
         const BBox2i& pb = GetPixelBounds();
         id.pixel_bounds[0] = pb.m_min.x; id.pixel_bounds[1] = pb.m_min.y; id.pixel_bounds[2] = pb.m_max.x; id.pixel_bounds[3] = pb.m_max.y;
         id.samples_per_pixel = sob.m_samplesPerPixel;
@@ -503,7 +527,7 @@ public:
         : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
           m_lightSampleStrategy(lightSampleStrategy) {}
 protected:
-    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) override {
+    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SamplerFields& sob) override {
         EnigmaIntegratorDesc id{};
         id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
         if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
@@ -526,7 +550,7 @@ public:
         : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_maxDepth(maxDepth), m_rrThreshold(rrThreshold),
           m_lightSampleStrategy(lightSampleStrategy) {}
 protected:
-    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SobolSampler& sob) override {
+    int ConfigureIntegrator(EnigmaCtx* h, size_t nLights, const SamplerFields& sob) override {
         EnigmaIntegratorDesc id{};
         id.max_depth = m_maxDepth; id.rr_threshold = m_rrThreshold;
         if (m_lightSampleStrategy == "uniform") id.light_strategy = ENIGMA_LIGHTS_UNIFORM;
@@ -549,7 +573,7 @@ public:
                                 const BBox2i& pixelBounds, int device = 0)
         : GpuSamplerIntegrator(camera, sampler, pixelBounds, device), m_strategy(strategy), m_maxDepth(maxDepth) {}
 protected:
-    int ConfigureIntegrator(EnigmaCtx* h, size_t, const SobolSampler& sob) override {
+    int ConfigureIntegrator(EnigmaCtx* h, size_t, const SamplerFields& sob) override {
         EnigmaDirectLightingDesc id{};
         id.max_depth = m_maxDepth;
         id.strategy = m_strategy == eLightStrategy::UniformSampleAll ? ENIGMA_DL_SAMPLE_ALL : ENIGMA_DL_SAMPLE_ONE;

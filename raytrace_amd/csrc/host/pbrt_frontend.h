@@ -643,8 +643,14 @@ public:
             R.camera.reset(new PerspectiveCamera(m_opt.CameraToWorld.ToFloat(), rasterToCamera.ToFloat(), cp.FindOneFloat("shutteropen", 0.f),
                                                  cp.FindOneFloat("shutterclose", 1.f), lensradius, focaldistance, std::move(film)));
         // sampler (Enigma/Sampler.cpp:554-559)
-        if (m_opt.SamplerName != "sobol") throw std::runtime_error("Sampler \"" + m_opt.SamplerName + "\" is not supported: the GPU integrators reproduce the sobol sampler");
-        R.sampler.reset(new SobolSampler(m_opt.SamplerParams.FindOneInt("pixelsamples", 16), filmPtr->GetSampleBounds()));
+        if (m_opt.SamplerName == "sobol") // CreateSobolSampler, Enigma/Sampler.cpp:554-559
+            R.sampler.reset(new SobolSampler(m_opt.SamplerParams.FindOneInt("pixelsamples", 16), filmPtr->GetSampleBounds()));
+        else if (m_opt.SamplerName == "halton") // CreateHaltonSampler, Enigma/Sampler.cpp:521-528; the name RenderOptions starts with (Enigma/Api.h:82)
+            R.sampler.reset(new HaltonSampler(m_opt.SamplerParams.FindOneInt("pixelsamples", 16), filmPtr->GetSampleBounds(),
+                                              m_opt.SamplerParams.FindOneBool("samplepixelcenter", false)));
+        else
+            throw std::runtime_error("Sampler \"" + m_opt.SamplerName + "\" is not supported: the GPU integrators reproduce the sobol and halton samplers "
+                                     "(the pixel samplers draw from a generator that runs on through the pixels of a tile)");
         // integrator (Enigma/PathIntegrator.cpp:182-201, Enigma/DirectLightingIntegrator.cpp:89-114)
         const ParamSet& ip = m_opt.IntegratorParams;
         R.integratorName = m_opt.IntegratorName;

@@ -43,8 +43,9 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     const bool environment = dynamic_cast<const EnvironmentCamera*>(R.camera.get()) != nullptr;
     static const ProjectiveCamera noProjection(Transform(), Transform(), 0.f, 1.f, 0.f, 1e30f, nullptr);
     const ProjectiveCamera& cam = environment ? noProjection : static_cast<const ProjectiveCamera&>(*R.camera);
-    const SobolSampler& sob = static_cast<const SobolSampler&>(*R.sampler);
-    const BBox2i &cb = film.m_croppedPixelBounds, &sb = sob.m_sampleBounds, &pb = R.pixelBounds;
+    const HaltonSampler* hal = dynamic_cast<const HaltonSampler*>(R.sampler.get());
+    const Sampler& sob = *R.sampler;
+    const BBox2i &cb = film.m_croppedPixelBounds, &sb = hal ? hal->m_sampleBounds : static_cast<const SobolSampler&>(*R.sampler).m_sampleBounds, &pb = R.pixelBounds;
     o << "{\"film\":{\"xres\":" << film.m_fullResolution.x << ",\"yres\":" << film.m_fullResolution.y << ",\"cropped\":[" << cb.m_min.x << "," << cb.m_min.y << ","
       << cb.m_max.x << "," << cb.m_max.y << "],\"filter\":\"" << R.filterName << "\",\"radius\":[" << film.m_filter->m_radius.x << "," << film.m_filter->m_radius.y
       << "],\"filename\":\"" << film.m_filename << "\",\"max_sample_luminance\":";
@@ -53,7 +54,8 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
     o << "},\n\"camera\":{\"type\":\"" << (environment ? "environment" : "perspective") << "\",\"c2w\":"; arr(&R.camera->m_cameraToWorld.m_mat[0][0], 16);
     o << ",\"r2c\":"; arr(&cam.m_rasterToCamera.m_mat[0][0], 16);
     o << ",\"lensradius\":"; arr(&cam.m_lensRadius, 1); o << ",\"focaldistance\":"; arr(&cam.m_focalDistance, 1);
-    o << "},\n\"sampler\":{\"spp\":" << sob.m_samplesPerPixel << ",\"sample_bounds\":[" << sb.m_min.x << "," << sb.m_min.y << "," << sb.m_max.x << "," << sb.m_max.y << "]},\n";
+    o << "},\n\"sampler\":{\"name\":\"" << (hal ? "halton" : "sobol") << "\",\"samplepixelcenter\":" << (hal && hal->m_sampleAtPixelCenter ? "true" : "false")
+      << ",\"spp\":" << sob.m_samplesPerPixel << ",\"sample_bounds\":[" << sb.m_min.x << "," << sb.m_min.y << "," << sb.m_max.x << "," << sb.m_max.y << "]},\n";
     o << "\"integrator\":{\"name\":\"" << R.integratorName << "\",\"maxdepth\":" << R.maxDepth << ",\"rrthreshold\":" << R.rrThreshold << ",\"lightsamplestrategy\":\""
       << R.lightStrategy << "\",\"strategy\":" << R.directStrategy << ",\"pixel_bounds\":[" << pb.m_min.x << "," << pb.m_min.y << "," << pb.m_max.x << "," << pb.m_max.y << "]},\n";
     o << "\"materials\":[";

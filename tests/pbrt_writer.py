@@ -97,13 +97,15 @@ def material_text(i, m):
 
 
 def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
-               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens="", texture_dir=None, ply_dir=None, camera="perspective"):
-    """ply_dir: the meshes go into <ply_dir>/mesh<k>.ply (formats in turn) and the scene names them with Shape "plymesh"."""
+               pixel_filter='PixelFilter "box"', film_extra="", world_prefix="", lens="", texture_dir=None, ply_dir=None, camera="perspective",
+               sampler='Sampler "sobol"'):
+    """sampler: the directive without its sample count; None leaves the line out (the reference then makes a halton sampler of 16 samples).
+    ply_dir: the meshes go into <ply_dir>/mesh<k>.ply (formats in turn) and the scene names them with Shape "plymesh"."""
     out = ["# written by tests/pbrt_writer.py",
            "LookAt %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g" % (tuple(eye) + tuple(look) + tuple(up)),
            'Camera "perspective" "float fov" %.9g %s' % (fov, lens) if camera == "perspective" else 'Camera "%s"' % camera,
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d] %s' % (xres, yres, film_extra),
-           'Sampler "sobol" "integer pixelsamples" %d' % spp, pixel_filter, integrator, "WorldBegin"]
+           ('%s "integer pixelsamples" %d' % (sampler, spp)) if sampler else "# no Sampler directive", pixel_filter, integrator, "WorldBegin"]
     if world_prefix:
         out.append(world_prefix)
     for i in range(getattr(sc, "n_textures", 0)):

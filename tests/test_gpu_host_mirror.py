@@ -204,3 +204,28 @@ def test_scene_description_with_the_environment_camera(tmp_path):
     o.render(0, 8, threads=4)
     assert common.mean_relative_error(_read_pfm(out_file), o.image()) < 1e-3
     o.close()
+
+
+@pytest.mark.parametrize("line,spp,center", [('Sampler "halton"', 6, False), ('Sampler "halton" "bool samplepixelcenter" "true"', 5, True), (None, 16, False)])
+def test_scene_description_with_the_halton_sampler(tmp_path, line, spp, center):
+    """Sampler "halton" (CreateHaltonSampler, Enigma/Sampler.cpp:521-528), and no Sampler directive at all, which is the same
+    sampler with 16 samples (Enigma/Api.h:82): the scene file through enigma_render against the oracle's HaltonSampler."""
+    import math
+    import pbrt_writer
+    sc = scenes.cornell_box("microfacet")
+    fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
+    text = pbrt_writer.scene_text(sc, (278, 273, -800), (278, 273, 0), (0, 1, 0), fov, 60, 44, spp, sampler=line)
+    assert ('\nSampler "' in text) == (line is not None)
+    scene_file, out_file = str(tmp_path / "h.pbrt"), str(tmp_path / "h.pfm")
+    with open(scene_file, "w") as f:
+        f.write(text)
+    p = subprocess.run([EXE, scene_file, out_file], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    cam, film = scenes.cornell_camera(60, 44), scenes.film_desc(60, 44)
+    o = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, spp), sampler="halton", sample_at_pixel_center=center)
+    o.render(0, spp, threads=4)
+    assert common.mean_relative_error(_read_pfm(out_file), o.image()) < 1e-3
+    o2 = orc.Oracle(sc, cam, film, scenes.integrator_desc(film, spp))            # not what the Sobol' sampler renders
+    o2.render(0, spp, threads=4)
+    assert common.mean_relative_error(_read_pfm(out_file), o2.image()) > 0.02
+    o.close(); o2.close()

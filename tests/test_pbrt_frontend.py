@@ -161,7 +161,7 @@ WorldEnd
     film = scenes.film_desc(1280, 720, "gaussian", (1.5, 1.5), crop=(0.25, 0.75, 0.25, 0.5))
     assert np.allclose(d["film"]["filter_table"], list(film.filter_table), rtol=1e-6, atol=1e-9)
     sb = scenes.sample_bounds(film)
-    assert d["sampler"] == {"spp": 16, "sample_bounds": sb}
+    assert d["sampler"] == {"name": "sobol", "samplepixelcenter": False, "spp": 16, "sample_bounds": sb}
     assert d["integrator"]["pixel_bounds"] == [max(sb[0], 330), max(sb[1], 185), min(sb[2], 600), min(sb[3], 300)]
     assert d["integrator"]["lightsamplestrategy"] == "uniform" and d["integrator"]["rrthreshold"] == 0.5
     m = d["materials"][0]
@@ -185,7 +185,8 @@ WorldEnd
     ('WorldBegin\nMaterial "subsurface"\nWorldEnd\n', "subsurface"),
     ('WorldBegin\nMakeNamedMaterial "a" "string type" "none"\nMaterial "mix" "string namedmaterial1" "a" "string namedmaterial2" "a"\nWorldEnd\n', "two materials"),
     ('WorldBegin\nShape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0] "vector S" [0 0 1 0 0 1 0 0 1]\nWorldEnd\n', "tangents"),
-    ('Sampler "halton"\nWorldBegin\nWorldEnd\n', "sobol"),
+    ('Sampler "stratified"\nWorldBegin\nWorldEnd\n', "sobol and halton"),
+    ('Sampler "random"\nWorldBegin\nWorldEnd\n', "generator that runs on"),
     ('Integrator "bdpt"\nSampler "sobol"\nWorldBegin\nWorldEnd\n', "bdpt"),
     ('WorldBegin\nCamera "perspective"\nWorldEnd\n', "world block"),
     ('Shape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]\n', "world block"),
@@ -640,3 +641,16 @@ WorldEnd
     table = np.array(d["film"]["filter_table"])
     assert np.allclose(table, list(film.filter_table), rtol=1e-4, atol=1e-6)
     assert table.min() < 0 < table.max()
+
+
+def test_samplers(tmp_path):
+    """MakeSampler's two GlobalSamplers (Enigma/Api.cpp:425-434): halton when the file names none (Enigma/Api.h:82), 16 samples
+    by default for both, the Halton sampler's count kept as given and the Sobol' one's rounded up, "samplepixelcenter"."""
+    d = dump(tmp_path, 'WorldBegin\nWorldEnd\n')["sampler"]
+    assert (d["name"], d["spp"], d["samplepixelcenter"]) == ("halton", 16, False)
+    d = dump(tmp_path, 'Sampler "halton" "integer pixelsamples" 5 "bool samplepixelcenter" "true"\nWorldBegin\nWorldEnd\n')["sampler"]
+    assert (d["name"], d["spp"], d["samplepixelcenter"]) == ("halton", 5, True)
+    d = dump(tmp_path, 'Sampler "sobol" "integer pixelsamples" 5\nWorldBegin\nWorldEnd\n')["sampler"]
+    assert (d["name"], d["spp"], d["samplepixelcenter"]) == ("sobol", 8, False)
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nWorldEnd\n')["sampler"]
+    assert (d["name"], d["spp"]) == ("sobol", 16)

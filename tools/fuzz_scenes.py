@@ -788,6 +788,7 @@ def compare_file(seed, directory, res=24, spp=4):
     import pbrt_writer
     d = {}
     sc, cam, film, integ, label = random_case(seed, res, spp, for_file=True, details=d)
+    spp = d["spp"]   # the sampler stream may have drawn another count
     out = {"seed": seed, "label": label}
     strategy = {abi.LIGHTS_UNIFORM: "uniform", abi.LIGHTS_POWER: "power", abi.LIGHTS_SPATIAL: "spatial"}[d["strategy"]]
     if d["integ_kind"] == "path":
@@ -801,7 +802,8 @@ def compare_file(seed, directory, res=24, spp=4):
     lens = '"float lensradius" %.9g "float focaldistance" %.9g' % (d["lens"], d["focal"]) if d["lens"] else ""
     text = pbrt_writer.scene_text(sc, d["eye"], d["look"], d["up"], d["fov"], d["xres"], d["yres"], spp, integrator=itext,
                                   pixel_filter='PixelFilter "%s"' % d["filter"], film_extra=film_extra, lens=lens, texture_dir=directory,
-                                  ply_dir=directory if d["ply"] else None, camera="environment" if d["environment"] else "perspective")
+                                  ply_dir=directory if d["ply"] else None, camera="environment" if d["environment"] else "perspective",
+                                  sampler='Sampler "sobol"' if d["sampler"] == "sobol" else 'Sampler "halton"' + (' "bool samplepixelcenter" "true"' if d["center"] else ""))
     scene_file, out_file = os.path.join(directory, "s%d.pbrt" % seed), os.path.join(directory, "s%d.pfm" % seed)
     with open(scene_file, "w") as f:
         f.write(text)
@@ -812,7 +814,7 @@ def compare_file(seed, directory, res=24, spp=4):
         return out
     o = oerr = None
     try:
-        o = orc.Oracle(sc, cam, film, integ)
+        o = orc.Oracle(sc, cam, film, integ, sampler=d["sampler"], sample_at_pixel_center=d["center"])
         o.render(0, spp, threads=8)
     except Exception as e:
         oerr = str(e)
