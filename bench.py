@@ -52,6 +52,8 @@ def parse_args():
                     help="path = PathIntegrator (the headline); direct-* = DirectLightingIntegrator with strategy all / one; volpath = VolPathIntegrator")
     ap.add_argument("--light-strategy", default="power", choices=["uniform", "power", "spatial"],
                     help="lightsamplestrategy of the path / volpath integrators (the headline configuration names power)")
+    ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"],
+                    help="the metric is quoted on the Sobol' sampler; halton is the reference's default sampler, for comparison")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=0, help="sample numbers per pixel the CPU baseline renders (0 = two per thread for Cornell scenes, one per eight threads for bigmesh: about 10 s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every CPU this process may run on)")
@@ -186,7 +188,9 @@ def run_workload(args, variant, steps, ctx):
         strat = abi.DL_SAMPLE_ALL if args.integrator == "direct-all" else abi.DL_SAMPLE_ONE
         integ = scenes.direct_lighting_desc(film, total_spp, max_depth=5, strategy=strat)
         integ_label = "DirectLightingIntegrator maxdepth 5 strategy %s, Sobol, box filter" % ("all" if strat == abi.DL_SAMPLE_ALL else "one")
-    r = ra.Renderer(ctx["local_rank"]).configure(scene, camera, film, integ)
+    if args.sampler == "halton":
+        integ_label = integ_label.replace("Sobol", "Halton")
+    r = ra.Renderer(ctx["local_rank"]).configure(scene, camera, film, integ, sampler=args.sampler)
     torch_reduce = None
     if world > 1:  # the library's own communicator: rank 0 makes the id, torch's process group only carries the 128 bytes
         ok = torch.ones(1, dtype=torch.int32, device=dev)
@@ -382,7 +386,7 @@ def run_workload(args, variant, steps, ctx):
         cores = args.cpu_threads or avail
         # about 10 s of wall time on the threads in use (measured: 0.33 s per Cornell spp and 6 s per BigMesh spp on 16 threads)
         cpu_spp = args.cpu_spp or (max(1, cores // 8) if variant == "bigmesh" else max(8, 2 * cores))
-        o = orc.Oracle(scene, camera, film, integ, fast=True)
+        o = orc.Oracle(scene, camera, film, integ, fast=True, sampler=args.sampler)
         o.render(0, cpu_spp, threads=cores)
         sc = o.stats()
         cpu_rays = sc["rays_closest"] + sc["rays_shadow"] + sc["rays_mis"]

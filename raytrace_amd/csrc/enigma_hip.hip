@@ -119,7 +119,7 @@ struct EnigmaCtx {
     int64_t spp = 0;
     uint32_t log2Res = 0, resolution = 0, nDims = 0;
     uint32_t samplerSelected = ENIGMA_SAMPLER_SOBOL, samplerKind = ENIGMA_SAMPLER_SOBOL; // chosen for the next configuration / of the configured integrator
-    bool centerSelected = false;
+    bool centerSelected = false, centerKind = false;                                       // "samplepixelcenter": chosen / configured
     enigma::HaltonTables haltonSampler;
     DevBuf<uint32_t> tx, ty, sampleConst;
     DevSampler sampler{};
@@ -1006,7 +1006,7 @@ static int uploadSampleSlots(EnigmaCtx* h, const int64_t* sampleNums, int64_t fi
 }
 
 // SobolSampler / HaltonSampler construction + the pixels the tile loop visits; shared by the integrators.
-static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32_t* sb, const int32_t* pixel_bounds, uint32_t nDims) {
+static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32_t* sb, const int32_t* pixel_bounds, uint32_t nDims, uint32_t kind, bool center) {
     if (samples_per_pixel <= 0 || samples_per_pixel > (1ll << 30)) return h->fail(ENIGMA_E_INVALID, "samples_per_pixel out of range");
     if (sb[2] <= sb[0] || sb[3] <= sb[1]) return h->fail(ENIGMA_E_INVALID, "empty sample bounds");
     const int64_t dx64 = (int64_t)sb[2] - sb[0], dy64 = (int64_t)sb[3] - sb[1];
@@ -1017,7 +1017,7 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
     // Arguments rejected above leave the configured integrator as it was.  From here on the sampler state is rewritten;
     // a failure below leaves it half rebuilt, so the handle has no integrator until the caller's configuration succeeds.
     h->haveInteg = false;
-    h->samplerKind = h->samplerSelected;
+    h->samplerKind = kind; h->centerKind = center;
     if (h->samplerKind == ENIGMA_SAMPLER_HALTON) {
         // HaltonSampler ctor, Enigma/Sampler.cpp:305-334: the sample count is kept as given
         // the VolPathIntegrator asks for every dimension its cursor can address (1023); the reference's prime table ends at
@@ -1025,7 +1025,7 @@ static int configureSampler(EnigmaCtx* h, int64_t samples_per_pixel, const int32
         if (nDims > 1023u) return h->fail(ENIGMA_E_INVALID, "dimension cursor overflow");
         h->spp = samples_per_pixel;
         h->resolution = 0; h->log2Res = 0;
-        enigma::build_halton_tables(sb, nDims, h->centerSelected, &h->haltonSampler);
+        enigma::build_halton_tables(sb, nDims, center, &h->haltonSampler);
         // the device takes the digits of an index off with 32-bit divisions
         if (((uint64_t)h->spp + 1ull) * h->haltonSampler.stride > (1ull << 32))
             return h->fail(ENIGMA_E_UNSUPPORTED, "%lld samples per pixel at a sample stride of %u exceed the 32-bit Halton index of this build", (long long)h->spp, h->haltonSampler.stride);
@@ -1082,7 +1082,7 @@ static int integratorConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
         return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
     // dimensions a path can consume: 5 (camera) + per bounce 1+2+2 (light) + 2 (BSDF) + 1 (roulette)
-    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u + 8u * (uint32_t)d->max_depth);
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u + 8u * (uint32_t)d->max_depth, h->samplerSelected, h->centerSelected);
     if (rc) return rc;
     h->integDesc = *d;
     h->integ.maxDepth = d->max_depth;
@@ -1103,7 +1103,7 @@ static int volpathConfigImpl(EnigmaCtx* h, const EnigmaIntegratorDesc* d) {
     if (d->max_depth < 0 || d->max_depth > 60) return h->fail(ENIGMA_E_INVALID, "max_depth out of range");
     if (d->light_strategy != ENIGMA_LIGHTS_UNIFORM && d->light_strategy != ENIGMA_LIGHTS_POWER && d->light_strategy != ENIGMA_LIGHTS_SPATIAL)
         return h->fail(ENIGMA_E_UNSUPPORTED, "light strategy %d is not supported (uniform, power and spatial are)", d->light_strategy);
-    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 1023u);
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 1023u, h->samplerSelected, h->centerSelected);
     if (rc) return rc;
     h->integDesc = *d;
     h->integ.maxDepth = d->max_depth;
@@ -1132,7 +1132,7 @@ static int directLightingConfigImpl(EnigmaCtx* h, const EnigmaDirectLightingDesc
     h->useVolPath = false;
     h->directDirty = true; // finished against the scene at render time (Preprocess needs the lights)
     // the sampler part does not depend on the scene: report its errors now
-    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u);
+    int rc = configureSampler(h, d->samples_per_pixel, d->sample_bounds, d->pixel_bounds, 5u, h->samplerSelected, h->centerSelected);
     h->haveInteg = rc == ENIGMA_OK;
     return rc;
 }
@@ -1170,15 +1170,17 @@ static int finishDirectLighting(EnigmaCtx* h) {
     // Li evaluations (nodes) per camera sample: 1 without specular lobes, a chain with one, a binary tree with two
     uint64_t nodes = !h->glassSpecular ? 1 : (!h->glassBranches ? (uint64_t)std::max(1, d.max_depth) : ((1ull << std::min(d.max_depth, 20)) - 1));
     uint64_t nDims = 5ull + 2ull * nArrays + nodes * (d.strategy == ENIGMA_DL_SAMPLE_ONE ? 9ull : 4ull);
-    const bool haltonNext = h->samplerSelected == ENIGMA_SAMPLER_HALTON;
+    const bool haltonNext = h->samplerKind == ENIGMA_SAMPLER_HALTON; // as configured (enigma_direct_lighting_config ran the sampler's part)
     if (nDims > (uint64_t)(haltonNext ? enigma::kHaltonDimensions : enigma::kNumSobolDimensions))
         return h->fail(ENIGMA_E_UNSUPPORTED, "DirectLightingIntegrator needs %llu sample dimensions here (%u sample arrays); the reference's %s sampler has %d",
                        (unsigned long long)nDims, nArrays, haltonNext ? "halton" : "sobol", haltonNext ? enigma::kHaltonDimensions : enigma::kNumSobolDimensions);
-    if (!haltonNext && (uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res)))
-        return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the Sobol' index width", maxN, (long long)h->spp);
-    int rc = configureSampler(h, d.samples_per_pixel, d.sample_bounds, d.pixel_bounds, (uint32_t)nDims);
+    int rc = configureSampler(h, d.samples_per_pixel, d.sample_bounds, d.pixel_bounds, (uint32_t)nDims, h->samplerKind, h->centerKind); // the sampler chosen when the integrator was configured
     if (rc) { h->haveInteg = false; return rc; } // the sampler tables are half rebuilt
     // entry k of a sample array of n entries is a sample of sample number (current sample number) * n + k (Enigma/Sampler.cpp:170-180)
+    if (h->samplerKind == ENIGMA_SAMPLER_SOBOL && (uint64_t)h->spp * maxN > (1ull << std::min(40, 52 - 2 * (int)h->log2Res))) {
+        h->haveInteg = false;
+        return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the Sobol' index width", maxN, (long long)h->spp);
+    }
     if (h->samplerKind == ENIGMA_SAMPLER_HALTON && ((uint64_t)h->spp * std::max(1u, maxN) + 1ull) * h->haltonSampler.stride > (1ull << 32)) {
         h->haveInteg = false;
         return h->fail(ENIGMA_E_UNSUPPORTED, "sample arrays of %u entries x %lld samples per pixel exceed the 32-bit Halton index of this build", maxN, (long long)h->spp);

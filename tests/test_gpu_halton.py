@@ -132,3 +132,36 @@ def test_halton_limits_and_unknown_kind():
     wsum = r.film()[..., 3]
     assert wsum.min() >= 10.0 and wsum.mean() < 10.1
     r.close()
+
+
+def test_sample_array_limits_of_both_samplers_on_a_fresh_handle():
+    """Entry k of a sample array of n entries is a sample of sample number s * n + k (Enigma/Sampler.cpp:170-180): strategy
+    "all" multiplies the largest sample number by the largest per-light sample count, and the first configuration of a handle
+    already sees that (the DirectLightingIntegrator's configuration is finished by the first render after it)."""
+    sc = scenes.cornell_box("diffuse")
+    sc.lights[0].n_samples = 2048
+    film = scenes.film_desc(16, 16)
+    r = ra.Renderer(0)
+    r.upload_scene(sc); r.set_camera(scenes.cornell_camera(16, 16)); r.set_film(film)
+
+    def configure_and_render(spp):
+        r.set_integrator(scenes.direct_lighting_desc(film, spp, strategy=abi.DL_SAMPLE_ALL))
+        r.render(0, 1)
+    with pytest.raises(ra.EnigmaError) as e:   # 2^30 x 2^11 sample numbers: past the 40 bits the Sobol' constants are tabulated for
+        configure_and_render(1 << 30)
+    assert e.value.code == -4 and "Sobol' index width" in str(e.value)
+    configure_and_render(1 << 20)
+    r.select_sampler("halton")
+    with pytest.raises(ra.EnigmaError) as e:   # (2^20 x 2^11 + 1) x 16 x 27 does not fit 32 bits
+        configure_and_render(1 << 20)
+    assert e.value.code == -4 and "Halton index" in str(e.value)
+    configure_and_render(4000)                 # 4000 x 2048 x 432 = 3.5e9 fits
+    r.set_integrator(scenes.direct_lighting_desc(film, 5000, strategy=abi.DL_SAMPLE_ALL))
+    r.select_sampler("sobol")                  # a selection after the configuration belongs to the next configuration
+    with pytest.raises(ra.EnigmaError) as e:
+        r.render(0, 1)
+    assert "Halton index" in str(e.value)
+    r.select_sampler("halton")
+    with pytest.raises(ra.EnigmaError):
+        configure_and_render(5000)
+    r.close()
