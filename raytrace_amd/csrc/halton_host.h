@@ -6,10 +6,12 @@
 //     through the rejection loop of RNG::randomUInt(b) (Enigma/RNG.cpp:30-38; Enigma/SamplerInclude.h:2639-2655);
 //   * the index offset of a pixel (GetIndexForSample, Enigma/Sampler.cpp:336-356) split into a term per column and a
 //     term per row, each reduced modulo the sample stride, so that the device adds two table entries;
-//   * per dimension the prime base and where its permutation starts.
+//   * per dimension the prime base, where its permutation starts, the two numbers that turn a division by the base into
+//     a multiplication, and the two float constants of the base that the radical inverse uses.
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -60,10 +62,17 @@ inline const std::vector<uint16_t>& halton_permutations(std::vector<uint32_t>* s
     return table;
 }
 
+// Per dimension the device holds: the prime, the word offset of its permutation, magic and shift of the division
+// (floor(n / d) = (t + ((n - t) >> 1)) >> shift with t = the high word of magic * n, for every 32-bit n: Granlund and
+// Montgomery's division by an invariant integer with l = ceil(log2 d), magic = floor(2^32 (2^l - d) / d) + 1, shift = l - 1),
+// 1 / base as the reference rounds it (SamplerInclude.h:51,68), and invBase * perm[0] / (1 - invBase) (:82).
+constexpr uint32_t kHaltonRecord = 6;
+inline uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
 struct HaltonTables {
     uint32_t scale[2] = {1, 1}, exponent[2] = {0, 0}, stride = 1, inverse[2] = {0, 0};
     std::vector<uint32_t> offX, offY; // per column / row of the sample bounds: its term of the index offset, modulo the stride
-    std::vector<uint32_t> words;      // device block: {stride, exponent[0], scale[1], sampleAtCenter}, {prime, permutation offset} per dimension, permutations
+    std::vector<uint32_t> words;      // device block: {stride, exponent[0], scale[1], sampleAtCenter}, kHaltonRecord words per dimension, permutations
 };
 
 // a^-1 modulo n for coprime a, n (multiplicativeInverse, Enigma/SamplerInclude.h:28-45), by the iterative Euclid
@@ -110,19 +119,28 @@ inline void build_halton_tables(const int32_t sb[4], uint32_t nDims, bool sample
     std::vector<uint32_t> starts;
     const std::vector<uint16_t>& perms = halton_permutations(&starts);
     const std::vector<uint32_t>& P = halton_primes();
-    T->words.assign(4 + 2 * (size_t)(nDims + 16u), 0u);
+    const uint32_t R = kHaltonRecord;
+    T->words.assign(4 + R * (size_t)(nDims + 16u), 0u);
     T->words[0] = T->stride; T->words[1] = T->exponent[0]; T->words[2] = T->scale[1]; T->words[3] = sampleAtCenter ? 1u : 0u;
     for (uint32_t d = 0; d < nDims + 16u; ++d) {
         const uint32_t use = std::min(d, dimsHeld - 1); // padding dimensions repeat the last real one; their values are never used
-        T->words[4 + 2 * (size_t)d] = P[use];
-        T->words[5 + 2 * (size_t)d] = 0; // filled below
+        const uint32_t base = P[use];
+        uint32_t l = 0;
+        while ((1ull << l) < base) ++l;
+        uint32_t* rec = &T->words[4 + R * (size_t)d];
+        rec[0] = base;
+        rec[2] = (uint32_t)(((1ull << 32) * ((1ull << l) - base)) / base + 1);
+        rec[3] = l - 1;
+        const float invBase = (float)1 / (float)base;
+        rec[4] = float_bits(invBase);
+        rec[5] = float_bits(invBase * (float)perms[starts[use]] / (1 - invBase));
     }
     for (uint32_t d = 0; d < dimsHeld; ++d) {
         const uint32_t at = (uint32_t)T->words.size();
         for (uint32_t k = 0; k < P[d]; ++k) T->words.push_back(perms[starts[d] + k]);
-        T->words[5 + 2 * (size_t)d] = at;
+        T->words[4 + R * (size_t)d + 1] = at;
     }
-    for (uint32_t d = dimsHeld; d < nDims + 16u; ++d) T->words[5 + 2 * (size_t)d] = T->words[5 + 2 * (size_t)(dimsHeld - 1)];
+    for (uint32_t d = dimsHeld; d < nDims + 16u; ++d) T->words[4 + R * (size_t)d + 1] = T->words[4 + R * (size_t)(dimsHeld - 1) + 1];
 }
 
 // GetIndexForSample for a pixel given relative to the sample-bounds origin

@@ -34,9 +34,11 @@ DEV uint32_t sobolBits(const DevSampler& S, uint32_t relx, uint32_t rely, uint32
 // HaltonSampler::GetIndexForSample + SampleDimension (Enigma/Sampler.cpp:336-367) with RadicalInverseSpecialized /
 // ScrambledRadicalInverseSpecialized (Enigma/SamplerInclude.h:49-84), the base a run-time value instead of one of the
 // reference's 1000 template instances.  The index of (pixel, sample number) is below 2^32 (checked when the sampler is
-// configured), so the digits come off with 32-bit divisions; the reversed digits need 64 bits as in the reference.
+// configured), so the digits come off in 32-bit arithmetic; the reversed digits need 64 bits as in the reference.
 // DevSampler::bitConst holds, for this sampler: {stride, exponent of 2, scale of 3, sample-at-centre flag}, then per
-// dimension {prime, word offset of its digit permutation}, then the permutations, one word per digit value.
+// dimension a record of six words (halton_host.h), then the permutations, one word per digit value.  A digit comes off
+// with a multiplication (the record's magic and shift: exact for every 32-bit numerator), 1 / base and the tail term
+// invBase * perm[0] / (1 - invBase) are the host's, rounded as the reference rounds them.
 // Kernels that draw samples are compiled once per sampler (template argument HAL): with the choice made at run time
 // the shade kernels of the Sobol' sampler, which never run this, were 3.5 % slower, inlined or not.  One copy per
 // module (not inlined): a shade kernel draws samples in a dozen places.
@@ -46,28 +48,30 @@ static __device__ __noinline__ float haltonValue(const uint32_t* H, uint32_t off
     if (off >= stride) off -= stride;                // the sum of two terms, each already reduced modulo the stride
     uint32_t a = off + sampleNum * stride;
     if (dim == 0u) return (float)__brev(a >> H[1]) * 0x1p-32f; // ReverseBits64(a) * 2^-64, one rounding to float in both forms
-    const uint32_t base = H[4u + 2u * dim];
-    const float invBase = 1.0f / (float)base;
+    // the dimension's record: base, permutation offset, magic and shift of the division by the base, 1 / base, the tail term
+    const uint32_t* rec = H + 4u + 6u * dim;
+    const uint32_t base = rec[0], magic = rec[2], shift = rec[3];
+    const float invBase = __uint_as_float(rec[4]);
     unsigned long long reversedDigits = 0;
     float invBaseN = 1.f;
     if (dim == 1u) {
         a /= H[2];
         while (a) {
-            uint32_t next = a / base, digit = a - next * base;
+            const uint32_t t = __umulhi(magic, a), next = (t + ((a - t) >> 1)) >> shift, digit = a - next * base;
             reversedDigits = reversedDigits * base + digit;
             invBaseN *= invBase;
             a = next;
         }
         return smin((float)reversedDigits * invBaseN, kOneMinusEpsilon);
     }
-    const uint32_t* perm = H + H[5u + 2u * dim];
+    const uint32_t* perm = H + rec[1];
     while (a) {
-        uint32_t next = a / base, digit = a - next * base;
+        const uint32_t t = __umulhi(magic, a), next = (t + ((a - t) >> 1)) >> shift, digit = a - next * base;
         reversedDigits = reversedDigits * base + perm[digit];
         invBaseN *= invBase;
         a = next;
     }
-    return smin(invBaseN * ((float)reversedDigits + invBase * (float)perm[0] / (1.f - invBase)), kOneMinusEpsilon);
+    return smin(invBaseN * ((float)reversedDigits + __uint_as_float(rec[5])), kOneMinusEpsilon);
 }
 DEV float haltonDimension(const DevSampler& S, uint32_t relx, uint32_t rely, uint32_t sampleNum, uint32_t dim) {
     return haltonValue(S.bitConst, S.tx[relx] + S.ty[rely], sampleNum, dim);
