@@ -98,6 +98,14 @@ typedef struct EnigmaTexture {
  * DistantLight (:656-708).  One DiffuseAreaLight exists per emissive triangle (Enigma/Api.cpp:863-874). */
 enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT = 2, ENIGMA_LIGHT_DISTANT = 3,
        ENIGMA_LIGHT_INFINITE = 4 /* InfiniteAreaLight, Enigma/Lights.cpp:395-546 */,
+       ENIGMA_LIGHT_PROJECTION = 6 /* ProjectionLight as the reference has it (Enigma/Lights.cpp:194-296): its constructor
+                                      clears the image it has read BEFORE it tests whether there is one (:220-221), so no
+                                      projection map ever exists and projection() answers 1 for every direction (:240-241).
+                                      What is left is a point light -- Sample_Li = I / d^2 all around, no cone, no image
+                                      (:282-289) -- whose Power() is the cone's, I * 2 pi (1 - cos_total_width) (:291-296):
+                                      that number decides how often the power and spatial light distributions pick it.
+                                      Fields: pos, L = I * scale, cos_total_width = m_cosTotalWidth =
+                                      cosf(atanf(tanf(radians(fov) / 2) * sqrtf(2))) (aspect 1 without a map, :225-234). */,
        ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE = 5 /* a DiffuseAreaLight whose shape is a Sphere (Sphere::sample / pdf,
                                                Enigma/ShapeImp.cpp:205-310): `triangle` is the index into spheres */ };
 
@@ -111,7 +119,7 @@ typedef struct EnigmaLight {
     float pos[3];       /* point / spot light: world position m_pos */
     float dir[3];       /* distant: m_lightDir = lightToWorld.transformVector(from - to); the reference does NOT
                            normalise it (Enigma/Lights.cpp:656-663) and neither does this library */
-    float cos_total_width;    /* spot: cosf(radians(coneangle)) (Enigma/Lights.cpp:138) */
+    float cos_total_width;    /* spot: cosf(radians(coneangle)) (Enigma/Lights.cpp:138); projection: see ENIGMA_LIGHT_PROJECTION */
     float cos_falloff_start;  /* spot: cosf(radians(coneangle - conedeltaangle)) (Enigma/Lights.cpp:139) */
     float world_to_light[9];  /* spot, infinite: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
     float light_to_world[9];  /* infinite: upper-left 3x3 of m_lightToWorld */

@@ -2089,6 +2089,7 @@ struct Light {
     std::shared_ptr<InfiniteData> inf; // InfiniteAreaLight (flags & 8)
     int flags; // 1 = delta position, 2 = delta direction, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
+    bool projection = false;  // ProjectionLight: a point light but for Power()
     bool spot = false; float cosTotalWidth = 0, cosFalloffStart = 0; float w2l[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // SpotLight
     Vec3 lightDir; float worldRadius = 0; // DistantLight (m_lightDir is not normalised, Lights.cpp:656-663)
     bool IsDelta() const { return (flags & 1) || (flags & 2); } // Lights.h:15-18
@@ -2116,6 +2117,7 @@ struct Light {
         if (flags & 4) { float scale = twoSided ? 2.0f : 1.0f; return I_or_L * (area * PI * scale); } // Lights.cpp:647-651
         if (flags & 2) return I_or_L * PI * worldRadius * worldRadius;                                   // Lights.cpp:705-708
         if (spot) return I_or_L * 2.f * PI * (1.f - .5f * (cosFalloffStart + cosTotalWidth));            // Lights.cpp:174-178
+        if (projection) return Spectrum(1.f) * I_or_L * 2.0f * PI * (1.f - cosTotalWidth);               // Lights.cpp:291-296
         return 4.0f * PI * I_or_L;                                                                       // Lights.cpp:126-129
     }
     // Lights.cpp:117-124 / 634-645.  vis endpoints returned in p1.
@@ -3202,8 +3204,11 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
         } else if (l.type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) {
             if (l.triangle >= s->n_spheres || s->spheres[l.triangle].light != i + 1) { h->o.error = "sphere light and sphere do not point at each other"; return -1; }
             L.flags = 4; L.twoSided = l.two_sided != 0; // shape and area follow the spheres below
-        } else if (l.type == ENIGMA_LIGHT_POINT || l.type == ENIGMA_LIGHT_SPOT) {
+        } else if (l.type == ENIGMA_LIGHT_POINT || l.type == ENIGMA_LIGHT_SPOT || l.type == ENIGMA_LIGHT_PROJECTION) {
             L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]);
+            // ProjectionLight (Lights.cpp:194-296): m_projMap is never made (:220-221 clears the image, then asks whether it is
+            // empty), projection() is 1 (:240-241), Sample_Li is the point light's (:282-289); Power() alone differs (:291-296)
+            if (l.type == ENIGMA_LIGHT_PROJECTION) { L.projection = true; L.cosTotalWidth = l.cos_total_width; }
             if (l.type == ENIGMA_LIGHT_SPOT) {
                 L.spot = true; L.cosTotalWidth = l.cos_total_width; L.cosFalloffStart = l.cos_falloff_start;
                 memcpy(L.w2l, l.world_to_light, sizeof(L.w2l));

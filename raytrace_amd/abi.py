@@ -5,7 +5,7 @@ import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
 MAT_MIRROR, MAT_TRANSLUCENT, MAT_SUBSTRATE, MAT_UBER, MAT_MIX = 4, 5, 6, 7, 8
-LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE = 0, 1, 2, 3, 4, 5
+LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE, LIGHT_PROJECTION = 0, 1, 2, 3, 4, 5, 6
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 CAMERA_PERSPECTIVE, CAMERA_ENVIRONMENT = 0, 1
 SAMPLER_SOBOL, SAMPLER_HALTON = 0, 1  # enigma_sampler_select
@@ -338,6 +338,18 @@ def point_light(pos, I, n_samples=1):
     l.n_samples = n_samples
     l.pos[:] = pos
     l.L[:] = I
+    return l
+
+
+def projection_light(pos, I, fov=45.0, n_samples=1):
+    """ProjectionLight as the reference has it (Enigma/Lights.cpp:194-296): no map survives its constructor, so it shines like a
+    point light; the cone of its field of view only sizes Power()."""
+    f32 = np.float32
+    l = point_light(pos, I, n_samples)
+    l.type = LIGHT_PROJECTION
+    opposite = f32(np.tan(f32(f32(f32(fov) * f32(np.pi / 180.0)) / f32(2))))
+    tan_diag = f32(opposite * f32(np.sqrt(f32(2))))
+    l.cos_total_width = float(f32(np.cos(f32(np.arctan(tan_diag)))))
     return l
 
 

@@ -804,6 +804,12 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             d.type = 0;
             float k = 4.0f * PI; // PointLight::Power, Enigma/Lights.cpp:126-129
             h->lightPower[i] = YW[0] * (d.L[0] * k) + YW[1] * (d.L[1] * k) + YW[2] * (d.L[2] * k);
+        } else if (l.type == ENIGMA_LIGHT_PROJECTION) {
+            // no projection map ever exists in the reference (Enigma/Lights.cpp:220-221): a point light to every kernel ...
+            d.type = 0;
+            float P[3]; // ... with ProjectionLight::Power, Enigma/Lights.cpp:291-296, evaluated left to right
+            for (int c = 0; c < 3; ++c) P[c] = 1.f * d.L[c] * 2.0f * PI * (1.f - l.cos_total_width);
+            h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
         } else if (l.type == ENIGMA_LIGHT_SPOT) {
             d.type = 2;
             d.cosTotalWidth = l.cos_total_width; d.cosFalloffStart = l.cos_falloff_start;

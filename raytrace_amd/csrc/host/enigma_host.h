@@ -306,6 +306,18 @@ public:
         l.pos[0] = from.x; l.pos[1] = from.y; l.pos[2] = from.z; l.L[0] = I[0]; l.L[1] = I[1]; l.L[2] = I[2];
         AddLight(l);
     }
+    // ProjectionLight(light2world, mi, I, texname, fov) (Enigma/Lights.cpp:194-235).  The constructor drops the image it reads
+    // (:220-221), the aspect ratio is therefore 1, and what the light keeps is its position, its intensity and the cosine of
+    // the cone around the projection, which only Power() reads.
+    void AddProjectionLight(const Vector3f& from, const Spectrum& I, float fov) {
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_PROJECTION;
+        l.pos[0] = from.x; l.pos[1] = from.y; l.pos[2] = from.z; l.L[0] = I[0]; l.L[1] = I[1]; l.L[2] = I[2];
+        const float aspect = 1.f;
+        float opposite = tanf(3.14159265358979323846f / 180.f * fov / 2.f);
+        float tanDiag = opposite * sqrtf(1.f + 1.f / (aspect * aspect));
+        l.cos_total_width = cosf(atanf(tanDiag));
+        AddLight(l);
+    }
     // SpotLight(light2world, mi, I, width, fall) (Enigma/Lights.cpp:133-140): position light2world(0,0,0), the cosines
     // of the two cone angles (degrees), and the upper 3x3 of the inverse for Falloff.
     void AddSpotLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& I, float width, float fall) {

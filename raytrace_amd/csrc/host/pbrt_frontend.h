@@ -429,7 +429,19 @@ public:
             NoteUnused("LightSource", p);
             return;
         }
-        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, infinite without a map, and diffuse area lights)");
+        if (name == "projection") { // CreateProjectionLight, Enigma/Lights.cpp:782-789: the light sits at lightToWorld(0,0,0); there is no "from"
+            Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+            float fov = p.FindOneFloat("fov", 45.f);
+            if (!p.FindOneString("mapname", "").empty())
+                Warn("LightSource \"projection\": the reference reads \"mapname\" and drops the image before it looks at it (Enigma/Lights.cpp:218-222); the light shines like a point light");
+            double zero[3] = {0, 0, 0}, pos[3];
+            m_ctm.Point(zero, pos);
+            m_res->scene.AddProjectionLight(Vector3f((float)pos[0], (float)pos[1], (float)pos[2]), Spectrum(I[0] * sc[0], I[1] * sc[1], I[2] * sc[2]), fov);
+            NoteUnused("LightSource", p);
+            return;
+        }
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, projection, infinite without a map, and diffuse area lights; "
+                                                       "goniometric needs its image's pyramid)");
         Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
         Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
         // l2w = Translate(P) * lightToWorld, position = l2w(0,0,0) (Enigma/Lights.cpp:742-750,89-95)

@@ -310,7 +310,7 @@ COPPER_ETA = (0.200, 0.924, 1.102)
 COPPER_K = (3.912, 2.452, 2.142)
 
 
-def cornell_box(variant="diffuse", delta_lights=False):
+def cornell_box(variant="diffuse", delta_lights=False, extra_lights=()):
     """S1 (all matte) or S1m (short block metal, tall block rough glass).  32 triangles, 2 lights.
     delta_lights: adds a spot light aimed at the short block and a distant light shining in through the
     open front (its direction deliberately not unit length: the reference never normalises it)."""
@@ -361,6 +361,7 @@ def cornell_box(variant="diffuse", delta_lights=False):
     if delta_lights:
         b.add_spot_light((278, 500, 100), (186, 165, 169), (4.0e5, 5.0e5, 6.0e5), coneangle=25.0, conedeltaangle=10.0)
         b.add_distant_light((0.3, 0.5, -1.1), (0, 0, 0), (1.5, 1.2, 0.9))
+    b.lights.extend(extra_lights)   # lights without a shape, after everything else
     return b.arrays()
 
 
@@ -557,7 +558,7 @@ def cornell_spheres(fog=False, textured=True, lamp=False):
     return b.arrays(weld=not fog)
 
 
-def cornell_fog(variant="diffuse", g=0.3):
+def cornell_fog(variant="diffuse", g=0.3, extra_lights=()):
     """The Cornell box for the VolPathIntegrator: a slab of scattering fog (a box of material-less triangles whose
     MediumInterface has the fog inside) floats in front of the blocks, and the tall block -- glass in the
     microfacet / specular variants -- is filled with an absorbing, faintly scattering medium."""
@@ -589,6 +590,7 @@ def cornell_fog(variant="diffuse", g=0.3):
             outward = c.copy()
             outward[axis] = val + side * 100.0
             b.add_quad(q, abi.NO_MATERIAL, toward=tuple(outward))
+    b.lights.extend(extra_lights)
     return b.arrays(weld=False)
 
 

@@ -131,6 +131,10 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
             l = point[emitted][1]
             if l.type == abi.LIGHT_POINT:
                 out.append('LightSource "point" %s "point from" [%.9g %.9g %.9g]' % (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2]))
+            elif l.type == abi.LIGHT_PROJECTION:   # placed by the CTM; the field of view back from the cosine of its cone
+                fov = 2 * math.degrees(math.atan(math.tan(math.acos(l.cos_total_width)) / math.sqrt(2.0)))
+                out.append('AttributeBegin\n  Translate %.9g %.9g %.9g\n  LightSource "projection" %s "float fov" %.9g "string mapname" "slide.pfm"\nAttributeEnd' %
+                           (l.pos[0], l.pos[1], l.pos[2], _rgb("I", l.L), fov))
             elif l.type == abi.LIGHT_SPOT:   # the light looks along the third row of its world-to-light rotation
                 d = [l.world_to_light[6], l.world_to_light[7], l.world_to_light[8]]
                 cone = math.degrees(math.acos(l.cos_total_width))

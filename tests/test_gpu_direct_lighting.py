@@ -158,3 +158,23 @@ def test_direct_lighting_matches_golden_fixture():
     got = np.array([st["camera_samples"], st["rays_closest"], st["rays_shadow"], st["rays_mis"]], dtype=np.int64)
     assert np.all(np.abs(got - g["one_rays"]) <= np.maximum(3, 1e-3 * g["one_rays"]))
     r.close()
+
+
+@pytest.mark.parametrize("integrator,strategy", [("path", abi.LIGHTS_POWER), ("path", abi.LIGHTS_SPATIAL), ("direct-all", None), ("volpath", abi.LIGHTS_POWER)])
+def test_projection_light_renders_like_the_oracle(integrator, strategy):
+    """ENIGMA_LIGHT_PROJECTION: the reference's ProjectionLight never has a map (Enigma/Lights.cpp:220-221): a point light whose
+    Power() is its cone's.  Next to the Cornell box's area light the power and spatial distributions must weigh it as the oracle does."""
+    extra = [abi.projection_light((150.0, 400.0, 150.0), (6.0e5, 4.0e5, 3.0e5), fov=60.0, n_samples=2)]
+    sc = scenes.cornell_fog("diffuse", extra_lights=extra) if integrator == "volpath" else scenes.cornell_box("microfacet", extra_lights=extra)
+    assert sc.lights[sc.n_lights - 1].type == abi.LIGHT_PROJECTION
+    cam, film = scenes.cornell_camera(80, 64), scenes.film_desc(80, 64)
+    desc = {"path": lambda: scenes.integrator_desc(film, 16, light_strategy=strategy), "volpath": lambda: scenes.volpath_desc(film, 16, light_strategy=strategy),
+            "direct-all": lambda: scenes.direct_lighting_desc(film, 16, strategy=abi.DL_SAMPLE_ALL)}[integrator]()
+    r, o = ra.Renderer(0).configure(sc, cam, film, desc), orc.Oracle(sc, cam, film, desc)
+    r.render(0, 16); o.render(0, 16, threads=8)
+    a, b = r.image(), o.image()
+    assert common.mean_relative_error(a, b) < (5e-3 if integrator == "volpath" else 1e-3)
+    so, st = o.stats(), r.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(st[k] - so[k]) <= max(3, 2e-3 * so[k]), (k, st[k], so[k])
+    r.close(); o.close()

@@ -1028,3 +1028,32 @@ print(" ".join(str(int(v)) for v in h["ambiguous"]))
         outs.append(run.stdout.split())
     assert outs[0] == outs[1]
     assert sum(int(v) > 0 for v in outs[0]) > 50      # rays through vertices and edges do tie
+
+
+def test_projection_light_shines_like_a_point_light_and_weighs_like_a_cone():
+    """ProjectionLight (Enigma/Lights.cpp:194-296): the constructor clears the image it read and then asks whether it is empty
+    (:220-221), so projection() is 1 everywhere (:240-241) and Sample_Li is the point light's (:282-289).  Under the uniform
+    light distribution the film is the point light's bit for bit; Power() = I 2 pi (1 - cos of the cone) (:291-296) is a fifteenth of
+    the point light's 4 pi I at a field of view of 45 degrees, so the power distribution picks the light less often."""
+    import orc
+    from raytrace_amd import abi, scenes
+    films = {}
+    for kind in ("point", "projection"):
+        for strategy in (abi.LIGHTS_UNIFORM, abi.LIGHTS_POWER):
+            b = scenes.MeshBuilder()
+            m = b.add_material(abi.matte((0.6, 0.6, 0.6)))
+            b.add_quad([(0, 0, 0), (10, 0, 0), (10, 0, 10), (0, 0, 10)], m, toward=(5, 5, 5))
+            b.add_quad([(4, 8, 4), (6, 8, 4), (6, 8, 6), (4, 8, 6)], m, toward=(5, 0, 5), emit=(3.0, 3.0, 3.0))
+            light = abi.point_light((2, 3, 2), (40.0, 30.0, 20.0)) if kind == "point" else abi.projection_light((2, 3, 2), (40.0, 30.0, 20.0), fov=45.0)
+            b.lights.append(light)
+            film = scenes.film_desc(32, 32)
+            cam = scenes.camera_desc((5, 12, -6), (5, 0, 5), (0, 1, 0), 50.0, 32, 32)
+            o = orc.Oracle(b.arrays(), cam, film, scenes.integrator_desc(film, 16, max_depth=2, light_strategy=strategy))
+            o.render(0, 16, threads=2)
+            films[kind, strategy] = o.film_xyzw().copy()
+            o.close()
+    assert np.array_equal(films["point", abi.LIGHTS_UNIFORM], films["projection", abi.LIGHTS_UNIFORM])
+    assert not np.array_equal(films["point", abi.LIGHTS_POWER], films["projection", abi.LIGHTS_POWER])
+    l = abi.projection_light((0, 0, 0), (1, 1, 1), fov=45.0)
+    assert abs(l.cos_total_width - np.cos(np.arctan(np.tan(np.radians(22.5)) * np.sqrt(2)))) < 1e-6
+    assert 0.06 < 2 * np.pi * (1 - l.cos_total_width) / (4 * np.pi) < 0.08

@@ -654,3 +654,18 @@ def test_samplers(tmp_path):
     assert (d["name"], d["spp"], d["samplepixelcenter"]) == ("sobol", 8, False)
     d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nWorldEnd\n')["sampler"]
     assert (d["name"], d["spp"]) == ("sobol", 16)
+
+
+def test_projection_light(tmp_path):
+    """LightSource "projection" (CreateProjectionLight, Enigma/Lights.cpp:782-789): at the CTM's origin, I x scale, the cone of
+    "fov" (default 45) at aspect 1; the map is named in a warning because the reference drops it (Enigma/Lights.cpp:218-222)."""
+    text = ('Sampler "sobol"\nWorldBegin\nAttributeBegin\nTranslate 1 2 3\nLightSource "projection" "rgb I" [2 4 6] "rgb scale" [0.5 0.5 0.5] "string mapname" "slide.exr"\n'
+            'AttributeEnd\nLightSource "projection" "float fov" 90\nLightSource "goniometric"\nWorldEnd\n')
+    err = dump(tmp_path, text, expect_fail=True)
+    assert "goniometric" in err
+    d = dump(tmp_path, text.replace('LightSource "goniometric"\n', ""))
+    a, b = d["lights"]
+    assert a["type"] == abi.LIGHT_PROJECTION and np.allclose(a["from"], [1, 2, 3]) and np.allclose(a["I"], [1, 2, 3])
+    assert np.isclose(a["cos_total_width"], np.cos(np.arctan(np.tan(np.radians(22.5)) * np.sqrt(2.0))), atol=1e-6)
+    assert np.allclose(b["from"], [0, 0, 0]) and np.allclose(b["I"], [1, 1, 1]) and np.isclose(b["cos_total_width"], np.cos(np.arctan(np.sqrt(2.0))), atol=1e-6)
+    assert any("drops the image" in w for w in d["warnings"])

@@ -160,6 +160,10 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
         b.add_distant_light(tuple(rng.uniform(-1, 1, 3) * 2), (0, 0, 0), tuple(float(x) for x in rng.uniform(0.5, 3, 3)))
     if rng.rand() < 0.2:
         b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if (rng.rand() < 0.5 and not for_file) else None))
+    # an eighth stream, for seeds from 1,800,000 on: a projection light (a point light whose weight in the light distributions is its cone's)
+    pr = np.random.RandomState((seed * 7919 + 0x9207) & 0x7fffffff)
+    if seed >= 1800000 and pr.rand() < 0.3:
+        b.lights.append(abi.projection_light(tuple(pr.uniform(0, extent, 3)), tuple(float(x) for x in pr.uniform(20, 300, 3)), fov=float(pr.uniform(5, 150))))
     if want_spheres and for_file:
         add_spheres()
     # ---- a second stream of choices (textures, a dense piece of mesh, boundary surfaces, a crop window): drawn apart from
