@@ -22,6 +22,7 @@
 #pragma once
 #include <cstring>
 #include <algorithm>
+#include <deque>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -300,7 +301,7 @@ public:
     // One GeometricPrimitive (and one DiffuseAreaLight if emissive) per triangle, in file order (Enigma/Api.cpp:863-874).
     void AddTriangleMesh(const TriangleMesh& mesh) { m_meshes.push_back(mesh); }
     // Lights without a shape (point, spot, distant) keep their place among the meshes' area lights.
-    void AddLight(const EnigmaLight& l) { m_lights.push_back(LightRec{l, NextLightOrder()}); }
+    void AddLight(const EnigmaLight& l, int mapIndex = -1) { m_lights.push_back(LightRec{l, NextLightOrder(), mapIndex}); }
     void AddPointLight(const Vector3f& from, const Spectrum& I) { // PointLight(light2world, mi, I): from = light2world(0,0,0)
         EnigmaLight l{}; l.type = ENIGMA_LIGHT_POINT;
         l.pos[0] = from.x; l.pos[1] = from.y; l.pos[2] = from.z; l.L[0] = I[0]; l.L[1] = I[1]; l.L[2] = I[2];
@@ -336,20 +337,27 @@ public:
         for (int c = 0; c < 3; ++c) l.L[c] = L[c];
         AddLight(l);
     }
-    // InfiniteAreaLight(light2world, L, nSamples, texmap) without a map file (Enigma/Lights.cpp:395-442): a constant
-    // environment.  A radiance map can be attached afterwards through m_lights.back().light.map_* (RGB texels, power-of-two sides).
-    void AddInfiniteLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& L, int nSamples = 1) {
+    // InfiniteAreaLight(light2world, L, nSamples, texmap) (Enigma/Lights.cpp:395-442); without a map a constant environment.
+    // map: the texels ReadImage returns for "mapname" (RGB, top row first = theta 0), kept by the scene until the upload
+    void AddInfiniteLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& L, int nSamples = 1,
+                          std::vector<float> map = std::vector<float>(), int mapWidth = 0, int mapHeight = 0) {
         EnigmaLight l{}; l.type = ENIGMA_LIGHT_INFINITE; l.n_samples = (uint32_t)std::max(1, nSamples);
+        int mapIndex = -1;
+        if (!map.empty()) { // map_rgb is pointed at the scene's copy when the lights are handed to the library (a Scene may be copied before)
+            m_lightMaps.push_back(std::move(map));
+            mapIndex = (int)m_lightMaps.size() - 1; l.map_width = (uint32_t)mapWidth; l.map_height = (uint32_t)mapHeight;
+        }
         for (int c = 0; c < 3; ++c) l.L[c] = L[c];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { l.light_to_world[3 * r + c] = lightToWorld.m_mat[r][c]; l.world_to_light[3 * r + c] = worldToLight.m_mat[r][c]; }
-        AddLight(l);
+        AddLight(l, mapIndex);
     }
     int getNumLights() const {
         int n = (int)m_lights.size();
         for (auto& m : m_meshes) if (m.emissive) n += m.m_nTriangles;
         return n;
     }
-    struct LightRec { EnigmaLight light; int order; };
+    struct LightRec { EnigmaLight light; int order; int map; }; // map: index into m_lightMaps, -1 = none
+    std::deque<std::vector<float>> m_lightMaps; // radiance maps of the infinite lights
     std::vector<TriangleMesh> m_meshes;
     std::vector<EnigmaMaterial> m_materials;
     std::vector<EnigmaMedium> m_media;
@@ -406,6 +414,7 @@ public:
         auto flushPointLights = [&](int upTo) {
             for (; pl < scene.m_lights.size() && scene.m_lights[pl].order <= upTo; ++pl) {
                 lights.push_back(scene.m_lights[pl].light);
+                if (scene.m_lights[pl].map >= 0) lights.back().map_rgb = scene.m_lightMaps[(size_t)scene.m_lights[pl].map].data();
                 if (lights.back().type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE) spheres[lights.back().triangle].light = (uint32_t)lights.size();
             }
         };

@@ -417,15 +417,23 @@ public:
         for (int y = 0; y < *h; ++y) std::copy(rows.begin() + (size_t)(*h - 1 - y) * rowLen, rows.begin() + (size_t)(*h - y) * rowLen, out.begin() + (size_t)y * rowLen);
         return out;
     }
-    void pbrtLightSource(const std::string& name, const ParamSet& p) {
+    void pbrtLightSource(const std::string& name, const ParamSet& p, const std::string& dir = "") {
         VerifyWorld("LightSource");
         if (name == "spot") { MakeSpotLight(p); NoteUnused("LightSource", p); return; }
         if (name == "distant") { MakeDistantLight(p); NoteUnused("LightSource", p); return; }
         if (name == "infinite" || name == "exinfinite") { // CreateInfiniteLight, Enigma/Lights.cpp:801-810
-            if (!p.FindOneString("mapname", "").empty()) throw std::runtime_error("LightSource \"infinite\": \"mapname\" needs an image reader, which this front end does not have; the library takes the texels through EnigmaLight::map_rgb");
+            std::string mapname = p.FindOneString("mapname", "");
+            std::vector<float> map;
+            int mw = 0, mh = 0;
+            if (!mapname.empty()) { // InfiniteAreaLight's constructor reads it (Enigma/Lights.cpp:395-420); PFM is the format this front end reads
+                if (mapname.size() < 4 || mapname.compare(mapname.size() - 4, 4, ".pfm") != 0)
+                    throw std::runtime_error("LightSource \"infinite\": only PFM image files are read (\"" + mapname + "\")");
+                if (mapname[0] != '/') mapname = dir + mapname;
+                map = ReadPfm(mapname, &mw, &mh);
+            }
             Spectrum L = p.FindOneSpectrum("L", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
             int nSamples = p.FindOneInt("samples", p.FindOneInt("nsamples", 1));
-            m_res->scene.AddInfiniteLight(m_ctm.ToFloat(), m_ctm.Inverse().ToFloat(), Spectrum(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]), nSamples);
+            m_res->scene.AddInfiniteLight(m_ctm.ToFloat(), m_ctm.Inverse().ToFloat(), Spectrum(L[0] * sc[0], L[1] * sc[1], L[2] * sc[2]), nSamples, std::move(map), mw, mh);
             NoteUnused("LightSource", p);
             return;
         }
@@ -440,7 +448,7 @@ public:
             NoteUnused("LightSource", p);
             return;
         }
-        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, projection, infinite without a map, and diffuse area lights; "
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, projection, infinite, and diffuse area lights; "
                                                        "goniometric needs its image's pyramid)");
         Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
         Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
@@ -951,7 +959,7 @@ private:
             else if (d == "Material") { std::string n = c.str("Material"); pbrtMaterial(n, ParseParams(c)); }
             else if (d == "MakeNamedMaterial") { std::string n = c.str("MakeNamedMaterial"); pbrtMakeNamedMaterial(n, ParseParams(c)); }
             else if (d == "NamedMaterial") pbrtNamedMaterial(c.str("NamedMaterial"));
-            else if (d == "LightSource") { std::string n = c.str("LightSource"); pbrtLightSource(n, ParseParams(c)); }
+            else if (d == "LightSource") { std::string n = c.str("LightSource"); pbrtLightSource(n, ParseParams(c), dir); }
             else if (d == "AreaLightSource") { std::string n = c.str("AreaLightSource"); pbrtAreaLightSource(n, ParseParams(c)); }
             else if (d == "Shape") { std::string n = c.str("Shape"); pbrtShape(n, ParseParams(c), dir); }
             else if (d == "Texture") { std::string n = c.str("Texture"), ty = c.str("Texture"), cl = c.str("Texture"); pbrtTexture(n, ty, cl, ParseParams(c), dir); }

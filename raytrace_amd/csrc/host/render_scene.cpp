@@ -112,6 +112,7 @@ static void dumpJson(const FrontEndResult& R, std::ostream& o) {
         o << ",\"I\":"; arr(l.L, 3); o << ",\"dir\":"; arr(l.dir, 3);
         o << ",\"cos_total_width\":"; arr(&l.cos_total_width, 1); o << ",\"cos_falloff_start\":"; arr(&l.cos_falloff_start, 1);
         o << ",\"world_to_light\":"; arr(l.world_to_light, 9); o << ",\"light_to_world\":"; arr(l.light_to_world, 9); o << ",\"nsamples\":" << l.n_samples
+          << ",\"map\":[" << l.map_width << "," << l.map_height << "]"
           << ",\"sphere\":" << (l.type == ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE ? (int)l.triangle : -1) << ",\"twosided\":" << l.two_sided << "}";
     }
     o << "],\n\"warnings\":[";

@@ -141,10 +141,15 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
                 start = math.degrees(math.acos(l.cos_falloff_start))
                 out.append('LightSource "spot" %s "point from" [%.9g %.9g %.9g] "point to" [%.9g %.9g %.9g] "float coneangle" %.9g "float conedeltaangle" %.9g' %
                            (_rgb("I", l.L), l.pos[0], l.pos[1], l.pos[2], l.pos[0] + 100 * d[0], l.pos[1] + 100 * d[1], l.pos[2] + 100 * d[2], cone, cone - start))
-            elif l.type == abi.LIGHT_INFINITE:      # constant environment only; the rotation goes into the CTM
+            elif l.type == abi.LIGHT_INFINITE:      # the rotation goes into the CTM, a radiance map into <texture_dir>/env<k>.pfm
                 m = [l.light_to_world[k] for k in range(9)]
-                out.append('AttributeBegin\n  ConcatTransform [%.9g %.9g %.9g 0  %.9g %.9g %.9g 0  %.9g %.9g %.9g 0  0 0 0 1]\n  LightSource "infinite" %s\nAttributeEnd' %
-                           (m[0], m[3], m[6], m[1], m[4], m[7], m[2], m[5], m[8], _rgb("L", l.L)))
+                mapname = ""
+                if l.map_rgb:
+                    texels = np.ctypeslib.as_array(C.cast(l.map_rgb, C.POINTER(C.c_float)), shape=(l.map_height, l.map_width, 3))
+                    write_pfm(os.path.join(texture_dir, "env%d.pfm" % emitted), texels)
+                    mapname = ' "string mapname" "env%d.pfm"' % emitted
+                out.append('AttributeBegin\n  ConcatTransform [%.9g %.9g %.9g 0  %.9g %.9g %.9g 0  %.9g %.9g %.9g 0  0 0 0 1]\n  LightSource "infinite" %s%s\nAttributeEnd' %
+                           (m[0], m[3], m[6], m[1], m[4], m[7], m[2], m[5], m[8], _rgb("L", l.L), mapname))
             elif l.type == abi.LIGHT_DISTANT:
                 out.append('LightSource "distant" %s "point from" [%.9g %.9g %.9g] "point to" [0 0 0]' % (_rgb("L", l.L), l.dir[0], l.dir[1], l.dir[2]))
             emitted += 1

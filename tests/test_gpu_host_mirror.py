@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath"), ("ply:smooth", "path"), ("ply:textured", "path"), ("textured_lobes", "path"), ("diffuse+projection", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("skymap:microfacet", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath"), ("ply:smooth", "path"), ("ply:textured", "path"), ("textured_lobes", "path"), ("diffuse+projection", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -93,8 +93,10 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
         variant, ply_dir = variant.split(":")[1], str(tmp_path)
     if variant.startswith("fog:"):
         sc = scenes.cornell_fog(variant.split(":")[1])
+    elif variant.startswith("skymap:"):
+        sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=True)       # LightSource "infinite" "string mapname": the radiance map in a PFM file
     elif variant.startswith("sky:"):
-        sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment: scene files carry no texels
+        sc = scenes.cornell_sky(variant.split(":")[1], radiance_map=False)      # a constant environment
     elif variant == "textured_lobes":
         sc = scenes.cornell_textured_lobes(True)   # "texture Kd" / "texture Ks" / "texture Kr" on uber, substrate, mirror, translucent, a matte inside a mix
     elif variant == "textured":

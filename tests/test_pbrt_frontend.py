@@ -669,3 +669,16 @@ def test_projection_light(tmp_path):
     assert np.isclose(a["cos_total_width"], np.cos(np.arctan(np.tan(np.radians(22.5)) * np.sqrt(2.0))), atol=1e-6)
     assert np.allclose(b["from"], [0, 0, 0]) and np.allclose(b["I"], [1, 1, 1]) and np.isclose(b["cos_total_width"], np.cos(np.arctan(np.sqrt(2.0))), atol=1e-6)
     assert any("drops the image" in w for w in d["warnings"])
+
+
+def test_infinite_light_reads_its_radiance_map_from_a_pfm_file(tmp_path):
+    """LightSource "infinite" "string mapname" (CreateInfiniteLight, Enigma/Lights.cpp:801-810): the front end reads PFM files,
+    relative to the scene file's directory."""
+    import pbrt_writer
+    pbrt_writer.write_pfm(str(tmp_path / "sky.pfm"), np.random.RandomState(1).rand(8, 16, 3).astype(np.float32))
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nLightSource "infinite" "rgb L" [2 2 2] "string mapname" "sky.pfm"\nLightSource "infinite"\nWorldEnd\n')
+    a, b = d["lights"]
+    assert a["type"] == abi.LIGHT_INFINITE and a["map"] == [16, 8] and np.allclose(a["I"], [2, 2, 2])
+    assert b["map"] == [0, 0]
+    assert "PFM" in dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nLightSource "infinite" "string mapname" "sky.exr"\nWorldEnd\n', expect_fail=True)
+    assert "sky2.pfm" in dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nLightSource "infinite" "string mapname" "sky2.pfm"\nWorldEnd\n', expect_fail=True)

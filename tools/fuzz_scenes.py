@@ -159,7 +159,7 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
     if rng.rand() < 0.2:
         b.add_distant_light(tuple(rng.uniform(-1, 1, 3) * 2), (0, 0, 0), tuple(float(x) for x in rng.uniform(0.5, 3, 3)))
     if rng.rand() < 0.2:
-        b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if (rng.rand() < 0.5 and not for_file) else None))
+        b.lights.append(abi.infinite_light(tuple(float(x) for x in rng.uniform(0.2, 1.5, 3)), radiance_map=scenes.sky_map() if (rng.rand() < 0.5 and (not for_file or seed >= 1800000)) else None))   # scene files carry the map as a PFM file (seeds from 1,800,000 on)
     # an eighth stream, for seeds from 1,800,000 on: a projection light (a point light whose weight in the light distributions is its cone's)
     pr = np.random.RandomState((seed * 7919 + 0x9207) & 0x7fffffff)
     if seed >= 1800000 and pr.rand() < 0.3:
