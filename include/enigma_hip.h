@@ -106,6 +106,13 @@ enum { ENIGMA_LIGHT_POINT = 0, ENIGMA_LIGHT_DIFFUSE_AREA = 1, ENIGMA_LIGHT_SPOT 
                                       that number decides how often the power and spatial light distributions pick it.
                                       Fields: pos, L = I * scale, cos_total_width = m_cosTotalWidth =
                                       cosf(atanf(tanf(radians(fov) / 2) * sqrtf(2))) (aspect 1 without a map, :225-234). */,
+       ENIGMA_LIGHT_GONIOMETRIC = 7 /* GonioPhotometricLight as the reference has it (Enigma/Lights.cpp:301-363).  scale() hands
+                                       the illuminant tag (the integer 1) to MipMap::lookup where the filter width belongs
+                                       (:327-328); width 1 selects the single texel at the top of the image pyramid
+                                       (Enigma/MipMap.h:355-361) whatever the direction.  The light is therefore a point light of
+                                       intensity I x that texel, and Power() = 4 pi^2 x lookup((.5, .5), width .5) without the
+                                       intensity (:359-363).  Fields: pos, L = I * scale, map_rgb / map_width / map_height = the
+                                       texels ReadImage returned for "mapname" (NULL: no map, scale() = 1). */,
        ENIGMA_LIGHT_DIFFUSE_AREA_SPHERE = 5 /* a DiffuseAreaLight whose shape is a Sphere (Sphere::sample / pdf,
                                                Enigma/ShapeImp.cpp:205-310): `triangle` is the index into spheres */ };
 
@@ -123,7 +130,8 @@ typedef struct EnigmaLight {
     float cos_falloff_start;  /* spot: cosf(radians(coneangle - conedeltaangle)) (Enigma/Lights.cpp:139) */
     float world_to_light[9];  /* spot, infinite: upper-left 3x3 of m_worldToLight, row major (Falloff, Enigma/Lights.cpp:180-190) */
     float light_to_world[9];  /* infinite: upper-left 3x3 of m_lightToWorld */
-    /* infinite: the latitude-longitude radiance map the constructor reads (ReadImage -> RGB texels, row 0 = theta 0),
+    /* goniometric: its map (see ENIGMA_LIGHT_GONIOMETRIC).
+     * infinite: the latitude-longitude radiance map the constructor reads (ReadImage -> RGB texels, row 0 = theta 0),
      * multiplied by L; NULL = the 1 x 1 map of colour L (no "mapname").  Sides that are not powers of two are zoomed with the
      * reference's Lanczos filter first (MipMap::resizeImage, Enigma/MipMap.h:155-237). */
     uint32_t map_width, map_height;

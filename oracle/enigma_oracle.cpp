@@ -2090,6 +2090,7 @@ struct Light {
     int flags; // 1 = delta position, 2 = delta direction, 4 = area (Defines.h:236-239)
     Spectrum I_or_L; Vec3 pos; const Triangle* shape = nullptr; bool twoSided = false; float area = 0; int index = -1;
     bool projection = false;  // ProjectionLight: a point light but for Power()
+    bool gonio = false; Spectrum gonioPower; // GonioPhotometricLight: a point light of intensity I x the map's top texel
     bool spot = false; float cosTotalWidth = 0, cosFalloffStart = 0; float w2l[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // SpotLight
     Vec3 lightDir; float worldRadius = 0; // DistantLight (m_lightDir is not normalised, Lights.cpp:656-663)
     bool IsDelta() const { return (flags & 1) || (flags & 2); } // Lights.h:15-18
@@ -2118,6 +2119,7 @@ struct Light {
         if (flags & 2) return I_or_L * PI * worldRadius * worldRadius;                                   // Lights.cpp:705-708
         if (spot) return I_or_L * 2.f * PI * (1.f - .5f * (cosFalloffStart + cosTotalWidth));            // Lights.cpp:174-178
         if (projection) return Spectrum(1.f) * I_or_L * 2.0f * PI * (1.f - cosTotalWidth);               // Lights.cpp:291-296
+        if (gonio) return gonioPower;                                                                    // Lights.cpp:359-363
         return 4.0f * PI * I_or_L;                                                                       // Lights.cpp:126-129
     }
     // Lights.cpp:117-124 / 634-645.  vis endpoints returned in p1.
@@ -3212,6 +3214,21 @@ int oracle_scene_upload(OracleCtx* h, const EnigmaSceneDesc* s, int split_method
             if (l.type == ENIGMA_LIGHT_SPOT) {
                 L.spot = true; L.cosTotalWidth = l.cos_total_width; L.cosFalloffStart = l.cos_falloff_start;
                 memcpy(L.w2l, l.world_to_light, sizeof(L.w2l));
+            }
+        } else if (l.type == ENIGMA_LIGHT_GONIOMETRIC) {
+            // GonioPhotometricLight (Lights.cpp:301-363): scale() = m_gonioMap->lookup(st, SPECTRUM_ILLUMINANT), the enum's 1 taken
+            // as the filter width (:327-328): the pyramid's top texel for every direction (MipMap.h:355-361).  Sample_Li =
+            // m_intensity * scale / d^2 (:351-357); Power() = 4 pi^2 lookup((.5, .5), .5), without the intensity (:359-363)
+            L.flags = 1; L.pos = Vec3(l.pos[0], l.pos[1], l.pos[2]);
+            L.gonio = true; L.gonioPower = 4.f * PI * PI * Spectrum(1.f);
+            if (l.map_rgb) {
+                if (!l.map_width || !l.map_height) { h->o.error = "empty goniometric map"; return -1; }
+                std::vector<Spectrum> texels((size_t)l.map_width * l.map_height);
+                for (size_t k = 0; k < texels.size(); ++k) texels[k] = Spectrum(l.map_rgb[3 * k], l.map_rgb[3 * k + 1], l.map_rgb[3 * k + 2]);
+                MipMapRGB m;
+                m.build((int)l.map_width, (int)l.map_height, texels);
+                L.I_or_L = L.I_or_L * m.lookup(Vec2(.5f, .5f), 1.f);
+                L.gonioPower = 4.f * PI * PI * m.lookup(Vec2(.5f, .5f), .5f);
             }
         } else if (l.type == ENIGMA_LIGHT_DISTANT) {
             L.flags = 2; L.lightDir = Vec3(l.dir[0], l.dir[1], l.dir[2]);

@@ -5,7 +5,7 @@ import numpy as np
 
 MAT_MATTE, MAT_METAL, MAT_GLASS, MAT_PLASTIC = 0, 1, 2, 3
 MAT_MIRROR, MAT_TRANSLUCENT, MAT_SUBSTRATE, MAT_UBER, MAT_MIX = 4, 5, 6, 7, 8
-LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE, LIGHT_PROJECTION = 0, 1, 2, 3, 4, 5, 6
+LIGHT_POINT, LIGHT_DIFFUSE_AREA, LIGHT_SPOT, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_DIFFUSE_AREA_SPHERE, LIGHT_PROJECTION, LIGHT_GONIOMETRIC = 0, 1, 2, 3, 4, 5, 6, 7
 LIGHTS_UNIFORM, LIGHTS_POWER, LIGHTS_SPATIAL = 0, 1, 2
 CAMERA_PERSPECTIVE, CAMERA_ENVIRONMENT = 0, 1
 SAMPLER_SOBOL, SAMPLER_HALTON = 0, 1  # enigma_sampler_select
@@ -397,6 +397,20 @@ def infinite_light(L, radiance_map=None, light_to_world=None, n_samples=1):
     l.world_to_light[:] = [float(np.float32(x)) for x in np.linalg.inv(m).reshape(-1)]
     if radiance_map is not None:
         a = np.ascontiguousarray(radiance_map, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[2] == 3
+        l.map_height, l.map_width = a.shape[0], a.shape[1]
+        l.map_rgb = a.ctypes.data_as(C.c_void_p)
+        l._map = a
+    return l
+
+
+def goniometric_light(pos, I, gonio_map=None, n_samples=1):
+    """GonioPhotometricLight as the reference has it (Enigma/Lights.cpp:301-363): a point light of intensity I x the texel at the
+    top of the map's image pyramid; gonio_map is a (height, width, 3) float32 image or None."""
+    l = point_light(pos, I, n_samples)
+    l.type = LIGHT_GONIOMETRIC
+    if gonio_map is not None:
+        a = np.ascontiguousarray(gonio_map, dtype=np.float32)
         assert a.ndim == 3 and a.shape[2] == 3
         l.map_height, l.map_width = a.shape[0], a.shape[1]
         l.map_rgb = a.ctypes.data_as(C.c_void_p)

@@ -810,6 +810,24 @@ static int sceneUpload(EnigmaCtx* h, const EnigmaSceneDesc* s) {
             float P[3]; // ... with ProjectionLight::Power, Enigma/Lights.cpp:291-296, evaluated left to right
             for (int c = 0; c < 3; ++c) P[c] = 1.f * d.L[c] * 2.0f * PI * (1.f - l.cos_total_width);
             h->lightPower[i] = YW[0] * P[0] + YW[1] * P[1] + YW[2] * P[2];
+        } else if (l.type == ENIGMA_LIGHT_GONIOMETRIC) {
+            // scale() looks its map up with filter width 1: the texel at the top of the pyramid, for every direction
+            // (Enigma/Lights.cpp:319-329, Enigma/MipMap.h:355-361): a point light of intensity I x that texel
+            enigma::Rgb top{1.f, 1.f, 1.f}, half{1.f, 1.f, 1.f};
+            if (l.map_rgb) {
+                if (!l.map_width || !l.map_height) return h->fail(ENIGMA_E_INVALID, "light %u: empty goniometric map", i);
+                if ((uint64_t)l.map_width * l.map_height > (1u << 26)) return h->fail(ENIGMA_E_UNSUPPORTED, "light %u: goniometric map too large", i);
+                std::vector<enigma::Rgb> tex((size_t)l.map_width * l.map_height);
+                for (size_t k = 0; k < tex.size(); ++k) tex[k] = enigma::Rgb{l.map_rgb[3 * k], l.map_rgb[3 * k + 1], l.map_rgb[3 * k + 2]};
+                enigma::EnvPyramid pyr;
+                pyr.build((int)l.map_width, (int)l.map_height, tex);
+                top = pyr.lookup(.5f, .5f, 1.f);
+                half = pyr.lookup(.5f, .5f, .5f);
+            }
+            d.type = 0;
+            d.L[0] = l.L[0] * top.r; d.L[1] = l.L[1] * top.g; d.L[2] = l.L[2] * top.b;
+            const float k = 4.f * PI * PI; // GonioPhotometricLight::Power, Enigma/Lights.cpp:359-363: the intensity is not in it
+            h->lightPower[i] = YW[0] * (k * half.r) + YW[1] * (k * half.g) + YW[2] * (k * half.b);
         } else if (l.type == ENIGMA_LIGHT_SPOT) {
             d.type = 2;
             d.cosTotalWidth = l.cos_total_width; d.cosFalloffStart = l.cos_falloff_start;

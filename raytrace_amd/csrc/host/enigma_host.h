@@ -319,6 +319,19 @@ public:
         l.cos_total_width = cosf(atanf(tanDiag));
         AddLight(l);
     }
+    // GonioPhotometricLight(light2world, mi, I, texname) (Enigma/Lights.cpp:301-317): position, intensity and the texels
+    // ReadImage returned (none: no map).  m_gonioMap is private in the reference; the binding keeps the texels where
+    // CreateGoniometricLight makes the light (Enigma/Lights.cpp:774-780).
+    void AddGoniometricLight(const Vector3f& from, const Spectrum& I, std::vector<float> map = std::vector<float>(), int mapWidth = 0, int mapHeight = 0) {
+        EnigmaLight l{}; l.type = ENIGMA_LIGHT_GONIOMETRIC;
+        l.pos[0] = from.x; l.pos[1] = from.y; l.pos[2] = from.z; l.L[0] = I[0]; l.L[1] = I[1]; l.L[2] = I[2];
+        int mapIndex = -1;
+        if (!map.empty()) {
+            m_lightMaps.push_back(std::move(map));
+            mapIndex = (int)m_lightMaps.size() - 1; l.map_width = (uint32_t)mapWidth; l.map_height = (uint32_t)mapHeight;
+        }
+        AddLight(l, mapIndex);
+    }
     // SpotLight(light2world, mi, I, width, fall) (Enigma/Lights.cpp:133-140): position light2world(0,0,0), the cosines
     // of the two cone angles (degrees), and the upper 3x3 of the inverse for Falloff.
     void AddSpotLight(const Transform& lightToWorld, const Transform& worldToLight, const Spectrum& I, float width, float fall) {
@@ -357,7 +370,7 @@ public:
         return n;
     }
     struct LightRec { EnigmaLight light; int order; int map; }; // map: index into m_lightMaps, -1 = none
-    std::deque<std::vector<float>> m_lightMaps; // radiance maps of the infinite lights
+    std::deque<std::vector<float>> m_lightMaps; // maps of the infinite and goniometric lights
     std::vector<TriangleMesh> m_meshes;
     std::vector<EnigmaMaterial> m_materials;
     std::vector<EnigmaMedium> m_media;

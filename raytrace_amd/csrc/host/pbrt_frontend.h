@@ -437,6 +437,23 @@ public:
             NoteUnused("LightSource", p);
             return;
         }
+        if (name == "goniometric") { // CreateGoniometricLight, Enigma/Lights.cpp:774-780: at lightToWorld(0,0,0), I x scale, the image named by "mapname"
+            Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
+            std::string mapname = p.FindOneString("mapname", "");
+            std::vector<float> map;
+            int mw = 0, mh = 0;
+            if (!mapname.empty()) {
+                if (mapname.size() < 4 || mapname.compare(mapname.size() - 4, 4, ".pfm") != 0)
+                    throw std::runtime_error("LightSource \"goniometric\": only PFM image files are read (\"" + mapname + "\")");
+                if (mapname[0] != '/') mapname = dir + mapname;
+                map = ReadPfm(mapname, &mw, &mh);
+            }
+            double zero[3] = {0, 0, 0}, pos[3];
+            m_ctm.Point(zero, pos);
+            m_res->scene.AddGoniometricLight(Vector3f((float)pos[0], (float)pos[1], (float)pos[2]), Spectrum(I[0] * sc[0], I[1] * sc[1], I[2] * sc[2]), std::move(map), mw, mh);
+            NoteUnused("LightSource", p);
+            return;
+        }
         if (name == "projection") { // CreateProjectionLight, Enigma/Lights.cpp:782-789: the light sits at lightToWorld(0,0,0); there is no "from"
             Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
             float fov = p.FindOneFloat("fov", 45.f);
@@ -448,8 +465,7 @@ public:
             NoteUnused("LightSource", p);
             return;
         }
-        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, projection, infinite, and diffuse area lights; "
-                                                       "goniometric needs its image's pyramid)");
+        if (name != "point") throw std::runtime_error("LightSource \"" + name + "\" is not supported (point, spot, distant, projection, goniometric, infinite, and diffuse area lights)");
         Spectrum I = p.FindOneSpectrum("I", Spectrum(1.f)), sc = p.FindOneSpectrum("scale", Spectrum(1.f));
         Vector3f P = p.FindOnePoint3f("from", Vector3f(0, 0, 0));
         // l2w = Translate(P) * lightToWorld, position = l2w(0,0,0) (Enigma/Lights.cpp:742-750,89-95)

@@ -135,6 +135,13 @@ def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "
                 fov = 2 * math.degrees(math.atan(math.tan(math.acos(l.cos_total_width)) / math.sqrt(2.0)))
                 out.append('AttributeBegin\n  Translate %.9g %.9g %.9g\n  LightSource "projection" %s "float fov" %.9g "string mapname" "slide.pfm"\nAttributeEnd' %
                            (l.pos[0], l.pos[1], l.pos[2], _rgb("I", l.L), fov))
+            elif l.type == abi.LIGHT_GONIOMETRIC:  # placed by the CTM, its map in <texture_dir>/gonio<k>.pfm
+                mapname = ""
+                if l.map_rgb:
+                    texels = np.ctypeslib.as_array(C.cast(l.map_rgb, C.POINTER(C.c_float)), shape=(l.map_height, l.map_width, 3))
+                    write_pfm(os.path.join(texture_dir, "gonio%d.pfm" % emitted), texels)
+                    mapname = ' "string mapname" "gonio%d.pfm"' % emitted
+                out.append('AttributeBegin\n  Translate %.9g %.9g %.9g\n  LightSource "goniometric" %s%s\nAttributeEnd' % (l.pos[0], l.pos[1], l.pos[2], _rgb("I", l.L), mapname))
             elif l.type == abi.LIGHT_SPOT:   # the light looks along the third row of its world-to-light rotation
                 d = [l.world_to_light[6], l.world_to_light[7], l.world_to_light[8]]
                 cone = math.degrees(math.acos(l.cos_total_width))

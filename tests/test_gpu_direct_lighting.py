@@ -178,3 +178,21 @@ def test_projection_light_renders_like_the_oracle(integrator, strategy):
     for k in ("rays_closest", "rays_shadow", "rays_mis"):
         assert abs(st[k] - so[k]) <= max(3, 2e-3 * so[k]), (k, st[k], so[k])
     r.close(); o.close()
+
+
+@pytest.mark.parametrize("integrator,strategy,with_map", [("path", abi.LIGHTS_POWER, True), ("path", abi.LIGHTS_SPATIAL, True), ("path", abi.LIGHTS_POWER, False), ("direct-all", None, True)])
+def test_goniometric_light_renders_like_the_oracle(integrator, strategy, with_map):
+    """ENIGMA_LIGHT_GONIOMETRIC: a point light of intensity I x the top texel of its map's pyramid (a non-power-of-two map goes
+    through the reference's Lanczos zoom first), weighed in the light distributions by 4 pi^2 x lookup((.5, .5), .5)."""
+    gmap = scenes.sky_map(12, 20) if with_map else None
+    extra = [abi.goniometric_light((150.0, 400.0, 150.0), (4.0e5, 4.0e5, 4.0e5), gmap, n_samples=2)]
+    sc = scenes.cornell_box("microfacet", extra_lights=extra)
+    cam, film = scenes.cornell_camera(80, 64), scenes.film_desc(80, 64)
+    desc = scenes.integrator_desc(film, 16, light_strategy=strategy) if integrator == "path" else scenes.direct_lighting_desc(film, 16, strategy=abi.DL_SAMPLE_ALL)
+    r, o = ra.Renderer(0).configure(sc, cam, film, desc), orc.Oracle(sc, cam, film, desc)
+    r.render(0, 16); o.render(0, 16, threads=8)
+    assert common.mean_relative_error(r.image(), o.image()) < 1e-3
+    so, st = o.stats(), r.stats()
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(st[k] - so[k]) <= max(3, 2e-3 * so[k]), (k, st[k], so[k])
+    r.close(); o.close()

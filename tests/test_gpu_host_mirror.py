@@ -80,7 +80,7 @@ def _read_pfm(path):
     return img[::-1]                                        # PFM stores the bottom row first
 
 
-@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("skymap:microfacet", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath"), ("ply:smooth", "path"), ("ply:textured", "path"), ("textured_lobes", "path"), ("diffuse+projection", "path")])
+@pytest.mark.parametrize("variant,integrator", [("microfacet", "path"), ("specular", "path"), ("diffuse", "directlighting"), ("diffuse+delta", "path"), ("fog:microfacet", "volpath"), ("sky:specular", "path"), ("skymap:microfacet", "path"), ("smooth", "path"), ("textured", "path"), ("spheres", "path"), ("spheres+fog", "volpath"), ("uber", "path"), ("mix", "path"), ("fog:mix", "volpath"), ("ply:smooth", "path"), ("ply:textured", "path"), ("textured_lobes", "path"), ("diffuse+projection", "path"), ("diffuse+goniometric", "path")])
 def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integrator):
     """pbrt-format text -> front end -> GpuPathIntegrator / GpuDirectLightingIntegrator -> PFM, against the oracle
     rendering the same scene built in Python."""
@@ -109,6 +109,8 @@ def test_scene_description_file_renders_like_the_oracle(tmp_path, variant, integ
         sc = scenes.cornell_smooth()       # per-vertex normals, uvs and ReverseOrientation through "normal N" / "float uv"
     else:
         extra = [abi.projection_light((150.0, 400.0, 150.0), (6.0e5, 4.0e5, 3.0e5), fov=60.0)] if variant.endswith("+projection") else []   # LightSource "projection" under Translate
+        if variant.endswith("+goniometric"):     # LightSource "goniometric" with its map in a PFM file
+            extra = [abi.goniometric_light((150.0, 400.0, 150.0), (4.0e5, 4.0e5, 4.0e5), scenes.sky_map(12, 20))]
         sc = scenes.cornell_box(variant.split("+")[0], delta_lights=variant.endswith("+delta"), extra_lights=extra)
     fov = 2 * math.degrees(math.atan(0.0125 / 0.035))
     itext = {"path": 'Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',

@@ -1057,3 +1057,32 @@ def test_projection_light_shines_like_a_point_light_and_weighs_like_a_cone():
     l = abi.projection_light((0, 0, 0), (1, 1, 1), fov=45.0)
     assert abs(l.cos_total_width - np.cos(np.arctan(np.tan(np.radians(22.5)) * np.sqrt(2)))) < 1e-6
     assert 0.06 < 2 * np.pi * (1 - l.cos_total_width) / (4 * np.pi) < 0.08
+
+
+def test_goniometric_light_is_a_point_light_scaled_by_the_top_of_its_pyramid():
+    """GonioPhotometricLight (Enigma/Lights.cpp:301-363): scale() passes the illuminant tag, 1, as MipMap::lookup's filter width
+    (:327-328), which selects the single texel at the top of the pyramid (Enigma/MipMap.h:355-361) for every direction.  With a
+    constant map of colour c the film is that of a point light of intensity I * c, bit for bit; without a map, of intensity I;
+    and a map with structure shines evenly all the same (its mean colour, by the box-filtered pyramid)."""
+    import orc
+    from raytrace_amd import abi, scenes
+
+    def film_of(light):
+        b = scenes.MeshBuilder()
+        m = b.add_material(abi.matte((0.6, 0.6, 0.6)))
+        b.add_quad([(0, 0, 0), (10, 0, 0), (10, 0, 10), (0, 0, 10)], m, toward=(5, 5, 5))
+        b.lights.append(light)
+        film = scenes.film_desc(24, 24)
+        cam = scenes.camera_desc((5, 12, -6), (5, 0, 5), (0, 1, 0), 50.0, 24, 24)
+        o = orc.Oracle(b.arrays(), cam, film, scenes.integrator_desc(film, 4, max_depth=1))
+        o.render(0, 4, threads=2)
+        out = o.film_xyzw().copy()
+        o.close()
+        return out
+    I, c = (40.0, 30.0, 20.0), (0.5, 0.25, 2.0)
+    const = np.tile(np.array(c, dtype=np.float32), (4, 8, 1))
+    assert np.array_equal(film_of(abi.goniometric_light((2, 3, 2), I, const)), film_of(abi.point_light((2, 3, 2), tuple(i * k for i, k in zip(I, c)))))
+    assert np.array_equal(film_of(abi.goniometric_light((2, 3, 2), I)), film_of(abi.point_light((2, 3, 2), I)))
+    split = np.zeros((4, 8, 3), dtype=np.float32)
+    split[:, :4] = (1.0, 0.0, 0.0)          # half red, half black: the top of the pyramid is (0.5, 0, 0) in every direction
+    assert np.array_equal(film_of(abi.goniometric_light((2, 3, 2), I, split)), film_of(abi.point_light((2, 3, 2), (20.0, 0.0, 0.0))))

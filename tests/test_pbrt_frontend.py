@@ -660,10 +660,10 @@ def test_projection_light(tmp_path):
     """LightSource "projection" (CreateProjectionLight, Enigma/Lights.cpp:782-789): at the CTM's origin, I x scale, the cone of
     "fov" (default 45) at aspect 1; the map is named in a warning because the reference drops it (Enigma/Lights.cpp:218-222)."""
     text = ('Sampler "sobol"\nWorldBegin\nAttributeBegin\nTranslate 1 2 3\nLightSource "projection" "rgb I" [2 4 6] "rgb scale" [0.5 0.5 0.5] "string mapname" "slide.exr"\n'
-            'AttributeEnd\nLightSource "projection" "float fov" 90\nLightSource "goniometric"\nWorldEnd\n')
+            'AttributeEnd\nLightSource "projection" "float fov" 90\nLightSource "laser"\nWorldEnd\n')
     err = dump(tmp_path, text, expect_fail=True)
-    assert "goniometric" in err
-    d = dump(tmp_path, text.replace('LightSource "goniometric"\n', ""))
+    assert "laser" in err
+    d = dump(tmp_path, text.replace('LightSource "laser"\n', ""))
     a, b = d["lights"]
     assert a["type"] == abi.LIGHT_PROJECTION and np.allclose(a["from"], [1, 2, 3]) and np.allclose(a["I"], [1, 2, 3])
     assert np.isclose(a["cos_total_width"], np.cos(np.arctan(np.tan(np.radians(22.5)) * np.sqrt(2.0))), atol=1e-6)
@@ -682,3 +682,14 @@ def test_infinite_light_reads_its_radiance_map_from_a_pfm_file(tmp_path):
     assert b["map"] == [0, 0]
     assert "PFM" in dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nLightSource "infinite" "string mapname" "sky.exr"\nWorldEnd\n', expect_fail=True)
     assert "sky2.pfm" in dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nLightSource "infinite" "string mapname" "sky2.pfm"\nWorldEnd\n', expect_fail=True)
+
+
+def test_goniometric_light(tmp_path):
+    """LightSource "goniometric" (CreateGoniometricLight, Enigma/Lights.cpp:774-780): at the CTM's origin, I x scale, its map read from a PFM file."""
+    import pbrt_writer
+    pbrt_writer.write_pfm(str(tmp_path / "g.pfm"), np.random.RandomState(2).rand(6, 10, 3).astype(np.float32))
+    d = dump(tmp_path, 'Sampler "sobol"\nWorldBegin\nAttributeBegin\nTranslate 4 5 6\nLightSource "goniometric" "rgb I" [2 4 6] "rgb scale" [2 2 2] "string mapname" "g.pfm"\n'
+                       'AttributeEnd\nLightSource "goniometric"\nWorldEnd\n')
+    a, b = d["lights"]
+    assert a["type"] == abi.LIGHT_GONIOMETRIC and np.allclose(a["from"], [4, 5, 6]) and np.allclose(a["I"], [4, 8, 12]) and a["map"] == [10, 6]
+    assert b["type"] == abi.LIGHT_GONIOMETRIC and np.allclose(b["I"], [1, 1, 1]) and b["map"] == [0, 0]

@@ -164,6 +164,9 @@ def random_case(seed, res=24, spp=4, for_file=False, details=None):
     pr = np.random.RandomState((seed * 7919 + 0x9207) & 0x7fffffff)
     if seed >= 1800000 and pr.rand() < 0.3:
         b.lights.append(abi.projection_light(tuple(pr.uniform(0, extent, 3)), tuple(float(x) for x in pr.uniform(20, 300, 3)), fov=float(pr.uniform(5, 150))))
+    if seed >= 1900000 and pr.rand() < 0.3:   # and from 1,900,000 on a goniometric light, with a map of any size in two cases of three
+        gmap = scenes.sky_map(int(pr.randint(1, 20)), int(pr.randint(1, 40))) if pr.rand() < 0.67 else None
+        b.lights.append(abi.goniometric_light(tuple(pr.uniform(0, extent, 3)), tuple(float(x) for x in pr.uniform(20, 300, 3)), gmap))
     if want_spheres and for_file:
         add_spheres()
     # ---- a second stream of choices (textures, a dense piece of mesh, boundary surfaces, a crop window): drawn apart from
