@@ -19,15 +19,15 @@ from raytrace_amd import distributed
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    spp = 8
+    spp, sampler = int(os.environ.get("DIST_SPP", "8")), os.environ.get("DIST_SAMPLER", "sobol")   # halton: any sample count, shared out unevenly
     sc, cam, film, integ = common.cornell_setup(res=32, spp=spp, variant="microfacet")
-    o = orc.Oracle(sc, cam, film, integ)
+    o = orc.Oracle(sc, cam, film, integ, sampler=sampler)
     lo, hi = distributed.shard_range(0, spp, rank, world)
     o.render(lo, hi, threads=2)
     t = torch.from_numpy(o.film_xyzw().copy())
     distributed.reduce_film(t, dst=0)
     if rank == 0:
-        full = orc.Oracle(sc, cam, film, integ)
+        full = orc.Oracle(sc, cam, film, integ, sampler=sampler)
         full.render(0, spp, threads=2)
         ref = full.film_xyzw()
         got = t.numpy()

@@ -16,13 +16,17 @@ def _free_port():
     return p
 
 
-def test_two_rank_sharded_render_matches_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("sampler,spp", [("sobol", 8), ("halton", 7)])
+def test_two_rank_sharded_render_matches_single_process(tmp_path, sampler, spp):
     port = _free_port()
     result = tmp_path / "result.txt"
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
+                   OMP_NUM_THREADS="2", DIST_SAMPLER=sampler, DIST_SPP=str(spp))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(result)], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
