@@ -374,12 +374,51 @@ public:
     // (CreateImageSpectrumTexture, Enigma/Texture.cpp:412-453; uv mapping; PFM files only)
     void pbrtTexture(const std::string& name, const std::string& type, const std::string& texname, const ParamSet& p, const std::string& dir) {
         VerifyWorld("Texture");
-        if (type == "float") throw std::runtime_error("Texture \"" + name + "\": float textures are not supported (the float material parameters are constants)");
+        // TextureParams::GetFloatTexture / GetSpectrumTexture (Enigma/ParameterSet.cpp:686-743): "texture <n>" names a texture made
+        // before, else the parameter's own value, else the default.  An operand here must be constant: the texture classes that
+        // combine others (scale, mix) are folded into constants when they are made, with the arithmetic their Evaluate has.
+        auto markTexture = [&](const char* n) { for (const auto& it : p.Items()) if (it.name == n && it.type == "texture") it.lookedUp = true; };
+        auto floatOperand = [&](const char* n, float def) -> float {
+            const std::string t = p.FindTexture(n);
+            if (t.empty()) return p.FindOneFloat(n, def);
+            markTexture(n);
+            auto f = m_floatTextures.find(t);
+            if (f == m_floatTextures.end()) throw std::runtime_error(std::string("Couldn't find float texture named \"") + t + "\" for parameter \"" + n + "\"");
+            return f->second;
+        };
+        auto spectrumOperand = [&](const char* n, float def) -> Spectrum {
+            const std::string t = p.FindTexture(n);
+            if (t.empty()) return p.FindOneSpectrum(n, Spectrum(def));
+            markTexture(n);
+            auto f = m_spectrumTextures.find(t);
+            if (f == m_spectrumTextures.end()) throw std::runtime_error(std::string("Couldn't find spectrum texture named \"") + t + "\" for parameter \"" + n + "\"");
+            if (f->second.index) throw std::runtime_error("Texture \"" + name + "\": \"" + texname + "\" of an image texture is evaluated per hit, which is not supported; its operands must be constant");
+            return f->second.value;
+        };
+        auto lerp = [](float a, float b, float t) { if (t < 0.f) return a; if (t > 1.f) return b; const float diff = (b - a) * t; return a + diff; }; // Lerp, Enigma/MathCommon.h:31-39
+        if (type == "float") {
+            if (m_floatTextures.count(name)) Warn("Texture \"" + name + "\" being redefined");
+            float v;
+            if (texname == "constant") v = p.FindOneFloat("value", 1.f);                                            // Enigma/Texture.cpp:158-161
+            else if (texname == "scale") v = floatOperand("tex1", 1.f) * floatOperand("tex2", 1.f);                  // ScaleTexture::Evaluate, Enigma/Texture.h:147-149
+            else if (texname == "mix") { const float a = floatOperand("tex1", 0.f), b = floatOperand("tex2", 1.f); v = lerp(a, b, floatOperand("amount", 0.5f)); } // MixTexture, :171-176
+            else throw std::runtime_error("Texture \"" + name + "\": float class \"" + texname + "\" is not supported (constant, scale and mix of constants)");
+            m_floatTextures[name] = v;
+            NoteUnused("Texture", p);
+            return;
+        }
         if (type != "spectrum" && type != "color") throw std::runtime_error("Texture type \"" + type + "\" unknown.");
         if (m_spectrumTextures.count(name)) Warn("Texture \"" + name + "\" being redefined");
         NamedTexture nt;
         if (texname == "constant") {
             nt.value = p.FindOneSpectrum("value", Spectrum(1.f));
+        } else if (texname == "scale") { // CreateScaleSpectrumTexture, Enigma/Texture.cpp:369-373
+            const Spectrum a = spectrumOperand("tex1", 1.f), b = spectrumOperand("tex2", 1.f);
+            nt.value = Spectrum(a[0] * b[0], a[1] * b[1], a[2] * b[2]);
+        } else if (texname == "mix") { // CreateMixSpectrumTexture, Enigma/Texture.cpp:375-380
+            const Spectrum a = spectrumOperand("tex1", 0.f), b = spectrumOperand("tex2", 1.f);
+            const float t = floatOperand("amount", 0.5f);
+            nt.value = Spectrum(lerp(a[0], b[0], t), lerp(a[1], b[1], t), lerp(a[2], b[2], t));
         } else if (texname == "imagemap") {
             if (p.FindOneString("mapping", "uv") != "uv") throw std::runtime_error("Texture \"" + name + "\": only the uv mapping is supported");
             const float su = p.FindOneFloat("uscale", 1.f), sv = p.FindOneFloat("vscale", 1.f), du = p.FindOneFloat("udelta", 0.f), dv = p.FindOneFloat("vdelta", 0.f);
@@ -396,7 +435,7 @@ public:
             int w = 0, hgt = 0;
             std::vector<float> rgb = ReadPfm(filename, &w, &hgt);
             nt.index = m_res->scene.AddImageTexture(w, hgt, std::move(rgb), trilerp, gamma ? 1.f : 0.f, scale, wrapMode, su, sv, du, dv);
-        } else throw std::runtime_error("Texture \"" + name + "\": class \"" + texname + "\" is not supported (constant, imagemap)");
+        } else throw std::runtime_error("Texture \"" + name + "\": class \"" + texname + "\" is not supported (constant, imagemap, scale and mix of constants)");
         m_spectrumTextures[name] = nt;
         NoteUnused("Texture", p);
     }
@@ -748,7 +787,24 @@ private:
     static void texGuard(const ParamSet& p, const char* n) {
         if (!p.FindTexture(n).empty()) throw std::runtime_error(std::string("material parameter \"") + n + "\" refers to a texture; only constant values are supported");
     }
-    int MakeMaterial(const std::string& name, const ParamSet& p) {
+    // Float parameters bound to a float texture ("texture roughness" "name") take that texture's value: every float texture
+    // this front end makes is a constant (GetFloatTexture, Enigma/ParameterSet.cpp:716-743).
+    ParamSet ResolveFloatTextures(const ParamSet& in) const {
+        ParamSet out;
+        for (const ParamSetItem& it : in.Items()) {
+            static const char* floats[] = {"sigma", "roughness", "uroughness", "vroughness", "index", "eta"};
+            bool isFloatParam = false;
+            for (const char* n : floats) isFloatParam = isFloatParam || it.name == n;
+            auto f = (it.type == "texture" && isFloatParam && !it.strs.empty()) ? m_floatTextures.find(it.strs[0]) : m_floatTextures.end();
+            if (f == m_floatTextures.end()) { out.Add(it); continue; }
+            ParamSetItem v;
+            v.type = "float"; v.name = it.name; v.nums.push_back((double)f->second);
+            out.Add(v);
+        }
+        return out;
+    }
+    int MakeMaterial(const std::string& name, const ParamSet& given) {
+        const ParamSet p = ResolveFloatTextures(given);
         EnigmaMaterial m{};
         for (const char* n : {"sigma", "roughness", "uroughness", "vroughness", "index", "bumpmap"}) texGuard(p, n);
         if (p.Has("bumpmap")) throw std::runtime_error("bump mapping is not supported");
@@ -1011,6 +1067,7 @@ private:
     int m_defaultMaterial = -1;
     struct NamedTexture { Spectrum value = Spectrum(1.f); uint32_t index = 0; }; // index: tex_* value of an image texture, 0 = the constant
     std::map<std::string, NamedTexture> m_spectrumTextures;
+    std::map<std::string, float> m_floatTextures; // every float texture made here is a constant
     std::map<std::string, int> m_namedMedia; // RenderOptions::namedMedia: name -> index in the scene's medium registry
     std::unique_ptr<FrontEndResult> m_res{new FrontEndResult()};
 };

@@ -181,6 +181,8 @@ WorldEnd
     ('WorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd\n', "cylinder"),
     ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "x.png"\nWorldEnd\n', "PFM"),
     ('WorldBegin\nMaterial "matte" "texture Kd" "t"\nWorldEnd\n', "texture"),
+    ('WorldBegin\nTexture "f" "float" "checkerboard"\nWorldEnd\n', "float class"),
+    ('WorldBegin\nMaterial "plastic" "texture roughness" "nope"\nWorldEnd\n', "only constant values"),
     ('WorldBegin\nTexture "t" "spectrum" "constant"\nMaterial "uber" "texture opacity" "t"\nWorldEnd\n', "constant values only"),
     ('WorldBegin\nMaterial "subsurface"\nWorldEnd\n', "subsurface"),
     ('WorldBegin\nMakeNamedMaterial "a" "string type" "none"\nMaterial "mix" "string namedmaterial1" "a" "string namedmaterial2" "a"\nWorldEnd\n', "two materials"),
@@ -564,7 +566,7 @@ WorldEnd
     assert np.allclose(m["kd"], [0.1, 0.2, 0.3]) and m["tex"] == [0, 1, 0, 0, 0, 0]
     t = d["textures"][0]
     assert (t["trilinear"], t["gamma"], t["wrap"]) == (0, 0, 0)
-    for body, needle in (('Texture "f" "float" "constant" "float value" 1', "float textures"),
+    for body, needle in (('Texture "f" "float" "windy"', "float class"),
                          ('Texture "x" "spectrum" "checkerboard"', "not supported"),
                          ('Texture "x" "spectrum" "imagemap" "string filename" "one.png"', "PFM"),
                          ('Texture "x" "spectrum" "imagemap" "string filename" "missing.pfm"', "unable to read"),
@@ -693,3 +695,40 @@ def test_goniometric_light(tmp_path):
     a, b = d["lights"]
     assert a["type"] == abi.LIGHT_GONIOMETRIC and np.allclose(a["from"], [4, 5, 6]) and np.allclose(a["I"], [4, 8, 12]) and a["map"] == [10, 6]
     assert b["type"] == abi.LIGHT_GONIOMETRIC and np.allclose(b["I"], [1, 1, 1]) and b["map"] == [0, 0]
+
+
+def test_constant_float_textures_and_scale_and_mix_of_constants(tmp_path):
+    """Texture classes that combine others are folded when they are made, with the arithmetic of their Evaluate (ScaleTexture:
+    the product, Enigma/Texture.h:147-149; MixTexture: the clamped Lerp, :171-176, Enigma/MathCommon.h:31-39); a float parameter
+    bound to a float texture takes its value (GetFloatTexture, Enigma/ParameterSet.cpp:716-743)."""
+    import pbrt_writer
+    pbrt_writer.write_pfm(str(tmp_path / "img.pfm"), np.ones((2, 2, 3), dtype=np.float32))
+    text = """Sampler "sobol"
+WorldBegin
+Texture "r" "float" "constant" "float value" 0.3
+Texture "r2" "float" "scale" "texture tex1" "r" "float tex2" 0.5
+Texture "r3" "float" "mix" "texture tex1" "r" "texture tex2" "r2" "float amount" 0.25
+Texture "c" "spectrum" "constant" "rgb value" [0.2 0.4 0.8]
+Texture "cs" "spectrum" "scale" "texture tex1" "c" "rgb tex2" [0.5 0.5 2]
+Texture "cm" "color" "mix" "texture tex1" "c" "texture tex2" "cs" "texture amount" "r3"
+Texture "over" "spectrum" "mix" "rgb tex1" [1 1 1] "rgb tex2" [3 3 3] "float amount" 1.5
+Material "plastic" "texture Kd" "cs" "texture Ks" "cm" "texture roughness" "r2"
+Shape "trianglemesh" "point P" [0 0 0 1 0 0 0 1 0]
+Material "matte" "texture Kd" "over" "texture sigma" "r3"
+Shape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1]
+WorldEnd
+"""
+    d = dump(tmp_path, text)
+    f32 = np.float32
+    r, r2 = f32(0.3), f32(0.3) * f32(0.5)
+    r3 = r + (r2 - r) * f32(0.25)
+    c = np.array([0.2, 0.4, 0.8], dtype=f32)
+    cs = c * np.array([0.5, 0.5, 2], dtype=f32)
+    cm = c + (cs - c) * r3
+    plastic, matte = d["materials"][-2], d["materials"][-1]
+    assert np.array_equal(np.array(plastic["kd"], dtype=f32), cs) and np.array_equal(np.array(plastic["ks"], dtype=f32), cm)
+    assert f32(plastic["uroughness"]) == r2 and f32(plastic["vroughness"]) == r2
+    assert np.array_equal(np.array(matte["kd"], dtype=f32), [3, 3, 3]) and f32(matte["sigma"]) == r3   # an amount above 1 gives the second texture
+    assert not [w for w in d["warnings"] if "not used" in w]
+    bad = text.replace('Texture "c" "spectrum" "constant" "rgb value" [0.2 0.4 0.8]', 'Texture "c" "spectrum" "imagemap" "string filename" "img.pfm"')
+    assert "evaluated per hit" in dump(tmp_path, bad, expect_fail=True)
