@@ -13,13 +13,15 @@
 // reference's Transform composition transposes on construction (Enigma/Transform.cpp:295-314) and gives
 // wrong matrices for chained operations; that defect is not reproduced.
 //
-// Inside the subset: trianglemesh (with N, uv / st) and sphere shapes; matte, metal (default spectra: the reference's
-// copper), glass, plastic and "none" materials; constant and imagemap (PFM) textures; point, spot, distant, infinite
-// and diffuse area lights; named media (homogeneous with the measured presets; heterogeneous as the reference has them: black) and medium interfaces; the path, directlighting and volpath
-// integrators; the sobol sampler, the perspective camera, the image film with its five filters.  Outside it (other
-// shapes and texture classes, spectra other than rgb, object instancing, other samplers / cameras /
-// lights / integrators) the front end throws std::runtime_error naming the directive; it never renders something
-// else silently.
+// Inside the subset: trianglemesh (with N, uv / st), plymesh and sphere shapes; matte, metal (default spectra: the reference's
+// copper), glass, plastic, mirror, translucent, substrate, uber, mix and "none" materials; constant and imagemap (PFM)
+// textures, constant float textures, scale and mix of constant operands; point, spot, distant, projection, goniometric,
+// infinite and diffuse area lights; named media (homogeneous with the measured presets; heterogeneous as the reference has
+// them: black) and medium interfaces; the path, directlighting and volpath integrators; the sobol and halton samplers
+// (halton when the file names none, as in the reference); the perspective and environment cameras; the image film with
+// its five filters.  Outside it (other shapes and texture classes, spectra other than rgb, object instancing, the pixel
+// samplers, other cameras / integrators) the front end throws std::runtime_error naming the directive; it never renders
+// something else silently.
 #pragma once
 #include "enigma_host.h"
 #include "medium_presets.inc"
