@@ -994,7 +994,13 @@ DEV void storeShadowRay(const DevRayQueue& q, size_t slot, F3 o, F3 d, F3 w) {
 // (re-measured with device code at -O1, where nothing is spilled at four / three waves: five / four 9-16 % slower, three /
 // three 3 % slower, four / four and four / two the same within 1 %)
 template <int MK, bool LDS_SCENE, bool VOL = false, bool SPH = false, bool HAL = false>
-__global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUGH || MK == MK_GLASS_SMOOTH) ? 4 : 3) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
+#ifndef ENIGMA_EXP_SHADE_OCC_A
+#define ENIGMA_EXP_SHADE_OCC_A 4
+#endif
+#ifndef ENIGMA_EXP_SHADE_OCC_B
+#define ENIGMA_EXP_SHADE_OCC_B 3
+#endif
+__global__ void __launch_bounds__(kBlock, (MK == MK_MATTE || MK == MK_MATTE_ROUGH || MK == MK_GLASS_SMOOTH) ? ENIGMA_EXP_SHADE_OCC_A : ENIGMA_EXP_SHADE_OCC_B) k_shade(DevScene sc, DevPaths P, DevSampler S, DevIntegrator I, DevRayQueue shq, DevRayQueue misq,
                                                   const uint32_t* matQueue, uint32_t* nextQueue, uint32_t nextIdx, DevCounters* ctr) {
     __shared__ uint32_t lds[32];
     extern __shared__ float4 sceneLds[];
