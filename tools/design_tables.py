@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Rewrites the measured columns of DESIGN.md's measurement tables from a kept set (tools/keep_set.sh <tag> <commit>).
-usage: python tools/design_tables.py <tag>      (reads profiles/<tag>_*, edits DESIGN.md in place, prints what changed)"""
+"""Rewrites the measured columns of the measurement tables in the design document at the repository root from a kept set
+(tools/keep_set.sh <tag> <commit>).
+usage: python tools/design_tables.py <tag>      (reads profiles/<tag>_*, edits the document in place, prints what changed)"""
 import json, os, re, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -18,7 +19,7 @@ def thousands(v):
     return "{:,}".format(v) if v >= 10000 else str(v)
 
 
-# workload table: | label | ms/step | Mrays/s | Msamples/s | whole job | round 2 | file |
+# workload table: | label | ms/step | Mrays/s | Msamples/s | whole job | earlier value | file |
 rows = 0
 for name in ("default", "bigmesh_path", "manylights_path", "manylights_path_spatial", "manylights_direct-one", "microfacet_direct-all", "fog_volpath", "bigmesh_fog_volpath"):
     m = re.search(r"^\|[^\n]*`r03_\w+_bench_%s\.json`[^\n]*$" % re.escape(name), text, re.M)
