@@ -40,9 +40,15 @@ DEV uint32_t sobolBits(const DevSampler& S, uint32_t relx, uint32_t rely, uint32
 // with a multiplication (the record's magic and shift: exact for every 32-bit numerator), 1 / base and the tail term
 // invBase * perm[0] / (1 - invBase) are the host's, rounded as the reference rounds them.
 // Kernels that draw samples are compiled once per sampler (template argument HAL): with the choice made at run time
-// the shade kernels of the Sobol' sampler, which never run this, were 3.5 % slower, inlined or not.  One copy per
-// module (not inlined): a shade kernel draws samples in a dozen places.
-static __device__ __noinline__ float haltonValue(const uint32_t* H, uint32_t off, uint32_t sampleNum, uint32_t dim) {
+// the shade kernels of the Sobol' sampler, which never run this, were 3.5 % slower, inlined or not.  Inlined into the
+// Halton builds: as one function per module, called from the dozen places where a shade kernel draws samples, those
+// kernels were 4 % slower.
+#ifdef ENIGMA_EXP_HALTON_NOINLINE
+#define ENIGMA_HALTON_LINKAGE __noinline__
+#else
+#define ENIGMA_HALTON_LINKAGE __forceinline__
+#endif
+static __device__ ENIGMA_HALTON_LINKAGE float haltonValue(const uint32_t* H, uint32_t off, uint32_t sampleNum, uint32_t dim) {
     if (dim < 2u && H[3] != 0u) return 0.5f;
     const uint32_t stride = H[0];
     if (off >= stride) off -= stride;                // the sum of two terms, each already reduced modulo the stride
