@@ -73,13 +73,20 @@ def material_text(i, m):
         if tex:
             parts.append('"texture %s" "t%d"' % (name, tex - 1))
     remap = '"bool remaproughness" "%s"' % ("true" if m.remap_roughness else "false")
-    if t == "matte":
+    pre = ""
+    if t == "matte" and i % 2 == 1:   # every other one through a float texture: a scale of two constants whose product is the value
+        pre = ('Texture "fs%d" "float" "constant" "float value" %.9g\nTexture "fsig%d" "float" "scale" "texture tex1" "fs%d" "float tex2" 1\n' % (i, m.sigma, i, i))
+        parts += [_rgb("Kd", m.kd), '"texture sigma" "fsig%d"' % i]
+    elif t == "matte":
         parts += [_rgb("Kd", m.kd), '"float sigma" %.9g' % m.sigma]
     elif t == "metal":
         parts += [_rgb("eta", m.eta), _rgb("k", m.k), '"float uroughness" %.9g' % m.uroughness, '"float vroughness" %.9g' % m.vroughness, remap]
     elif t == "glass":
         parts += [_rgb("Kr", m.kr), _rgb("Kt", m.kt), '"float index" %.9g' % m.index, '"float uroughness" %.9g' % m.uroughness,
                   '"float vroughness" %.9g' % m.vroughness, remap]
+    elif t == "plastic" and i % 2 == 1:
+        pre = 'Texture "fr%d" "float" "constant" "float value" %.9g\n' % (i, m.uroughness)
+        parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), '"texture roughness" "fr%d"' % i, remap]
     elif t == "plastic":
         parts += [_rgb("Kd", m.kd), _rgb("Ks", m.ks), '"float roughness" %.9g' % m.uroughness, remap]
     elif t == "mirror":
@@ -93,7 +100,7 @@ def material_text(i, m):
                   '"float vroughness" %.9g' % m.vroughness, '"float index" %.9g' % m.index, remap]
     else:
         parts += ['"string namedmaterial1" "m%d"' % m.mix_a, '"string namedmaterial2" "m%d"' % m.mix_b, _rgb("amount", m.amount)]
-    return " ".join(parts)
+    return pre + " ".join(parts)
 
 
 def scene_text(sc, eye, look, up, fov, xres, yres, spp, integrator='Integrator "path" "integer maxdepth" 5 "string lightsamplestrategy" "power"',
